@@ -1,0 +1,154 @@
+/*
+ * t2v_hip.h — C ABI of libt2v_hip.so, the MI355X (gfx950) implementation of the
+ * ModelScope / ZeroScope text-to-video denoising hot path.
+ *
+ * The reference (kabachuha/sd-webui-text2video) has no FFI: its seam is Python duck-typing
+ * (SURVEY.md §8b).  This header is the boundary a maintainer binds with ctypes
+ *  to replace the torch.nn delegation layer under
+ *   - UNetSD.forward / _forward_single      scripts/modelscope/t2v_model.py:386-501   (B4)
+ *   - AutoencoderKL.decode                  scripts/modelscope/t2v_model.py:1646-1649 (B5)
+ *   - GaussianDiffusion.sample step update  scripts/samplers/ddim/gaussian_sampler.py:257-283
+ *
+ * Design: the host (Python) lowers a model + shape into a flat *denoise program* — an array
+ * of t2v_op records over one activation arena and one packed-weight arena — and this library
+ * executes the program by launching hand-written HIP kernels on the caller's HIP stream.
+ * Plain pointers and sizes only; no torch types.  All device memory is owned by the caller;
+ * pointers are borrowed for the duration of a call.  No internal threads; one in-flight call
+ * per plan.  Every function returns 0 on success or a negative T2V_ERR_* code; the message of
+ * the last failure is available from t2v_last_error().
+ */
+#ifndef T2V_HIP_H
+#define T2V_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define T2V_ABI_VERSION 1
+
+/* error codes */
+#define T2V_OK 0
+#define T2V_ERR_BAD_ARG (-1)
+#define T2V_ERR_UNSUPPORTED (-2)
+#define T2V_ERR_LAUNCH (-3)
+#define T2V_ERR_NO_DEVICE (-4)
+
+/* ---- op kinds ------------------------------------------------------------------------- */
+enum t2v_op_kind {
+  T2V_OP_GEMM = 1,        /* implicit-GEMM conv / linear on MFMA, fused epilogue            */
+  T2V_OP_GROUPNORM = 2,   /* GroupNorm(32) (+SiLU), per-frame or cross-frame statistics     */
+  T2V_OP_LAYERNORM = 3,   /* row LayerNorm fp32 -> fp16                                     */
+  T2V_OP_ATTENTION = 4,   /* softmax(QK^T * scale) V, head_dim 64, strided batch            */
+  T2V_OP_SOFTMAX = 5,     /* row softmax fp32 -> fp16 (VAE single-head attention)           */
+  T2V_OP_NCTHW_TO_CL = 6, /* [B,C,F,H,W] -> channels-last fp16 tokens [B*F*H*W, ld]         */
+  T2V_OP_CL_TO_NCTHW = 7, /* channels-last fp32 tokens -> [B,C,F,H,W]                       */
+  T2V_OP_TIME_EMBED = 8,  /* sinusoidal timestep embedding (cos | sin) -> fp16              */
+  T2V_OP_COPY2D = 9,      /* strided 2-D copy / cast / SiLU (concat, fp32->fp16 staging)    */
+  T2V_OP_DDIM_STEP = 10,  /* DDIM_Gaussian update with half-channel CFG                     */
+  T2V_OP_MEMSET = 11,     /* zero a byte range                                              */
+  T2V_OP_KIND_MAX = 12
+};
+
+/* GEMM gather modes: how row m / reduction index k of the A operand are addressed          */
+enum t2v_gather {
+  T2V_GATHER_PLAIN = 0,   /* A[m*lda + k]                                   (nn.Linear, 1x1) */
+  T2V_GATHER_CONV3X3 = 1, /* 3x3 spatial conv, pad 1, stride 1|2, optional nearest-2x
+                             upsample folded in; K = 9*Cin, Cin % 64 == 0                    */
+  T2V_GATHER_TCONV3 = 2,  /* (3,1,1) temporal conv over frames, pad (1,0,0); K = 3*Cin       */
+  T2V_GATHER_CONV3X3_C8 = 3 /* 3x3 spatial conv with Cin == 8 (4 real + 4 zero channels)     */
+};
+
+/* GEMM epilogues */
+#define T2V_EPI_NONE 0
+#define T2V_EPI_GEGLU 1   /* out[m, j] = (a_j + b_j) * gelu(g_j + c_j); weight rows interleaved
+                             in blocks of 16 = 8 value rows | 8 gate rows                    */
+
+/* dtype tags */
+#define T2V_F16 0
+#define T2V_F32 1
+
+/* external pointer slots: a pointer field whose value is < T2V_EXT_SLOTS is replaced at run
+ * time by ext[value] (value 0 = null). */
+#define T2V_EXT_SLOTS 16
+#define T2V_EXT_X 1      /* UNet: x [B,4,F,h,w]   | VAE: z [n,4,h,w]                         */
+#define T2V_EXT_T 2      /* UNet: timesteps, float32 [B]                                     */
+#define T2V_EXT_CTX 3    /* UNet: context [B,L,ctx_dim]                                      */
+#define T2V_EXT_OUT 4    /* UNet: eps [B,4,F,h,w] | VAE: image [n,3,8h,8w]                   */
+#define T2V_EXT_XT 5     /* DDIM: x_t in                                                     */
+#define T2V_EXT_XT_OUT 6 /* DDIM: x_{t-1} out                                                */
+#define T2V_EXT_NOISE 7  /* DDIM: eta-noise (may be null when sigma == 0)                    */
+#define T2V_EXT_EPS 8    /* DDIM: stacked UNet outputs [2,C,F,h,w] (cond, uncond)            */
+
+#define T2V_OP_NI 24
+#define T2V_OP_NF 8
+#define T2V_OP_NP 8
+
+/* One program record.  Field meaning per kind:
+ *
+ * GEMM:  out[M,N] = epi( gather(A)[M,K] * W[N,K]^T )       fp16 operands, fp32 accumulate
+ *   i: 0 M, 1 N, 2 K, 3 lda, 4 ldw, 5 ldc, 6 ldr, 7 gather, 8 Hin|F, 9 Win|HW, 10 Cin,
+ *      11 stride, 12 upsample, 13 Hout, 14 Wout, 15 rows_per_batch, 16 epilogue,
+ *      17 out dtype, 18 act (0 none, 1 SiLU), 19 split_k, 20 bias_along_m, 21 ldrb
+ *   p: 0 A fp16, 1 W fp16 [N,K], 2 bias fp32 [N] (or [M] if bias_along_m), 3 rowbias fp32
+ *      [M/rows_per_batch, ldrb], 4 residual fp32 [M,ldr], 5 out, 6 split-K workspace fp32
+ * GROUPNORM: i: 0 n_inst, 1 rows_per_inst, 2 C, 3 ld_in, 4 groups, 5 in dtype, 6 silu,
+ *      7 ld_out;  f: 0 eps;  p: 0 x, 1 gamma, 2 beta, 3 out fp16, 4 stats scratch (fp64)
+ * LAYERNORM: i: 0 M, 1 C, 2 ld_in, 3 ld_out; f: 0 eps; p: 0 x fp32, 1 gamma, 2 beta, 3 out fp16
+ * ATTENTION: i: 0 nq, 1 nk, 2 heads, 3 batch_outer, 4 batch_inner, 5..7 q strides (seq,
+ *      outer, inner), 8..10 k/v strides, 11..13 out strides (elements; head h at +64h);
+ *      f: 0 scale; p: 0 q, 1 k, 2 v, 3 out (all fp16)
+ * SOFTMAX: i: 0 rows, 1 cols, 2 ld_in, 3 ld_out; f: 0 scale; p: 0 in fp32, 1 out fp16
+ * NCTHW_TO_CL: i: 0 B, 1 C, 2 F, 3 HW, 4 ld_out, 5 in dtype; f: 0 scale; p: 0 in, 1 out fp16
+ * CL_TO_NCTHW: i: 0 B, 1 C, 2 F, 3 HW, 4 ld_in, 5 out dtype; p: 0 in fp32, 1 out
+ * TIME_EMBED: i: 0 B, 1 dim; p: 0 t fp32 [B], 1 freqs fp32 [dim/2], 2 out fp16 [B,dim]
+ * COPY2D: i: 0 rows, 1 cols, 2 ld_src, 3 ld_dst, 4 src dtype, 5 dst dtype, 6 act; p: 0 src, 1 dst
+ * DDIM_STEP: i: 0 C, 1 inner (F*h*w), 2 guided channels, 3 eps dtype, 4 x dtype;
+ *      f: 0 sqrt_recip_ac, 1 sqrt_recipm1_ac, 2 sqrt(a_prev), 3 dir coef, 4 sigma (masked),
+ *         5 guidance scale; p: 0 xt, 1 eps pair, 2 noise, 3 out
+ * MEMSET: i: 0 bytes (lo), 1 bytes (hi); p: 0 dst
+ */
+typedef struct t2v_op {
+  int32_t kind;
+  int32_t tag;                 /* free for the host (debug id) */
+  int32_t i[T2V_OP_NI];
+  float f[T2V_OP_NF];
+  uint64_t p[T2V_OP_NP];
+} t2v_op;
+
+typedef struct t2v_plan t2v_plan; /* opaque: a validated copy of a program */
+
+/* library / device */
+int t2v_abi_version(void);
+const char* t2v_last_error(void);
+/* fills name (<= len bytes), number of CUs and total HBM bytes of the current HIP device */
+int t2v_device_info(char* name, int len, int* compute_units, uint64_t* hbm_bytes);
+
+/* Execute `n` ops in order on `stream` (a hipStream_t; null = default stream). */
+int t2v_run_ops(const t2v_op* ops, int n, const uint64_t* ext, int n_ext, void* stream);
+
+/* Plans: validate + copy a program once, run it many times. */
+int t2v_plan_create(const t2v_op* ops, int n, t2v_plan** out);
+int t2v_plan_num_ops(const t2v_plan* plan);
+int t2v_plan_run(t2v_plan* plan, const uint64_t* ext, int n_ext, void* stream);
+/* Same, bracketing every op with HIP events on `stream`; ms[i] = duration of op i.
+ * Synchronises the stream.  Used by bench.py for the live roofline measurement. */
+int t2v_plan_run_timed(t2v_plan* plan, const uint64_t* ext, int n_ext, void* stream, float* ms);
+void t2v_plan_destroy(t2v_plan* plan);
+
+/* Drop-in entry points for the reference's call sites (thin wrappers over t2v_plan_run that
+ * fix the external-slot convention):
+ *   t2v_unet_forward  <->  eps = UNetSD.forward(x, t, y)      t2v_model.py:386
+ *   t2v_vae_decode    <->  img = AutoencoderKL.decode(z)      t2v_model.py:1646
+ *   t2v_ddim_step     <->  loop body of GaussianDiffusion.sample  gaussian_sampler.py:257-283 */
+int t2v_unet_forward(t2v_plan* plan, const void* x, const float* t, const void* ctx, void* eps_out,
+                     void* stream);
+int t2v_vae_decode(t2v_plan* plan, const void* z, void* img_out, void* stream);
+int t2v_ddim_step(t2v_plan* plan, const void* xt, const void* eps_pair, const void* noise,
+                  void* xt_out, const float coef[6], void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* T2V_HIP_H */

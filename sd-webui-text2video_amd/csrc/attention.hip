@@ -1,0 +1,241 @@
+// Fused softmax(Q K^T * scale) V for head_dim 64 on gfx950 MFMA (wave64).
+//
+// Replaces CrossAttention.forward's SDPA / einsum-softmax-einsum dispatch
+// (reference scripts/modelscope/t2v_model.py:540-584) for the three call shapes of the UNet
+// (SURVEY.md §2.3 K6-K8):
+//   spatial self-attention   n_q = n_k = h*w,  batch = (b f) x heads
+//   text cross-attention     n_q = h*w, n_k = 77 (K/V broadcast over frames via stride 0)
+//   temporal self-attention  n_q = n_k = F,    batch = (b h w) x heads, sequence stride = h*w*ld
+// Q/K/V/O are addressed by (sequence, batch_outer, batch_inner) element strides + 64*head, so
+// the fused QKV GEMM output [tokens, 3C] is consumed in place — none of the reference's
+// 'b n (h d) -> (b h) n d' / '(b f) c h w -> (b h w) f c' rearrange copies exist.
+//
+// Structure: one wave owns 32 query rows; a workgroup (NW waves) shares 64-key K/V tiles in
+// LDS.  S^T = K Q^T is computed with the *key* index on the MFMA row axis, so every lane
+// holds 2x16 scores of ONE query: the online-softmax max/sum are in-lane reductions plus one
+// lane^32 exchange.  The P fragment for P·V is taken from the accumulator registers directly
+// (the key order inside a 16-slot MFMA step is a free permutation as long as V^T uses the
+// same one), so P never goes through LDS.  V is transposed while being written to LDS
+// ([d][key], 136-B rows: conflict-free 8-byte fragment reads).
+#include "t2v_kernels.h"
+
+namespace {
+
+struct AttnParams {
+  const f16* q; const f16* k; const f16* v; f16* o;
+  int nq, nk, heads, b_outer, b_inner;
+  long sq_seq, sq_out, sq_in;
+  long sk_seq, sk_out, sk_in;
+  long so_seq, so_out, so_in;
+  float scale_log2;
+};
+
+constexpr int KT = 64;         // keys per LDS tile
+constexpr int VT_ROW = 136;    // bytes per V^T row (64 keys * 2 B + 8 B pad)
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnParams p) {
+  constexpr int NT = NW * 64;
+  __shared__ __attribute__((aligned(16))) unsigned char k_lds[KT * 128];     // [key][64 d], swizzled chunks
+  __shared__ __attribute__((aligned(16))) unsigned char vt_lds[64 * VT_ROW]; // [d][64 keys]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int head = blockIdx.y;
+  const int bo = blockIdx.z / p.b_inner, bi = blockIdx.z % p.b_inner;
+  const int q0 = blockIdx.x * (32 * NW) + wave * 32;
+  const int frow = lane & 31, fhalf = lane >> 5;
+
+  const f16* qb = p.q + bo * p.sq_out + bi * p.sq_in + head * 64;
+  const f16* kb = p.k + bo * p.sk_out + bi * p.sk_in + head * 64;
+  const f16* vb = p.v + bo * p.sk_out + bi * p.sk_in + head * 64;
+  f16* ob = p.o + bo * p.so_out + bi * p.so_in + head * 64;
+
+  // Q fragments: query (lane&31), d = kk*16 + 8*fhalf + 0..7
+  const int qrow = q0 + frow;
+  f16x8 qf[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    if (qrow < p.nq)
+      qf[kk] = *reinterpret_cast<const f16x8*>(qb + (long)qrow * p.sq_seq + kk * 16 + fhalf * 8);
+    else
+      for (int e = 0; e < 8; ++e) qf[kk][e] = (f16)0.f;
+  }
+
+  f32x16 oacc[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  for (int kt0 = 0; kt0 < p.nk; kt0 += KT) {
+    __syncthreads();  // previous tile fully consumed
+    // ---- K tile: 64 rows x 8 chunks of 16 B ---------------------------------------
+    for (int u = tid; u < KT * 8; u += NT) {
+      const int row = u >> 3, c = u & 7;
+      const int key = kt0 + row;
+      f16x8 val;
+      if (key < p.nk)
+        val = *reinterpret_cast<const f16x8*>(kb + (long)key * p.sk_seq + c * 8);
+      else
+        for (int e = 0; e < 8; ++e) val[e] = (f16)0.f;
+      *reinterpret_cast<f16x8*>(k_lds + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = val;
+    }
+    // ---- V tile, transposed: unit = (key pair, 4 d) -> 4 x 32-bit {V[2kp][d], V[2kp+1][d]}
+    for (int u = tid; u < 32 * 16; u += NT) {
+      const int kp = u >> 4, dq = u & 15;
+      const int key = kt0 + 2 * kp;
+      f16x4 a, b;
+      if (key < p.nk) a = *reinterpret_cast<const f16x4*>(vb + (long)key * p.sk_seq + dq * 4);
+      else for (int e = 0; e < 4; ++e) a[e] = (f16)0.f;
+      if (key + 1 < p.nk) b = *reinterpret_cast<const f16x4*>(vb + (long)(key + 1) * p.sk_seq + dq * 4);
+      else for (int e = 0; e < 4; ++e) b[e] = (f16)0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        typedef f16 f16x2 __attribute__((ext_vector_type(2)));
+        f16x2 w = {a[e], b[e]};
+        *reinterpret_cast<f16x2*>(vt_lds + (dq * 4 + e) * VT_ROW + kp * 4) = w;
+      }
+    }
+    __syncthreads();
+
+    // ---- S^T = K Q^T : two 32-key tiles -------------------------------------------
+    const bool t1_live = (kt0 + 32) < p.nk;   // wave-uniform
+    f32x16 s[2];
+#pragma unroll
+    for (int T = 0; T < 2; ++T) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[T][r] = 0.f;
+      if (T == 1 && !t1_live) continue;
+      const int row = T * 32 + frow;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int chunk = kk * 2 + fhalf;
+        const f16x8 kf = *reinterpret_cast<const f16x8*>(k_lds + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+        s[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[kk], s[T], 0, 0, 0);
+      }
+    }
+    // ---- online softmax for this lane's query -------------------------------------
+    float mx = -INFINITY;
+#pragma unroll
+    for (int T = 0; T < 2; ++T)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt0 + T * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+        const float x = (key < p.nk) ? s[T][r] * p.scale_log2 : -INFINITY;
+        s[T][r] = x;
+        mx = fmaxf(mx, x);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);          // finite: key kt0 is always valid
+    const float alpha = exp2f(m_run - m_new);      // exp2(-inf) = 0 on the first tile
+    float psum = 0.f;
+#pragma unroll
+    for (int T = 0; T < 2; ++T)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = exp2f(s[T][r] - m_new);
+        s[T][r] = pv;
+        psum += pv;
+      }
+    psum += __shfl_xor(psum, 32);
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+
+    // ---- O^T += V^T P^T -----------------------------------------------------------
+#pragma unroll
+    for (int T = 0; T < 2; ++T) {
+      if (T == 1 && !t1_live) continue;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        f16x8 pf;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pf[e] = (f16)s[T][8 * t + e];
+        const int kofs = (T * 32 + t * 16 + 4 * fhalf) * 2;  // byte offset of key slot e=0
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          const unsigned char* vrow = vt_lds + (d * 32 + frow) * VT_ROW + kofs;
+          const f16x4 lo = *reinterpret_cast<const f16x4*>(vrow);
+          const f16x4 hi = *reinterpret_cast<const f16x4*>(vrow + 16);
+          const f16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, oacc[d], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  if (qrow < p.nq) {
+    const float inv = 1.0f / l_run;
+    f16* orow = ob + (long)qrow * p.so_seq;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        f16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (f16)(oacc[d][4 * qd + r] * inv);
+        *reinterpret_cast<f16x4*>(orow + d * 32 + 8 * qd + 4 * fhalf) = o;
+      }
+  }
+}
+
+// ---- row softmax fp32 -> fp16 (VAE AttnBlock, autoencoder_modules.py:104-106) -----------
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* in, f16* out, int rows, int cols,
+                                                           int ld_in, int ld_out, float scale) {
+  __shared__ float red[4];
+  const int row = blockIdx.x;
+  if (row >= rows) return;
+  const float* x = in + (size_t)row * ld_in;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float mx = -INFINITY;
+  for (int c = tid; c < cols; c += 256) mx = fmaxf(mx, x[c] * scale);
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float sum = 0.f;
+  for (int c = tid; c < cols; c += 256) sum += __expf(x[c] * scale - mx);
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  if (lane == 0) red[wave] = sum;
+  __syncthreads();
+  sum = red[0] + red[1] + red[2] + red[3];
+  const float inv = 1.0f / sum;
+  f16* y = out + (size_t)row * ld_out;
+  for (int c = tid; c < cols; c += 256) y[c] = (f16)(__expf(x[c] * scale - mx) * inv);
+}
+
+}  // namespace
+
+hipError_t t2v_launch_attention(const t2v_op& op, hipStream_t s) {
+  AttnParams p;
+  p.q = reinterpret_cast<const f16*>(op.p[0]);
+  p.k = reinterpret_cast<const f16*>(op.p[1]);
+  p.v = reinterpret_cast<const f16*>(op.p[2]);
+  p.o = reinterpret_cast<f16*>(op.p[3]);
+  p.nq = op.i[0]; p.nk = op.i[1]; p.heads = op.i[2]; p.b_outer = op.i[3]; p.b_inner = op.i[4];
+  p.sq_seq = op.i[5]; p.sq_out = op.i[6]; p.sq_in = op.i[7];
+  p.sk_seq = op.i[8]; p.sk_out = op.i[9]; p.sk_in = op.i[10];
+  p.so_seq = op.i[11]; p.so_out = op.i[12]; p.so_in = op.i[13];
+  p.scale_log2 = op.f[0] * 1.44269504088896340736f;
+  if (p.nq <= 0 || p.nk <= 0) return hipErrorInvalidValue;
+  const int nbatch = p.b_outer * p.b_inner;
+  if (p.nq <= 32) {
+    hipLaunchKernelGGL(attn_kernel<1>, dim3(1, p.heads, nbatch), dim3(64), 0, s, p);
+  } else {
+    hipLaunchKernelGGL(attn_kernel<4>, dim3((p.nq + 127) / 128, p.heads, nbatch), dim3(256), 0, s, p);
+  }
+  return hipGetLastError();
+}
+
+hipError_t t2v_launch_softmax(const t2v_op& op, hipStream_t s) {
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(op.i[0]), dim3(256), 0, s,
+                     reinterpret_cast<const float*>(op.p[0]), reinterpret_cast<f16*>(op.p[1]), op.i[0],
+                     op.i[1], op.i[2], op.i[3], op.f[0]);
+  return hipGetLastError();
+}

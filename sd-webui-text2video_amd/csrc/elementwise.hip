@@ -1,0 +1,189 @@
+// Layout, pointwise and sampler-update kernels (HBM-bound, vectorised), gfx950.
+//
+//   ncthw_to_cl   'b c f h w -> (b f h w) c' entry conversion of the 4-channel latent
+//                 (reference does this as rearrange + .contiguous(), t2v_model.py:429)
+//   cl_to_ncthw   exit conversion of eps / decoded RGB            (t2v_model.py:456-458)
+//   time_embed    sinusoidal_embedding (cos | sin), t2v_model.py:504-515
+//   copy2d        strided 2-D copy / fp32->fp16 cast / SiLU: torch.cat of skip connections
+//                 (t2v_model.py:444), operand staging, SiLU(e) of emb_layers (:936)
+//   ddim_step     DDIM_Gaussian update incl. half-channel classifier-free guidance
+//                 (samplers/ddim/gaussian_sampler.py:125-136, 103-108, 199-211, 269-283)
+#include "t2v_kernels.h"
+
+namespace {
+
+template <typename TIN>
+__global__ __launch_bounds__(256) void ncthw_to_cl_kernel(const TIN* in, f16* out, int B, int C, int F, int HW,
+                                                          int ld, float scale) {
+  // one thread per output token; writes ld (>= C, multiple of 4) channels, zero padded
+  const long total = (long)B * F * HW;
+  for (long tkn = (long)blockIdx.x * 256 + threadIdx.x; tkn < total; tkn += (long)gridDim.x * 256) {
+    const long bf = tkn / HW;
+    const int pix = (int)(tkn - bf * HW);
+    const int b = (int)(bf / F), f = (int)(bf - (long)b * F);
+    f16* o = out + tkn * ld;
+    for (int c = 0; c < ld; ++c) {
+      float v = 0.f;
+      if (c < C) v = (float)in[(((size_t)b * C + c) * F + f) * HW + pix] * scale;
+      o[c] = (f16)v;
+    }
+  }
+}
+
+template <typename TOUT>
+__global__ __launch_bounds__(256) void cl_to_ncthw_kernel(const float* in, TOUT* out, int B, int C, int F, int HW,
+                                                          int ld) {
+  // one thread per output element (coalesced along pixels)
+  const long total = (long)B * C * F * HW;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int pix = (int)(idx % HW);
+    long r = idx / HW;
+    const int f = (int)(r % F); r /= F;
+    const int c = (int)(r % C);
+    const int b = (int)(r / C);
+    out[idx] = (TOUT)in[(((size_t)b * F + f) * HW + pix) * ld + c];
+  }
+}
+
+__global__ __launch_bounds__(256) void time_embed_kernel(const float* t, const float* freqs, f16* out, int B,
+                                                         int dim) {
+  const int half = dim / 2;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= B * half) return;
+  const int b = idx / half, i = idx - b * half;
+  const float a = t[b] * freqs[i];
+  out[(size_t)b * dim + i] = (f16)cosf(a);
+  out[(size_t)b * dim + half + i] = (f16)sinf(a);
+}
+
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void copy2d_kernel(const TS* src, TD* dst, int rows, int cols, int lds_,
+                                                     int ldd, int act) {
+  const int cv = cols >> 2;
+  const long total = (long)rows * cv;
+  for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < total; u += (long)gridDim.x * 256) {
+    const long r = u / cv;
+    const int c = (int)(u - r * cv) * 4;
+    const TS* s = src + r * lds_ + c;
+    TD* d = dst + r * ldd + c;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (float)s[e];
+    if (act == 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = t2v_silu(v[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) d[e] = (TD)v[e];
+  }
+}
+
+struct DdimParams {
+  const void* xt; const void* eps; const float* noise; void* out;
+  int C, inner, guided, eps_f32, x_f32;
+  float a_recip, a_recipm1, sqrt_aprev, dir_coef, sigma, gscale;
+};
+
+template <typename TX, typename TE>
+__global__ __launch_bounds__(256) void ddim_step_kernel(const DdimParams p) {
+  // x_t [1,C,inner]; eps pair [2,C,inner] (0 = conditional, 1 = unconditional)
+  const TX* xt = reinterpret_cast<const TX*>(p.xt);
+  const TE* ec = reinterpret_cast<const TE*>(p.eps);
+  const TE* eu = ec + (size_t)p.C * p.inner;
+  TX* out = reinterpret_cast<TX*>(p.out);
+  const long total = (long)p.C * p.inner;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int c = (int)(idx / p.inner);
+    const float x = (float)xt[idx];
+    const float y = (float)ec[idx];
+    float o = y;
+    if (c < p.guided) {
+      const float u = (float)eu[idx];
+      o = u + p.gscale * (y - u);
+    }
+    // same operation order as the reference (all fp32)
+    const float x0 = p.a_recip * x - p.a_recipm1 * o;
+    const float eps = (p.a_recip * x - x0) / p.a_recipm1;
+    float xn = p.sqrt_aprev * x0 + p.dir_coef * eps;
+    if (p.noise != nullptr && p.sigma != 0.f) xn += p.sigma * p.noise[idx];
+    out[idx] = (TX)xn;
+  }
+}
+
+inline int grid_for(long n) {
+  const long g = (n + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+}  // namespace
+
+hipError_t t2v_launch_ncthw_to_cl(const t2v_op& op, hipStream_t s) {
+  const int B = op.i[0], C = op.i[1], F = op.i[2], HW = op.i[3], ld = op.i[4];
+  const long n = (long)B * F * HW;
+  f16* out = reinterpret_cast<f16*>(op.p[1]);
+  if (op.i[5] == T2V_F32)
+    hipLaunchKernelGGL(ncthw_to_cl_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s,
+                       reinterpret_cast<const float*>(op.p[0]), out, B, C, F, HW, ld, op.f[0]);
+  else
+    hipLaunchKernelGGL(ncthw_to_cl_kernel<f16>, dim3(grid_for(n)), dim3(256), 0, s,
+                       reinterpret_cast<const f16*>(op.p[0]), out, B, C, F, HW, ld, op.f[0]);
+  return hipGetLastError();
+}
+
+hipError_t t2v_launch_cl_to_ncthw(const t2v_op& op, hipStream_t s) {
+  const int B = op.i[0], C = op.i[1], F = op.i[2], HW = op.i[3], ld = op.i[4];
+  const long n = (long)B * C * F * HW;
+  const float* in = reinterpret_cast<const float*>(op.p[0]);
+  if (op.i[5] == T2V_F32)
+    hipLaunchKernelGGL(cl_to_ncthw_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s, in,
+                       reinterpret_cast<float*>(op.p[1]), B, C, F, HW, ld);
+  else
+    hipLaunchKernelGGL(cl_to_ncthw_kernel<f16>, dim3(grid_for(n)), dim3(256), 0, s, in,
+                       reinterpret_cast<f16*>(op.p[1]), B, C, F, HW, ld);
+  return hipGetLastError();
+}
+
+hipError_t t2v_launch_time_embed(const t2v_op& op, hipStream_t s) {
+  const int B = op.i[0], dim = op.i[1];
+  hipLaunchKernelGGL(time_embed_kernel, dim3((B * (dim / 2) + 255) / 256), dim3(256), 0, s,
+                     reinterpret_cast<const float*>(op.p[0]), reinterpret_cast<const float*>(op.p[1]),
+                     reinterpret_cast<f16*>(op.p[2]), B, dim);
+  return hipGetLastError();
+}
+
+hipError_t t2v_launch_copy2d(const t2v_op& op, hipStream_t s) {
+  const int rows = op.i[0], cols = op.i[1], lds_ = op.i[2], ldd = op.i[3], sdt = op.i[4], ddt = op.i[5];
+  const int act = op.i[6];
+  if (cols % 4 != 0) return hipErrorInvalidValue;
+  const int g = grid_for((long)rows * (cols / 4));
+  if (sdt == T2V_F32 && ddt == T2V_F32)
+    hipLaunchKernelGGL((copy2d_kernel<float, float>), dim3(g), dim3(256), 0, s, reinterpret_cast<const float*>(op.p[0]),
+                       reinterpret_cast<float*>(op.p[1]), rows, cols, lds_, ldd, act);
+  else if (sdt == T2V_F32 && ddt == T2V_F16)
+    hipLaunchKernelGGL((copy2d_kernel<float, f16>), dim3(g), dim3(256), 0, s, reinterpret_cast<const float*>(op.p[0]),
+                       reinterpret_cast<f16*>(op.p[1]), rows, cols, lds_, ldd, act);
+  else if (sdt == T2V_F16 && ddt == T2V_F16)
+    hipLaunchKernelGGL((copy2d_kernel<f16, f16>), dim3(g), dim3(256), 0, s, reinterpret_cast<const f16*>(op.p[0]),
+                       reinterpret_cast<f16*>(op.p[1]), rows, cols, lds_, ldd, act);
+  else
+    hipLaunchKernelGGL((copy2d_kernel<f16, float>), dim3(g), dim3(256), 0, s, reinterpret_cast<const f16*>(op.p[0]),
+                       reinterpret_cast<float*>(op.p[1]), rows, cols, lds_, ldd, act);
+  return hipGetLastError();
+}
+
+hipError_t t2v_launch_ddim_step(const t2v_op& op, hipStream_t s) {
+  DdimParams p;
+  p.xt = reinterpret_cast<const void*>(op.p[0]);
+  p.eps = reinterpret_cast<const void*>(op.p[1]);
+  p.noise = reinterpret_cast<const float*>(op.p[2]);
+  p.out = reinterpret_cast<void*>(op.p[3]);
+  p.C = op.i[0]; p.inner = op.i[1]; p.guided = op.i[2]; p.eps_f32 = op.i[3] == T2V_F32; p.x_f32 = op.i[4] == T2V_F32;
+  p.a_recip = op.f[0]; p.a_recipm1 = op.f[1]; p.sqrt_aprev = op.f[2]; p.dir_coef = op.f[3]; p.sigma = op.f[4];
+  p.gscale = op.f[5];
+  const int g = grid_for((long)p.C * p.inner);
+  if (p.x_f32 && p.eps_f32) hipLaunchKernelGGL((ddim_step_kernel<float, float>), dim3(g), dim3(256), 0, s, p);
+  else if (p.x_f32) hipLaunchKernelGGL((ddim_step_kernel<float, f16>), dim3(g), dim3(256), 0, s, p);
+  else if (p.eps_f32) hipLaunchKernelGGL((ddim_step_kernel<f16, float>), dim3(g), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((ddim_step_kernel<f16, f16>), dim3(g), dim3(256), 0, s, p);
+  return hipGetLastError();
+}

@@ -1,0 +1,253 @@
+// C-ABI of libt2v_hip.so (see include/t2v_hip.h): validates a denoise program and executes it
+// by launching the HIP kernels of this directory on the caller's stream.  No torch types, no
+// allocation on the data path, no CPU fallback: without a HIP device every entry point fails.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "t2v_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+struct Resolved {
+  t2v_op op;
+};
+
+inline bool resolve_ptrs(t2v_op& op, const uint64_t* ext, int n_ext) {
+  for (int k = 0; k < T2V_OP_NP; ++k) {
+    const uint64_t v = op.p[k];
+    if (v != 0 && v < T2V_EXT_SLOTS) {
+      if ((int)v >= n_ext || ext == nullptr) return false;
+      op.p[k] = ext[v];
+    }
+  }
+  return true;
+}
+
+int validate_op(const t2v_op& op, int idx) {
+  char buf[160];
+  auto bad = [&](const char* why) {
+    snprintf(buf, sizeof buf, "op %d (kind %d, tag %d): %s", idx, op.kind, op.tag, why);
+    return fail(T2V_ERR_BAD_ARG, buf);
+  };
+  switch (op.kind) {
+    case T2V_OP_GEMM: {
+      const int M = op.i[0], N = op.i[1], K = op.i[2], g = op.i[7];
+      if (M <= 0 || N <= 0 || K <= 0) return bad("empty GEMM");
+      if (N % 4 != 0) return bad("N must be a multiple of 4");
+      if (K % 8 != 0 || op.i[3] % 8 != 0 || op.i[4] % 8 != 0) return bad("K, lda, ldw must be multiples of 8");
+      if (op.i[5] % 4 != 0) return bad("ldc must be a multiple of 4");
+      if (g == T2V_GATHER_CONV3X3 || g == T2V_GATHER_TCONV3) {
+        if (op.i[10] % 64 != 0) return bad("conv Cin must be a multiple of 64");
+        if (K != (g == T2V_GATHER_CONV3X3 ? 9 : 3) * op.i[10]) return bad("K != taps*Cin");
+      } else if (g == T2V_GATHER_CONV3X3_C8) {
+        if (op.i[10] != 8 || K != 72 || op.i[3] != 8) return bad("C8 conv needs Cin == lda == 8, K == 72");
+      } else if (g != T2V_GATHER_PLAIN) {
+        return bad("unknown gather mode");
+      }
+      if (g == T2V_GATHER_CONV3X3 || g == T2V_GATHER_CONV3X3_C8) {
+        if (op.i[11] != 1 && op.i[11] != 2) return bad("stride must be 1 or 2");
+        if (op.i[12] != 0 && op.i[12] != 1) return bad("upsample must be 0 or 1");
+        if (op.i[13] <= 0 || op.i[14] <= 0 || M % (op.i[13] * op.i[14]) != 0) return bad("M not a multiple of Hout*Wout");
+      }
+      if (g == T2V_GATHER_TCONV3 && (op.i[8] <= 0 || op.i[9] <= 0 || M % (op.i[8] * op.i[9]) != 0))
+        return bad("M not a multiple of F*HW");
+      if (op.i[16] == T2V_EPI_GEGLU && (N % 32 != 0 || op.i[17] != T2V_F16)) return bad("GEGLU needs N % 32 == 0, fp16 out");
+      if (op.i[19] > 1 && op.p[6] == 0) return bad("split-K without workspace");
+      if (op.p[3] != 0 && op.i[15] <= 0) return bad("rowbias without rows_per_batch");
+      return 0;
+    }
+    case T2V_OP_GROUPNORM:
+    case T2V_OP_LAYERNORM:
+    case T2V_OP_ATTENTION:
+    case T2V_OP_SOFTMAX:
+    case T2V_OP_NCTHW_TO_CL:
+    case T2V_OP_CL_TO_NCTHW:
+    case T2V_OP_TIME_EMBED:
+    case T2V_OP_COPY2D:
+    case T2V_OP_DDIM_STEP:
+    case T2V_OP_MEMSET:
+      return 0;
+    default:
+      return bad("unknown op kind");
+  }
+}
+
+hipError_t launch_op(const t2v_op& op, hipStream_t s) {
+  switch (op.kind) {
+    case T2V_OP_GEMM: {
+      GemmParams p;
+      memset(&p, 0, sizeof p);
+      p.M = op.i[0]; p.N = op.i[1]; p.K = op.i[2];
+      p.lda = op.i[3]; p.ldw = op.i[4]; p.ldc = op.i[5]; p.ldr = op.i[6];
+      p.gather = op.i[7];
+      if (p.gather == T2V_GATHER_TCONV3) { p.F = op.i[8]; p.HW = op.i[9]; }
+      else { p.Hin = op.i[8]; p.Win = op.i[9]; }
+      p.Cin = op.i[10]; p.stride = op.i[11]; p.up = op.i[12]; p.Hout = op.i[13]; p.Wout = op.i[14];
+      p.rows_per_batch = op.i[15] > 0 ? op.i[15] : 1;
+      p.epi = op.i[16]; p.out_f32 = op.i[17] == T2V_F32; p.act = op.i[18];
+      p.splitk = op.i[19] > 1 ? op.i[19] : 1;
+      p.bias_m = op.i[20]; p.ldrb = op.i[21];
+      p.A = reinterpret_cast<const f16*>(op.p[0]);
+      p.W = reinterpret_cast<const f16*>(op.p[1]);
+      p.bias = reinterpret_cast<const float*>(op.p[2]);
+      p.rowbias = reinterpret_cast<const float*>(op.p[3]);
+      p.res = reinterpret_cast<const float*>(op.p[4]);
+      p.out = reinterpret_cast<void*>(op.p[5]);
+      p.ws = reinterpret_cast<float*>(op.p[6]);
+      const int KT = (p.K + 63) / 64;
+      if (p.splitk > KT) p.splitk = KT;
+      p.kt_per_split = (KT + p.splitk - 1) / p.splitk;
+      p.splitk = (KT + p.kt_per_split - 1) / p.kt_per_split;  // no empty splits
+      return t2v_launch_gemm(p, s);
+    }
+    case T2V_OP_GROUPNORM: return t2v_launch_groupnorm(op, s);
+    case T2V_OP_LAYERNORM: return t2v_launch_layernorm(op, s);
+    case T2V_OP_ATTENTION: return t2v_launch_attention(op, s);
+    case T2V_OP_SOFTMAX: return t2v_launch_softmax(op, s);
+    case T2V_OP_NCTHW_TO_CL: return t2v_launch_ncthw_to_cl(op, s);
+    case T2V_OP_CL_TO_NCTHW: return t2v_launch_cl_to_ncthw(op, s);
+    case T2V_OP_TIME_EMBED: return t2v_launch_time_embed(op, s);
+    case T2V_OP_COPY2D: return t2v_launch_copy2d(op, s);
+    case T2V_OP_DDIM_STEP: return t2v_launch_ddim_step(op, s);
+    case T2V_OP_MEMSET: {
+      const size_t bytes = (size_t)(uint32_t)op.i[0] | ((size_t)(uint32_t)op.i[1] << 32);
+      return hipMemsetAsync(reinterpret_cast<void*>(op.p[0]), 0, bytes, s);
+    }
+    default: return hipErrorInvalidValue;
+  }
+}
+
+int run_resolved(const t2v_op* ops, int n, const uint64_t* ext, int n_ext, hipStream_t s, float* ms) {
+  std::vector<hipEvent_t> ev;
+  if (ms) {
+    ev.resize(n + 1);
+    for (auto& e : ev)
+      if (hipEventCreate(&e) != hipSuccess) return fail(T2V_ERR_LAUNCH, "hipEventCreate failed");
+    (void)hipEventRecord(ev[0], s);
+  }
+  for (int k = 0; k < n; ++k) {
+    t2v_op op = ops[k];
+    if (!resolve_ptrs(op, ext, n_ext)) {
+      char buf[96];
+      snprintf(buf, sizeof buf, "op %d (tag %d): unresolved external pointer slot", k, op.tag);
+      return fail(T2V_ERR_BAD_ARG, buf);
+    }
+    const hipError_t e = launch_op(op, s);
+    if (e != hipSuccess) {
+      char buf[200];
+      snprintf(buf, sizeof buf, "op %d (kind %d, tag %d) launch failed: %s", k, op.kind, op.tag, hipGetErrorString(e));
+      return fail(T2V_ERR_LAUNCH, buf);
+    }
+    if (ms) (void)hipEventRecord(ev[k + 1], s);
+  }
+  if (ms) {
+    if (hipStreamSynchronize(s) != hipSuccess) return fail(T2V_ERR_LAUNCH, "stream sync failed");
+    for (int k = 0; k < n; ++k) (void)hipEventElapsedTime(&ms[k], ev[k], ev[k + 1]);
+    for (auto& e : ev) (void)hipEventDestroy(e);
+  }
+  return T2V_OK;
+}
+
+}  // namespace
+
+struct t2v_plan {
+  std::vector<t2v_op> ops;
+};
+
+extern "C" {
+
+int t2v_abi_version(void) { return T2V_ABI_VERSION; }
+
+const char* t2v_last_error(void) { return g_err.c_str(); }
+
+int t2v_device_info(char* name, int len, int* compute_units, uint64_t* hbm_bytes) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return fail(T2V_ERR_NO_DEVICE, "no HIP device");
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail(T2V_ERR_NO_DEVICE, "hipGetDeviceProperties failed");
+  if (name && len > 0) {
+    strncpy(name, prop.gcnArchName, (size_t)len - 1);
+    name[len - 1] = 0;
+  }
+  if (compute_units) *compute_units = prop.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = (uint64_t)prop.totalGlobalMem;
+  return T2V_OK;
+}
+
+int t2v_run_ops(const t2v_op* ops, int n, const uint64_t* ext, int n_ext, void* stream) {
+  if (ops == nullptr || n < 0) return fail(T2V_ERR_BAD_ARG, "null program");
+  for (int k = 0; k < n; ++k) {
+    const int rc = validate_op(ops[k], k);
+    if (rc != 0) return rc;
+  }
+  return run_resolved(ops, n, ext, n_ext, reinterpret_cast<hipStream_t>(stream), nullptr);
+}
+
+int t2v_plan_create(const t2v_op* ops, int n, t2v_plan** out) {
+  if (ops == nullptr || n <= 0 || out == nullptr) return fail(T2V_ERR_BAD_ARG, "null program");
+  for (int k = 0; k < n; ++k) {
+    const int rc = validate_op(ops[k], k);
+    if (rc != 0) return rc;
+  }
+  t2v_plan* p = new t2v_plan();
+  p->ops.assign(ops, ops + n);
+  *out = p;
+  return T2V_OK;
+}
+
+int t2v_plan_num_ops(const t2v_plan* plan) { return plan ? (int)plan->ops.size() : 0; }
+
+int t2v_plan_run(t2v_plan* plan, const uint64_t* ext, int n_ext, void* stream) {
+  if (!plan) return fail(T2V_ERR_BAD_ARG, "null plan");
+  return run_resolved(plan->ops.data(), (int)plan->ops.size(), ext, n_ext, reinterpret_cast<hipStream_t>(stream), nullptr);
+}
+
+int t2v_plan_run_timed(t2v_plan* plan, const uint64_t* ext, int n_ext, void* stream, float* ms) {
+  if (!plan || !ms) return fail(T2V_ERR_BAD_ARG, "null plan / ms");
+  return run_resolved(plan->ops.data(), (int)plan->ops.size(), ext, n_ext, reinterpret_cast<hipStream_t>(stream), ms);
+}
+
+void t2v_plan_destroy(t2v_plan* plan) { delete plan; }
+
+int t2v_unet_forward(t2v_plan* plan, const void* x, const float* t, const void* ctx, void* eps_out, void* stream) {
+  uint64_t ext[T2V_EXT_SLOTS] = {0};
+  ext[T2V_EXT_X] = (uint64_t)x;
+  ext[T2V_EXT_T] = (uint64_t)t;
+  ext[T2V_EXT_CTX] = (uint64_t)ctx;
+  ext[T2V_EXT_OUT] = (uint64_t)eps_out;
+  return t2v_plan_run(plan, ext, T2V_EXT_SLOTS, stream);
+}
+
+int t2v_vae_decode(t2v_plan* plan, const void* z, void* img_out, void* stream) {
+  uint64_t ext[T2V_EXT_SLOTS] = {0};
+  ext[T2V_EXT_X] = (uint64_t)z;
+  ext[T2V_EXT_OUT] = (uint64_t)img_out;
+  return t2v_plan_run(plan, ext, T2V_EXT_SLOTS, stream);
+}
+
+int t2v_ddim_step(t2v_plan* plan, const void* xt, const void* eps_pair, const void* noise, void* xt_out,
+                  const float coef[6], void* stream) {
+  if (!plan || plan->ops.size() != 1 || plan->ops[0].kind != T2V_OP_DDIM_STEP)
+    return fail(T2V_ERR_BAD_ARG, "t2v_ddim_step needs a single DDIM_STEP plan");
+  t2v_op op = plan->ops[0];
+  for (int k = 0; k < 6; ++k) op.f[k] = coef[k];
+  uint64_t ext[T2V_EXT_SLOTS] = {0};
+  ext[T2V_EXT_XT] = (uint64_t)xt;
+  ext[T2V_EXT_EPS] = (uint64_t)eps_pair;
+  ext[T2V_EXT_NOISE] = (uint64_t)noise;
+  ext[T2V_EXT_XT_OUT] = (uint64_t)xt_out;
+  return run_resolved(&op, 1, ext, T2V_EXT_SLOTS, reinterpret_cast<hipStream_t>(stream), nullptr);
+}
+
+}  // extern "C"

@@ -1,0 +1,48 @@
+// Internal launch interface between executor.hip and the kernel translation units.
+// gfx950 (MI355X / CDNA4) only: wave64, MFMA 32x32x16 f16, 160 KiB LDS per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/t2v_hip.h"
+
+typedef _Float16 f16;
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GemmParams {
+  const f16* A;
+  const f16* W;
+  const float* bias;
+  const float* rowbias;
+  const float* res;
+  void* out;
+  float* ws;
+  int M, N, K;
+  int lda, ldw, ldc, ldr, ldrb;
+  int gather;
+  int Hin, Win, Cin, stride, up, Hout, Wout;  // conv3x3: input / output spatial dims
+  int F, HW;                                   // tconv3: frames per clip, pixels per frame
+  int rows_per_batch;
+  int epi, out_f32, act, splitk, bias_m;
+  int kt_per_split;                            // k-tiles (of 64) per split
+};
+
+// Each returns hipSuccess or the launch error.
+hipError_t t2v_launch_gemm(const GemmParams& p, hipStream_t s);
+hipError_t t2v_launch_groupnorm(const t2v_op& op, hipStream_t s);
+hipError_t t2v_launch_layernorm(const t2v_op& op, hipStream_t s);
+hipError_t t2v_launch_attention(const t2v_op& op, hipStream_t s);
+hipError_t t2v_launch_softmax(const t2v_op& op, hipStream_t s);
+hipError_t t2v_launch_ncthw_to_cl(const t2v_op& op, hipStream_t s);
+hipError_t t2v_launch_cl_to_ncthw(const t2v_op& op, hipStream_t s);
+hipError_t t2v_launch_time_embed(const t2v_op& op, hipStream_t s);
+hipError_t t2v_launch_copy2d(const t2v_op& op, hipStream_t s);
+hipError_t t2v_launch_ddim_step(const t2v_op& op, hipStream_t s);
+
+__device__ __forceinline__ float t2v_silu(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float t2v_gelu_erf(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
