@@ -1,0 +1,85 @@
+"""ctypes binding of libt2v_hip.so (include/t2v_hip.h).  Loading is strict: if the shared
+library is missing or cannot be loaded, every product entry point raises — there is no CPU
+or PyTorch fallback on the product path."""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libt2v_hip.so")
+
+# ---- mirrors of include/t2v_hip.h (checked against the header by tests/test_abi.py) -------
+ABI_VERSION = 1
+OP_GEMM, OP_GROUPNORM, OP_LAYERNORM, OP_ATTENTION, OP_SOFTMAX = 1, 2, 3, 4, 5
+OP_NCTHW_TO_CL, OP_CL_TO_NCTHW, OP_TIME_EMBED, OP_COPY2D, OP_DDIM_STEP, OP_MEMSET = 6, 7, 8, 9, 10, 11
+GATHER_PLAIN, GATHER_CONV3X3, GATHER_TCONV3, GATHER_CONV3X3_C8 = 0, 1, 2, 3
+EPI_NONE, EPI_GEGLU = 0, 1
+F16, F32 = 0, 1
+EXT_SLOTS = 16
+EXT_X, EXT_T, EXT_CTX, EXT_OUT, EXT_XT, EXT_XT_OUT, EXT_NOISE, EXT_EPS = 1, 2, 3, 4, 5, 6, 7, 8
+OP_NI, OP_NF, OP_NP = 24, 8, 8
+GN_STATS_LEN = 4096 * 32 * 2     # doubles per ping-pong statistics buffer (csrc/norm.hip)
+
+EXPORTS = [
+    "t2v_abi_version", "t2v_last_error", "t2v_device_info", "t2v_run_ops", "t2v_plan_create",
+    "t2v_plan_num_ops", "t2v_plan_run", "t2v_plan_run_timed", "t2v_plan_destroy",
+    "t2v_unet_forward", "t2v_vae_decode", "t2v_ddim_step",
+]
+
+
+class T2VOp(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int32), ("tag", ctypes.c_int32),
+                ("i", ctypes.c_int32 * OP_NI), ("f", ctypes.c_float * OP_NF),
+                ("p", ctypes.c_uint64 * OP_NP)]
+
+
+class T2VError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libt2v_hip.so (once).  Raises T2VError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise T2VError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, u64p = ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)
+    opp = ctypes.POINTER(T2VOp)
+    lib.t2v_abi_version.restype = ctypes.c_int
+    lib.t2v_last_error.restype = ctypes.c_char_p
+    lib.t2v_device_info.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int), u64p]
+    lib.t2v_run_ops.argtypes = [opp, ctypes.c_int, u64p, ctypes.c_int, vp]
+    lib.t2v_plan_create.argtypes = [opp, ctypes.c_int, ctypes.POINTER(vp)]
+    lib.t2v_plan_num_ops.argtypes = [vp]
+    lib.t2v_plan_run.argtypes = [vp, u64p, ctypes.c_int, vp]
+    lib.t2v_plan_run_timed.argtypes = [vp, u64p, ctypes.c_int, vp, ctypes.POINTER(ctypes.c_float)]
+    lib.t2v_plan_destroy.argtypes = [vp]
+    lib.t2v_plan_destroy.restype = None
+    lib.t2v_unet_forward.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.t2v_vae_decode.argtypes = [vp, vp, vp, vp]
+    lib.t2v_ddim_step.argtypes = [vp, vp, vp, vp, vp, ctypes.POINTER(ctypes.c_float), vp]
+    if lib.t2v_abi_version() != ABI_VERSION:
+        raise T2VError(f"libt2v_hip.so ABI {lib.t2v_abi_version()} != binding {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc: int):
+    if rc != 0:
+        msg = load().t2v_last_error()
+        raise T2VError(f"libt2v_hip error {rc}: {msg.decode() if msg else '?'}")
+
+
+def device_info():
+    lib = load()
+    name = ctypes.create_string_buffer(64)
+    cus, mem = ctypes.c_int(0), ctypes.c_uint64(0)
+    check(lib.t2v_device_info(name, 64, ctypes.byref(cus), ctypes.byref(mem)))
+    return name.value.decode(), cus.value, mem.value

@@ -1,0 +1,81 @@
+"""Weight plumbing: turns the reference-layout state dict (torch [Cout, Cin, k...] tensors)
+into the GEMM-ready packed images the HIP kernels read ([N, K] fp16, K tap-major /
+channels-last; fp32 bias / affine vectors).  Pure layout work with torch ops, run once per
+weight version (and again after `invalidate()`, e.g. when the LoRA hook of the reference,
+scripts/stable_lora/stable_utils/lora_processor.py:215-246, has mutated `.weight` in place).
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Tuple
+
+import torch
+
+Recipe = Callable[[Dict[str, torch.Tensor]], torch.Tensor]
+
+
+def _f16(t: torch.Tensor, device) -> torch.Tensor:
+    return t.detach().to(device=device, dtype=torch.float16).contiguous()
+
+
+def _f32(t: torch.Tensor, device) -> torch.Tensor:
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+def pad_rows(w: torch.Tensor, mult: int = 4) -> torch.Tensor:
+    n = w.shape[0]
+    if n % mult == 0:
+        return w
+    pad = mult - n % mult
+    return torch.cat([w, w.new_zeros((pad,) + tuple(w.shape[1:]))], dim=0)
+
+
+def linear(w: torch.Tensor) -> torch.Tensor:
+    """nn.Linear / Conv1d k=1 / Conv2d 1x1 weight -> [N, K]."""
+    return w.reshape(w.shape[0], -1)
+
+
+def conv3x3(w: torch.Tensor, cin_pad: int = 0) -> torch.Tensor:
+    """[Co, Ci, 3, 3] -> [Co, 9*Ci'] with k = (ky*3+kx)*Ci' + ci (Ci' = Ci zero-padded to cin_pad)."""
+    co, ci = w.shape[0], w.shape[1]
+    w = w.permute(0, 2, 3, 1)                      # Co, ky, kx, Ci
+    if cin_pad and cin_pad > ci:
+        w = torch.cat([w, w.new_zeros(co, 3, 3, cin_pad - ci)], dim=3)
+    return w.reshape(co, -1)
+
+
+def tconv3(w: torch.Tensor) -> torch.Tensor:
+    """[Co, Ci, 3, 1, 1] -> [Co, 3*Ci] with k = kt*Ci + ci."""
+    co, ci = w.shape[0], w.shape[1]
+    return w[:, :, :, 0, 0].permute(0, 2, 1).reshape(co, 3 * ci)
+
+
+def geglu_perm(n_half: int, device=None) -> torch.Tensor:
+    """Row permutation for the fused GEGLU epilogue: packed row 16u + 8g + j  <-  source row
+    (g ? n_half : 0) + 8u + j   (value rows first, gate rows second in nn.Linear(dim, 2*inner),
+    reference t2v_model.py:817-821)."""
+    assert n_half % 8 == 0
+    u = torch.arange(n_half // 8, device=device).view(-1, 1, 1)
+    g = torch.arange(2, device=device).view(1, -1, 1)
+    j = torch.arange(8, device=device).view(1, 1, -1)
+    return (g * n_half + 8 * u + j).reshape(-1)
+
+
+class WeightPacker:
+    """Collects (name -> recipe) pairs during lowering and materialises them on a device."""
+
+    def __init__(self):
+        self.recipes: List[Tuple[str, str, Recipe]] = []   # (name, 'f16'|'f32', fn)
+        self._names = set()
+
+    def add(self, name: str, dtype: str, fn: Recipe) -> str:
+        if name not in self._names:
+            self._names.add(name)
+            self.recipes.append((name, dtype, fn))
+        return name
+
+    def materialise(self, sd: Dict[str, torch.Tensor], device) -> Dict[str, torch.Tensor]:
+        out = {}
+        for name, dtype, fn in self.recipes:
+            t = fn(sd)
+            out[name] = _f16(t, device) if dtype == "f16" else _f32(t, device)
+        return out

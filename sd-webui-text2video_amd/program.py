@@ -1,0 +1,350 @@
+"""Denoise-program IR: the host lowers a network + input geometry into a flat list of op
+records over one activation arena and a packed-weight store; libt2v_hip.so executes it.
+
+Everything here is shape/pointer bookkeeping (no arithmetic on activations).  The record
+layout mirrors `t2v_op` in include/t2v_hip.h field by field.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+from . import _lib as L
+
+_ITEM = {"f16": 2, "f32": 4, "f64": 8, "u8": 1}
+_DT = {"f16": L.F16, "f32": L.F32}
+
+
+# ------------------------------------------------------------------------------------------
+# symbolic pointers
+# ------------------------------------------------------------------------------------------
+@dataclass(frozen=True)
+class Ref:
+    space: str            # 'arena' | 'weight' | 'ext' | 'null'
+    off: int = 0          # byte offset (arena / weight) or slot index (ext)
+    name: str = ""        # weight tensor name
+
+    def shifted(self, nbytes: int) -> "Ref":
+        assert self.space in ("arena", "weight")
+        return Ref(self.space, self.off + nbytes, self.name)
+
+
+NULL = Ref("null")
+
+
+@dataclass
+class Buf:
+    """A row-major 2-D view [rows, cols] with leading dimension `ld` (elements)."""
+    ref: Ref
+    rows: int
+    cols: int
+    ld: int
+    dtype: str
+    alloc_off: int = -1   # arena allocation this view belongs to (for free())
+
+    @property
+    def item(self) -> int:
+        return _ITEM[self.dtype]
+
+    def col_slice(self, c0: int, c1: int) -> "Buf":
+        return Buf(self.ref.shifted(c0 * self.item), self.rows, c1 - c0, self.ld, self.dtype, self.alloc_off)
+
+    def row_slice(self, r0: int, r1: int) -> "Buf":
+        return Buf(self.ref.shifted(r0 * self.ld * self.item), r1 - r0, self.cols, self.ld, self.dtype, self.alloc_off)
+
+
+class Arena:
+    """First-fit allocator over one device buffer; 256-byte granularity; tracks the high-water mark."""
+
+    ALIGN = 256
+
+    def __init__(self):
+        self.free_list: List[Tuple[int, int]] = []   # (offset, size), sorted, coalesced
+        self.top = 0
+        self.live: Dict[int, int] = {}
+        self.high = 0
+
+    def alloc(self, nbytes: int) -> int:
+        n = (max(nbytes, 1) + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        for idx, (off, size) in enumerate(self.free_list):
+            if size >= n:
+                if size == n:
+                    self.free_list.pop(idx)
+                else:
+                    self.free_list[idx] = (off + n, size - n)
+                self.live[off] = n
+                return off
+        # grow: merge with a trailing free block if it touches the top
+        if self.free_list and self.free_list[-1][0] + self.free_list[-1][1] == self.top:
+            off, size = self.free_list.pop()
+            self.top = off
+        off = self.top
+        self.top += n
+        self.high = max(self.high, self.top)
+        self.live[off] = n
+        return off
+
+    def free(self, off: int):
+        n = self.live.pop(off)
+        self.free_list.append((off, n))
+        self.free_list.sort()
+        merged: List[Tuple[int, int]] = []
+        for o, s in self.free_list:
+            if merged and merged[-1][0] + merged[-1][1] == o:
+                merged[-1] = (merged[-1][0], merged[-1][1] + s)
+            else:
+                merged.append((o, s))
+        self.free_list = merged
+
+
+@dataclass
+class Op:
+    kind: int
+    name: str
+    i: List[int] = field(default_factory=lambda: [0] * L.OP_NI)
+    f: List[float] = field(default_factory=lambda: [0.0] * L.OP_NF)
+    p: List[Ref] = field(default_factory=lambda: [NULL] * L.OP_NP)
+    flops: float = 0.0            # algorithmic 2*MAC (matmul/conv only), for the roofline
+    meta: dict = field(default_factory=dict)
+
+
+class Program:
+    def __init__(self, label: str = ""):
+        self.label = label
+        self.ops: List[Op] = []
+        self.arena = Arena()
+        self.taps: Dict[str, Buf] = {}          # debug: named live buffers (never freed when tapping)
+        self.keep_taps = False
+        self._gn_count = 0
+        self._gn_max = 0
+        self._gn_ops: List[Op] = []
+        self.gn_stats: Optional[Buf] = None
+        self.target_blocks = 512                # split-K heuristic: aim for this many workgroups
+
+    # ---- memory ---------------------------------------------------------------------------
+    def alloc(self, rows: int, cols: int, dtype: str, ld: Optional[int] = None) -> Buf:
+        ld = cols if ld is None else ld
+        off = self.arena.alloc(rows * ld * _ITEM[dtype])
+        return Buf(Ref("arena", off), rows, cols, ld, dtype, off)
+
+    def free(self, *bufs: Buf):
+        for b in bufs:
+            if b is None or b.alloc_off < 0:
+                continue
+            if self.keep_taps and any(t.alloc_off == b.alloc_off for t in self.taps.values()):
+                continue
+            self.arena.free(b.alloc_off)
+
+    def tap(self, name: str, buf: Buf):
+        if self.keep_taps:
+            self.taps[name] = buf
+
+    def _emit(self, op: Op) -> Op:
+        self.ops.append(op)
+        return op
+
+    # ---- ops ------------------------------------------------------------------------------
+    def begin(self):
+        """Program prologue: statistics scratch for GroupNorm (two fp64 ping-pong buffers)."""
+        self.gn_stats = self.alloc(2 * L.GN_STATS_LEN, 1, "f64")
+        op = Op(L.OP_MEMSET, "gn_stats.zero")
+        nbytes = 2 * L.GN_STATS_LEN * 8
+        op.i[0], op.i[1] = nbytes & 0xFFFFFFFF, nbytes >> 32
+        op.p[0] = self.gn_stats.ref
+        self._emit(op)
+
+    def finish(self):
+        for op in self._gn_ops:
+            op.i[9] = self._gn_max
+
+    def gemm(self, name: str, a: Buf, w: Ref, n: int, k: int, out: Buf, *, bias: Ref = NULL,
+             ldw: Optional[int] = None, gather: int = L.GATHER_PLAIN, conv: Optional[dict] = None,
+             rowbias: Optional[Buf] = None, rows_per_batch: int = 0, residual: Optional[Buf] = None,
+             epi: int = L.EPI_NONE, act: int = 0, bias_along_m: bool = False, m: Optional[int] = None,
+             allow_splitk: bool = True) -> Op:
+        """out[M, n_out] = epi(gather(a)[M, k] @ w[n, k]^T)."""
+        conv = conv or {}
+        M = out.rows if m is None else m
+        n_out = n // 2 if epi == L.EPI_GEGLU else n
+        assert out.cols == n_out, (name, out.cols, n_out)
+        assert a.dtype == "f16" and n % 4 == 0 and k % 8 == 0
+        op = Op(L.OP_GEMM, name)
+        I = op.i
+        I[0], I[1], I[2] = M, n, k
+        I[3], I[4], I[5] = a.ld, (k if ldw is None else ldw), out.ld
+        I[6] = residual.ld if residual is not None else 0
+        I[7] = gather
+        if gather == L.GATHER_TCONV3:
+            I[8], I[9] = conv["F"], conv["HW"]
+        elif gather in (L.GATHER_CONV3X3, L.GATHER_CONV3X3_C8):
+            I[8], I[9] = conv["Hin"], conv["Win"]
+            I[11], I[12], I[13], I[14] = conv.get("stride", 1), conv.get("up", 0), conv["Hout"], conv["Wout"]
+        I[10] = conv.get("Cin", 0)
+        I[15] = rows_per_batch
+        I[16], I[17], I[18] = epi, _DT[out.dtype], act
+        I[20] = 1 if bias_along_m else 0
+        I[21] = rowbias.ld if rowbias is not None else 0
+        op.p[0], op.p[1], op.p[2] = a.ref, w, bias
+        op.p[3] = rowbias.ref if rowbias is not None else NULL
+        op.p[4] = residual.ref if residual is not None else NULL
+        op.p[5] = out.ref
+        if residual is not None:
+            assert residual.dtype == "f32" and residual.rows >= M and residual.cols == n_out
+        # split-K: fill the chip when the output tile grid is small and the reduction is long
+        bn = 64 if (n % 128 != 0 and n % 128 <= 64) else 128
+        tiles = math.ceil(M / 128) * math.ceil(n / bn)
+        kt = math.ceil(k / 64)
+        split = 1
+        if allow_splitk and tiles < self.target_blocks // 2 and kt >= 8:
+            split = max(1, min(self.target_blocks // tiles, kt // 4, 32))
+        I[19] = split
+        ws = None
+        if split > 1:
+            ws = self.alloc(split * M, n, "f32")
+            op.p[6] = ws.ref
+        op.flops = 2.0 * M * n * k
+        op.meta = dict(M=M, N=n, K=k, gather=gather, conv=dict(conv), epi=epi, split=split)
+        self._emit(op)
+        if ws is not None:
+            self.free(ws)     # stream order makes immediate reuse safe
+        return op
+
+    def groupnorm(self, name: str, x: Buf, gamma: Ref, beta: Ref, out: Buf, *, n_inst: int, eps: float,
+                  silu: bool, groups: int = 32) -> Op:
+        rows = x.rows // n_inst
+        assert rows * n_inst == x.rows and out.dtype == "f16" and x.cols % 4 == 0
+        op = Op(L.OP_GROUPNORM, name)
+        op.i[0:9] = [n_inst, rows, x.cols, x.ld, groups, _DT[x.dtype], int(silu), out.ld, self._gn_count & 1]
+        op.f[0] = eps
+        op.p[0:5] = [x.ref, gamma, beta, out.ref, self.gn_stats.ref]
+        self._gn_count += 1
+        self._gn_max = max(self._gn_max, n_inst * groups * 2)
+        assert n_inst * groups * 2 <= L.GN_STATS_LEN
+        self._gn_ops.append(op)
+        return self._emit(op)
+
+    def layernorm(self, name: str, x: Buf, gamma: Ref, beta: Ref, out: Buf, eps: float = 1e-5) -> Op:
+        assert x.dtype == "f32" and out.dtype == "f16"
+        op = Op(L.OP_LAYERNORM, name)
+        op.i[0:4] = [x.rows, x.cols, x.ld, out.ld]
+        op.f[0] = eps
+        op.p[0:4] = [x.ref, gamma, beta, out.ref]
+        return self._emit(op)
+
+    def attention(self, name: str, q: Ref, k: Ref, v: Ref, o: Ref, *, nq: int, nk: int, heads: int,
+                  b_outer: int, b_inner: int, q_strides, kv_strides, o_strides, scale: float) -> Op:
+        op = Op(L.OP_ATTENTION, name)
+        op.i[0:5] = [nq, nk, heads, b_outer, b_inner]
+        op.i[5:8] = list(q_strides)
+        op.i[8:11] = list(kv_strides)
+        op.i[11:14] = list(o_strides)
+        for s in list(q_strides) + list(kv_strides) + list(o_strides):
+            assert 0 <= s < 2 ** 31
+        op.f[0] = scale
+        op.p[0:4] = [q, k, v, o]
+        op.flops = 4.0 * nq * nk * 64 * heads * b_outer * b_inner
+        return self._emit(op)
+
+    def softmax(self, name: str, x: Buf, out: Buf, scale: float) -> Op:
+        op = Op(L.OP_SOFTMAX, name)
+        op.i[0:4] = [x.rows, x.cols, x.ld, out.ld]
+        op.f[0] = scale
+        op.p[0:2] = [x.ref, out.ref]
+        return self._emit(op)
+
+    def ncthw_to_cl(self, name: str, src: Ref, src_dtype: str, out: Buf, *, B, C, F, HW, scale=1.0) -> Op:
+        op = Op(L.OP_NCTHW_TO_CL, name)
+        op.i[0:6] = [B, C, F, HW, out.ld, _DT[src_dtype]]
+        op.f[0] = scale
+        op.p[0:2] = [src, out.ref]
+        return self._emit(op)
+
+    def cl_to_ncthw(self, name: str, x: Buf, dst: Ref, dst_dtype: str, *, B, C, F, HW) -> Op:
+        op = Op(L.OP_CL_TO_NCTHW, name)
+        op.i[0:6] = [B, C, F, HW, x.ld, _DT[dst_dtype]]
+        op.p[0:2] = [x.ref, dst]
+        return self._emit(op)
+
+    def time_embed(self, name: str, t: Ref, freqs: Ref, out: Buf) -> Op:
+        op = Op(L.OP_TIME_EMBED, name)
+        op.i[0:2] = [out.rows, out.cols]
+        op.p[0:3] = [t, freqs, out.ref]
+        return self._emit(op)
+
+    def copy2d(self, name: str, src: Buf, dst: Buf, act: int = 0) -> Op:
+        assert src.rows == dst.rows and src.cols == dst.cols and src.cols % 4 == 0
+        op = Op(L.OP_COPY2D, name)
+        op.i[0:7] = [src.rows, src.cols, src.ld, dst.ld, _DT[src.dtype], _DT[dst.dtype], act]
+        op.p[0:2] = [src.ref, dst.ref]
+        return self._emit(op)
+
+    def ddim_step(self, name: str, *, C: int, inner: int, guided: int, eps_dtype: str, x_dtype: str) -> Op:
+        op = Op(L.OP_DDIM_STEP, name)
+        op.i[0:5] = [C, inner, guided, _DT[eps_dtype], _DT[x_dtype]]
+        op.p[0:4] = [Ref("ext", L.EXT_XT), Ref("ext", L.EXT_EPS), Ref("ext", L.EXT_NOISE), Ref("ext", L.EXT_XT_OUT)]
+        return self._emit(op)
+
+    # ---- stats ----------------------------------------------------------------------------
+    def total_flops(self) -> float:
+        return sum(op.flops for op in self.ops)
+
+
+# ------------------------------------------------------------------------------------------
+# binding to device memory + execution through the C ABI
+# ------------------------------------------------------------------------------------------
+class BoundProgram:
+    """A Program whose symbolic pointers are resolved against a device arena and weight
+    tensors, compiled into a `t2v_plan`."""
+
+    def __init__(self, prog: Program, arena_ptr: int, weight_ptrs: Dict[str, int]):
+        self.prog = prog
+        lib = L.load()
+        n = len(prog.ops)
+        arr = (L.T2VOp * n)()
+        for idx, op in enumerate(prog.ops):
+            r = arr[idx]
+            r.kind, r.tag = op.kind, idx
+            for j, v in enumerate(op.i):
+                r.i[j] = int(v)
+            for j, v in enumerate(op.f):
+                r.f[j] = float(v)
+            for j, ref in enumerate(op.p):
+                if ref.space == "null":
+                    r.p[j] = 0
+                elif ref.space == "arena":
+                    r.p[j] = arena_ptr + ref.off
+                elif ref.space == "weight":
+                    r.p[j] = weight_ptrs[ref.name] + ref.off
+                elif ref.space == "ext":
+                    r.p[j] = ref.off
+                else:
+                    raise ValueError(ref.space)
+        self._arr = arr
+        handle = ctypes.c_void_p()
+        L.check(lib.t2v_plan_create(arr, n, ctypes.byref(handle)))
+        self.handle = handle
+        self._lib = lib
+
+    def run(self, ext: Dict[int, int], stream: int):
+        e = (ctypes.c_uint64 * L.EXT_SLOTS)()
+        for k, v in ext.items():
+            e[k] = v
+        L.check(self._lib.t2v_plan_run(self.handle, e, L.EXT_SLOTS, ctypes.c_void_p(stream)))
+
+    def run_timed(self, ext: Dict[int, int], stream: int) -> List[float]:
+        e = (ctypes.c_uint64 * L.EXT_SLOTS)()
+        for k, v in ext.items():
+            e[k] = v
+        ms = (ctypes.c_float * len(self.prog.ops))()
+        L.check(self._lib.t2v_plan_run_timed(self.handle, e, L.EXT_SLOTS, ctypes.c_void_p(stream), ms))
+        return list(ms)
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self._lib.t2v_plan_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass

@@ -1,0 +1,697 @@
+"""UNetSD — drop-in for the reference's 3-D UNet denoiser (boundary B4).
+
+Same constructor keywords, same `state_dict()` key set / shapes (1480 tensors for the
+ModelScope config, including the reference's `temopral_conv` spelling), same
+`forward(x, t, y)` contract and `register_schedule` buffers as
+reference scripts/modelscope/t2v_model.py:98-501 — but `forward` does no torch arithmetic:
+it lowers the network + input geometry once into a denoise program (program.py) and executes
+it with the hand-written HIP kernels of libt2v_hip.so.
+
+The nn.Module tree below exists only to hold parameters under the reference's names (so that
+`load_state_dict(strict=True)`, `.half()`, `.to()` and the LoRA hook keep working); the
+sub-modules' own `forward`s are never called.
+
+Internal data layout (resident in HBM between kernels):
+  * activations: channels-last tokens, row m = ((b*F + f)*H + y)*W + x, C contiguous.
+    Residual-stream tensors are fp32, MFMA operands (outputs of norms / activations /
+    projections feeding a GEMM or attention) are fp16.
+  * weights: packed once to [N, K] fp16 with K tap-major (packing.py).
+Every `rearrange(...).contiguous()` of the reference (t2v_model.py:429,458,648,655,727-761,
+1006-1008) is folded into GEMM addressing or attention strides.
+"""
+from __future__ import annotations
+
+import math
+from functools import partial
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import packing as pk
+from .program import NULL, BoundProgram, Buf, Program, Ref
+
+
+# ------------------------------------------------------------------------------------------
+# topology (shared by the parameter tree and the lowering)
+# ------------------------------------------------------------------------------------------
+def unet_layout(dim, dim_mult, num_res_blocks, attn_scales, temporal_attention=True):
+    """Block list in execution order.  Each entry: (prefix, [(kind, cin, cout), ...]).
+    Mirrors the constructor loop of the reference (t2v_model.py:148-318)."""
+    enc = [dim * u for u in [1] + list(dim_mult)]
+    dec = [dim * u for u in [dim_mult[-1]] + list(dim_mult[::-1])]
+    shortcut = [dim]
+    scale = 1.0
+    inputs, middle, outputs = [], [], []
+    stem = [("stem", None, dim)] + ([("tt", dim, dim)] if temporal_attention else [])
+    inputs.append(("input_blocks.0", stem, False))
+    idx = 1
+    cout = dim
+    for i, (cin, cout) in enumerate(zip(enc[:-1], enc[1:])):
+        for j in range(num_res_blocks):
+            parts = [("res", cin, cout)]
+            if scale in attn_scales:
+                parts.append(("st", cout, cout))
+                if temporal_attention:
+                    parts.append(("tt", cout, cout))
+            cin = cout
+            inputs.append((f"input_blocks.{idx}", parts, False))
+            idx += 1
+            shortcut.append(cout)
+            if i != len(dim_mult) - 1 and j == num_res_blocks - 1:
+                inputs.append((f"input_blocks.{idx}", [("down", cout, cout)], True))
+                idx += 1
+                shortcut.append(cout)
+                scale /= 2.0
+    middle = [("res", cout, cout), ("st", cout, cout)] + ([("tt", cout, cout)] if temporal_attention else []) + \
+             [("res", cout, cout)]
+    oidx = 0
+    for i, (cin, cout) in enumerate(zip(dec[:-1], dec[1:])):
+        for j in range(num_res_blocks + 1):
+            parts = [("res", cin + shortcut.pop(), cout)]
+            if scale in attn_scales:
+                parts.append(("st", cout, cout))
+                if temporal_attention:
+                    parts.append(("tt", cout, cout))
+            cin = cout
+            if i != len(dim_mult) - 1 and j == num_res_blocks:
+                parts.append(("up", cout, cout))
+                scale *= 2.0
+            outputs.append((f"output_blocks.{oidx}", parts, False))
+            oidx += 1
+    return inputs, middle, outputs, cout
+
+
+# ------------------------------------------------------------------------------------------
+# parameter containers (reference key names)
+# ------------------------------------------------------------------------------------------
+def _attn_params(query_dim, context_dim, heads, dim_head):
+    inner = heads * dim_head
+    m = nn.Module()
+    m.to_q = nn.Linear(query_dim, inner, bias=False)
+    m.to_k = nn.Linear(context_dim or query_dim, inner, bias=False)
+    m.to_v = nn.Linear(context_dim or query_dim, inner, bias=False)
+    m.to_out = nn.Sequential(nn.Linear(inner, query_dim), nn.Dropout(0.0))
+    return m
+
+
+def _transformer_block_params(dim, heads, d_head, context_dim):
+    m = nn.Module()
+    m.attn1 = _attn_params(dim, None, heads, d_head)
+    ff = nn.Module()
+    geglu = nn.Module()
+    geglu.proj = nn.Linear(dim, dim * 4 * 2)
+    ff.net = nn.Sequential(geglu, nn.Dropout(0.0), nn.Linear(dim * 4, dim))
+    m.ff = ff
+    m.attn2 = _attn_params(dim, context_dim, heads, d_head)
+    m.norm1, m.norm2, m.norm3 = nn.LayerNorm(dim), nn.LayerNorm(dim), nn.LayerNorm(dim)
+    return m
+
+
+def _spatial_transformer_params(channels, heads, d_head, context_dim):
+    inner = heads * d_head
+    m = nn.Module()
+    m.norm = nn.GroupNorm(32, channels, eps=1e-6, affine=True)
+    m.proj_in = nn.Linear(channels, inner)
+    m.transformer_blocks = nn.ModuleList([_transformer_block_params(inner, heads, d_head, context_dim)])
+    m.proj_out = nn.Linear(channels, inner)     # (in, out) order as in the reference, t2v_model.py:636
+    return m
+
+
+def _temporal_transformer_params(channels, heads, d_head):
+    inner = heads * d_head
+    m = nn.Module()
+    m.norm = nn.GroupNorm(32, channels, eps=1e-6, affine=True)
+    m.proj_in = nn.Conv1d(channels, inner, kernel_size=1)
+    m.transformer_blocks = nn.ModuleList([_transformer_block_params(inner, heads, d_head, None)])
+    m.proj_out = nn.Conv1d(inner, channels, kernel_size=1)
+    return m
+
+
+def _temporal_conv_params(c, dropout):
+    m = nn.Module()
+    m.conv1 = nn.Sequential(nn.GroupNorm(32, c), nn.SiLU(), nn.Conv3d(c, c, (3, 1, 1), padding=(1, 0, 0)))
+    for name in ("conv2", "conv3", "conv4"):
+        setattr(m, name, nn.Sequential(nn.GroupNorm(32, c), nn.SiLU(), nn.Dropout(dropout),
+                                       nn.Conv3d(c, c, (3, 1, 1), padding=(1, 0, 0))))
+    return m
+
+
+def _res_block_params(cin, emb, cout, dropout):
+    m = nn.Module()
+    m.in_layers = nn.Sequential(nn.GroupNorm(32, cin), nn.SiLU(), nn.Conv2d(cin, cout, 3, padding=1))
+    m.emb_layers = nn.Sequential(nn.SiLU(), nn.Linear(emb, cout))
+    m.out_layers = nn.Sequential(nn.GroupNorm(32, cout), nn.SiLU(), nn.Dropout(dropout),
+                                 nn.Conv2d(cout, cout, 3, padding=1))
+    m.skip_connection = nn.Identity() if cin == cout else nn.Conv2d(cin, cout, 1)
+    m.temopral_conv = _temporal_conv_params(cout, 0.1)
+    return m
+
+
+def _conv_holder(attr, cin, cout, **kw):
+    m = nn.Module()
+    setattr(m, attr, nn.Conv2d(cin, cout, 3, **kw))
+    return m
+
+
+class UNetSD(nn.Module):
+    """See module docstring.  Extra keyword (not in the reference): `init_weights=False` skips
+    the (slow, 1.4 G parameter) default initialisation when a state dict is loaded right after."""
+
+    supports_cfg_batch = True     # the sampler may stack cond/uncond into one b=2 call
+
+    def __init__(self, in_dim=7, dim=512, y_dim=512, context_dim=512, out_dim=6, dim_mult=[1, 2, 3, 4],
+                 num_heads=None, head_dim=64, num_res_blocks=3, attn_scales=[1 / 2, 1 / 4, 1 / 8],
+                 use_scale_shift_norm=True, dropout=0.1, temporal_attn_times=2, temporal_attention=True,
+                 use_checkpoint=False, use_image_dataset=False, use_fps_condition=False, use_sim_mask=False,
+                 parameterization="eps", init_weights=True):
+        super().__init__()
+        if use_fps_condition or use_image_dataset:
+            raise NotImplementedError("fps conditioning / image-dataset mode are not on the hot path")
+        embed_dim = dim * 4
+        num_heads = num_heads if num_heads else dim // 32
+        self.in_dim, self.dim, self.y_dim, self.context_dim = in_dim, dim, y_dim, context_dim
+        self.embed_dim, self.out_dim, self.dim_mult = embed_dim, out_dim, list(dim_mult)
+        self.num_heads, self.head_dim, self.num_res_blocks = num_heads, head_dim, num_res_blocks
+        self.attn_scales = list(attn_scales)
+        self.temporal_attention = temporal_attention
+        self.parameterization = parameterization
+        self.v_posterior = 0
+        if head_dim != 64:
+            raise NotImplementedError("attention kernel is specialised for head_dim 64")
+
+        self._layout = unet_layout(dim, dim_mult, num_res_blocks, attn_scales, temporal_attention)
+        inputs, middle, outputs, last = self._layout
+
+        ctx = torch.device("meta") if not init_weights else torch.device("cpu")
+        with ctx:
+            self.time_embed = nn.Sequential(nn.Linear(dim, embed_dim), nn.SiLU(), nn.Linear(embed_dim, embed_dim))
+            self.input_blocks = nn.ModuleList()
+            self.middle_block = nn.ModuleList()
+            self.output_blocks = nn.ModuleList()
+            for prefix, parts, bare in inputs:
+                mods = [self._make(kind, cin, cout, dropout, decoder=False, stem=(prefix == "input_blocks.0"))
+                        for kind, cin, cout in parts]
+                self.input_blocks.append(mods[0] if bare else nn.ModuleList(mods))
+            for kind, cin, cout in middle:
+                self.middle_block.append(self._make(kind, cin, cout, dropout, decoder=False))
+            for prefix, parts, bare in outputs:
+                self.output_blocks.append(nn.ModuleList(
+                    [self._make(kind, cin, cout, dropout, decoder=True) for kind, cin, cout in parts]))
+            self.out = nn.Sequential(nn.GroupNorm(32, last), nn.SiLU(), nn.Conv2d(last, out_dim, 3, padding=1))
+        if not init_weights:
+            self.to_empty(device="cpu")
+        else:
+            self._zero_init()
+
+        # runtime state (not part of the state dict)
+        self._programs: Dict[tuple, "_Compiled"] = {}
+        self._packed: Optional[Dict[str, torch.Tensor]] = None
+        self._packed_sig = None
+        self._packed_device = None
+        self.debug_taps = False
+        self.auto_refresh = True      # re-check parameter versions on every forward (~1 ms); the sampler
+                                      # turns this off inside its loop after one explicit refresh
+        self.device = torch.device("cpu")
+
+    # ---- parameter tree -------------------------------------------------------------------
+    def _make(self, kind, cin, cout, dropout, decoder, stem=False):
+        if kind == "stem":
+            return nn.Conv2d(self.in_dim, cout, 3, padding=1)
+        if kind == "res":
+            return _res_block_params(cin, self.embed_dim, cout, dropout)
+        if kind == "st":
+            # decoder SpatialTransformers hard-code context_dim=1024 in the reference (:293)
+            return _spatial_transformer_params(cout, cout // self.head_dim, self.head_dim,
+                                               1024 if decoder else self.context_dim)
+        if kind == "tt":
+            # the stem TemporalTransformer gets (num_heads, head_dim) from the config (:171-179),
+            # all others cout // head_dim heads
+            heads = self.num_heads if stem else cout // self.head_dim
+            return _temporal_transformer_params(cout, heads, self.head_dim)
+        if kind == "down":
+            return _conv_holder("op", cin, cout, stride=2, padding=1)
+        if kind == "up":
+            return _conv_holder("conv", cin, cout, padding=1)
+        raise ValueError(kind)
+
+    def _zero_init(self):
+        """The reference zero-initialises the last layer of every residual branch
+        (t2v_model.py:326,631-636,708-713,955-956,1215-1216)."""
+        with torch.no_grad():
+            for n, m in self.named_modules():
+                if n.endswith("proj_out") or n.endswith("out_layers.3"):
+                    for p in m.parameters():
+                        p.zero_()
+                if n.endswith("temopral_conv.conv4.3"):
+                    m.weight.zero_(); m.bias.zero_()
+            self.out[-1].weight.zero_()
+
+    # ---- schedule buffers (t2v_model.py:329-384) --------------------------------------------
+    def register_schedule(self, given_betas=None, beta_schedule="linear", timesteps=1000, linear_start=1e-4,
+                          linear_end=2e-2, cosine_s=8e-3):
+        if given_betas is None:
+            raise NotImplementedError("pass given_betas (the pipeline always does, t2v_pipeline.py:113)")
+        betas = np.asarray(given_betas, dtype=np.float64)
+        alphas = 1.0 - betas
+        ac = np.cumprod(alphas, axis=0)
+        ac_prev = np.append(1.0, ac[:-1])
+        self.num_timesteps = int(betas.shape[0])
+        self.linear_start, self.linear_end = linear_start, linear_end
+        t32 = partial(torch.tensor, dtype=torch.float32)
+        reg = self.register_buffer
+        reg("betas", t32(betas)); reg("alphas_cumprod", t32(ac)); reg("alphas_cumprod_prev", t32(ac_prev))
+        reg("sqrt_alphas_cumprod", t32(np.sqrt(ac)))
+        reg("sqrt_one_minus_alphas_cumprod", t32(np.sqrt(1.0 - ac)))
+        reg("log_one_minus_alphas_cumprod", t32(np.log(1.0 - ac)))
+        reg("sqrt_recip_alphas_cumprod", t32(np.sqrt(1.0 / ac)))
+        reg("sqrt_recipm1_alphas_cumprod", t32(np.sqrt(1.0 / ac - 1)))
+        pv = (1 - self.v_posterior) * betas * (1.0 - ac_prev) / (1.0 - ac) + self.v_posterior * betas
+        reg("posterior_variance", t32(pv))
+        reg("posterior_log_variance_clipped", t32(np.log(np.maximum(pv, 1e-20))))
+        reg("posterior_mean_coef1", t32(betas * np.sqrt(ac_prev) / (1.0 - ac)))
+        reg("posterior_mean_coef2", t32((1.0 - ac_prev) * np.sqrt(alphas) / (1.0 - ac)))
+
+    # ---- weights --------------------------------------------------------------------------
+    def _param_signature(self):
+        return tuple((id(p), p._version, p.device.type, p.dtype) for p in self.parameters())
+
+    def invalidate(self):
+        """Drop the packed weight images (call after mutating parameters in place)."""
+        self._packed = None
+        self._packed_sig = None
+
+    def refresh_weights(self, device=None):
+        """(Re)pack weights if any parameter object / version changed since the last pack."""
+        device = torch.device(device) if device is not None else self._packed_device
+        if device is None:
+            return
+        sig = self._param_signature()
+        if self._packed is not None and sig == self._packed_sig and device == self._packed_device:
+            return
+        comp = self._get_compiled_any()
+        sd = {k: v for k, v in self.state_dict().items()}
+        self._packed = comp.packer.materialise(sd, device)
+        self._packed_sig, self._packed_device = sig, device
+        for c in self._programs.values():
+            c.bound = None
+
+    def _get_compiled_any(self):
+        if self._programs:
+            return next(iter(self._programs.values()))
+        return self._compile(1, 1, 8, 8, 77, "f32", "f32")
+
+    # ---- forward --------------------------------------------------------------------------
+    def forward(self, x, t, y, fps=None, video_mask=None, focus_present_mask=None, prob_focus_present=0.0,
+                mask_last_frame_num=0):
+        """eps = model(x[b,4,F,h,w], t[b], y[b,L,ctx])  — reference t2v_model.py:386-459.
+        Output dtype follows the reference under autocast: fp16 for fp16 weights, else x.dtype."""
+        if not x.is_cuda:
+            raise L.T2VError("UNetSD.forward needs device tensors on an AMD GPU (no CPU fallback); "
+                             "use oracle/torch_port.py for a CPU reference")
+        B, C, F, H, W = x.shape
+        assert C == self.in_dim and y.shape[0] == B and y.shape[2] == self.context_dim
+        x = x.contiguous()
+        y = y.contiguous()
+        if x.dtype not in (torch.float16, torch.float32):
+            x = x.float()
+        if y.dtype not in (torch.float16, torch.float32):
+            y = y.float()
+        p0 = next(self.parameters())
+        out_dtype = torch.float16 if p0.dtype == torch.float16 else torch.float32
+        tf = t.to(device=x.device, dtype=torch.float32).contiguous()
+        if tf.ndim == 0:
+            tf = tf.expand(B).contiguous()
+        key = (B, F, H, W, y.shape[1], _dt(x.dtype), _dt(y.dtype), _dt(out_dtype))
+        comp = self._programs.get(key)
+        if comp is None:
+            comp = self._compile(B, F, H, W, y.shape[1], _dt(x.dtype), _dt(out_dtype), _dt(y.dtype))
+            self._programs[key] = comp
+        if self._packed is None or self._packed_device != x.device or self.auto_refresh:
+            self.refresh_weights(x.device)
+        comp.ensure_bound(self._packed, x.device)
+        out = torch.empty((B, self.out_dim, F, H, W), device=x.device, dtype=out_dtype)
+        ext = {L.EXT_X: x.data_ptr(), L.EXT_T: tf.data_ptr(), L.EXT_CTX: y.data_ptr(), L.EXT_OUT: out.data_ptr()}
+        comp.bound.run(ext, torch.cuda.current_stream(x.device).cuda_stream)
+        comp.keepalive = (x, tf, y)
+        return out
+
+    def forward_timed(self, x, t, y):
+        """Like forward, but returns (eps, per-op milliseconds) using HIP events around every op
+        on the launch stream (bench.py roofline measurement)."""
+        out = self.forward(x, t, y)
+        comp = self._programs[(x.shape[0], x.shape[2], x.shape[3], x.shape[4], y.shape[1], _dt(x.dtype),
+                               _dt(y.dtype), _dt(out.dtype))]
+        xs, tf, ys = comp.keepalive
+        ext = {L.EXT_X: xs.data_ptr(), L.EXT_T: tf.data_ptr(), L.EXT_CTX: ys.data_ptr(), L.EXT_OUT: out.data_ptr()}
+        ms = comp.bound.run_timed(ext, torch.cuda.current_stream(x.device).cuda_stream)
+        return out, ms, comp.prog
+
+    # ---- lowering -------------------------------------------------------------------------
+    def _compile(self, B, F, H, W, Lctx, x_dt, out_dt, ctx_dt="f32"):
+        low = _Lowering(self, B, F, H, W, Lctx, x_dt, out_dt, ctx_dt, keep_taps=self.debug_taps)
+        prog = low.build()
+        return _Compiled(prog, low.packer)
+
+
+def _dt(dtype) -> str:
+    return "f16" if dtype == torch.float16 else "f32"
+
+
+class _Compiled:
+    def __init__(self, prog: Program, packer: pk.WeightPacker):
+        self.prog = prog
+        self.packer = packer
+        self.bound: Optional[BoundProgram] = None
+        self.arena: Optional[torch.Tensor] = None
+        self.keepalive = None
+
+    def ensure_bound(self, packed: Dict[str, torch.Tensor], device):
+        if self.bound is not None and self.arena is not None and self.arena.device == device:
+            return
+        self.arena = torch.empty(self.prog.arena.high + 256, dtype=torch.uint8, device=device)
+        self.bound = BoundProgram(self.prog, self.arena.data_ptr(), {k: v.data_ptr() for k, v in packed.items()})
+
+
+# ------------------------------------------------------------------------------------------
+# lowering: network + geometry -> denoise program
+# ------------------------------------------------------------------------------------------
+class _Lowering:
+    def __init__(self, net: UNetSD, B, F, H, W, Lctx, x_dt, out_dt, ctx_dt, keep_taps=False):
+        self.net, self.B, self.F, self.H, self.W, self.Lctx = net, B, F, H, W, Lctx
+        self.x_dt, self.out_dt, self.ctx_dt = x_dt, out_dt, ctx_dt
+        self.P = Program(f"unet b{B} f{F} {H}x{W}")
+        self.P.keep_taps = keep_taps
+        self.packer = pk.WeightPacker()
+        self.emb_slices: Dict[str, Tuple[int, int]] = {}
+        self.kv_slices: Dict[str, Tuple[int, int]] = {}
+
+    # -- packed-weight declarations ------------------------------------------------------------
+    def w_linear(self, key) -> Ref:
+        return Ref("weight", 0, self.packer.add(key + ":lin", "f16", lambda sd, k=key: pk.pad_rows(pk.linear(sd[k + ".weight"]))))
+
+    def w_conv3(self, key, cin_pad=0) -> Ref:
+        return Ref("weight", 0, self.packer.add(key + ":c3", "f16", lambda sd, k=key, c=cin_pad: pk.pad_rows(pk.conv3x3(sd[k + ".weight"], c))))
+
+    def w_tconv(self, key) -> Ref:
+        return Ref("weight", 0, self.packer.add(key + ":t3", "f16", lambda sd, k=key: pk.tconv3(sd[k + ".weight"])))
+
+    def w_qkv(self, prefix) -> Ref:
+        def fn(sd, p=prefix):
+            return torch.cat([sd[p + ".to_q.weight"], sd[p + ".to_k.weight"], sd[p + ".to_v.weight"]], dim=0)
+        return Ref("weight", 0, self.packer.add(prefix + ":qkv", "f16", fn))
+
+    def w_geglu(self, key) -> Tuple[Ref, Ref]:
+        def wfn(sd, k=key):
+            w = sd[k + ".weight"]
+            return w[pk.geglu_perm(w.shape[0] // 2, w.device)]
+        def bfn(sd, k=key):
+            b = sd[k + ".bias"]
+            return b[pk.geglu_perm(b.shape[0] // 2, b.device)]
+        return (Ref("weight", 0, self.packer.add(key + ":geglu", "f16", wfn)),
+                Ref("weight", 0, self.packer.add(key + ":geglu_b", "f32", bfn)))
+
+    def vec(self, key) -> Ref:
+        """fp32 vector (bias / norm affine), zero-padded to a multiple of 4."""
+        return Ref("weight", 0, self.packer.add(key + ":v", "f32", lambda sd, k=key: pk.pad_rows(sd[k])))
+
+    # -- geometry helpers ----------------------------------------------------------------------
+    def M(self, h, w):
+        return self.B * self.F * h * w
+
+    # -- building blocks ------------------------------------------------------------------------
+    def gn(self, name, x: Buf, key, *, per_frame: bool, eps, silu) -> Buf:
+        out = self.P.alloc(x.rows, x.cols, "f16")
+        n_inst = self.B * self.F if per_frame else self.B
+        self.P.groupnorm(name, x, self.vec(key + ".weight"), self.vec(key + ".bias"), out, n_inst=n_inst, eps=eps, silu=silu)
+        return out
+
+    def conv3(self, name, a: Buf, key, cout, h, w, *, stride=1, up=0, out_dtype="f32", rowbias=None,
+              residual=None, cin=None) -> Buf:
+        cin = a.cols if cin is None else cin
+        ho, wo = (h * 2, w * 2) if up else ((h + 1) // 2 if stride == 2 else h, (w + 1) // 2 if stride == 2 else w)
+        Mo = self.B * self.F * ho * wo
+        n = (cout + 3) // 4 * 4
+        out = self.P.alloc(Mo, n, out_dtype)
+        gather = L.GATHER_CONV3X3_C8 if cin == 8 else L.GATHER_CONV3X3
+        self.P.gemm(name, a, self.w_conv3(key, 8 if cin == 8 else 0), n, 9 * cin, out, bias=self.vec(key + ".bias"),
+                    gather=gather, conv=dict(Hin=h, Win=w, Cin=cin, stride=stride, up=up, Hout=ho, Wout=wo),
+                    rowbias=rowbias, rows_per_batch=self.F * ho * wo if rowbias is not None else 0,
+                    residual=residual)
+        return out
+
+    def res_block(self, prefix, x: Buf, cin, cout, h, w) -> Buf:
+        P = self.P
+        a = self.gn(prefix + ".in_layers.0", x, prefix + ".in_layers.0", per_frame=True, eps=1e-5, silu=True)
+        e0, e1 = self.emb_slices[prefix]
+        h1 = self.conv3(prefix + ".in_layers.2", a, prefix + ".in_layers.2", cout, h, w,
+                        rowbias=self.emb_out.col_slice(e0, e1))
+        P.free(a)
+        b = self.gn(prefix + ".out_layers.0", h1, prefix + ".out_layers.0", per_frame=True, eps=1e-5, silu=True)
+        P.free(h1)
+        if cin != cout:
+            x16 = P.alloc(x.rows, cin, "f16")
+            P.copy2d(prefix + ".skip.cast", x, x16)
+            skip = P.alloc(x.rows, cout, "f32")
+            P.gemm(prefix + ".skip_connection", x16, self.w_linear(prefix + ".skip_connection"), cout, cin, skip,
+                   bias=self.vec(prefix + ".skip_connection.bias"))
+            P.free(x16)
+        else:
+            skip = x
+        h2 = self.conv3(prefix + ".out_layers.3", b, prefix + ".out_layers.3", cout, h, w, residual=skip)
+        P.free(b)
+        if skip is not x:
+            P.free(skip)
+        # temporal convolution block: 4 x (GN over all frames + SiLU + (3,1,1) conv), identity residual
+        t = h2
+        tp = prefix + ".temopral_conv"
+        for name, idx in (("conv1", 2), ("conv2", 3), ("conv3", 3), ("conv4", 3)):
+            nrm = self.gn(f"{tp}.{name}.0", t, f"{tp}.{name}.0", per_frame=False, eps=1e-5, silu=True)
+            if t is not h2:
+                P.free(t)
+            t = P.alloc(h2.rows, cout, "f32")
+            key = f"{tp}.{name}.{idx}"
+            P.gemm(key, nrm, self.w_tconv(key), cout, 3 * cout, t, bias=self.vec(key + ".bias"),
+                   gather=L.GATHER_TCONV3, conv=dict(F=self.F, HW=h * w, Cin=cout),
+                   residual=h2 if name == "conv4" else None)
+            P.free(nrm)
+        P.free(h2)
+        return t
+
+    def transformer_block(self, prefix, x1: Buf, inner, heads, kind, h, w) -> Buf:
+        """x1: fp32 [M, inner] residual stream (consumed).  Returns fp16 [M, inner] (feeds proj_out)."""
+        P, Mrows, hw, F, B = self.P, x1.rows, h * w, self.F, self.B
+        scale = 64 ** -0.5
+
+        def self_attention(tag, xin: Buf) -> Buf:
+            n = P.alloc(Mrows, inner, "f16")
+            P.layernorm(f"{prefix}.norm{tag}", xin, self.vec(f"{prefix}.norm{tag}.weight"), self.vec(f"{prefix}.norm{tag}.bias"), n)
+            qkv = P.alloc(Mrows, 3 * inner, "f16")
+            P.gemm(f"{prefix}.attn{tag}.qkv", n, self.w_qkv(f"{prefix}.attn{tag}"), 3 * inner, inner, qkv)
+            P.free(n)
+            a = P.alloc(Mrows, inner, "f16")
+            ld = 3 * inner
+            q, k, v = qkv.col_slice(0, inner), qkv.col_slice(inner, 2 * inner), qkv.col_slice(2 * inner, 3 * inner)
+            if kind == "spatial":
+                P.attention(f"{prefix}.attn{tag}", q.ref, k.ref, v.ref, a.ref, nq=hw, nk=hw, heads=heads,
+                            b_outer=B * F, b_inner=1, q_strides=(ld, hw * ld, 0), kv_strides=(ld, hw * ld, 0),
+                            o_strides=(inner, hw * inner, 0), scale=scale)
+            else:   # temporal: sequence = frames of one pixel
+                P.attention(f"{prefix}.attn{tag}", q.ref, k.ref, v.ref, a.ref, nq=F, nk=F, heads=heads,
+                            b_outer=B, b_inner=hw, q_strides=(hw * ld, F * hw * ld, ld),
+                            kv_strides=(hw * ld, F * hw * ld, ld),
+                            o_strides=(hw * inner, F * hw * inner, inner), scale=scale)
+            P.free(qkv)
+            xo = P.alloc(Mrows, inner, "f32")
+            P.gemm(f"{prefix}.attn{tag}.to_out", a, self.w_linear(f"{prefix}.attn{tag}.to_out.0"), inner, inner, xo,
+                   bias=self.vec(f"{prefix}.attn{tag}.to_out.0.bias"), residual=xin)
+            P.free(a, xin)
+            return xo
+
+        x2 = self_attention(1, x1)
+        if kind == "spatial":
+            n = P.alloc(Mrows, inner, "f16")
+            P.layernorm(f"{prefix}.norm2", x2, self.vec(f"{prefix}.norm2.weight"), self.vec(f"{prefix}.norm2.bias"), n)
+            q = P.alloc(Mrows, inner, "f16")
+            P.gemm(f"{prefix}.attn2.to_q", n, self.w_linear(f"{prefix}.attn2.to_q"), inner, inner, q)
+            P.free(n)
+            k0, k1 = self.kv_slices[prefix + ".attn2"]
+            kv = self.kv_all
+            kbuf, vbuf = kv.col_slice(k0, k0 + inner), kv.col_slice(k0 + inner, k1)
+            a = P.alloc(Mrows, inner, "f16")
+            Lc = self.Lctx
+            P.attention(f"{prefix}.attn2", q.ref, kbuf.ref, vbuf.ref, a.ref, nq=hw, nk=Lc, heads=heads,
+                        b_outer=B, b_inner=F, q_strides=(inner, F * hw * inner, hw * inner),
+                        kv_strides=(kv.ld, Lc * kv.ld, 0), o_strides=(inner, F * hw * inner, hw * inner), scale=scale)
+            P.free(q)
+            x3 = P.alloc(Mrows, inner, "f32")
+            P.gemm(f"{prefix}.attn2.to_out", a, self.w_linear(f"{prefix}.attn2.to_out.0"), inner, inner, x3,
+                   bias=self.vec(f"{prefix}.attn2.to_out.0.bias"), residual=x2)
+            P.free(a, x2)
+        else:
+            x3 = self_attention(2, x2)
+        # feed-forward: GEGLU fused in the first GEMM's epilogue
+        n = P.alloc(Mrows, inner, "f16")
+        P.layernorm(f"{prefix}.norm3", x3, self.vec(f"{prefix}.norm3.weight"), self.vec(f"{prefix}.norm3.bias"), n)
+        wg, bg = self.w_geglu(f"{prefix}.ff.net.0.proj")
+        g = P.alloc(Mrows, 4 * inner, "f16")
+        P.gemm(f"{prefix}.ff.geglu", n, wg, 8 * inner, inner, g, bias=bg, epi=L.EPI_GEGLU)
+        P.free(n)
+        x4 = P.alloc(Mrows, inner, "f16")
+        P.gemm(f"{prefix}.ff.net.2", g, self.w_linear(f"{prefix}.ff.net.2"), inner, 4 * inner, x4,
+               bias=self.vec(f"{prefix}.ff.net.2.bias"), residual=x3)
+        P.free(g, x3)
+        return x4
+
+    def spatial_transformer(self, prefix, x: Buf, c, h, w) -> Buf:
+        P = self.P
+        heads = c // 64
+        n = self.gn(prefix + ".norm", x, prefix + ".norm", per_frame=True, eps=1e-6, silu=False)
+        x1 = P.alloc(x.rows, c, "f32")
+        P.gemm(prefix + ".proj_in", n, self.w_linear(prefix + ".proj_in"), c, c, x1, bias=self.vec(prefix + ".proj_in.bias"))
+        P.free(n)
+        x4 = self.transformer_block(prefix + ".transformer_blocks.0", x1, c, heads, "spatial", h, w)
+        out = P.alloc(x.rows, c, "f32")
+        P.gemm(prefix + ".proj_out", x4, self.w_linear(prefix + ".proj_out"), c, c, out,
+               bias=self.vec(prefix + ".proj_out.bias"), residual=x)
+        P.free(x4)
+        return out
+
+    def temporal_transformer(self, prefix, x: Buf, c, heads, h, w) -> Buf:
+        P = self.P
+        inner = heads * 64
+        n = self.gn(prefix + ".norm", x, prefix + ".norm", per_frame=False, eps=1e-6, silu=False)
+        x1 = P.alloc(x.rows, inner, "f32")
+        P.gemm(prefix + ".proj_in", n, self.w_linear(prefix + ".proj_in"), inner, c, x1, bias=self.vec(prefix + ".proj_in.bias"))
+        P.free(n)
+        x4 = self.transformer_block(prefix + ".transformer_blocks.0", x1, inner, heads, "temporal", h, w)
+        out = P.alloc(x.rows, c, "f32")
+        P.gemm(prefix + ".proj_out", x4, self.w_linear(prefix + ".proj_out"), c, inner, out,
+               bias=self.vec(prefix + ".proj_out.bias"), residual=x)
+        P.free(x4)
+        return out
+
+    def resample(self, prefix, attr, x: Buf, c, h, w, *, up) -> Buf:
+        P = self.P
+        x16 = P.alloc(x.rows, c, "f16")
+        P.copy2d(prefix + ".cast", x, x16)
+        out = self.conv3(f"{prefix}.{attr}", x16, f"{prefix}.{attr}", c, h, w, stride=1 if up else 2, up=1 if up else 0)
+        P.free(x16)
+        return out
+
+    # -- whole network ------------------------------------------------------------------------------
+    def build(self) -> Program:
+        net, P, B, F = self.net, self.P, self.B, self.F
+        inputs, middle, outputs, last = net._layout
+        dim, emb = net.dim, net.embed_dim
+        h, w = self.H, self.W
+        P.begin()
+
+        # ---- step-level prologue: time embedding, all ResBlock emb projections, all cross-attn K/V
+        res_prefixes, st_prefixes = [], []
+        for prefix, parts, bare in inputs + [("middle_block", middle, False)] + outputs:
+            for i, (kind, cin, cout) in enumerate(parts):
+                p = prefix if bare else f"{prefix}.{i}"
+                if kind == "res":
+                    res_prefixes.append((p, cout))
+                elif kind == "st":
+                    st_prefixes.append((p, cout))
+        off = 0
+        for p, cout in res_prefixes:
+            self.emb_slices[p] = (off, off + cout)
+            off += cout
+        n_emb = off
+        off = 0
+        for p, c in st_prefixes:
+            self.kv_slices[p + ".transformer_blocks.0.attn2"] = (off, off + 2 * c)
+            off += 2 * c
+        n_kv = off
+
+        freqs = Ref("weight", 0, self.packer.add("time_freqs", "f32", lambda sd, d=dim: torch.pow(
+            10000, -torch.arange(d // 2).to(torch.float32).div(d // 2))))
+        te = P.alloc(B, dim, "f16")
+        P.time_embed("time_embed.sincos", Ref("ext", L.EXT_T), freqs, te)
+        e1 = P.alloc(B, emb, "f16")
+        P.gemm("time_embed.0", te, self.w_linear("time_embed.0"), emb, dim, e1, bias=self.vec("time_embed.0.bias"), act=1)
+        P.free(te)
+        e_silu = P.alloc(B, emb, "f16")       # SiLU(e): the only form in which e is consumed (emb_layers = SiLU -> Linear)
+        P.gemm("time_embed.2", e1, self.w_linear("time_embed.2"), emb, emb, e_silu, bias=self.vec("time_embed.2.bias"), act=1)
+        P.free(e1)
+        w_emb = Ref("weight", 0, self.packer.add("emb_all:lin", "f16", lambda sd, ps=tuple(p for p, _ in res_prefixes):
+                                                 torch.cat([sd[p + ".emb_layers.1.weight"] for p in ps], dim=0)))
+        b_emb = Ref("weight", 0, self.packer.add("emb_all:v", "f32", lambda sd, ps=tuple(p for p, _ in res_prefixes):
+                                                 torch.cat([sd[p + ".emb_layers.1.bias"] for p in ps], dim=0)))
+        self.emb_out = P.alloc(B, n_emb, "f32")
+        P.gemm("emb_layers.all", e_silu, w_emb, n_emb, emb, self.emb_out, bias=b_emb)
+        P.free(e_silu)
+
+        ctx16 = P.alloc(B * self.Lctx, net.context_dim, "f16")
+        ctx_src = Buf(Ref("ext", L.EXT_CTX), B * self.Lctx, net.context_dim, net.context_dim, self.ctx_dt)
+        P.copy2d("context.cast", ctx_src, ctx16)
+        if n_kv:
+            w_kv = Ref("weight", 0, self.packer.add("kv_all:lin", "f16", lambda sd, ps=tuple(p for p, _ in st_prefixes): torch.cat(
+                [torch.cat([sd[p + ".transformer_blocks.0.attn2.to_k.weight"], sd[p + ".transformer_blocks.0.attn2.to_v.weight"]], dim=0)
+                 for p in ps], dim=0)))
+            self.kv_all = P.alloc(B * self.Lctx, n_kv, "f16")
+            P.gemm("attn2.kv.all", ctx16, w_kv, n_kv, net.context_dim, self.kv_all)
+        P.free(ctx16)
+
+        # ---- entry layout conversion: b c f h w -> tokens x 8 channels (4 real + 4 zero)
+        xin = P.alloc(self.M(h, w), 8, "f16")
+        P.ncthw_to_cl("x.to_tokens", Ref("ext", L.EXT_X), self.x_dt, xin, B=B, C=net.in_dim, F=F, HW=h * w)
+
+        def run_parts(prefix, parts, bare, x, h, w):
+            for i, (kind, cin, cout) in enumerate(parts):
+                p = prefix if bare else f"{prefix}.{i}"
+                if kind == "stem":
+                    y = self.conv3(p, x, p, cout, h, w, cin=8)
+                elif kind == "res":
+                    y = self.res_block(p, x, cin, cout, h, w)
+                elif kind == "st":
+                    y = self.spatial_transformer(p, x, cout, h, w)
+                elif kind == "tt":
+                    heads = net.num_heads if p == "input_blocks.0.1" else cout // 64
+                    y = self.temporal_transformer(p, x, cout, heads, h, w)
+                elif kind == "down":
+                    y = self.resample(p, "op", x, cout, h, w, up=False)
+                    h, w = (h + 1) // 2, (w + 1) // 2
+                elif kind == "up":
+                    y = self.resample(p, "conv", x, cout, h, w, up=True)
+                    h, w = h * 2, w * 2
+                else:
+                    raise ValueError(kind)
+                P.tap(p, y)
+                if not any(x is sk for sk in skips):
+                    P.free(x)
+                x = y
+            return x, h, w
+
+        skips: List[Buf] = []
+        x = xin
+        for prefix, parts, bare in inputs:
+            x, h, w = run_parts(prefix, parts, bare, x, h, w)
+            skips.append(x)
+        x, h, w = run_parts("middle_block", middle, False, x, h, w)
+        for prefix, parts, bare in outputs:
+            s = skips.pop()
+            cat = P.alloc(x.rows, x.cols + s.cols, "f32")
+            P.copy2d(prefix + ".cat.x", x, cat.col_slice(0, x.cols))
+            P.copy2d(prefix + ".cat.skip", s, cat.col_slice(x.cols, x.cols + s.cols))
+            if x is not s:
+                P.free(x)
+            P.free(s)
+            x, h, w = run_parts(prefix, parts, bare, cat, h, w)
+
+        # ---- head: GN + SiLU + conv 3x3 -> out_dim, then tokens -> b c f h w
+        a = self.gn("out.0", x, "out.0", per_frame=True, eps=1e-5, silu=True)
+        P.free(x)
+        y = self.conv3("out.2", a, "out.2", net.out_dim, h, w)
+        P.free(a)
+        P.cl_to_ncthw("eps.from_tokens", y, Ref("ext", L.EXT_OUT), self.out_dt, B=B, C=net.out_dim, F=F, HW=h * w)
+        P.free(y, self.emb_out)
+        if n_kv:
+            P.free(self.kv_all)
+        P.finish()
+        return P

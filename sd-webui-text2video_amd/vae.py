@@ -1,0 +1,334 @@
+"""AutoencoderKL — drop-in for the reference's VAE on the decode side (boundary B5).
+
+Same constructor (`ddconfig`, `embed_dim`, `ckpt_path`), same state-dict keys
+(`post_quant_conv.*`, `decoder.*`, and — as parameter holders only — `encoder.*`,
+`quant_conv.*`) and `decode(z[n,4,h,w]) -> [n,3,8h,8w]` contract as
+reference scripts/modelscope/t2v_model.py:1585-1649, whose Decoder comes from Stability's
+`ldm.modules.diffusionmodules.model` (not vendored; in-tree twin followed here:
+scripts/videocrafter/lvdm/models/modules/autoencoder_modules.py:484-596).
+
+`decode` lowers the decoder into a denoise program executed by libt2v_hip.so: conv 3x3 as
+implicit GEMM (nearest-2x upsample folded into the gather), GroupNorm(eps 1e-6)+swish fused,
+the single-head d=C mid attention as  S = Q K^T (GEMM) -> row softmax -> O = P V (GEMM with
+V^T produced directly by a swapped-operand GEMM).  VAE *encode* (vid2vid) is SURVEY §8(f)-2
+("next") and not built yet: `encode` raises.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import packing as pk
+from .program import NULL, Buf, Program, Ref
+from .unet import _Compiled, _dt
+
+
+def _resnet_params(cin, cout):
+    m = nn.Module()
+    m.norm1 = nn.GroupNorm(32, cin, eps=1e-6, affine=True)
+    m.conv1 = nn.Conv2d(cin, cout, 3, padding=1)
+    m.norm2 = nn.GroupNorm(32, cout, eps=1e-6, affine=True)
+    m.conv2 = nn.Conv2d(cout, cout, 3, padding=1)
+    if cin != cout:
+        m.nin_shortcut = nn.Conv2d(cin, cout, 1)
+    return m
+
+
+def _attn_params(c):
+    m = nn.Module()
+    m.norm = nn.GroupNorm(32, c, eps=1e-6, affine=True)
+    m.q, m.k, m.v, m.proj_out = nn.Conv2d(c, c, 1), nn.Conv2d(c, c, 1), nn.Conv2d(c, c, 1), nn.Conv2d(c, c, 1)
+    return m
+
+
+def _decoder_params(ch, out_ch, ch_mult, num_res_blocks, z_channels, **_):
+    d = nn.Module()
+    nres = len(ch_mult)
+    block_in = ch * ch_mult[nres - 1]
+    d.conv_in = nn.Conv2d(z_channels, block_in, 3, padding=1)
+    d.mid = nn.Module()
+    d.mid.block_1 = _resnet_params(block_in, block_in)
+    d.mid.attn_1 = _attn_params(block_in)
+    d.mid.block_2 = _resnet_params(block_in, block_in)
+    ups = []
+    for lvl in reversed(range(nres)):
+        up = nn.Module()
+        block_out = ch * ch_mult[lvl]
+        blocks = []
+        for _j in range(num_res_blocks + 1):
+            blocks.append(_resnet_params(block_in, block_out))
+            block_in = block_out
+        up.block = nn.ModuleList(blocks)
+        up.attn = nn.ModuleList()
+        if lvl != 0:
+            us = nn.Module()
+            us.conv = nn.Conv2d(block_in, block_in, 3, padding=1)
+            up.upsample = us
+        ups.insert(0, up)
+    d.up = nn.ModuleList(ups)
+    d.norm_out = nn.GroupNorm(32, block_in, eps=1e-6, affine=True)
+    d.conv_out = nn.Conv2d(block_in, out_ch, 3, padding=1)
+    return d
+
+
+def _encoder_params(ch, ch_mult, num_res_blocks, in_channels, z_channels, double_z=True, **_):
+    """Parameter holder only (keys/shapes of ldm Encoder) so that strict checkpoint loading works."""
+    e = nn.Module()
+    nres = len(ch_mult)
+    e.conv_in = nn.Conv2d(in_channels, ch, 3, padding=1)
+    in_mult = (1,) + tuple(ch_mult)
+    downs = []
+    block_in = ch
+    for lvl in range(nres):
+        dn = nn.Module()
+        block_in = ch * in_mult[lvl]
+        block_out = ch * ch_mult[lvl]
+        blocks = []
+        for _j in range(num_res_blocks):
+            blocks.append(_resnet_params(block_in, block_out))
+            block_in = block_out
+        dn.block = nn.ModuleList(blocks)
+        dn.attn = nn.ModuleList()
+        if lvl != nres - 1:
+            ds = nn.Module()
+            ds.conv = nn.Conv2d(block_in, block_in, 3, stride=2, padding=0)
+            dn.downsample = ds
+        downs.append(dn)
+    e.down = nn.ModuleList(downs)
+    e.mid = nn.Module()
+    e.mid.block_1 = _resnet_params(block_in, block_in)
+    e.mid.attn_1 = _attn_params(block_in)
+    e.mid.block_2 = _resnet_params(block_in, block_in)
+    e.norm_out = nn.GroupNorm(32, block_in, eps=1e-6, affine=True)
+    e.conv_out = nn.Conv2d(block_in, 2 * z_channels if double_z else z_channels, 3, padding=1)
+    return e
+
+
+class AutoencoderKL(nn.Module):
+    def __init__(self, ddconfig, embed_dim, ckpt_path=None, image_key="image", colorize_nlabels=None,
+                 monitor=None, ema_decay=None, learn_logvar=False, init_weights=True):
+        super().__init__()
+        assert ddconfig["double_z"]
+        if ddconfig.get("attn_resolutions"):
+            raise NotImplementedError("attention at up/down levels is not used by the reference config")
+        self.ddconfig = dict(ddconfig)
+        self.embed_dim = embed_dim
+        ctx = torch.device("meta") if not init_weights else torch.device("cpu")
+        with ctx:
+            self.encoder = _encoder_params(**ddconfig)
+            self.decoder = _decoder_params(**ddconfig)
+            self.quant_conv = nn.Conv2d(2 * ddconfig["z_channels"], 2 * embed_dim, 1)
+            self.post_quant_conv = nn.Conv2d(embed_dim, ddconfig["z_channels"], 1)
+        if not init_weights:
+            self.to_empty(device="cpu")
+        self._programs: Dict[tuple, _Compiled] = {}
+        self._packed = None
+        self._packed_sig = None
+        self._packed_device = None
+        self.debug_taps = False
+        if ckpt_path is not None:
+            self.init_from_ckpt(ckpt_path)
+
+    def init_from_ckpt(self, path):
+        """Keys filtered by the 'first_stage_model.' prefix, as reference t2v_model.py:1619-1631."""
+        sd = torch.load(path, map_location="cpu")["state_dict"]
+        new = {k.split("first_stage_model.")[-1]: v for k, v in sd.items() if "first_stage_model" in k}
+        self.load_state_dict(new, strict=True)
+
+    def encode(self, x):
+        raise NotImplementedError("VAE encode (vid2vid input side) is SURVEY §8(f)-2, not built yet")
+
+    # ---- weights ------------------------------------------------------------------------------
+    def _param_signature(self):
+        return tuple((id(p), p._version, p.device.type, p.dtype) for p in self.parameters())
+
+    def invalidate(self):
+        self._packed, self._packed_sig = None, None
+
+    def _refresh(self, comp, device):
+        sig = self._param_signature()
+        if self._packed is not None and sig == self._packed_sig and device == self._packed_device:
+            return
+        self._packed = comp.packer.materialise(self.state_dict(), device)
+        self._packed_sig, self._packed_device = sig, device
+        for c in self._programs.values():
+            c.bound = None
+
+    # ---- decode -------------------------------------------------------------------------------
+    def decode(self, z):
+        """z [n, 4, h, w] (the pipeline passes x0/0.18215, t2v_pipeline.py:348) -> [n, 3, 8h, 8w]."""
+        if not z.is_cuda:
+            raise L.T2VError("AutoencoderKL.decode needs device tensors on an AMD GPU (no CPU fallback)")
+        n, c, h, w = z.shape
+        z = z.contiguous()
+        if z.dtype not in (torch.float16, torch.float32):
+            z = z.float()
+        p0 = next(self.parameters())
+        out_dtype = torch.float16 if p0.dtype == torch.float16 else torch.float32
+        key = (n, h, w, _dt(z.dtype), _dt(out_dtype))
+        comp = self._programs.get(key)
+        if comp is None:
+            low = _VaeLowering(self, n, h, w, _dt(z.dtype), _dt(out_dtype), self.debug_taps)
+            comp = _Compiled(low.build(), low.packer)
+            self._programs[key] = comp
+        self._refresh(comp, z.device)
+        comp.ensure_bound(self._packed, z.device)
+        out = torch.empty((n, self.ddconfig["out_ch"], 8 * h, 8 * w), device=z.device, dtype=out_dtype)
+        comp.bound.run({L.EXT_X: z.data_ptr(), L.EXT_OUT: out.data_ptr()},
+                       torch.cuda.current_stream(z.device).cuda_stream)
+        comp.keepalive = (z,)
+        return out
+
+    def forward(self, input, sample_posterior=True):
+        raise NotImplementedError("only decode() is on the hot path")
+
+
+class _VaeLowering:
+    def __init__(self, vae: AutoencoderKL, n, h, w, z_dt, out_dt, keep_taps=False):
+        self.vae, self.n, self.h, self.w, self.z_dt, self.out_dt = vae, n, h, w, z_dt, out_dt
+        self.P = Program(f"vae n{n} {h}x{w}")
+        self.P.keep_taps = keep_taps
+        self.packer = pk.WeightPacker()
+
+    def w_linear(self, key) -> Ref:
+        return Ref("weight", 0, self.packer.add(key + ":lin", "f16", lambda sd, k=key: pk.pad_rows(pk.linear(sd[k + ".weight"]))))
+
+    def w_conv3(self, key, cin_pad=0) -> Ref:
+        return Ref("weight", 0, self.packer.add(key + ":c3", "f16", lambda sd, k=key, c=cin_pad: pk.pad_rows(pk.conv3x3(sd[k + ".weight"], c))))
+
+    def vec(self, key) -> Ref:
+        return Ref("weight", 0, self.packer.add(key + ":v", "f32", lambda sd, k=key: pk.pad_rows(sd[k])))
+
+    def gn(self, key, x: Buf, silu: bool) -> Buf:
+        out = self.P.alloc(x.rows, x.cols, "f16")
+        self.P.groupnorm(key, x, self.vec(key + ".weight"), self.vec(key + ".bias"), out, n_inst=self.n, eps=1e-6, silu=silu)
+        return out
+
+    def conv3(self, key, a: Buf, cout, h, w, *, up=0, residual=None, cin=None) -> Buf:
+        cin = a.cols if cin is None else cin
+        ho, wo = (2 * h, 2 * w) if up else (h, w)
+        nn_ = (cout + 3) // 4 * 4
+        out = self.P.alloc(self.n * ho * wo, nn_, "f32")
+        gather = L.GATHER_CONV3X3_C8 if cin == 8 else L.GATHER_CONV3X3
+        self.P.gemm(key, a, self.w_conv3(key, 8 if cin == 8 else 0), nn_, 9 * cin, out, bias=self.vec(key + ".bias"),
+                    gather=gather, conv=dict(Hin=h, Win=w, Cin=cin, stride=1, up=up, Hout=ho, Wout=wo), residual=residual)
+        return out
+
+    def resnet(self, p, x: Buf, cin, cout, h, w) -> Buf:
+        P = self.P
+        a = self.gn(p + ".norm1", x, True)
+        h1 = self.conv3(p + ".conv1", a, cout, h, w)
+        P.free(a)
+        b = self.gn(p + ".norm2", h1, True)
+        P.free(h1)
+        if cin != cout:
+            x16 = P.alloc(x.rows, cin, "f16")
+            P.copy2d(p + ".skip.cast", x, x16)
+            skip = P.alloc(x.rows, cout, "f32")
+            P.gemm(p + ".nin_shortcut", x16, self.w_linear(p + ".nin_shortcut"), cout, cin, skip,
+                   bias=self.vec(p + ".nin_shortcut.bias"))
+            P.free(x16)
+        else:
+            skip = x
+        out = self.conv3(p + ".conv2", b, cout, h, w, residual=skip)
+        P.free(b)
+        if skip is not x:
+            P.free(skip)
+        return out
+
+    def attn(self, p, x: Buf, c, h, w) -> Buf:
+        """Single-head attention with d = C over the h*w tokens of each image (AttnBlock)."""
+        P, hw = self.P, h * w
+        nrm = self.gn(p + ".norm", x, False)
+        wqk = Ref("weight", 0, self.packer.add(p + ":qk", "f16", lambda sd, k=p: torch.cat(
+            [pk.linear(sd[k + ".q.weight"]), pk.linear(sd[k + ".k.weight"])], dim=0)))
+        bqk = Ref("weight", 0, self.packer.add(p + ":qk_b", "f32", lambda sd, k=p: torch.cat([sd[k + ".q.bias"], sd[k + ".k.bias"]], dim=0)))
+        qk = P.alloc(x.rows, 2 * c, "f16")
+        P.gemm(p + ".qk", nrm, wqk, 2 * c, c, qk, bias=bqk)
+        out_attn = P.alloc(x.rows, c, "f16")
+        for img in range(self.n):
+            rows = slice(img * hw, (img + 1) * hw)
+            nrm_i = nrm.row_slice(rows.start, rows.stop)
+            # V^T [c, hw] = Wv [c, c] x nrm_i^T : swapped operands, bias along rows
+            vt = P.alloc(c, hw, "f16")
+            wv_as_a = Buf(self.w_linear(p + ".v"), c, c, c, "f16")
+            P.gemm(f"{p}.vT.{img}", wv_as_a, nrm_i.ref, hw, c, vt, bias=self.vec(p + ".v.bias"), ldw=nrm_i.ld,
+                   bias_along_m=True, allow_splitk=False)
+            q_i = qk.row_slice(rows.start, rows.stop).col_slice(0, c)
+            k_i = qk.row_slice(rows.start, rows.stop).col_slice(c, 2 * c)
+            s = P.alloc(hw, hw, "f32")
+            P.gemm(f"{p}.qk^T.{img}", q_i, k_i.ref, hw, c, s, ldw=k_i.ld, allow_splitk=False)
+            pm = P.alloc(hw, hw, "f16")
+            P.softmax(f"{p}.softmax.{img}", s, pm, float(int(c) ** (-0.5)))
+            P.free(s)
+            P.gemm(f"{p}.pv.{img}", pm, vt.ref, c, hw, out_attn.row_slice(rows.start, rows.stop), ldw=vt.ld,
+                   allow_splitk=False)
+            P.free(pm, vt)
+        P.free(nrm, qk)
+        out = P.alloc(x.rows, c, "f32")
+        P.gemm(p + ".proj_out", out_attn, self.w_linear(p + ".proj_out"), c, c, out, bias=self.vec(p + ".proj_out.bias"),
+               residual=x)
+        P.free(out_attn)
+        return out
+
+    def build(self) -> Program:
+        P, n, h, w = self.P, self.n, self.h, self.w
+        dd = self.vae.ddconfig
+        ch, ch_mult, nrb = dd["ch"], list(dd["ch_mult"]), dd["num_res_blocks"]
+        nres = len(ch_mult)
+        zc = dd["z_channels"]
+        assert zc == 4 and self.vae.embed_dim == 4
+        P.begin()
+        zin = P.alloc(n * h * w, 8, "f16")
+        P.ncthw_to_cl("z.to_tokens", Ref("ext", L.EXT_X), self.z_dt, zin, B=n, C=zc, F=1, HW=h * w)
+        # post_quant_conv 1x1 (4 -> 4), written as an 8-channel fp16 token tensor (channels 4..7 = 0)
+        wpq = Ref("weight", 0, self.packer.add("post_quant_conv:lin8", "f16", lambda sd: _pad2(pk.linear(sd["post_quant_conv.weight"]), 8, 8)))
+        bpq = Ref("weight", 0, self.packer.add("post_quant_conv:b8", "f32", lambda sd: pk.pad_rows(sd["post_quant_conv.bias"], 8)))
+        z2 = P.alloc(n * h * w, 8, "f16")
+        P.gemm("post_quant_conv", zin, wpq, 8, 8, z2, bias=bpq)
+        P.free(zin)
+        block_in = ch * ch_mult[-1]
+        x = self.conv3("decoder.conv_in", z2, block_in, h, w, cin=8)
+        P.free(z2)
+        P.tap("decoder.conv_in", x)
+
+        def step(fn, name, *a):
+            nonlocal x
+            y = fn(name, x, *a)
+            P.tap(name, y)
+            P.free(x)
+            x = y
+
+        step(self.resnet, "decoder.mid.block_1", block_in, block_in, h, w)
+        step(self.attn, "decoder.mid.attn_1", block_in, h, w)
+        step(self.resnet, "decoder.mid.block_2", block_in, block_in, h, w)
+        for lvl in reversed(range(nres)):
+            block_out = ch * ch_mult[lvl]
+            for j in range(nrb + 1):
+                step(self.resnet, f"decoder.up.{lvl}.block.{j}", block_in, block_out, h, w)
+                block_in = block_out
+            if lvl != 0:
+                x16 = P.alloc(x.rows, block_in, "f16")
+                P.copy2d(f"decoder.up.{lvl}.upsample.cast", x, x16)
+                y = self.conv3(f"decoder.up.{lvl}.upsample.conv", x16, block_in, h, w, up=1)
+                P.free(x16, x)
+                x = y
+                h, w = 2 * h, 2 * w
+                P.tap(f"decoder.up.{lvl}.upsample", x)
+        a = self.gn("decoder.norm_out", x, True)
+        P.free(x)
+        y = self.conv3("decoder.conv_out", a, dd["out_ch"], h, w)
+        P.free(a)
+        P.cl_to_ncthw("img.from_tokens", y, Ref("ext", L.EXT_OUT), self.out_dt, B=n, C=dd["out_ch"], F=1, HW=h * w)
+        P.free(y)
+        P.finish()
+        return P
+
+
+def _pad2(w: torch.Tensor, rows: int, cols: int) -> torch.Tensor:
+    out = w.new_zeros(rows, cols)
+    out[: w.shape[0], : w.shape[1]] = w
+    return out

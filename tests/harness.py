@@ -1,0 +1,48 @@
+"""Shared helpers for the parity tests (test infrastructure)."""
+from __future__ import annotations
+
+import torch
+
+from interp import Interp
+from sd_webui_text2video_amd import _lib as L
+from sd_webui_text2video_amd.program import BoundProgram, Buf, Program
+
+TD = {"f16": torch.float16, "f32": torch.float32}
+
+
+def rel_l2(a: torch.Tensor, b: torch.Tensor) -> float:
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def fill(it: Interp, buf: Buf, gen: torch.Generator, scale: float = 1.0, total_cols=None):
+    """Random-fill a buffer (all `ld` columns of its rows unless total_cols given) in the CPU arena."""
+    v = it.mat(buf.ref, buf.rows, buf.cols, buf.ld, TD[buf.dtype], {})
+    v.copy_((torch.randn(buf.rows, buf.cols, generator=gen) * scale).to(v.dtype))
+    return v
+
+
+def read(arena_or_interp, buf: Buf) -> torch.Tensor:
+    it = arena_or_interp
+    return it.mat(buf.ref, buf.rows, buf.cols, buf.ld, TD[buf.dtype], {}).clone()
+
+
+def run_both(prog: Program, weights_cpu: dict, ext_cpu: dict, init):
+    """Run `prog` in the CPU interpreter and on the GPU from identical initial arena contents.
+    Returns (interp_after, gpu_arena_as_interp_view, ext_gpu_back_on_cpu)."""
+    it = Interp(prog, weights_cpu, poison=False)
+    init(it)
+    arena0 = it.arena.clone()
+    ext_ref = {k: v.clone() for k, v in ext_cpu.items()}
+    it.run(ext_ref)
+
+    dev = torch.device("cuda:0")
+    arena_gpu = arena0.to(dev)
+    w_gpu = {k: v.to(dev).contiguous() for k, v in weights_cpu.items()}
+    ext_gpu = {k: v.to(dev).contiguous() for k, v in ext_cpu.items()}
+    bound = BoundProgram(prog, arena_gpu.data_ptr(), {k: v.data_ptr() for k, v in w_gpu.items()})
+    bound.run({k: v.data_ptr() for k, v in ext_gpu.items()}, torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize()
+    got = Interp(prog, weights_cpu, poison=False)
+    got.arena = arena_gpu.cpu()
+    return it, got, ext_ref, {k: v.cpu() for k, v in ext_gpu.items()}

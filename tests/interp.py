@@ -1,0 +1,213 @@
+"""TEST INFRASTRUCTURE — a CPU interpreter for denoise programs (sd_webui_text2video_amd.program).
+
+It executes the SAME op list, arena offsets and packed weights that libt2v_hip.so executes
+on the GPU, with plain torch on the CPU, so the host logic — lowering, arena liveness,
+weight packing, stride bookkeeping — can be validated against the oracle without a GPU
+(`pytest -m "not gpu"`).  It is NOT a fallback: nothing under sd-webui-text2video_amd/
+imports it, and the product path fails loudly without the HIP library.
+
+Storage precision is emulated (fp16 buffers hold fp16-rounded values, fp32 accumulate), so
+the interpreter also predicts the quantisation error of the device path.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict
+
+import torch
+import torch.nn.functional as F
+
+from sd_webui_text2video_amd import _lib as L
+from sd_webui_text2video_amd.program import Program, Ref
+
+_TD = {L.F16: torch.float16, L.F32: torch.float32}
+
+
+class Interp:
+    def __init__(self, prog: Program, weights: Dict[str, torch.Tensor], poison: bool = True):
+        self.prog = prog
+        self.weights = {k: v.cpu() for k, v in weights.items()}
+        self.arena = torch.zeros(prog.arena.high + 256, dtype=torch.uint8)
+        if poison:      # NaN-poison so that reads of never-written memory are caught
+            self.arena.view(torch.float16)[:] = float("nan")
+
+    # ---- memory views -------------------------------------------------------------------------
+    def _flat(self, ref: Ref, dtype, ext):
+        item = torch.empty((), dtype=dtype).element_size()
+        if ref.space == "arena":
+            assert ref.off % item == 0
+            return self.arena.view(dtype), ref.off // item
+        if ref.space == "weight":
+            w = self.weights[ref.name]
+            assert w.dtype == dtype, (ref.name, w.dtype, dtype)
+            assert ref.off % item == 0
+            return w.reshape(-1), ref.off // item
+        if ref.space == "ext":
+            t = ext[ref.off]
+            assert t.dtype == dtype, (t.dtype, dtype)
+            return t.reshape(-1), 0
+        raise ValueError(ref.space)
+
+    def view(self, ref: Ref, shape, strides, dtype, ext):
+        flat, off = self._flat(ref, dtype, ext)
+        return torch.as_strided(flat, tuple(shape), tuple(strides), off)
+
+    def mat(self, ref: Ref, rows, cols, ld, dtype, ext):
+        return self.view(ref, (rows, cols), (ld, 1), dtype, ext)
+
+    # ---- execution -----------------------------------------------------------------------------
+    def run(self, ext: Dict[int, torch.Tensor]):
+        for op in self.prog.ops:
+            getattr(self, f"_op{op.kind}")(op, ext)
+
+    # GEMM ------------------------------------------------------------------------------------------
+    def _op1(self, op, ext):
+        I = op.i
+        M, N, K, lda, ldw, ldc, ldr, gather = I[0:8]
+        A16 = None
+        if gather == L.GATHER_PLAIN:
+            A = self.mat(op.p[0], M, K, lda, torch.float16, ext).float()
+        elif gather in (L.GATHER_CONV3X3, L.GATHER_CONV3X3_C8):
+            Hin, Win, Cin, stride, up, Hout, Wout = I[8], I[9], I[10], I[11], I[12], I[13], I[14]
+            nimg = M // (Hout * Wout)
+            X = self.view(op.p[0], (nimg, Hin, Win, Cin), (Hin * Win * lda, Win * lda, lda, 1), torch.float16, ext).float()
+            if up:
+                X = X.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
+            Xp = F.pad(X, (0, 0, 1, 1, 1, 1))
+            cols = []
+            for ky in range(3):
+                for kx in range(3):
+                    cols.append(Xp[:, ky:ky + stride * Hout:stride, kx:kx + stride * Wout:stride, :])
+            A = torch.cat(cols, dim=3).reshape(M, 9 * Cin)
+            assert K == 9 * Cin
+        elif gather == L.GATHER_TCONV3:
+            Fr, HW, Cin = I[8], I[9], I[10]
+            nb = M // (Fr * HW)
+            X = self.view(op.p[0], (nb, Fr, HW, Cin), (Fr * HW * lda, HW * lda, lda, 1), torch.float16, ext).float()
+            Xp = F.pad(X, (0, 0, 0, 0, 1, 1))
+            A = torch.cat([Xp[:, kt:kt + Fr] for kt in range(3)], dim=3).reshape(M, 3 * Cin)
+        else:
+            raise ValueError(gather)
+        W = self.mat(op.p[1], N, K, ldw, torch.float16, ext).float()
+        acc = A @ W.t()
+        if op.p[2].space != "null":
+            if I[20]:
+                acc = acc + self.view(op.p[2], (M,), (1,), torch.float32, ext)[:, None]
+            else:
+                acc = acc + self.view(op.p[2], (N,), (1,), torch.float32, ext)[None, :]
+        epi = I[16]
+        if epi == L.EPI_GEGLU:
+            a = acc.view(M, N // 16, 2, 8)
+            val, gate = a[:, :, 0, :].reshape(M, N // 2), a[:, :, 1, :].reshape(M, N // 2)
+            res = val * F.gelu(gate)
+            n_out = N // 2
+        else:
+            res, n_out = acc, N
+            if op.p[3].space != "null":
+                rpb, ldrb = I[15], I[21]
+                rb = self.mat(op.p[3], M // rpb, N, ldrb, torch.float32, ext)
+                res = res + rb.repeat_interleave(rpb, dim=0)
+            if I[18] == 1:
+                res = F.silu(res)
+            if op.p[4].space != "null":
+                res = res + self.mat(op.p[4], M, N, ldr, torch.float32, ext)
+        out = self.mat(op.p[5], M, n_out, ldc, _TD[I[17]], ext)
+        out.copy_(res.to(out.dtype))
+
+    # GROUPNORM ----------------------------------------------------------------------------------------
+    def _op2(self, op, ext):
+        n_inst, rows, C, ld_in, groups, in_dt, silu, ld_out = op.i[0:8]
+        x = self.mat(op.p[0], n_inst * rows, C, ld_in, _TD[in_dt], ext).double().view(n_inst, rows, groups, C // groups)
+        mean = x.mean(dim=(1, 3), keepdim=True)
+        var = (x * x).mean(dim=(1, 3), keepdim=True) - mean * mean
+        y = ((x - mean) / torch.sqrt(var.clamp_min(0) + op.f[0])).view(n_inst * rows, C).float()
+        g = self.view(op.p[1], (C,), (1,), torch.float32, ext)
+        b = self.view(op.p[2], (C,), (1,), torch.float32, ext)
+        y = y * g + b
+        if silu:
+            y = F.silu(y)
+        self.mat(op.p[3], n_inst * rows, C, ld_out, torch.float16, ext).copy_(y.half())
+
+    # LAYERNORM ----------------------------------------------------------------------------------------
+    def _op3(self, op, ext):
+        M, C, ld_in, ld_out = op.i[0:4]
+        x = self.mat(op.p[0], M, C, ld_in, torch.float32, ext)
+        g = self.view(op.p[1], (C,), (1,), torch.float32, ext)
+        b = self.view(op.p[2], (C,), (1,), torch.float32, ext)
+        y = F.layer_norm(x, (C,), g, b, op.f[0])
+        self.mat(op.p[3], M, C, ld_out, torch.float16, ext).copy_(y.half())
+
+    # ATTENTION ----------------------------------------------------------------------------------------
+    def _op4(self, op, ext):
+        nq, nk, heads, bo, bi = op.i[0:5]
+        sq, sk, so = op.i[5:8], op.i[8:11], op.i[11:14]
+
+        def v(ref, n, s):
+            return self.view(ref, (bo, bi, heads, n, 64), (s[1], s[2], 64, s[0], 1), torch.float16, ext)
+
+        q, k, vv = v(op.p[0], nq, sq).float(), v(op.p[1], nk, sk).float(), v(op.p[2], nk, sk).float()
+        s = torch.einsum("abhid,abhjd->abhij", q, k) * op.f[0]
+        p = torch.softmax(s, dim=-1)
+        o = torch.einsum("abhij,abhjd->abhid", p, vv)
+        v(op.p[3], nq, so).copy_(o.half())
+
+    # SOFTMAX ------------------------------------------------------------------------------------------
+    def _op5(self, op, ext):
+        rows, cols, ld_in, ld_out = op.i[0:4]
+        x = self.mat(op.p[0], rows, cols, ld_in, torch.float32, ext)
+        self.mat(op.p[1], rows, cols, ld_out, torch.float16, ext).copy_(torch.softmax(x * op.f[0], dim=1).half())
+
+    # NCTHW_TO_CL --------------------------------------------------------------------------------------
+    def _op6(self, op, ext):
+        B, C, Fr, HW, ld, in_dt = op.i[0:6]
+        x = self.view(op.p[0], (B, C, Fr, HW), (C * Fr * HW, Fr * HW, HW, 1), _TD[in_dt], ext).float() * op.f[0]
+        out = self.mat(op.p[1], B * Fr * HW, ld, ld, torch.float16, ext)
+        out.zero_()
+        out[:, :C] = x.permute(0, 2, 3, 1).reshape(B * Fr * HW, C).half()
+
+    # CL_TO_NCTHW --------------------------------------------------------------------------------------
+    def _op7(self, op, ext):
+        B, C, Fr, HW, ld, out_dt = op.i[0:6]
+        x = self.mat(op.p[0], B * Fr * HW, C, ld, torch.float32, ext)
+        out = self.view(op.p[1], (B, C, Fr, HW), (C * Fr * HW, Fr * HW, HW, 1), _TD[out_dt], ext)
+        out.copy_(x.view(B, Fr, HW, C).permute(0, 3, 1, 2).to(out.dtype))
+
+    # TIME_EMBED ---------------------------------------------------------------------------------------
+    def _op8(self, op, ext):
+        B, dim = op.i[0:2]
+        t = self.view(op.p[0], (B,), (1,), torch.float32, ext)
+        fr = self.view(op.p[1], (dim // 2,), (1,), torch.float32, ext)
+        a = torch.outer(t, fr)
+        self.mat(op.p[2], B, dim, dim, torch.float16, ext).copy_(torch.cat([torch.cos(a), torch.sin(a)], dim=1).half())
+
+    # COPY2D -------------------------------------------------------------------------------------------
+    def _op9(self, op, ext):
+        rows, cols, lds, ldd, sdt, ddt, act = op.i[0:7]
+        x = self.mat(op.p[0], rows, cols, lds, _TD[sdt], ext).float()
+        if act == 1:
+            x = F.silu(x)
+        out = self.mat(op.p[1], rows, cols, ldd, _TD[ddt], ext)
+        out.copy_(x.to(out.dtype))
+
+    # DDIM_STEP ----------------------------------------------------------------------------------------
+    def _op10(self, op, ext):
+        C, inner, guided, edt, xdt = op.i[0:5]
+        a_recip, a_recipm1, sqrt_aprev, dir_coef, sigma, gscale = op.f[0:6]
+        xt = self.view(op.p[0], (C, inner), (inner, 1), _TD[xdt], ext).float()
+        e = self.view(op.p[1], (2, C, inner), (C * inner, inner, 1), _TD[edt], ext).float()
+        y, u = e[0], e[1]
+        o = y.clone()
+        o[:guided] = u[:guided] + gscale * (y[:guided] - u[:guided])
+        x0 = a_recip * xt - a_recipm1 * o
+        eps = (a_recip * xt - x0) / a_recipm1
+        xn = sqrt_aprev * x0 + dir_coef * eps
+        if op.p[2].space != "null" and sigma != 0.0 and ext.get(L.EXT_NOISE) is not None:
+            xn = xn + sigma * self.view(op.p[2], (C, inner), (inner, 1), torch.float32, ext)
+        out = self.view(op.p[3], (C, inner), (inner, 1), _TD[xdt], ext)
+        out.copy_(xn.to(out.dtype))
+
+    # MEMSET -------------------------------------------------------------------------------------------
+    def _op11(self, op, ext):
+        nbytes = (op.i[0] & 0xFFFFFFFF) | (op.i[1] << 32)
+        assert op.p[0].space == "arena"
+        self.arena[op.p[0].off: op.p[0].off + nbytes] = 0

@@ -1,0 +1,88 @@
+"""CPU: pin the travelling oracle (oracle/torch_port.py) against the golden fixtures generated
+from the REAL reference (tests/golden/make_golden.py) and, when /root/reference is mounted,
+against the reference's own classes run live."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import configs, ref_bootstrap as rb, synth, torch_port as tp
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _tiny_inputs():
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 4, 3, 16, 16, generator=g)
+    y = torch.randn(2, 7, configs.TINY_UNET["context_dim"], generator=g)
+    z = torch.randn(2, 4, 8, 8, generator=g)
+    c = torch.randn(1, 7, configs.TINY_UNET["context_dim"], generator=g)
+    uc = torch.randn(1, 7, configs.TINY_UNET["context_dim"], generator=g)
+    return x, torch.tensor([801, 401]), y, z, c, uc
+
+
+def _spec_unet(cfg):
+    from sd_webui_text2video_amd import unet
+    return synth.param_spec(unet.UNetSD(**cfg, init_weights=False))
+
+
+def _spec_vae(dd):
+    from sd_webui_text2video_amd import vae
+    return synth.param_spec(vae.AutoencoderKL(dd, 4, init_weights=False))
+
+
+def test_port_matches_reference_golden_tiny():
+    gold = np.load(os.path.join(GOLD, "tiny.npz"))
+    x, t, y, z, c, uc = _tiny_inputs()
+    sd = synth.synth_state_dict(_spec_unet(configs.TINY_UNET), seed=0)
+    eps = tp.unet_forward(sd, configs.TINY_UNET, x, t, y)
+    assert np.abs(eps.numpy() - gold["unet_eps"]).max() < 2e-5
+    vsd = synth.synth_state_dict(_spec_vae(configs.TINY_VAE_DDCONFIG), seed=3)
+    img = tp.vae_decode(vsd, configs.TINY_VAE_DDCONFIG, z)
+    assert np.abs(img.numpy() - gold["vae_img"]).max() < 2e-5
+    betas = tp.beta_schedule_linear_sd()
+    noise, _, _ = synth.synth_inputs(3, 128, 128)
+    x0 = tp.ddim_gaussian_sample(lambda a, b, cc: tp.unet_forward(sd, configs.TINY_UNET, a, b, cc), betas, noise, 4, c, uc, 9.0, 0.0)
+    assert np.abs(x0.numpy() - gold["sampler_x0"]).max() < 2e-4 * np.abs(gold["sampler_x0"]).max()
+
+
+def test_timestep_grid_matches_reference_quirk():
+    # S=5 -> [801,601,401,201,1]; S=50 -> [981,...,1]
+    assert tp.ddim_gaussian_timesteps(1000, 5).tolist() == [801, 601, 401, 201, 1]
+    ts = tp.ddim_gaussian_timesteps(1000, 50)
+    assert ts[0] == 981 and ts[-1] == 1 and len(ts) == 50
+
+
+def test_tensor2vid_truncates():
+    v = torch.tensor([0.999, -1.0, 1.0, 0.0]).view(1, 1, 1, 1, 4).repeat(1, 3, 1, 1, 1)
+    out = tp.tensor2vid_uint8(v)[0]
+    assert out[0, :, 0].tolist() == [254, 0, 255, 127]     # (x*0.5+0.5)*255 truncated
+
+
+@pytest.mark.skipif(not rb.reference_available(), reason="/root/reference not mounted (GPU box)")
+def test_port_matches_live_reference_blocks():
+    """Per-sub-module agreement with the reference's own forward (hooks), tiny config."""
+    cfg = configs.TINY_UNET
+    unet, _ = rb.build_reference_unet(cfg)
+    sd = synth.load_synth(unet, seed=0)
+    x, t, y, *_ = _tiny_inputs()
+    got = {}
+    hooks = []
+    for name, mod in unet.named_modules():
+        if name.count(".") == 2 and name.split(".")[0] in ("input_blocks", "output_blocks") or \
+                (name.startswith("middle_block.") and name.count(".") == 1):
+            hooks.append(mod.register_forward_hook(lambda m, i, o, n=name: got.__setitem__(n, o)))
+    with torch.no_grad():
+        ref = unet(x, t, y)
+    for h in hooks:
+        h.remove()
+    taps = {}
+    mine = tp.unet_forward(sd, cfg, x, t, y, taps=taps)
+    assert (mine - ref).abs().max() < 2e-5
+    checked = 0
+    for name, r in got.items():
+        if name in taps and r.ndim == 4:
+            assert (taps[name] - r).abs().max() < 5e-5 * max(1.0, float(r.abs().max())), name
+            checked += 1
+    assert checked > 40
