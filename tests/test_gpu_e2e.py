@@ -1,0 +1,206 @@
+"""GPU (-m gpu): end-to-end parity of the drop-in entry points against the golden fixtures
+generated from the REAL reference (tests/golden/) and the travelling oracle (oracle/torch_port.py).
+
+Tolerances (rel-L2 = |y - y_ref|_2 / |y_ref|_2 vs the fp32 CPU reference):
+  * the product computes with fp16 MFMA operands, fp32 accumulate, fp32 residual stream and
+    fp32 norm/softmax statistics.  The reference's own GPU path (.half() + autocast) measures
+    2.2e-3 on one UNet forward — that is the noise floor of fp16 operands.
+  * UNet forward      <= 5e-3   (expected ~2e-3)
+  * VAE decode        <= 4e-3   (expected ~1.2e-3)
+  * 5-step sampling   <= 2e-2   (error compounds through guidance scale 9)
+north_star's 1e-3 is NOT met with single-pass fp16 operands; see DESIGN.md "Precision".
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from harness import rel_l2
+from oracle import configs, synth, torch_port as tp
+from sd_webui_text2video_amd import samplers, unet as U, vae as V
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+DEV = "cuda:0"
+
+
+def _tiny_inputs():
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 4, 3, 16, 16, generator=g)
+    y = torch.randn(2, 7, configs.TINY_UNET["context_dim"], generator=g)
+    z = torch.randn(2, 4, 8, 8, generator=g)
+    c = torch.randn(1, 7, configs.TINY_UNET["context_dim"], generator=g)
+    uc = torch.randn(1, 7, configs.TINY_UNET["context_dim"], generator=g)
+    return x, torch.tensor([801, 401]), y, z, c, uc
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    net = U.UNetSD(**configs.TINY_UNET)
+    sd = synth.load_synth(net, seed=0)
+    betas = tp.beta_schedule_linear_sd()
+    net.register_schedule(given_betas=betas.numpy())
+    return net, sd, betas
+
+
+def test_tiny_unet_forward_matches_reference_golden(tiny):
+    net, sd, _ = tiny
+    x, t, y, *_ = _tiny_inputs()
+    gold = torch.from_numpy(np.load(os.path.join(GOLD, "tiny.npz"))["unet_eps"])
+    net.debug_taps = True
+    net._programs.clear()
+    eps = net(x.to(DEV), t.to(DEV), y.to(DEV)).float().cpu()
+    net.debug_taps = False
+    r = rel_l2(eps, gold)
+    # localise a failure: per-sub-module comparison against the oracle's taps
+    if not r < 5e-3:
+        taps = {}
+        tp.unet_forward(sd, configs.TINY_UNET, x, t, y, taps=taps)
+        comp = next(iter(net._programs.values()))
+        arena = comp.arena.cpu()
+        lines = []
+        for name, buf in comp.prog.taps.items():
+            if name not in taps:
+                continue
+            rr = taps[name]
+            bf, c, hh, ww = rr.shape
+            dt = torch.float32 if buf.dtype == "f32" else torch.float16
+            flat = arena.view(dt)
+            mine = torch.as_strided(flat, (buf.rows, buf.cols), (buf.ld, 1), buf.ref.off // (4 if buf.dtype == "f32" else 2)).float()
+            mine = mine.view(bf, hh, ww, c).permute(0, 3, 1, 2)
+            lines.append(f"{name}: {rel_l2(mine, rr):.2e}")
+        pytest.fail(f"rel-L2 {r:.3e}\n" + "\n".join(lines))
+    net._programs.clear()
+
+
+def test_tiny_unet_fp16_weights_and_io(tiny):
+    """The webui path: .half() weights, fp16 context, fp32 latent -> fp16 eps (autocast semantics)."""
+    net, sd, _ = tiny
+    x, t, y, *_ = _tiny_inputs()
+    ref = tp.unet_forward(sd, configs.TINY_UNET, x, t, y)
+    net16 = U.UNetSD(**configs.TINY_UNET)
+    net16.load_state_dict(net.state_dict(), strict=True)
+    net16 = net16.half().to(DEV)
+    eps = net16(x.to(DEV), t.to(DEV), y.to(DEV).half())
+    assert eps.dtype == torch.float16
+    assert rel_l2(eps.float().cpu(), ref) < 6e-3
+
+
+def test_weight_mutation_is_picked_up(tiny):
+    """LoRA-style in-place mutation between calls must invalidate the packed weights."""
+    net, sd, _ = tiny
+    x, t, y, *_ = _tiny_inputs()
+    a = net(x.to(DEV), t.to(DEV), y.to(DEV)).float().cpu()
+    w = net.out[2].weight
+    old = w.detach().clone()
+    with torch.no_grad():
+        w.mul_(2.0)
+    b = net(x.to(DEV), t.to(DEV), y.to(DEV)).float().cpu()
+    with torch.no_grad():
+        w.copy_(old)
+    c = net(x.to(DEV), t.to(DEV), y.to(DEV)).float().cpu()
+    bias = net.out[2].bias.detach().view(1, -1, 1, 1, 1)
+    assert rel_l2(b - bias, 2 * (a - bias)) < 2e-3
+    assert torch.equal(a, c)
+
+
+def test_tiny_sampler_matches_reference_golden(tiny):
+    net, sd, betas = tiny
+    *_, c, uc = _tiny_inputs()
+    gold = torch.from_numpy(np.load(os.path.join(GOLD, "tiny.npz"))["sampler_x0"])
+    smp = samplers.Txt2VideoSampler(net, torch.device(DEV), betas=betas, sampler_name="DDIM_Gaussian")
+    smp.progress = False
+    _, noise, shape = smp.get_noise(1, 4, 3, 128, 128, seed=1234)
+    calls = []
+    x0 = smp.sampler.sample(S=4, conditioning=c.to(DEV), unconditional_conditioning=uc.to(DEV), x_T=noise, shape=shape,
+                            unconditional_guidance_scale=9.0, eta=0.0, callback=lambda i: calls.append(i))
+    assert calls == [0, 1, 2, 3]
+    assert rel_l2(x0.float().cpu(), gold) < 2e-2
+    # facade + webui-style step counter
+    x0b = smp.sample_loop(steps=4, strength=None, conditioning=c.to(DEV), unconditional_conditioning=uc.to(DEV),
+                          batch_size=1, shape=shape, noise=noise, guidance_scale=9.0, eta=0.0, sampler_name="DDIM_Gaussian")
+    assert torch.equal(x0b, x0)
+    assert samplers.state.sampling_step == 4
+
+
+def test_sampler_interrupt_raises(tiny):
+    net, sd, betas = tiny
+    *_, c, uc = _tiny_inputs()
+    smp = samplers.Txt2VideoSampler(net, torch.device(DEV), betas=betas, sampler_name="DDIM_Gaussian")
+    smp.progress = False
+    _, noise, shape = smp.get_noise(1, 4, 3, 128, 128, seed=1)
+    samplers.state.interrupted = True
+    try:
+        with pytest.raises(samplers.InterruptedException):
+            smp.sample_loop(steps=3, strength=None, conditioning=c.to(DEV), unconditional_conditioning=uc.to(DEV),
+                            batch_size=1, shape=shape, noise=noise, guidance_scale=9.0, eta=0.0, sampler_name="DDIM_Gaussian")
+    finally:
+        samplers.state.interrupted = False
+
+
+def test_tiny_vae_decode_matches_reference_golden():
+    dd = configs.TINY_VAE_DDCONFIG
+    ae = V.AutoencoderKL(dd, 4)
+    synth.load_synth(ae, seed=3)
+    *_, z, _, _ = _tiny_inputs()
+    gold = torch.from_numpy(np.load(os.path.join(GOLD, "tiny.npz"))["vae_img"])
+    img = ae.decode(z.to(DEV)).float().cpu()
+    assert rel_l2(img, gold) < 4e-3
+    # frames are independent: decoding one frame alone gives the same image (size-independent property)
+    img0 = ae.decode(z[:1].to(DEV)).float().cpu()
+    assert rel_l2(img0, img[:1]) < 1e-3
+
+
+def test_unet_frame_count_edge_cases(tiny):
+    """F=1 (single frame: temporal convs see only padding) and odd spatial sizes."""
+    net, sd, _ = tiny
+    g = torch.Generator().manual_seed(9)
+    for (B, F, H, W, Lc) in [(1, 1, 8, 8, 3), (1, 5, 8, 24, 77), (2, 2, 16, 8, 1)]:
+        x = torch.randn(B, 4, F, H, W, generator=g)
+        y = torch.randn(B, Lc, 1024, generator=g)
+        t = torch.randint(0, 1000, (B,), generator=g)
+        ref = tp.unet_forward(sd, configs.TINY_UNET, x, t, y)
+        eps = net(x.to(DEV), t.to(DEV), y.to(DEV)).float().cpu()
+        assert rel_l2(eps, ref) < 6e-3, (B, F, H, W, Lc)
+
+
+@pytest.fixture(scope="module")
+def full():
+    """ModelScope configuration (1.41 G parameters), seeded synthetic weights."""
+    net = U.UNetSD(**configs.MODELSCOPE_UNET, init_weights=False)
+    synth.load_synth(net, seed=0)
+    betas = tp.beta_schedule_linear_sd()
+    net.register_schedule(given_betas=betas.numpy())
+    return net, betas
+
+
+def test_modelscope_8f_forward_and_sampling_match_reference_golden(full):
+    """BASELINE.json configs[0]: ModelScope, 8 frames @256x256, 5 DDIM steps, vs the reference's CPU fp32 output."""
+    net, betas = full
+    gold = np.load(os.path.join(GOLD, "modelscope_8f.npz"))
+    noise, cond, uncond = synth.synth_inputs(8, 256, 256)
+    eps = net(noise.to(DEV), torch.tensor([801], device=DEV), cond.to(DEV)).float().cpu()
+    r = rel_l2(eps, torch.from_numpy(gold["unet_eps"]))
+    print(f"ModelScope 8f UNet forward rel-L2 vs reference fp32: {r:.3e}")
+    assert r < 5e-3
+    smp = samplers.Txt2VideoSampler(net, torch.device(DEV), betas=betas, sampler_name="DDIM_Gaussian")
+    smp.progress = False
+    _, nz, shape = smp.get_noise(1, 4, 8, 256, 256, seed=1234)
+    assert torch.equal(nz.cpu(), noise)
+    x0 = smp.sample_loop(steps=5, strength=None, conditioning=cond.to(DEV), unconditional_conditioning=uncond.to(DEV),
+                         batch_size=1, shape=shape, noise=nz, guidance_scale=9.0, eta=0.0, sampler_name="DDIM_Gaussian")
+    r = rel_l2(x0.float().cpu(), torch.from_numpy(gold["sampler_x0"]))
+    print(f"ModelScope 8f 5-step DDIM_Gaussian rel-L2 vs reference fp32: {r:.3e}")
+    assert r < 2e-2
+
+
+def test_modelscope_vae_decode_matches_reference_golden():
+    gold = np.load(os.path.join(GOLD, "modelscope_8f.npz"))
+    ae = V.AutoencoderKL(configs.VAE_DDCONFIG, 4, init_weights=False)
+    synth.load_synth(ae, seed=3)
+    x0 = torch.from_numpy(gold["sampler_x0"])
+    img = ae.decode((x0[:, :, 0] / configs.SCALE_FACTOR).to(DEV)).float().cpu()
+    r = rel_l2(img, torch.from_numpy(gold["vae_img_frame0"]))
+    print(f"ModelScope VAE decode 256x256 rel-L2 vs reference fp32: {r:.3e}")
+    assert r < 4e-3

@@ -1,0 +1,296 @@
+"""GPU (-m gpu): per-kernel parity through the C ABI.  Every op kind / template variant is run
+on the MI355X and in the CPU interpreter from identical arena contents; outputs must agree to
+rounding (fp32 accumulate order differs; fp16 outputs differ by <= 1-2 ulp)."""
+import math
+
+import pytest
+import torch
+
+from harness import fill, read, rel_l2, run_both
+from sd_webui_text2video_amd import _lib as L
+from sd_webui_text2video_amd import packing as pk
+from sd_webui_text2video_amd.program import Buf, Program, Ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _g(seed=0):
+    return torch.Generator().manual_seed(seed)
+
+
+def _check(it, got, buf, tol, what=""):
+    a, b = read(got, buf).float(), read(it, buf).float()
+    assert not torch.isnan(a).any(), f"NaN in GPU output {what}"
+    r = rel_l2(a, b)
+    assert r < tol, f"{what}: rel-L2 {r:.3e} (max abs {float((a - b).abs().max()):.3e})"
+
+
+def test_mfma_layout_asymmetric_gemm():
+    """A = identity-like / asymmetric operands: catches a transposed or mis-mapped MFMA fragment."""
+    M, N, K = 128, 128, 64
+    P = Program()
+    a, out = P.alloc(M, K, "f16"), P.alloc(M, N, "f32")
+    w = {"w": torch.zeros(N, K, dtype=torch.float16)}
+    for n in range(N):
+        w["w"][n, n % K] = 1.0 + n / 256.0            # asymmetric: W[n, n%K]
+    P.gemm("g", a, Ref("weight", 0, "w"), N, K, out)
+
+    def init(it):
+        v = it.mat(a.ref, M, K, K, torch.float16, {})
+        v.copy_((torch.arange(M).view(-1, 1) * 0.01 + torch.arange(K).view(1, -1) * 1.0).half())
+    it, got, _, _ = run_both(P, w, {}, init)
+    assert torch.allclose(read(got, out), read(it, out), rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 320, 320), (1000, 640, 1280), (77, 4, 2880 // 9 * 9 // 64 * 64),
+                                   (2, 1280, 320), (256, 960, 320), (130, 8, 8), (4096, 2560, 320)])
+def test_gemm_plain_shapes(M, N, K):
+    P = Program()
+    a, out = P.alloc(M, K, "f16"), P.alloc(M, N, "f32")
+    g = _g(1)
+    w = {"w": (torch.randn(N, K, generator=g) / math.sqrt(K)).half(), "b": torch.randn(N, generator=g)}
+    P.gemm("g", a, Ref("weight", 0, "w"), N, K, out, bias=Ref("weight", 0, "b"))
+    it, got, _, _ = run_both(P, w, {}, lambda it: fill(it, a, g))
+    _check(it, got, out, 2e-5, f"gemm {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("out_dtype,act,with_res,with_rowbias", [("f16", 0, False, False), ("f32", 1, True, False),
+                                                                 ("f16", 0, True, True), ("f32", 0, False, True)])
+def test_gemm_epilogues(out_dtype, act, with_res, with_rowbias):
+    M, N, K, rpb = 384, 320, 640, 96
+    P = Program()
+    g = _g(2)
+    a, out = P.alloc(M, K, "f16"), P.alloc(M, N, out_dtype)
+    res = P.alloc(M, N, "f32") if with_res else None
+    rb = P.alloc(M // rpb, 2 * N, "f32") if with_rowbias else None
+    w = {"w": (torch.randn(N, K, generator=g) / math.sqrt(K)).half(), "b": torch.randn(N, generator=g)}
+    P.gemm("g", a, Ref("weight", 0, "w"), N, K, out, bias=Ref("weight", 0, "b"), act=act, residual=res,
+           rowbias=rb.col_slice(N, 2 * N) if rb is not None else None, rows_per_batch=rpb if rb is not None else 0)
+
+    def init(it):
+        fill(it, a, g)
+        if res is not None: fill(it, res, g)
+        if rb is not None: fill(it, rb, g)
+    it, got, _, _ = run_both(P, w, {}, init)
+    _check(it, got, out, 1e-3 if out_dtype == "f16" else 2e-5, "epilogue")
+
+
+def test_gemm_geglu_epilogue():
+    M, C = 200, 320
+    P = Program()
+    g = _g(3)
+    a, out = P.alloc(M, C, "f16"), P.alloc(M, 4 * C, "f16")
+    wsrc, bsrc = torch.randn(8 * C, C, generator=g) / math.sqrt(C), torch.randn(8 * C, generator=g) * 0.1
+    perm = pk.geglu_perm(4 * C)
+    w = {"w": wsrc[perm].half(), "b": bsrc[perm].contiguous()}
+    P.gemm("g", a, Ref("weight", 0, "w"), 8 * C, C, out, bias=Ref("weight", 0, "b"), epi=L.EPI_GEGLU)
+    it, got, _, _ = run_both(P, w, {}, lambda it: fill(it, a, g))
+    _check(it, got, out, 1e-3, "geglu")
+    # and against the unpermuted definition: x * gelu(gate)
+    x = read(it, a).float()
+    hg = x @ wsrc.half().float().t() + bsrc
+    ref = hg[:, :4 * C] * torch.nn.functional.gelu(hg[:, 4 * C:])
+    assert rel_l2(read(got, out).float(), ref) < 2e-3
+
+
+@pytest.mark.parametrize("split", [2, 5, 16])
+def test_gemm_split_k(split):
+    M, N, K = 96, 1280, 5760
+    P = Program()
+    P.target_blocks = 10 * split * 2 + 1          # steer the heuristic
+    g = _g(4)
+    a, out, res = P.alloc(M, K, "f16"), P.alloc(M, N, "f32"), P.alloc(M, N, "f32")
+    w = {"w": (torch.randn(N, K, generator=g) / math.sqrt(K)).half(), "b": torch.randn(N, generator=g)}
+    op = P.gemm("g", a, Ref("weight", 0, "w"), N, K, out, bias=Ref("weight", 0, "b"), residual=res)
+    assert op.i[19] > 1
+
+    def init(it):
+        fill(it, a, g); fill(it, res, g)
+    it, got, _, _ = run_both(P, w, {}, init)
+    _check(it, got, out, 2e-5, f"split-K {op.i[19]}")
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride,up", [(3, 16, 16, 64, 128, 1, 0), (2, 8, 8, 128, 64, 2, 0),
+                                                      (2, 6, 10, 64, 64, 1, 1), (5, 4, 4, 320, 320, 1, 0),
+                                                      (2, 9, 7, 64, 4, 1, 0)])
+def test_conv3x3_gather(B, H, W, Cin, Cout, stride, up):
+    Ho, Wo = (2 * H, 2 * W) if up else ((H + 1) // 2, (W + 1) // 2) if stride == 2 else (H, W)
+    P = Program()
+    g = _g(5)
+    a, out = P.alloc(B * H * W, Cin, "f16"), P.alloc(B * Ho * Wo, Cout, "f32")
+    wt = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    w = {"w": pk.conv3x3(wt).half(), "b": torch.randn(Cout, generator=g)}
+    P.gemm("c", a, Ref("weight", 0, "w"), Cout, 9 * Cin, out, bias=Ref("weight", 0, "b"), gather=L.GATHER_CONV3X3,
+           conv=dict(Hin=H, Win=W, Cin=Cin, stride=stride, up=up, Hout=Ho, Wout=Wo))
+    it, got, _, _ = run_both(P, w, {}, lambda it: fill(it, a, g))
+    _check(it, got, out, 2e-5, "conv3x3")
+    # independent check against torch's own convolution
+    x = read(it, a).float().view(B, H, W, Cin).permute(0, 3, 1, 2)
+    if up:
+        x = torch.nn.functional.interpolate(x, scale_factor=2, mode="nearest")
+    ref = torch.nn.functional.conv2d(x, wt.half().float(), w["b"], stride=stride, padding=1)
+    mine = read(got, out).view(B, Ho, Wo, Cout).permute(0, 3, 1, 2)
+    assert rel_l2(mine, ref) < 1e-4
+
+
+def test_conv3x3_c8_stem():
+    B, H, W, Cout = 3, 16, 16, 320
+    P = Program()
+    g = _g(6)
+    a, out = P.alloc(B * H * W, 8, "f16"), P.alloc(B * H * W, Cout, "f32")
+    wt = torch.randn(Cout, 4, 3, 3, generator=g) / 6.0
+    w = {"w": pk.conv3x3(wt, 8).half(), "b": torch.randn(Cout, generator=g)}
+    P.gemm("c", a, Ref("weight", 0, "w"), Cout, 72, out, bias=Ref("weight", 0, "b"), gather=L.GATHER_CONV3X3_C8,
+           conv=dict(Hin=H, Win=W, Cin=8, stride=1, up=0, Hout=H, Wout=W))
+
+    def init(it):
+        v = fill(it, a, g)
+        v[:, 4:] = 0
+    it, got, _, _ = run_both(P, w, {}, init)
+    _check(it, got, out, 2e-5, "stem conv")
+    x = read(it, a).float()[:, :4].reshape(B, H, W, 4).permute(0, 3, 1, 2)
+    ref = torch.nn.functional.conv2d(x, wt.half().float(), w["b"], padding=1)
+    assert rel_l2(read(got, out).view(B, H, W, Cout).permute(0, 3, 1, 2), ref) < 1e-4
+
+
+@pytest.mark.parametrize("B,F,HW,C", [(2, 5, 16, 64), (1, 24, 4, 128), (2, 3, 64, 320)])
+def test_temporal_conv_gather(B, F, HW, C):
+    P = Program()
+    g = _g(7)
+    M = B * F * HW
+    a, out, res = P.alloc(M, C, "f16"), P.alloc(M, C, "f32"), P.alloc(M, C, "f32")
+    wt = torch.randn(C, C, 3, 1, 1, generator=g) / math.sqrt(3 * C)
+    w = {"w": pk.tconv3(wt).half(), "b": torch.randn(C, generator=g)}
+    P.gemm("t", a, Ref("weight", 0, "w"), C, 3 * C, out, bias=Ref("weight", 0, "b"), gather=L.GATHER_TCONV3,
+           conv=dict(F=F, HW=HW, Cin=C), residual=res)
+
+    def init(it):
+        fill(it, a, g); fill(it, res, g)
+    it, got, _, _ = run_both(P, w, {}, init)
+    _check(it, got, out, 2e-5, "tconv")
+    x = read(it, a).float().view(B, F, HW, 1, C).permute(0, 4, 1, 2, 3)
+    ref = torch.nn.functional.conv3d(x, wt.half().float(), w["b"], padding=(1, 0, 0))
+    ref = ref.permute(0, 2, 3, 4, 1).reshape(M, C) + read(it, res)
+    assert rel_l2(read(got, out), ref) < 1e-4
+
+
+@pytest.mark.parametrize("n_inst,rows,C,dt,silu", [(6, 256, 320, "f32", True), (2, 24 * 64, 640, "f32", True),
+                                                   (4, 16, 1280, "f32", False), (3, 64, 64, "f16", True),
+                                                   (2, 100, 2560, "f32", True), (2, 4096, 128, "f32", True)])
+def test_groupnorm(n_inst, rows, C, dt, silu):
+    P = Program()
+    P.begin()
+    g = _g(8)
+    x, out = P.alloc(n_inst * rows, C, dt), P.alloc(n_inst * rows, C, "f16")
+    out2 = P.alloc(n_inst * rows, C, "f16")
+    w = {"g": 1 + 0.1 * torch.randn(C, generator=g), "b": 0.1 * torch.randn(C, generator=g)}
+    P.groupnorm("gn", x, Ref("weight", 0, "g"), Ref("weight", 0, "b"), out, n_inst=n_inst, eps=1e-5, silu=silu)
+    P.groupnorm("gn2", x, Ref("weight", 0, "g"), Ref("weight", 0, "b"), out2, n_inst=n_inst, eps=1e-6, silu=silu)   # ping-pong buffer
+    P.finish()
+
+    def init(it):
+        v = fill(it, x, g, scale=2.0)
+        v += 0.7
+    it, got, _, _ = run_both(P, w, {}, init)
+    _check(it, got, out, 1e-3, "groupnorm")
+    _check(it, got, out2, 1e-3, "groupnorm (second, other stats buffer)")
+
+
+@pytest.mark.parametrize("M,C", [(1000, 320), (77, 512), (513, 640), (64, 1280), (10, 64)])
+def test_layernorm(M, C):
+    P = Program()
+    g = _g(9)
+    x, out = P.alloc(M, C, "f32"), P.alloc(M, C, "f16")
+    w = {"g": 1 + 0.1 * torch.randn(C, generator=g), "b": 0.1 * torch.randn(C, generator=g)}
+    P.layernorm("ln", x, Ref("weight", 0, "g"), Ref("weight", 0, "b"), out)
+    it, got, _, _ = run_both(P, w, {}, lambda it: fill(it, x, g, 3.0))
+    _check(it, got, out, 1e-3, "layernorm")
+
+
+@pytest.mark.parametrize("kind,B,F,hw,heads,Lc", [("spatial", 1, 2, 1024, 5, 0), ("spatial", 2, 3, 256, 2, 0),
+                                                  ("spatial", 1, 2, 16, 4, 0), ("spatial", 1, 1, 144, 3, 0),
+                                                  ("cross", 2, 3, 64, 2, 77), ("cross", 1, 2, 256, 5, 7),
+                                                  ("temporal", 2, 24, 16, 3, 0), ("temporal", 1, 125, 4, 2, 0),
+                                                  ("temporal", 1, 3, 64, 8, 0)])
+def test_attention(kind, B, F, hw, heads, Lc):
+    inner = heads * 64
+    M = B * F * hw
+    P = Program()
+    g = _g(10)
+    scale = 64 ** -0.5
+    if kind == "cross":
+        q, kv, o = P.alloc(M, inner, "f16"), P.alloc(B * Lc, 2 * inner + 64, "f16"), P.alloc(M, inner, "f16")
+        k, v = kv.col_slice(64, 64 + inner), kv.col_slice(64 + inner, 64 + 2 * inner)
+        P.attention("a", q.ref, k.ref, v.ref, o.ref, nq=hw, nk=Lc, heads=heads, b_outer=B, b_inner=F,
+                    q_strides=(inner, F * hw * inner, hw * inner), kv_strides=(kv.ld, Lc * kv.ld, 0),
+                    o_strides=(inner, F * hw * inner, hw * inner), scale=scale)
+        bufs = [q, kv]
+    else:
+        qkv, o = P.alloc(M, 3 * inner, "f16"), P.alloc(M, inner, "f16")
+        ld = 3 * inner
+        q, k, v = qkv.col_slice(0, inner), qkv.col_slice(inner, 2 * inner), qkv.col_slice(2 * inner, 3 * inner)
+        if kind == "spatial":
+            P.attention("a", q.ref, k.ref, v.ref, o.ref, nq=hw, nk=hw, heads=heads, b_outer=B * F, b_inner=1,
+                        q_strides=(ld, hw * ld, 0), kv_strides=(ld, hw * ld, 0), o_strides=(inner, hw * inner, 0), scale=scale)
+        else:
+            P.attention("a", q.ref, k.ref, v.ref, o.ref, nq=F, nk=F, heads=heads, b_outer=B, b_inner=hw,
+                        q_strides=(hw * ld, F * hw * ld, ld), kv_strides=(hw * ld, F * hw * ld, ld),
+                        o_strides=(hw * inner, F * hw * inner, inner), scale=scale)
+        bufs = [qkv]
+
+    def init(it):
+        for b in bufs:
+            fill(it, b, g, 1.5)
+    it, got, _, _ = run_both(P, {}, {}, init)
+    _check(it, got, o, 3e-3, f"attention {kind}")
+
+
+def test_attention_peaked_softmax():
+    """Large logits: exercises the running-max rescale path of the online softmax."""
+    hw, heads = 300, 1
+    P = Program()
+    g = _g(11)
+    qkv, o = P.alloc(hw, 192, "f16"), P.alloc(hw, 64, "f16")
+    q, k, v = qkv.col_slice(0, 64), qkv.col_slice(64, 128), qkv.col_slice(128, 192)
+    P.attention("a", q.ref, k.ref, v.ref, o.ref, nq=hw, nk=hw, heads=1, b_outer=1, b_inner=1, q_strides=(192, 0, 0),
+                kv_strides=(192, 0, 0), o_strides=(64, 0, 0), scale=0.125)
+
+    def init(it):
+        t = fill(it, qkv, g, 1.0)
+        t[:, :128] *= 6.0           # |logit| up to ~ 6*6*8 -> strongly peaked rows, late maxima
+        t[250:, 64:128] *= 2.0
+    it, got, _, _ = run_both(P, {}, {}, init)
+    _check(it, got, o, 5e-3, "peaked attention")
+
+
+def test_softmax_rows():
+    P = Program()
+    g = _g(12)
+    x, out = P.alloc(300, 1024, "f32"), P.alloc(300, 1024, "f16")
+    P.softmax("s", x, out, 0.044)
+    it, got, _, _ = run_both(P, {}, {}, lambda it: fill(it, x, g, 30.0))
+    _check(it, got, out, 1e-3, "softmax")
+
+
+def test_layout_time_embed_copy_ddim():
+    B, C, F, HW = 2, 4, 3, 64
+    P = Program()
+    g = _g(13)
+    tok = P.alloc(B * F * HW, 8, "f16")
+    P.ncthw_to_cl("in", Ref("ext", L.EXT_X), "f32", tok, B=B, C=C, F=F, HW=HW, scale=0.5)
+    y32 = P.alloc(B * F * HW, 8, "f32")
+    P.copy2d("cast", tok, y32, act=1)
+    P.cl_to_ncthw("out", y32, Ref("ext", L.EXT_OUT), "f16", B=B, C=C, F=F, HW=HW)
+    te = P.alloc(B, 320, "f16")
+    w = {"fr": torch.pow(10000, -torch.arange(160).float().div(160))}
+    P.time_embed("te", Ref("ext", L.EXT_T), Ref("weight", 0, "fr"), te)
+    P.ddim_step("s", C=C, inner=F * HW, guided=2, eps_dtype="f16", x_dtype="f32")
+    P.ops[-1].f[0:6] = [1.3, 0.83, 0.9, 0.43, 0.2, 9.0]
+    ext = {L.EXT_X: torch.randn(B, C, F, HW, generator=g), L.EXT_OUT: torch.zeros(B, C, F, HW, dtype=torch.float16),
+           L.EXT_T: torch.tensor([981.0, 1.0]), L.EXT_XT: torch.randn(1, C, F * HW, generator=g),
+           L.EXT_EPS: torch.randn(2, C, F * HW, generator=g).half(), L.EXT_NOISE: torch.randn(1, C, F * HW, generator=g),
+           L.EXT_XT_OUT: torch.zeros(1, C, F * HW)}
+    it, got, ext_ref, ext_got = run_both(P, w, ext, lambda it: None)
+    assert rel_l2(ext_got[L.EXT_OUT].float(), ext_ref[L.EXT_OUT].float()) < 1e-3
+    assert rel_l2(read(got, te).float(), read(it, te).float()) < 2e-3
+    assert rel_l2(ext_got[L.EXT_XT_OUT], ext_ref[L.EXT_XT_OUT]) < 1e-6

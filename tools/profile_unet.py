@@ -1,0 +1,102 @@
+"""Per-op timing of one UNet step on the GPU (HIP events around every op of the denoise program).
+Usage: python tools/profile_unet.py [frames] [latent_h] [latent_w] [batch]"""
+import collections
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import configs  # noqa: E402  (hyper-parameters only)
+from sd_webui_text2video_amd import _lib as L, unet as U  # noqa: E402
+
+
+def random_weights_(module, seed=0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    with torch.no_grad():
+        for n, p in module.named_parameters():
+            if p.ndim >= 2:
+                fan_in = p[0].numel()
+                p.normal_(0, 1.0 / fan_in ** 0.5, generator=g)
+            elif n.endswith("weight"):
+                p.normal_(1.0, 0.1, generator=g)
+            else:
+                p.normal_(0.0, 0.05, generator=g)
+
+
+def main():
+    F = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+    H = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+    W = int(sys.argv[3]) if len(sys.argv) > 3 else 32
+    B = int(sys.argv[4]) if len(sys.argv) > 4 else 2
+    dev = torch.device("cuda:0")
+    print(L.device_info())
+    t0 = time.time()
+    net = U.UNetSD(**configs.MODELSCOPE_UNET, init_weights=False).half().to(dev)
+    random_weights_(net)
+    print(f"model on device in {time.time() - t0:.1f}s")
+    x = torch.randn(B, 4, F, H, W, device=dev)
+    y = torch.randn(B, 77, 1024, device=dev, dtype=torch.float16)
+    t = torch.full((B,), 500, device=dev)
+    for _ in range(2):
+        out = net(x, t, y)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()
+    n = 5
+    t0 = time.time()
+    for _ in range(n):
+        out = net(x, t, y)
+    torch.cuda.synchronize()
+    wall = (time.time() - t0) / n * 1e3
+    net.auto_refresh = False
+    t0 = time.time()
+    for _ in range(n):
+        out = net(x, t, y)
+    torch.cuda.synchronize()
+    wall2 = (time.time() - t0) / n * 1e3
+    _, ms, prog = net.forward_timed(x, t, y)
+    _, ms, prog = net.forward_timed(x, t, y)
+    tot = sum(ms)
+    flops = prog.total_flops()
+    print(f"geometry b{B} f{F} {H}x{W}: ops {len(ms)}  wall/forward {wall:.2f} ms (no auto-refresh {wall2:.2f} ms)  "
+          f"sum(op events) {tot:.2f} ms")
+    print(f"algorithmic {flops / 1e12:.3f} TFLOP -> {flops / (wall2 * 1e-3) / 1e12:.1f} TF/s wall, "
+          f"{flops / (tot * 1e-3) / 1e12:.1f} TF/s by events; arena {prog.arena.high / 2**30:.2f} GiB")
+    kinds = collections.defaultdict(lambda: [0.0, 0, 0.0])
+    names = {1: "gemm", 2: "groupnorm", 3: "layernorm", 4: "attention", 5: "softmax", 6: "to_cl", 7: "from_cl",
+             8: "time_embed", 9: "copy2d", 10: "ddim", 11: "memset"}
+    for op, m in zip(prog.ops, ms):
+        k = names[op.kind]
+        if op.kind == 1:
+            k = "gemm/" + {0: "plain", 1: "conv3x3", 2: "tconv", 3: "conv_c8"}[op.meta["gather"]]
+        kinds[k][0] += m; kinds[k][1] += 1; kinds[k][2] += op.flops
+    print(f"{'kind':16s} {'ms':>9s} {'%':>6s} {'count':>6s} {'TF/s':>8s}")
+    for k, (m, c, fl) in sorted(kinds.items(), key=lambda kv: -kv[1][0]):
+        print(f"{k:16s} {m:9.3f} {100 * m / tot:6.1f} {c:6d} {fl / max(m, 1e-9) / 1e9:8.1f}")
+    shapes = collections.defaultdict(lambda: [0.0, 0, 0.0])
+    for op, m in zip(prog.ops, ms):
+        if op.kind == 1:
+            key = (op.meta["gather"], op.meta["M"], op.meta["N"], op.meta["K"], op.meta["split"], op.meta["epi"])
+            shapes[key][0] += m; shapes[key][1] += 1; shapes[key][2] += op.flops
+    print("top GEMM shapes (gather, M, N, K, split, epi): ms total, count, TF/s")
+    for key, (m, c, fl) in sorted(shapes.items(), key=lambda kv: -kv[1][0])[:40]:
+        print(f"  {str(key):44s} {m:8.3f} {c:4d} {fl / max(m, 1e-9) / 1e9:8.1f}")
+    att = collections.defaultdict(lambda: [0.0, 0, 0.0])
+    for op, m in zip(prog.ops, ms):
+        if op.kind == 4:
+            key = (op.i[0], op.i[1], op.i[2], op.i[3] * op.i[4])
+            att[key][0] += m; att[key][1] += 1; att[key][2] += op.flops
+    print("attention (nq, nk, heads, batch): ms total, count, TF/s")
+    for key, (m, c, fl) in sorted(att.items(), key=lambda kv: -kv[1][0]):
+        print(f"  {str(key):32s} {m:8.3f} {c:4d} {fl / max(m, 1e-9) / 1e9:8.1f}")
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", f"unet_ops_b{B}_f{F}_{H}x{W}.json"), "w") as f:
+        json.dump([dict(name=op.name, kind=op.kind, ms=m, flops=op.flops, meta={k: v for k, v in op.meta.items() if k != "conv"})
+                   for op, m in zip(prog.ops, ms)], f)
+
+
+if __name__ == "__main__":
+    main()
