@@ -1,0 +1,191 @@
+#!/usr/bin/env python
+"""bench.py — denoised frames/sec (UNet sampling loop + VAE decode), BASELINE.json's metric.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is ONE whole video through the hot path behind the reference's entry points:
+`TextToVideoSynthesis.infer_conditioned` = Txt2VideoSampler.sample_loop (50 DDIM_Gaussian steps,
+classifier-free guidance 9, eta 0; cond+uncond batched => 50 b=2 UNet forwards + 50 fused
+update kernels) + batched VAE decode of all frames + uint8 conversion, all on device
+(inputs — noise, conditioning, weights — are resident in HBM before the timed region).
+Workload at N=1: BASELINE.json configs[1] — ModelScope t2v fp16, 24 frames @256x256.
+Weights are random-init of the exact ModelScope architecture (no checkpoints offline).
+
+Prints ONE JSON line (rank 0) with the driver's fields plus
+  roofline     — dominant kernel = the MFMA implicit-GEMM family (conv3x3 / temporal conv /
+                 linear): algorithmic FLOPs of its launches in one UNet step / their summed
+                 durations, measured live with HIP events on the launch stream
+  cpu_baseline — the oracle port (oracle/torch_port.py, fp32, torch CPU) timed on the host
+                 cores on a bounded sample of the same workload, extrapolated to frames/s
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = 2500.0      # dense fp16/bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+UNET_TFLOP_PER_FRAME = 0.3057  # algorithmic 2*MAC per frame per forward @256x256
+VAE_TFLOP_PER_FRAME = 0.622
+
+
+def random_weights_(module, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    with torch.no_grad():
+        for n, p in module.named_parameters():
+            if p.ndim >= 2:
+                p.normal_(0, 1.0 / p[0].numel() ** 0.5, generator=g)
+            elif n.endswith("weight"):
+                p.normal_(1.0, 0.1, generator=g)
+            else:
+                p.normal_(0.0, 0.05, generator=g)
+
+
+def cpu_baseline(unet, vae, cfg, ddcfg, frames, ddim_steps, max_seconds=30.0):
+    """Time the oracle port on the host cores: ONE UNet forward (b=1, 2 frames @256x256) and ONE
+    VAE frame decode, fp32.  frames/s for the full workload is extrapolated as
+    F / (2*steps*F*t_unet_per_frame + F*t_vae_frame) (UNet cost is linear in F)."""
+    from oracle import torch_port as tp
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = {k: v.detach().float().cpu() for k, v in unet.state_dict().items() if v.is_floating_point()}
+    fs = 2
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 4, fs, 32, 32, generator=g)
+    y = torch.randn(1, 77, 1024, generator=g)
+    t0 = time.time()
+    with torch.no_grad():
+        tp.unet_forward(sd, cfg, x, torch.tensor([500]), y)
+    t_unet = time.time() - t0
+    del sd
+    vsd = {k: v.detach().float().cpu() for k, v in vae.state_dict().items()}
+    z = torch.randn(1, 4, 32, 32, generator=g)
+    t0 = time.time()
+    with torch.no_grad():
+        tp.vae_decode(vsd, ddcfg, z)
+    t_vae = time.time() - t0
+    per_frame = 2 * ddim_steps * (t_unet / fs) + t_vae
+    return {"value": round(1.0 / per_frame, 5), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/torch_port.py fp32 on {cores} host threads: 1 UNet forward b=1 {fs}f@256x256 "
+                      f"({t_unet:.2f}s) + 1 VAE frame decode ({t_vae:.2f}s); extrapolated to "
+                      f"{frames}f x {ddim_steps} steps x 2 (CFG) + decode"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2, help="timed videos")
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=24)
+    ap.add_argument("--height", type=int, default=256)
+    ap.add_argument("--width", type=int, default=256)
+    ap.add_argument("--ddim-steps", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl")      # "nccl" is RCCL on ROCm
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from oracle import configs            # hyper-parameter dicts only
+    from sd_webui_text2video_amd import parallel, pipeline, unet as U, vae as V
+
+    cfg, ddcfg = configs.MODELSCOPE_UNET, configs.VAE_DDCONFIG
+    net = U.UNetSD(**cfg, init_weights=False).half().to(dev).eval()
+    random_weights_(net, 0)
+    ae = V.AutoencoderKL(ddcfg, 4, init_weights=False).half().to(dev).eval()
+    random_weights_(ae, 3)
+    pipe = pipeline.TextToVideoSynthesis(sd_model=net, autoencoder=ae, device=dev)
+    pipe.diffusion.progress = False
+    g = torch.Generator().manual_seed(1)
+    cond = torch.randn(1, 77, 1024, generator=g).half().to(dev)
+    uncond = torch.randn(1, 77, 1024, generator=g).half().to(dev)
+
+    # weak scaling: every rank group generates its own frames; N=1 is the configs[1] workload.
+    runner = parallel.make_runner(pipe, world, rank, frames=args.frames, height=args.height, width=args.width,
+                                  ddim_steps=args.ddim_steps, guidance=9.0)
+
+    def one_video(seed):
+        return runner(cond, uncond, seed)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        one_video(1234 + i)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = one_video(1234 + i)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    assert out is not None and out.dtype == torch.uint8
+
+    total_frames = runner.frames_per_video_all_ranks * args.steps
+    value = total_frames / elapsed
+    ms_per_step = elapsed / args.steps * 1e3
+
+    result = {
+        "metric": "denoised frames/sec (UNet+VAE), ModelScope 24f@256x256",
+        "value": round(value, 4), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f16", "data": "synthetic",
+        "config": {"workload": f"ModelScope t2v fp16 (random-init 1.41B UNetSD + VAE decoder), {args.frames} frames @ "
+                               f"{args.width}x{args.height}, {args.ddim_steps} DDIM_Gaussian steps, CFG 9.0 "
+                               f"(BASELINE.json configs[1]); one step = one whole video",
+                   "frames_per_video": runner.frames_per_video_all_ranks, "parallelism": runner.describe},
+    }
+
+    if rank == 0:
+        # ---- live roofline of the dominant kernel (HIP events on the launch stream) -------------
+        F_loc = runner.unet_frames
+        x = torch.randn(runner.unet_batch, 4, F_loc, args.height // 8, args.width // 8, device=dev)
+        y = torch.cat([cond, uncond], 0)[: runner.unet_batch].contiguous()
+        t = torch.full((runner.unet_batch,), 500, device=dev)
+        net.forward_timed(x, t, y)
+        _, ms, prog = net.forward_timed(x, t, y)
+        gemm_ms = sum(m for op, m in zip(prog.ops, ms) if op.kind == 1)
+        gemm_fl = sum(op.flops for op in prog.ops if op.kind == 1)
+        n_gemm = sum(1 for op in prog.ops if op.kind == 1)
+        step_ms = sum(ms)
+        achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12
+        result["roofline"] = {
+            "bound": "mfma", "kernel": "gemm_kernel<BM,BN,WM,WN,GATHER> (implicit-GEMM conv3x3 / temporal conv / linear)",
+            "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
+            "traffic": None,
+            "launches_per_unet_step": n_gemm, "avg_launch_us": round(gemm_ms / n_gemm * 1e3, 2),
+            "flops_per_unet_step_T": round(gemm_fl / 1e12, 3),
+            "unet_step_ms_events": round(step_ms, 3),
+            "unet_step_tflops_all_kernels": round(prog.total_flops() / (step_ms * 1e-3) / 1e12, 1),
+            "unet_step_frac_of_peak": round(prog.total_flops() / (step_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+        }
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(net, ae, cfg, ddcfg, args.frames, args.ddim_steps)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -19,7 +19,7 @@ F16, F32 = 0, 1
 EXT_SLOTS = 16
 EXT_X, EXT_T, EXT_CTX, EXT_OUT, EXT_XT, EXT_XT_OUT, EXT_NOISE, EXT_EPS = 1, 2, 3, 4, 5, 6, 7, 8
 OP_NI, OP_NF, OP_NP = 24, 8, 8
-GN_STATS_LEN = 4096 * 32 * 2     # doubles per ping-pong statistics buffer (csrc/norm.hip)
+GN_ROWS_PER_BLOCK = 64           # T2V_GN_ROWS_PER_BLOCK
 
 EXPORTS = [
     "t2v_abi_version", "t2v_last_error", "t2v_device_info", "t2v_run_ops", "t2v_plan_create",
@@ -49,6 +49,9 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise T2VError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # torch ships its own libamdhip64; import it FIRST so that this library binds to the same
+    # HIP runtime instance (two runtimes in one process => "no ROCm-capable device").
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     vp, u64p = ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)
     opp = ctypes.POINTER(T2VOp)

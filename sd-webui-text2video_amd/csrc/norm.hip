@@ -10,9 +10,10 @@
 // A statistics "instance" is a contiguous run of `rows` token rows (one frame, or all F frames
 // of one sample) x one of 32 channel groups.  Input is the fp32 (or fp16) residual stream
 // [rows, C]; output is fp16 — the operand format of the following MFMA GEMM.
-//   pass 1: per-thread fp32 partial sums over a row chunk -> LDS per-channel -> per-group
-//           fp64 atomics into stats[inst][group] = {sum, sumsq}
-//   pass 2: normalise + affine (+SiLU), 4 channels per thread, 8-byte stores
+//   pass 1: per-thread fp32 partial sums over a 64-row chunk -> LDS -> ordered fp64 fold per
+//           group -> one partial per (instance, block, group); no atomics (bitwise reproducible)
+//   pass 2: one wave per (instance, group): ordered fold of the partials -> {mean, rstd}
+//   pass 3: normalise + affine (+SiLU), 4 channels per thread, 8-byte stores
 // HBM-bound: 4 B + 4 B read, 2 B written per element.
 #include "t2v_kernels.h"
 
@@ -30,26 +31,26 @@ template <> struct Load4<f16> {
   }
 };
 
-constexpr int GN_ROWS_PER_BLOCK = 64;  // rows of one instance reduced by one workgroup
+constexpr int GN_ROWS_PER_BLOCK = T2V_GN_ROWS_PER_BLOCK;  // rows of one instance reduced by one workgroup
 
-// grid: (ceil(rows / GN_ROWS_PER_BLOCK), n_inst)
+// Pass 1 — grid (nblk, n_inst).  Deterministic: per-thread fp32 partials over <= 64 rows are
+// parked in LDS [R][C]; 32 threads then fold replicas + the channels of their group in a fixed
+// order in fp64 and store ONE partial per (instance, block, group).  No atomics anywhere, so
+// results are bitwise reproducible run to run.
 template <typename T>
-__global__ __launch_bounds__(256) void gn_stats_kernel(const T* x, double* stats, int rows, int C, int ld,
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* x, double* partials, int rows, int C, int ld,
                                                        int groups) {
-  extern __shared__ float sh[];  // [2][C] per-channel sum / sumsq
-  float* csum = sh;
-  float* csq = sh + C;
+  extern __shared__ float sh[];  // [2][R][C]
   const int tid = threadIdx.x;
-  for (int c = tid; c < 2 * C; c += 256) sh[c] = 0.f;
-  __syncthreads();
   const int inst = blockIdx.y;
   const int r0 = blockIdx.x * GN_ROWS_PER_BLOCK;
   const int r1 = min(rows, r0 + GN_ROWS_PER_BLOCK);
   const T* base = x + ((size_t)inst * rows) * ld;
   const int cv = C >> 2;  // float4 units per row
+  const int R = cv <= 256 ? 256 / cv : 1;
+  float* psum = sh;
+  float* psq = sh + R * C;
   if (cv <= 256) {
-    // R row-replicas, each thread owns one channel quad
-    const int R = 256 / cv;
     if (tid < R * cv) {
       const int c4 = (tid % cv) * 4, rr = tid / cv;
       f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
@@ -59,10 +60,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* x, double* stats
         q += v * v;
       }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        atomicAdd(&csum[c4 + e], s[e]);
-        atomicAdd(&csq[c4 + e], q[e]);
-      }
+      for (int e = 0; e < 4; ++e) { psum[rr * C + c4 + e] = s[e]; psq[rr * C + c4 + e] = q[e]; }
     }
   } else {
     for (int u = tid; u < cv; u += 256) {
@@ -74,31 +72,51 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* x, double* stats
         q += v * v;
       }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { csum[c4 + e] = s[e]; csq[c4 + e] = q[e]; }
+      for (int e = 0; e < 4; ++e) { psum[c4 + e] = s[e]; psq[c4 + e] = q[e]; }
     }
   }
   __syncthreads();
   if (tid < groups) {
     const int cpg = C / groups;
     double s = 0.0, q = 0.0;
-    for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { s += (double)csum[c]; q += (double)csq[c]; }
-    double* st = stats + ((size_t)inst * groups + tid) * 2;
-    atomicAdd(st, s);
-    atomicAdd(st + 1, q);
+    for (int rr = 0; rr < R; ++rr)
+      for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { s += (double)psum[rr * C + c]; q += (double)psq[rr * C + c]; }
+    double* st = partials + (((size_t)inst * gridDim.x + blockIdx.x) * groups + tid) * 2;
+    st[0] = s;
+    st[1] = q;
   }
 }
 
-// grid-stride over float4 units of the whole [n_inst*rows, C] tensor
+// Pass 2 — one wave per (instance, group): ordered fold of the block partials -> {mean, rstd}.
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const double* partials, float* finals, int n_inst, int nblk,
+                                                          int groups, double inv_n, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);  // (inst, group) pair
+  if (idx >= n_inst * groups) return;
+  const int inst = idx / groups, g = idx - inst * groups;
+  double s = 0.0, q = 0.0;
+  for (int b = lane; b < nblk; b += 64) {
+    const double* st = partials + (((size_t)inst * nblk + b) * groups + g) * 2;
+    s += st[0];
+    q += st[1];
+  }
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+  if (lane == 0) {
+    const double m = s * inv_n;
+    double var = q * inv_n - m * m;
+    var = var < 0.0 ? 0.0 : var;
+    finals[2 * idx] = (float)m;
+    finals[2 * idx + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
+// Pass 3 — grid-stride over float4 units of the whole [n_inst*rows, C] tensor
 template <typename T>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const T* x, const double* stats, const float* gamma,
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* x, const float* finals, const float* gamma,
                                                        const float* beta, f16* out, int n_inst, int rows, int C,
-                                                       int ld_in, int ld_out, int groups, float eps, int silu,
-                                                       double* stats_next, int stats_next_len) {
-  // housekeeping for the ping-pong statistics scratch: zero the *other* buffer for the next op
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < stats_next_len; i += gridDim.x * 256) stats_next[i] = 0.0;
+                                                       int ld_in, int ld_out, int groups, int silu) {
   const int cv = C >> 2;
   const int cpg = C / groups;
-  const double inv_n = 1.0 / ((double)rows * cpg);
   const long total = (long)n_inst * rows * cv;
   for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < total; u += (long)gridDim.x * 256) {
     const long row = u / cv;
@@ -108,21 +126,11 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* x, const double*
     const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c4);
     const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c4);
     f16x4 o;
-    int gprev = -1;
-    float mean = 0.f, rstd = 0.f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int grp = (c4 + e) / cpg;
-      if (grp != gprev) {
-        const double* st = stats + ((size_t)inst * groups + grp) * 2;
-        const double m = st[0] * inv_n;
-        double var = st[1] * inv_n - m * m;
-        var = var < 0.0 ? 0.0 : var;
-        mean = (float)m;
-        rstd = (float)(1.0 / sqrt(var + (double)eps));
-        gprev = grp;
-      }
-      float y = (v[e] - mean) * rstd * g[e] + b[e];
+      const float2 mr = *reinterpret_cast<const float2*>(finals + 2 * ((size_t)inst * groups + grp));
+      float y = (v[e] - mr.x) * mr.y * g[e] + b[e];
       if (silu) y = t2v_silu(y);
       o[e] = (f16)y;
     }
@@ -179,37 +187,39 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
 
 }  // namespace
 
-// stats scratch layout (fp64): two ping-pong buffers of `T2V_GN_STATS_LEN` doubles each.
-// op.i[8] selects the buffer used by THIS op (0/1); its apply pass zeroes the first op.i[9]
-// doubles of the other one (the host passes the largest n_inst*groups*2 of the program and
-// zeroes both buffers with a MEMSET op at program start).
-static constexpr int T2V_GN_STATS_LEN = 4096 * 32 * 2;  // up to 4096 instances x 32 groups
-
+// Scratch (op.p[4], owned by the caller): fp64 partials [n_inst][nblk][groups][2] followed by
+// fp32 finals [n_inst][groups][2], nblk = ceil(rows / T2V_GN_ROWS_PER_BLOCK).
 hipError_t t2v_launch_groupnorm(const t2v_op& op, hipStream_t s) {
   const int n_inst = op.i[0], rows = op.i[1], C = op.i[2], ld_in = op.i[3], groups = op.i[4];
-  const int in_dt = op.i[5], silu = op.i[6], ld_out = op.i[7], which = op.i[8] & 1;
-  if (C % 4 != 0 || C % groups != 0 || groups > 256 || n_inst * groups * 2 > T2V_GN_STATS_LEN)
+  const int in_dt = op.i[5], silu = op.i[6], ld_out = op.i[7];
+  if (C % 4 != 0 || C % groups != 0 || groups > 256 || n_inst <= 0 || rows <= 0 || op.p[4] == 0)
     return hipErrorInvalidValue;
-  double* stats = reinterpret_cast<double*>(op.p[4]) + (size_t)which * T2V_GN_STATS_LEN;
-  double* other = reinterpret_cast<double*>(op.p[4]) + (size_t)(which ^ 1) * T2V_GN_STATS_LEN;
-  const dim3 g1((rows + GN_ROWS_PER_BLOCK - 1) / GN_ROWS_PER_BLOCK, n_inst);
-  const size_t lds = 2 * (size_t)C * sizeof(float);
-  const long units = (long)n_inst * rows * (C / 4);
-  const int g2 = (int)((units + 255) / 256 < 4096 ? (units + 255) / 256 : 4096);
+  const int nblk = (rows + GN_ROWS_PER_BLOCK - 1) / GN_ROWS_PER_BLOCK;
+  double* partials = reinterpret_cast<double*>(op.p[4]);
+  float* finals = reinterpret_cast<float*>(partials + (size_t)n_inst * nblk * groups * 2);
+  const dim3 g1(nblk, n_inst);
+  const int cv = C / 4;
+  const int R = cv <= 256 ? 256 / cv : 1;
+  const size_t lds = 2 * (size_t)R * C * sizeof(float);
+  const long units = (long)n_inst * rows * cv;
+  const int g3 = (int)((units + 255) / 256 < 4096 ? (units + 255) / 256 : 4096);
+  const int g2 = (n_inst * groups + 3) / 4;
+  const double inv_n = 1.0 / ((double)rows * (C / groups));
   const float* gamma = reinterpret_cast<const float*>(op.p[1]);
   const float* beta = reinterpret_cast<const float*>(op.p[2]);
   f16* out = reinterpret_cast<f16*>(op.p[3]);
-  const int zero_len = op.i[9] < T2V_GN_STATS_LEN ? op.i[9] : T2V_GN_STATS_LEN;
   if (in_dt == T2V_F32) {
     const float* x = reinterpret_cast<const float*>(op.p[0]);
-    hipLaunchKernelGGL(gn_stats_kernel<float>, g1, dim3(256), lds, s, x, stats, rows, C, ld_in, groups);
-    hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(g2), dim3(256), 0, s, x, stats, gamma, beta, out, n_inst,
-                       rows, C, ld_in, ld_out, groups, op.f[0], silu, other, zero_len);
+    hipLaunchKernelGGL(gn_stats_kernel<float>, g1, dim3(256), lds, s, x, partials, rows, C, ld_in, groups);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(g2), dim3(256), 0, s, partials, finals, n_inst, nblk, groups, inv_n, op.f[0]);
+    hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(g3), dim3(256), 0, s, x, finals, gamma, beta, out, n_inst, rows, C,
+                       ld_in, ld_out, groups, silu);
   } else {
     const f16* x = reinterpret_cast<const f16*>(op.p[0]);
-    hipLaunchKernelGGL(gn_stats_kernel<f16>, g1, dim3(256), lds, s, x, stats, rows, C, ld_in, groups);
-    hipLaunchKernelGGL(gn_apply_kernel<f16>, dim3(g2), dim3(256), 0, s, x, stats, gamma, beta, out, n_inst,
-                       rows, C, ld_in, ld_out, groups, op.f[0], silu, other, zero_len);
+    hipLaunchKernelGGL(gn_stats_kernel<f16>, g1, dim3(256), lds, s, x, partials, rows, C, ld_in, groups);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(g2), dim3(256), 0, s, partials, finals, n_inst, nblk, groups, inv_n, op.f[0]);
+    hipLaunchKernelGGL(gn_apply_kernel<f16>, dim3(g3), dim3(256), 0, s, x, finals, gamma, beta, out, n_inst, rows, C,
+                       ld_in, ld_out, groups, silu);
   }
   return hipGetLastError();
 }

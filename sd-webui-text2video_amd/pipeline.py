@@ -1,0 +1,193 @@
+"""TextToVideoSynthesis / process_modelscope — the reference's outer entry points (boundaries
+B1/B2) over the MI355X hot path.
+
+`TextToVideoSynthesis.infer` keeps the signature and return triple of
+reference scripts/modelscope/t2v_pipeline.py:197-216,385:
+    (frames_bgr_list, last_tensor, infotext)
+and the same stages: conditioning -> seeded CPU noise -> sample_loop -> VAE decode of
+x0/0.18215 -> tensor2vid (x*0.5+0.5, clamp, *255 truncated to uint8, RGB->BGR).
+
+What is NOT rebuilt here (out of scope per SURVEY §2.1): the OpenCLIP text encoder
+(clip_hardcode.py) — pass a `clip_encoder` callable/object, or call `infer_conditioned` with
+pre-computed conditioning tensors; file / ffmpeg / Gradio plumbing of process_modelscope.py.
+
+MI355X differences inside the stages: cond+uncond UNet evaluations are one batched forward,
+and all frames are decoded by ONE batched VAE program (the reference decodes frame by frame and
+copies each to the host, t2v_pipeline.py:329-355).
+"""
+from __future__ import annotations
+
+import json
+import os
+import random
+from types import SimpleNamespace
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from .samplers import Txt2VideoSampler, available_samplers
+from .unet import UNetSD
+from .vae import AutoencoderKL
+
+SCALE_FACTOR = 0.18215          # t2v_pipeline.py:297
+
+VAE_DDCONFIG = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=128,
+                    ch_mult=[1, 2, 4, 4], num_res_blocks=2, attn_resolutions=[], dropout=0.0)
+
+
+def beta_schedule(schedule, num_timesteps=1000, init_beta=None, last_beta=None):
+    """t2v_model.py:1240-1249."""
+    if schedule == "linear_sd":
+        return torch.linspace(init_beta ** 0.5, last_beta ** 0.5, num_timesteps, dtype=torch.float64) ** 2
+    raise ValueError(f"Unsupported schedule: {schedule}")
+
+
+def tensor2vid_device(video: torch.Tensor) -> torch.Tensor:
+    """[1,3,F,H,W] float -> uint8 [F,H,W,3] RGB on the same device; x*0.5+0.5, clamp, *255 with
+    TRUNCATION like `(image.numpy()*255).astype('uint8')` (t2v_pipeline.py:447-460)."""
+    v = video.float().mul(0.5).add_(0.5).clamp_(0, 1)
+    v = v.permute(2, 3, 0, 4, 1).reshape(v.shape[2], v.shape[3], v.shape[0] * v.shape[4], v.shape[1])
+    return v.mul(255).to(torch.uint8)
+
+
+def tensor2vid(video: torch.Tensor) -> List[np.ndarray]:
+    frames = tensor2vid_device(video).cpu().numpy()
+    return [frames[i] for i in range(frames.shape[0])]
+
+
+def create_infotext(vars_: dict) -> str:
+    vars_ = dict(vars_)
+    prompt = vars_.pop("prompt", "")
+    n_prompt = vars_.pop("n_prompt", "")
+    params = ", ".join(f"{k}: {v}" for k, v in vars_.items() if v is not None)
+    neg = "\nNegative prompt: " + n_prompt if len(n_prompt) > 0 else ""
+    return f"{prompt}{neg}\n{params}".strip()
+
+
+class TextToVideoSynthesis(object):
+    def __init__(self, model_dir: Optional[str] = None, *, sd_model: Optional[UNetSD] = None,
+                 autoencoder: Optional[AutoencoderKL] = None, clip_encoder=None, betas=None,
+                 device=None):
+        """Either `model_dir` (configuration.json + checkpoints, as t2v_pipeline.py:45-146) or
+        ready-made `sd_model` / `autoencoder` modules."""
+        self.model_dir = model_dir
+        self.device = torch.device(device) if device is not None else torch.device("cuda")
+        self.keep_in_vram = "All"
+        self.clip_encoder = clip_encoder
+        if model_dir is not None and sd_model is None:
+            with open(os.path.join(model_dir, "configuration.json"), "r") as f:
+                self.config = SimpleNamespace(**json.load(f))
+            cfg = self.config.model["model_cfg"]
+            cfg["temporal_attention"] = True if cfg["temporal_attention"] == "True" else False
+            sd_model = UNetSD(in_dim=cfg["unet_in_dim"], dim=cfg["unet_dim"], y_dim=cfg["unet_y_dim"],
+                              context_dim=cfg["unet_context_dim"], out_dim=cfg["unet_out_dim"],
+                              dim_mult=cfg["unet_dim_mult"], num_heads=cfg["unet_num_heads"],
+                              head_dim=cfg["unet_head_dim"], num_res_blocks=cfg["unet_res_blocks"],
+                              attn_scales=cfg["unet_attn_scales"], dropout=cfg["unet_dropout"],
+                              parameterization=cfg["mean_type"], temporal_attention=cfg["temporal_attention"],
+                              init_weights=False)
+            args = self.config.model["model_args"]
+            sd_model.load_state_dict(torch.load(os.path.join(model_dir, args["ckpt_unet"]), map_location="cpu"), strict=True)
+            sd_model.eval().half()
+            betas = beta_schedule("linear_sd", cfg["num_timesteps"], init_beta=0.00085, last_beta=0.0120)
+            autoencoder = AutoencoderKL(VAE_DDCONFIG, 4, os.path.join(model_dir, args["ckpt_autoencoder"]), init_weights=False)
+        if betas is None:
+            betas = beta_schedule("linear_sd", 1000, init_beta=0.00085, last_beta=0.0120)
+        self.sd_model = sd_model
+        self.autoencoder = autoencoder.eval() if autoencoder is not None else None
+        self.betas = betas
+        self.sd_model.register_schedule(given_betas=betas.numpy())
+        self.diffusion = Txt2VideoSampler(self.sd_model, self.device, betas=betas)
+        self.noise_gen = torch.Generator(device="cpu")
+        self.last_tensor = None
+
+    # ---- conditioning (out of scope: delegated) --------------------------------------------------
+    def preprocess(self, prompt, n_prompt, steps):
+        if self.clip_encoder is None:
+            raise RuntimeError("no text encoder attached: pass clip_encoder=... (the reference's "
+                               "FrozenOpenCLIPEmbedder) or call infer_conditioned(c, uc, ...)")
+        enc = self.clip_encoder
+        c = enc([prompt]) if callable(enc) else enc.encode([prompt])
+        uc = enc([n_prompt]) if callable(enc) else enc.encode([n_prompt])
+        return c, uc
+
+    # ---- the hot path ---------------------------------------------------------------------------
+    @torch.no_grad()
+    def infer_conditioned(self, c, uc, steps, frames, seed, scale, width=256, height=256, eta=0.0,
+                          device=None, latents=None, strength=None, mask=None, is_vid2vid=False,
+                          sampler=available_samplers[0].name, decode=True, to_host=True, _keep_sampler=False):
+        """Stages 2-4 of `infer` for given conditioning tensors c, uc [1, 77k, 1024].
+        Returns (frames, last_tensor): frames = list of HxWx3 uint8 BGR arrays (to_host) or a
+        uint8 device tensor [F,H,W,3] RGB (to_host=False), or None when decode=False."""
+        dev = torch.device(device) if device is not None else self.device
+        self.device = dev
+        self.diffusion.device = dev
+        self.sd_model.to(dev)
+        if not _keep_sampler:
+            self.diffusion.get_sampler(sampler, return_sampler=False)
+        latents, noise, shape = self.diffusion.get_noise(1, 4, frames, height, width, seed=seed, latents=latents)
+        x0 = self.diffusion.sample_loop(
+            steps=steps, strength=strength, eta=eta, conditioning=c.to(dev), unconditional_conditioning=uc.to(dev),
+            batch_size=1, guidance_scale=scale, latents=latents, shape=shape, noise=noise, is_vid2vid=is_vid2vid,
+            sampler_name=sampler, mask=mask)
+        self.last_tensor = x0
+        if not decode:
+            return None, x0
+        rgb = self.decode_frames(x0)
+        if not to_host:
+            return rgb, x0
+        arr = rgb.cpu().numpy()
+        return [np.ascontiguousarray(arr[i][:, :, ::-1]) for i in range(arr.shape[0])], x0   # RGB -> BGR
+
+    @torch.no_grad()
+    def decode_frames(self, x0: torch.Tensor) -> torch.Tensor:
+        """latent [b,4,F,h,w] -> uint8 [F,H,(b W),3] RGB on device: ONE batched VAE program over all
+        frames of x0/0.18215 (t2v_pipeline.py:329-355 decodes them one at a time) + tensor2vid."""
+        self.autoencoder.to(x0.device)
+        bs, _, F, h, w = x0.shape
+        z = (x0 * (1.0 / SCALE_FACTOR)).permute(0, 2, 1, 3, 4).reshape(bs * F, 4, h, w)   # '(b f) c h w'
+        img = self.autoencoder.decode(z)                                                 # [(b f), 3, 8h, 8w]
+        vd = img.view(bs, F, 3, img.shape[2], img.shape[3]).permute(0, 2, 1, 3, 4)
+        return tensor2vid_device(vd)
+
+    def infer(self, prompt, n_prompt, steps, frames, seed, scale, width=256, height=256, eta=0.0,
+              cpu_vae="GPU (half precision)", device=torch.device("cuda"), latents=None, skip_steps=0,
+              strength=0, mask=None, is_vid2vid=False, sampler=available_samplers[0].name):
+        vars_ = dict(prompt=prompt, n_prompt=n_prompt, steps=steps, frames=frames, seed=seed, scale=scale,
+                     width=width, height=height, eta=eta, cpu_vae=cpu_vae, device=str(device),
+                     skip_steps=skip_steps, strength=strength, is_vid2vid=is_vid2vid, sampler=sampler)
+        seed = seed if seed != -1 else random.randint(0, 2 ** 32 - 1)
+        vars_["seed"] = seed
+        if "CPU" in str(cpu_vae):
+            raise NotImplementedError("CPU VAE modes are host plumbing of the reference; this build decodes on the GPU")
+        steps = steps - skip_steps
+        c, uc = self.preprocess(prompt, n_prompt, steps)
+        strength = None if (strength == 0.0 and not is_vid2vid) else strength
+        frames_bgr, x0 = self.infer_conditioned(c, uc, steps, frames, seed, scale, width, height, eta, device,
+                                                latents, strength, mask, is_vid2vid, sampler)
+        return frames_bgr, self.last_tensor, create_infotext(vars_)
+
+
+pipe: Optional[TextToVideoSynthesis] = None     # module-global model cache, as process_modelscope.py:29
+
+
+def process_modelscope(args_dict: dict, extra_args=None):
+    """Entry-point name kept (process_modelscope.py:34).  The reference body is webui file / ffmpeg /
+    Gradio plumbing and is out of scope; this minimal form runs the hot path for
+    args_dict = {model_dir | pipe, prompt, n_prompt, steps, frames, seed, cfg_scale, width, height,
+    eta, sampler, clip_encoder | (cond, uncond)} and returns the list of BGR uint8 frames."""
+    global pipe
+    a = SimpleNamespace(**args_dict)
+    if getattr(a, "pipe", None) is not None:
+        pipe = a.pipe
+    elif pipe is None:
+        pipe = TextToVideoSynthesis(a.model_dir, clip_encoder=getattr(a, "clip_encoder", None))
+    common = dict(steps=a.steps, frames=a.frames, seed=a.seed, scale=a.cfg_scale, width=getattr(a, "width", 256),
+                  height=getattr(a, "height", 256), eta=getattr(a, "eta", 0.0),
+                  sampler=getattr(a, "sampler", available_samplers[0].name))
+    if getattr(a, "cond", None) is not None:
+        frames, _ = pipe.infer_conditioned(a.cond, a.uncond, **common)
+        return frames
+    frames, _, _ = pipe.infer(a.prompt, getattr(a, "n_prompt", ""), **common)
+    return frames

@@ -108,6 +108,7 @@ class Op:
     p: List[Ref] = field(default_factory=lambda: [NULL] * L.OP_NP)
     flops: float = 0.0            # algorithmic 2*MAC (matmul/conv only), for the roofline
     meta: dict = field(default_factory=dict)
+    out: Optional["Buf"] = None   # arena buffer this op writes (debug / determinism tooling)
 
 
 class Program:
@@ -117,10 +118,6 @@ class Program:
         self.arena = Arena()
         self.taps: Dict[str, Buf] = {}          # debug: named live buffers (never freed when tapping)
         self.keep_taps = False
-        self._gn_count = 0
-        self._gn_max = 0
-        self._gn_ops: List[Op] = []
-        self.gn_stats: Optional[Buf] = None
         self.target_blocks = 512                # split-K heuristic: aim for this many workgroups
 
     # ---- memory ---------------------------------------------------------------------------
@@ -147,17 +144,10 @@ class Program:
 
     # ---- ops ------------------------------------------------------------------------------
     def begin(self):
-        """Program prologue: statistics scratch for GroupNorm (two fp64 ping-pong buffers)."""
-        self.gn_stats = self.alloc(2 * L.GN_STATS_LEN, 1, "f64")
-        op = Op(L.OP_MEMSET, "gn_stats.zero")
-        nbytes = 2 * L.GN_STATS_LEN * 8
-        op.i[0], op.i[1] = nbytes & 0xFFFFFFFF, nbytes >> 32
-        op.p[0] = self.gn_stats.ref
-        self._emit(op)
+        """Program prologue (kept for symmetry; nothing to initialise)."""
 
     def finish(self):
-        for op in self._gn_ops:
-            op.i[9] = self._gn_max
+        pass
 
     def gemm(self, name: str, a: Buf, w: Ref, n: int, k: int, out: Buf, *, bias: Ref = NULL,
              ldw: Optional[int] = None, gather: int = L.GATHER_PLAIN, conv: Optional[dict] = None,
@@ -205,6 +195,7 @@ class Program:
             ws = self.alloc(split * M, n, "f32")
             op.p[6] = ws.ref
         op.flops = 2.0 * M * n * k
+        op.out = out
         op.meta = dict(M=M, N=n, K=k, gather=gather, conv=dict(conv), epi=epi, split=split)
         self._emit(op)
         if ws is not None:
@@ -216,14 +207,15 @@ class Program:
         rows = x.rows // n_inst
         assert rows * n_inst == x.rows and out.dtype == "f16" and x.cols % 4 == 0
         op = Op(L.OP_GROUPNORM, name)
-        op.i[0:9] = [n_inst, rows, x.cols, x.ld, groups, _DT[x.dtype], int(silu), out.ld, self._gn_count & 1]
+        op.i[0:8] = [n_inst, rows, x.cols, x.ld, groups, _DT[x.dtype], int(silu), out.ld]
         op.f[0] = eps
-        op.p[0:5] = [x.ref, gamma, beta, out.ref, self.gn_stats.ref]
-        self._gn_count += 1
-        self._gn_max = max(self._gn_max, n_inst * groups * 2)
-        assert n_inst * groups * 2 <= L.GN_STATS_LEN
-        self._gn_ops.append(op)
-        return self._emit(op)
+        nblk = (rows + L.GN_ROWS_PER_BLOCK - 1) // L.GN_ROWS_PER_BLOCK
+        scratch = self.alloc(n_inst * nblk * groups * 16 + n_inst * groups * 8, 1, "u8")
+        op.p[0:5] = [x.ref, gamma, beta, out.ref, scratch.ref]
+        op.out = out
+        self._emit(op)
+        self.free(scratch)      # stream order makes immediate reuse safe
+        return op
 
     def layernorm(self, name: str, x: Buf, gamma: Ref, beta: Ref, out: Buf, eps: float = 1e-5) -> Op:
         assert x.dtype == "f32" and out.dtype == "f16"
@@ -231,9 +223,10 @@ class Program:
         op.i[0:4] = [x.rows, x.cols, x.ld, out.ld]
         op.f[0] = eps
         op.p[0:4] = [x.ref, gamma, beta, out.ref]
+        op.out = out
         return self._emit(op)
 
-    def attention(self, name: str, q: Ref, k: Ref, v: Ref, o: Ref, *, nq: int, nk: int, heads: int,
+    def attention(self, name: str, q: Ref, k: Ref, v: Ref, o: Ref, *, out_buf: Optional[Buf] = None, nq: int, nk: int, heads: int,
                   b_outer: int, b_inner: int, q_strides, kv_strides, o_strides, scale: float) -> Op:
         op = Op(L.OP_ATTENTION, name)
         op.i[0:5] = [nq, nk, heads, b_outer, b_inner]
@@ -245,6 +238,7 @@ class Program:
         op.f[0] = scale
         op.p[0:4] = [q, k, v, o]
         op.flops = 4.0 * nq * nk * 64 * heads * b_outer * b_inner
+        op.out = out_buf
         return self._emit(op)
 
     def softmax(self, name: str, x: Buf, out: Buf, scale: float) -> Op:
@@ -252,6 +246,7 @@ class Program:
         op.i[0:4] = [x.rows, x.cols, x.ld, out.ld]
         op.f[0] = scale
         op.p[0:2] = [x.ref, out.ref]
+        op.out = out
         return self._emit(op)
 
     def ncthw_to_cl(self, name: str, src: Ref, src_dtype: str, out: Buf, *, B, C, F, HW, scale=1.0) -> Op:
@@ -259,6 +254,7 @@ class Program:
         op.i[0:6] = [B, C, F, HW, out.ld, _DT[src_dtype]]
         op.f[0] = scale
         op.p[0:2] = [src, out.ref]
+        op.out = out
         return self._emit(op)
 
     def cl_to_ncthw(self, name: str, x: Buf, dst: Ref, dst_dtype: str, *, B, C, F, HW) -> Op:
@@ -271,6 +267,7 @@ class Program:
         op = Op(L.OP_TIME_EMBED, name)
         op.i[0:2] = [out.rows, out.cols]
         op.p[0:3] = [t, freqs, out.ref]
+        op.out = out
         return self._emit(op)
 
     def copy2d(self, name: str, src: Buf, dst: Buf, act: int = 0) -> Op:
@@ -278,6 +275,7 @@ class Program:
         op = Op(L.OP_COPY2D, name)
         op.i[0:7] = [src.rows, src.cols, src.ld, dst.ld, _DT[src.dtype], _DT[dst.dtype], act]
         op.p[0:2] = [src.ref, dst.ref]
+        op.out = dst
         return self._emit(op)
 
     def ddim_step(self, name: str, *, C: int, inner: int, guided: int, eps_dtype: str, x_dtype: str) -> Op:

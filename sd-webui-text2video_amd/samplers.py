@@ -124,6 +124,7 @@ class GaussianDiffusion(object):
         self.sqrt_recip_alphas_cumprod = torch.sqrt(1.0 / self.alphas_cumprod)
         self.sqrt_recipm1_alphas_cumprod = torch.sqrt(1.0 / self.alphas_cumprod - 1)
         self._step_plans = {}
+        self.cfg_parallel = None      # parallel.CfgPair: cond / uncond forwards on two GPUs (parallel.py)
 
     # -- schedule helpers (gaussian_sampler.py:73-91) --------------------------------------------
     def get_time_steps(self, ddim_timesteps, batch_size=1, step=None):
@@ -197,6 +198,11 @@ class GaussianDiffusion(object):
                 if self.is_unconditional(guide):
                     eps = model(xt, tt, c)
                     guided, gscale = 0, 1.0
+                elif self.cfg_parallel is not None and self.cfg_parallel.size == 2:
+                    # CFG pair: this rank evaluates ONE of the two forwards; one eps all-gather per step
+                    mine = c if self.cfg_parallel.role == 0 else uc
+                    eps = self.cfg_parallel.exchange_eps(model(xt, tt, mine))
+                    guided, gscale = C // 2 if not self.var_type.startswith("fixed") else C, float(guide)
                 else:
                     if getattr(model, "supports_cfg_batch", False):
                         eps = model(torch.cat([xt, xt], dim=0), torch.cat([tt, tt]), torch.cat([c, uc], dim=0))

@@ -495,11 +495,11 @@ class _Lowering:
             ld = 3 * inner
             q, k, v = qkv.col_slice(0, inner), qkv.col_slice(inner, 2 * inner), qkv.col_slice(2 * inner, 3 * inner)
             if kind == "spatial":
-                P.attention(f"{prefix}.attn{tag}", q.ref, k.ref, v.ref, a.ref, nq=hw, nk=hw, heads=heads,
+                P.attention(f"{prefix}.attn{tag}", q.ref, k.ref, v.ref, a.ref, out_buf=a, nq=hw, nk=hw, heads=heads,
                             b_outer=B * F, b_inner=1, q_strides=(ld, hw * ld, 0), kv_strides=(ld, hw * ld, 0),
                             o_strides=(inner, hw * inner, 0), scale=scale)
             else:   # temporal: sequence = frames of one pixel
-                P.attention(f"{prefix}.attn{tag}", q.ref, k.ref, v.ref, a.ref, nq=F, nk=F, heads=heads,
+                P.attention(f"{prefix}.attn{tag}", q.ref, k.ref, v.ref, a.ref, out_buf=a, nq=F, nk=F, heads=heads,
                             b_outer=B, b_inner=hw, q_strides=(hw * ld, F * hw * ld, ld),
                             kv_strides=(hw * ld, F * hw * ld, ld),
                             o_strides=(hw * inner, F * hw * inner, inner), scale=scale)
@@ -522,7 +522,7 @@ class _Lowering:
             kbuf, vbuf = kv.col_slice(k0, k0 + inner), kv.col_slice(k0 + inner, k1)
             a = P.alloc(Mrows, inner, "f16")
             Lc = self.Lctx
-            P.attention(f"{prefix}.attn2", q.ref, kbuf.ref, vbuf.ref, a.ref, nq=hw, nk=Lc, heads=heads,
+            P.attention(f"{prefix}.attn2", q.ref, kbuf.ref, vbuf.ref, a.ref, out_buf=a, nq=hw, nk=Lc, heads=heads,
                         b_outer=B, b_inner=F, q_strides=(inner, F * hw * inner, hw * inner),
                         kv_strides=(kv.ld, Lc * kv.ld, 0), o_strides=(inner, F * hw * inner, hw * inner), scale=scale)
             P.free(q)

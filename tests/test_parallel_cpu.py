@@ -1,0 +1,62 @@
+"""CPU, world_size 2 over gloo: the N>1 communication logic of parallel.py (pair layout, eps
+exchange ordering, uneven frame partition + gather)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from sd_webui_text2video_amd import parallel
+
+
+def test_partition_frames_uneven():
+    parts = parallel.partition_frames(125, 8)
+    assert parts[0] == (0, 16) and parts[-1][1] == 125
+    assert [b - a for a, b in parts] == [16] * 5 + [15] * 3
+    assert parallel.partition_frames(24, 2) == [(0, 12), (12, 24)]
+    assert parallel.partition_frames(3, 4) == [(0, 1), (1, 2), (2, 3), (3, 3)]
+
+
+def test_pair_layout():
+    assert [parallel.pair_layout(8, r) for r in range(8)] == [(r // 2, r % 2, 2) for r in range(8)]
+    assert parallel.pair_layout(3, 2) == (1, 0, 1)
+    assert parallel.pair_layout(1, 0) == (0, 0, 1)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pair = parallel.CfgPair(world, rank)
+        assert (pair.index, pair.role, pair.size) == (0, rank, 2)
+        eps_local = torch.full((1, 4, 5, 2, 2), float(rank + 1))
+        both = pair.exchange_eps(eps_local)
+        assert both.shape == (2, 4, 5, 2, 2)
+        assert torch.all(both[0] == 1.0) and torch.all(both[1] == 2.0)      # index 0 = conditional rank
+        # uneven frame split: 5 frames over 2 ranks -> 3 + 2
+        f0, f1 = pair.my_frames(5)
+        assert (f0, f1) == ((0, 3) if rank == 0 else (3, 5))
+        local = torch.arange(f0, f1, dtype=torch.uint8).view(-1, 1, 1, 1).expand(-1, 2, 2, 3).contiguous()
+        full = pair.gather_frames(local, 5)
+        assert full.shape == (5, 2, 2, 3)
+        assert full[:, 0, 0, 0].tolist() == [0, 1, 2, 3, 4]
+        ret[rank] = 1
+    finally:
+        dist.destroy_process_group()
+
+
+def test_cfg_pair_collectives_gloo_world2():
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert dict(ret) == {0: 1, 1: 1}
