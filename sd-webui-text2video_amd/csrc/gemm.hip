@@ -360,7 +360,22 @@ hipError_t launch_tile(const GemmParams& p, hipStream_t s) {
 
 }  // namespace
 
-hipError_t t2v_launch_gemm(const GemmParams& p, hipStream_t s) {
+hipError_t t2v_launch_splitk_reduce(const GemmParams& p, hipStream_t s) {
+  const long quads = (long)p.M * ((p.epi == T2V_EPI_GEGLU ? p.N / 2 : p.N) / 4);
+  const int blocks = (int)min((long)2048, (quads + 255) / 256);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
+hipError_t t2v_launch_gemm(const GemmParams& pin, hipStream_t s) {
+  GemmParams p = pin;
+  {
+    const int KT = (p.K + BK - 1) / BK;
+    if (p.splitk > KT) p.splitk = KT;
+    if (p.splitk < 1) p.splitk = 1;
+    p.kt_per_split = (KT + p.splitk - 1) / p.splitk;
+    p.splitk = (KT + p.kt_per_split - 1) / p.kt_per_split;  // no empty splits
+  }
   hipError_t e;
   // Tile choice: 128x128 by default; 128x64 when the last 128-wide column tile would be at
   // most half full (N = 320, 960, 4, 8 ...), to avoid 25-97 % padded columns.
@@ -370,11 +385,6 @@ hipError_t t2v_launch_gemm(const GemmParams& p, hipStream_t s) {
   else
     e = launch_tile<128, 128, 2, 2>(p, s);
   if (e != hipSuccess) return e;
-  if (p.splitk > 1) {
-    const long quads = (long)p.M * ((p.epi == T2V_EPI_GEGLU ? p.N / 2 : p.N) / 4);
-    const int blocks = (int)min((long)2048, (quads + 255) / 256);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, p);
-    e = hipGetLastError();
-  }
+  if (p.splitk > 1) e = t2v_launch_splitk_reduce(p, s);
   return e;
 }

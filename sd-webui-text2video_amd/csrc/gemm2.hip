@@ -1,0 +1,351 @@
+// Second-generation implicit-GEMM kernel (large tiles, deep LDS-DMA ring) for gfx950.
+//
+// Same contract as gemm.hip (out[M,N] = epilogue(gather(A)[M,K] · W[N,K]^T), fp16 operands,
+// fp32 accumulate, swapped MFMA operands so a lane owns 4 consecutive output channels), but
+// built for the regime the UNet lives in: a 128x128 tile needs ~64 B/clk/CU of operand
+// traffic at MFMA peak — above what one CU gets from L2 — so tiles here are 256x256,
+// 256x320, 128x256 and 128x320 (29-45 B/clk/CU).  N = 320*k (every C-output GEMM of the
+// ModelScope UNet: 320, 640, 960, 1280, 1920, 2560 ...) uses the 320-wide tile with no padded
+// columns.
+//
+// Pipeline: k-tiles of 32 (64-byte LDS rows), STAGES-deep ring filled by `global_load_lds`
+// 16-byte LDS-DMA; STAGES-1 k-tiles are always in flight.  Per k-tile each wave executes
+//     s_waitcnt vmcnt(LPS*(STAGES-2))   -> its own DMA pieces of the tile to compute have landed
+//     s_barrier                          -> everyone's have; everyone finished the previous tile
+//     issue the DMA of tile t+STAGES-1 into the slot just freed
+//     ds_read_b128 fragments + MFMA 32x32x16
+// i.e. ONE barrier per k-tile and no vmcnt(0) drain anywhere in the main loop (the loads of
+// k-tiles past the end are redirected to a zero page so the outstanding-load count is constant).
+// LDS image: row r, 16-byte chunk c at r*64 + ((c ^ ((r>>2)&3))<<4): conflict-free for the
+// fragment reads; the XOR is applied to the per-lane DMA *source* (the destination is
+// lane-linear) and again on the read.
+#include "t2v_kernels.h"
+
+#define AS1 __attribute__((address_space(1)))
+#define AS3 __attribute__((address_space(3)))
+
+
+namespace {
+
+__device__ __attribute__((aligned(256))) unsigned char g2_zero_page[256];
+
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const AS1 void*)gsrc, (AS3 void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// ---- epilogue helpers (identical semantics to gemm.hip) ----------------------------------
+__device__ __forceinline__ void epi_store(const GemmParams& p, int m, int n, float v0, float v1, float v2, float v3) {
+  if (p.bias) {
+    if (p.bias_m) {
+      const float b = p.bias[m];
+      v0 += b; v1 += b; v2 += b; v3 += b;
+    } else {
+      const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
+      v0 += b[0]; v1 += b[1]; v2 += b[2]; v3 += b[3];
+    }
+  }
+  if (p.rowbias) {
+    const f32x4 b = *reinterpret_cast<const f32x4*>(p.rowbias + (size_t)(m / p.rows_per_batch) * p.ldrb + n);
+    v0 += b[0]; v1 += b[1]; v2 += b[2]; v3 += b[3];
+  }
+  if (p.act == 1) {
+    v0 = t2v_silu(v0); v1 = t2v_silu(v1); v2 = t2v_silu(v2); v3 = t2v_silu(v3);
+  }
+  if (p.res) {
+    const f32x4 r = *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.ldr + n);
+    v0 += r[0]; v1 += r[1]; v2 += r[2]; v3 += r[3];
+  }
+  if (p.out_f32) {
+    f32x4 o = {v0, v1, v2, v3};
+    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n) = o;
+  } else {
+    f16x4 o = {(f16)v0, (f16)v1, (f16)v2, (f16)v3};
+    *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(p.out) + (size_t)m * p.ldc + n) = o;
+  }
+}
+
+__device__ __forceinline__ void epi_store_geglu(const GemmParams& p, int m, int n_val, int n_out, const float* v,
+                                                const float* g) {
+  float bv[4] = {0, 0, 0, 0}, bg[4] = {0, 0, 0, 0};
+  if (p.bias) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p.bias + n_val);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n_val + 8);
+    for (int r = 0; r < 4; ++r) { bv[r] = a[r]; bg[r] = b[r]; }
+  }
+  f16x4 o;
+  for (int r = 0; r < 4; ++r) o[r] = (f16)((v[r] + bv[r]) * t2v_gelu_erf(g[r] + bg[r]));
+  *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(p.out) + (size_t)m * p.ldc + n_out) = o;
+}
+
+// WM x WN waves; each wave owns TM x TN MFMA tiles (32 tokens x 32 channels each).
+template <int WM, int WN, int TM, int TN, int BK, int STAGES, int MINW, int GATHER>
+__global__ __launch_bounds__(WM * WN * 64, MINW) void gemm2_kernel(const GemmParams p) {
+  constexpr int NW = WM * WN;
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr int ROW_BYTES = BK * 2;                          // 64 (BK=32) or 128 (BK=64) bytes per LDS row
+  constexpr int RPS = 1024 / ROW_BYTES;                      // rows per 1-KiB DMA piece: 16 or 8
+  constexpr int CPR = BK / 8;                                // 16-byte chunks per row: 4 or 8
+  constexpr int XSLABS = BM / RPS, WSLABS = BN / RPS;        // 1-KiB DMA pieces per tile
+  static_assert(XSLABS % NW == 0, "token slabs must divide evenly over the waves");
+  constexpr int XPW = XSLABS / NW;
+  constexpr int WPW = (WSLABS + NW - 1) / NW;                // the last may be a dummy piece
+  constexpr int LPS = XPW + WPW;                             // DMA instructions per wave per stage
+  constexpr int STAGE_BYTES = (XSLABS + WSLABS) * 1024;
+  constexpr int DUMMY_OFF = STAGES * STAGE_BYTES;            // 1 KiB scratch for dummy pieces
+  static_assert(LPS * (STAGES - 1) < 64, "vmcnt is a 6-bit counter");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+
+  // ---- XCD-aware tile order: blocks of one XCD (id % 8) walk consecutive tiles, n fastest,
+  //      so the activation tile shared by the N-tiles of one M-row stays in that XCD's L2.
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int ntiles = tiles_m * tiles_n;
+  int lin;
+  {
+    const int b = blockIdx.x, q = ntiles >> 3, r = ntiles & 7, xcd = b & 7, j = b >> 3;
+    lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int tile_m = lin / tiles_n, tile_n = lin - tile_m * tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int KT = (p.K + BK - 1) / BK;
+  const int kt_begin = blockIdx.y * p.kt_per_split;          // in units of BK-wide k-tiles
+  const int kt_end = min(KT, kt_begin + p.kt_per_split);
+  const int nkt = kt_end - kt_begin;
+
+  const unsigned char* zero = g2_zero_page;
+
+  // ---- per-lane DMA descriptors --------------------------------------------------------------
+  const int lrow = lane / CPR;     // row inside a 1-KiB piece
+  const int pchunk = lane % CPR;   // physical 16-B chunk inside the row
+  // chunk swizzle: conflict-free ds_read_b128 fragment reads for 64-B and 128-B rows
+  auto swz = [](int r) { return BK == 64 ? ((r >> 1) & 7) : ((r >> 2) & 3); };
+
+  long xoff[XPW];
+  int xy[XPW], xx[XPW], xlc[XPW];
+  bool xvalid[XPW];
+#pragma unroll
+  for (int j = 0; j < XPW; ++j) {
+    const int r = (wave + j * NW) * RPS + lrow;   // row inside the token tile
+    const int m = m0 + r;
+    xlc[j] = pchunk ^ swz(r);
+    xvalid[j] = m < p.M;
+    xoff[j] = 0; xy[j] = 0; xx[j] = 0;
+    if (GATHER == T2V_GATHER_PLAIN) {
+      xoff[j] = (long)m * p.lda;
+    } else if (GATHER == T2V_GATHER_CONV3X3) {
+      const int hw = p.Hout * p.Wout;
+      const int img = m / hw, rem = m - img * hw;
+      const int yo = rem / p.Wout, xo = rem - yo * p.Wout;
+      xoff[j] = (long)img * p.Hin * p.Win;
+      xy[j] = yo * p.stride;
+      xx[j] = xo * p.stride;
+    } else {  // TCONV3
+      xoff[j] = (long)m;
+      xy[j] = (m / p.HW) % p.F;
+    }
+  }
+  const f16* wrow[WPW];
+  int wlc[WPW];
+  bool wdummy[WPW];
+#pragma unroll
+  for (int j = 0; j < WPW; ++j) {
+    const int s = wave + j * NW;                 // piece index inside the weight tile
+    const int r = s * RPS + lrow;
+    const int n = n0 + r;
+    wlc[j] = pchunk ^ swz(r);
+    wdummy[j] = s >= WSLABS;                     // wave-uniform
+    wrow[j] = (!wdummy[j] && n < p.N) ? (p.W + (size_t)n * p.ldw) : nullptr;
+  }
+
+  auto stage = [&](int slot, int kt) {
+    unsigned char* base = smem + slot * STAGE_BYTES;
+    const bool live = kt < kt_end;               // wave-uniform; dead stages read the zero page
+    const int k0 = kt * BK;
+    int tap = 0, ci0 = k0;
+    if (GATHER != T2V_GATHER_PLAIN) {
+      tap = k0 / p.Cin;
+      ci0 = k0 - tap * p.Cin;
+    }
+#pragma unroll
+    for (int j = 0; j < XPW; ++j) {
+      bool ok = live && xvalid[j];
+      long eoff;  // element offset into A
+      if (GATHER == T2V_GATHER_PLAIN) {
+        const int kc = k0 + xlc[j] * 8;
+        ok = ok && kc < p.K;
+        eoff = xoff[j] + kc;
+      } else if (GATHER == T2V_GATHER_CONV3X3) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int yv = xy[j] + ky - 1, xv = xx[j] + kx - 1;
+        const int hv = p.Hin << p.up, wv = p.Win << p.up;
+        ok = ok && yv >= 0 && yv < hv && xv >= 0 && xv < wv;
+        const long row = xoff[j] + (long)(yv >> p.up) * p.Win + (xv >> p.up);
+        eoff = row * p.lda + ci0 + xlc[j] * 8;
+      } else {
+        const int fi = xy[j] + tap - 1;
+        ok = ok && fi >= 0 && fi < p.F;
+        const long row = xoff[j] + (long)(tap - 1) * p.HW;
+        eoff = row * p.lda + ci0 + xlc[j] * 8;
+      }
+      const void* src = ok ? (const void*)(p.A + eoff) : (const void*)zero;
+      glds16(src, base + (wave + j * NW) * 1024);
+    }
+#pragma unroll
+    for (int j = 0; j < WPW; ++j) {
+      const int kc = k0 + wlc[j] * 8;
+      const bool ok = live && wrow[j] != nullptr && kc < p.K;
+      const void* src = ok ? (const void*)(wrow[j] + kc) : (const void*)zero;
+      unsigned char* dst = wdummy[j] ? (smem + DUMMY_OFF) : (base + (XSLABS + wave + j * NW) * 1024);
+      glds16(src, dst);
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // prologue: STAGES-1 k-tiles in flight
+#pragma unroll
+  for (int g = 0; g < STAGES - 1; ++g) stage(g, kt_begin + g);
+
+  const int frow = lane & 31, fhalf = lane >> 5;
+  int slot = 0;
+  for (int t = 0; t < nkt; ++t) {
+    wait_vmcnt<LPS*(STAGES - 2)>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    {
+      int fs = slot + STAGES - 1;
+      if (fs >= STAGES) fs -= STAGES;
+      stage(fs, kt_begin + t + STAGES - 1);
+    }
+    const unsigned char* xt = smem + slot * STAGE_BYTES;
+    const unsigned char* wt = xt + XSLABS * 1024;
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      const int lchunk = kk * 2 + fhalf;
+      f16x8 xf[TM], wf[TN];
+#pragma unroll
+      for (int a = 0; a < TM; ++a) {
+        const int r = (wm * TM + a) * 32 + frow;
+        xf[a] = *reinterpret_cast<const f16x8*>(xt + r * ROW_BYTES + ((lchunk ^ swz(r)) << 4));
+      }
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        const int r = (wn * TN + b) * 32 + frow;
+        wf[b] = *reinterpret_cast<const f16x8*>(wt + r * ROW_BYTES + ((lchunk ^ swz(r)) << 4));
+      }
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[b], xf[a], acc[a][b], 0, 0, 0);
+    }
+    slot = slot + 1 == STAGES ? 0 : slot + 1;
+  }
+  wait_vmcnt<0>();   // drain the zero-page loads of the dead stages before the LDS goes away
+
+  // ---- epilogue ---------------------------------------------------------------------------------
+  const int mlane = lane & 31, nhalf = (lane >> 5) * 4;
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+    const int m = m0 + (wm * TM + a) * 32 + mlane;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const int nt = n0 + (wn * TN + b) * 32;
+      if (p.splitk > 1) {
+        float* ws = p.ws + ((size_t)blockIdx.y * p.M + m) * p.N;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = nt + 8 * q + nhalf;
+          if (n < p.N) {
+            f32x4 o = {acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
+            *reinterpret_cast<f32x4*>(ws + n) = o;
+          }
+        }
+      } else if (p.epi == T2V_EPI_GEGLU) {
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+          const int n_val = nt + 16 * qq + nhalf;
+          if (n_val < p.N) {
+            float v[4], g[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[r] = acc[a][b][8 * qq + r]; g[r] = acc[a][b][8 * qq + 4 + r]; }
+            epi_store_geglu(p, m, n_val, (nt >> 1) + 8 * qq + nhalf, v, g);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = nt + 8 * q + nhalf;
+          if (n < p.N)
+            epi_store(p, m, n, acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]);
+        }
+      }
+    }
+  }
+}
+
+template <int WM, int WN, int TM, int TN, int BK, int STAGES, int MINW, int GATHER>
+hipError_t launch_cfg_gather(const GemmParams& p, hipStream_t s) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr int lds = STAGES * (BM + BN) * BK * 2 + 1024;
+  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  auto k = gemm2_kernel<WM, WN, TM, TN, BK, STAGES, MINW, GATHER>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k, dim3(tiles, p.splitk > 1 ? p.splitk : 1), dim3(WM * WN * 64), lds, s, p);
+  return hipGetLastError();
+}
+
+template <int WM, int WN, int TM, int TN, int BK, int STAGES, int MINW>
+hipError_t launch_cfg(const GemmParams& pin, hipStream_t s) {
+  GemmParams p = pin;
+  const int KT = (p.K + BK - 1) / BK;
+  if (p.splitk > KT) p.splitk = KT;
+  if (p.splitk < 1) p.splitk = 1;
+  p.kt_per_split = (KT + p.splitk - 1) / p.splitk;
+  p.splitk = (KT + p.kt_per_split - 1) / p.kt_per_split;  // no empty splits
+  hipError_t e;
+  switch (p.gather) {
+    case T2V_GATHER_PLAIN: e = launch_cfg_gather<WM, WN, TM, TN, BK, STAGES, MINW, T2V_GATHER_PLAIN>(p, s); break;
+    case T2V_GATHER_CONV3X3: e = launch_cfg_gather<WM, WN, TM, TN, BK, STAGES, MINW, T2V_GATHER_CONV3X3>(p, s); break;
+    case T2V_GATHER_TCONV3: e = launch_cfg_gather<WM, WN, TM, TN, BK, STAGES, MINW, T2V_GATHER_TCONV3>(p, s); break;
+    default: return hipErrorInvalidValue;
+  }
+  if (e != hipSuccess) return e;
+  if (p.splitk > 1) e = t2v_launch_splitk_reduce(p, s);
+  return e;
+}
+
+}  // namespace
+
+// tile ids (t2v_op.i[22]):  1 = 256x256, 2 = 256x320, 3 = 128x256 — all 8 waves, 64-wide k-tiles
+// (full 128-byte lines per row), 2-3 stage ring, one workgroup per CU;  4 = 128x320 (32-wide k-tiles).
+hipError_t t2v_launch_gemm2(const GemmParams& p, int tile, hipStream_t s) {
+  switch (tile) {
+    case 1: return launch_cfg<2, 4, 4, 2, 64, 2, 2>(p, s);   // 2 x 64 KiB
+    case 2: return launch_cfg<4, 2, 2, 5, 64, 2, 2>(p, s);   // 2 x 72 KiB
+    case 3: return launch_cfg<2, 4, 2, 2, 64, 3, 2>(p, s);   // 3 x 48 KiB
+    case 4: return launch_cfg<2, 2, 2, 5, 32, 3, 1>(p, s);   // 3 x 28 KiB, 4 waves
+    default: return hipErrorInvalidValue;
+  }
+}

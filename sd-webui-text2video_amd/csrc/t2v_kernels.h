@@ -31,7 +31,9 @@ struct GemmParams {
 };
 
 // Each returns hipSuccess or the launch error.
-hipError_t t2v_launch_gemm(const GemmParams& p, hipStream_t s);
+hipError_t t2v_launch_gemm(const GemmParams& p, hipStream_t s);             // 128x128 / 128x64 tiles (any N, C8 stem)
+hipError_t t2v_launch_gemm2(const GemmParams& p, int tile, hipStream_t s);  // 256/128 x 256/320 tiles, deep DMA ring
+hipError_t t2v_launch_splitk_reduce(const GemmParams& p, hipStream_t s);
 hipError_t t2v_launch_groupnorm(const t2v_op& op, hipStream_t s);
 hipError_t t2v_launch_layernorm(const t2v_op& op, hipStream_t s);
 hipError_t t2v_launch_attention(const t2v_op& op, hipStream_t s);

@@ -118,7 +118,8 @@ class Program:
         self.arena = Arena()
         self.taps: Dict[str, Buf] = {}          # debug: named live buffers (never freed when tapping)
         self.keep_taps = False
-        self.target_blocks = 512                # split-K heuristic: aim for this many workgroups
+        self.target_cus = 256                   # MI355X compute units (tile / split-K policy)
+        self.force_tile = None                  # tests: pin a tile id
 
     # ---- memory ---------------------------------------------------------------------------
     def alloc(self, rows: int, cols: int, dtype: str, ld: Optional[int] = None) -> Buf:
@@ -141,6 +142,43 @@ class Program:
     def _emit(self, op: Op) -> Op:
         self.ops.append(op)
         return op
+
+    # ---- GEMM tiling policy ----------------------------------------------------------------
+    def choose_tile(self, M: int, n: int, k: int, gather: int, allow_splitk: bool = True):
+        """-> (tile id, split_k).  Tile ids as in t2v_op.i[22]: 0 = 128x128-class kernel (any N, the C8
+        stem); 1 256x256, 2 256x320, 3 128x256, 4 128x320 (large-tile kernel, csrc/gemm2.hip).
+        Policy for a 256-CU chip: the widest tile whose grid still gives >= ~0.75 wave of
+        workgroups; otherwise the 128x256 tile, then split-K over the (long) reduction."""
+        cus = self.target_cus
+        if self.force_tile is not None:
+            tile = self.force_tile
+        elif gather == L.GATHER_CONV3X3_C8 or n < 256 or k < 64:
+            tile = 0
+        elif n % 320 == 0 and M >= 32768:
+            tile = 2                                   # 32x32 level: 256x320 tiles, no padded columns
+        elif n >= 2560 and M >= 2048:
+            tile = 2 if (n % 320 == 0 and M >= 8192) else 1    # wide GEGLU / QKV outputs
+        elif gather == L.GATHER_CONV3X3 and k >= 8192 and M <= 4096:
+            tile = 1                                   # deep-level convs: long reduction, few rows
+        else:
+            tile = 0
+        if tile == 0:
+            bm, bn, bk = 128, (64 if (n % 128 != 0 and n % 128 <= 64) else 128), 64
+        else:
+            bm, bn, bk = {1: (256, 256, 64), 2: (256, 320, 64), 3: (128, 256, 64), 4: (128, 320, 32)}[tile]
+        tiles = math.ceil(M / bm) * math.ceil(n / bn)
+        kt = math.ceil(k / bk)
+        split = 1
+        if allow_splitk and kt >= 16:
+            if tile == 0:
+                # measured (tools/gemm_sweep.py): aim for ~2 workgroups per CU when the reduction is long
+                if kt >= 32 and tiles < cus:
+                    split = max(1, min(round(2 * cus / tiles), kt // 16, 32))
+                elif tiles < 0.5 * cus:
+                    split = max(1, min(round(2 * cus / tiles), kt // 8, 32))
+            elif tiles < 0.6 * cus:
+                split = max(1, min(round(cus / tiles), kt // 8, 32))
+        return tile, split
 
     # ---- ops ------------------------------------------------------------------------------
     def begin(self):
@@ -182,21 +220,15 @@ class Program:
         op.p[5] = out.ref
         if residual is not None:
             assert residual.dtype == "f32" and residual.rows >= M and residual.cols == n_out
-        # split-K: fill the chip when the output tile grid is small and the reduction is long
-        bn = 64 if (n % 128 != 0 and n % 128 <= 64) else 128
-        tiles = math.ceil(M / 128) * math.ceil(n / bn)
-        kt = math.ceil(k / 64)
-        split = 1
-        if allow_splitk and tiles < self.target_blocks // 2 and kt >= 8:
-            split = max(1, min(self.target_blocks // tiles, kt // 4, 32))
-        I[19] = split
+        tile, split = self.choose_tile(M, n, k, gather, allow_splitk)
+        I[19], I[22] = split, tile
         ws = None
         if split > 1:
             ws = self.alloc(split * M, n, "f32")
             op.p[6] = ws.ref
         op.flops = 2.0 * M * n * k
         op.out = out
-        op.meta = dict(M=M, N=n, K=k, gather=gather, conv=dict(conv), epi=epi, split=split)
+        op.meta = dict(M=M, N=n, K=k, gather=gather, conv=dict(conv), epi=epi, split=split, tile=tile)
         self._emit(op)
         if ws is not None:
             self.free(ws)     # stream order makes immediate reuse safe

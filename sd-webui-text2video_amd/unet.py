@@ -212,6 +212,10 @@ class UNetSD(nn.Module):
         self._packed_sig = None
         self._packed_device = None
         self.debug_taps = False
+        # Storage type of tensors that are consumed ONLY by a GroupNorm (ResBlock's first conv output
+        # and the three inner temporal-conv outputs): "f16" halves their HBM traffic (what the
+        # reference's .half() path stores everywhere), "f32" keeps them in the fp32 stream.
+        self.norm_input_dtype = "f16"
         self.auto_refresh = True      # re-check parameter versions on every forward (~1 ms); the sampler
                                       # turns this off inside its loop after one explicit refresh
         self.device = torch.device("cpu")
@@ -447,7 +451,7 @@ class _Lowering:
         a = self.gn(prefix + ".in_layers.0", x, prefix + ".in_layers.0", per_frame=True, eps=1e-5, silu=True)
         e0, e1 = self.emb_slices[prefix]
         h1 = self.conv3(prefix + ".in_layers.2", a, prefix + ".in_layers.2", cout, h, w,
-                        rowbias=self.emb_out.col_slice(e0, e1))
+                        rowbias=self.emb_out.col_slice(e0, e1), out_dtype=self.net.norm_input_dtype)
         P.free(a)
         b = self.gn(prefix + ".out_layers.0", h1, prefix + ".out_layers.0", per_frame=True, eps=1e-5, silu=True)
         P.free(h1)
@@ -471,7 +475,7 @@ class _Lowering:
             nrm = self.gn(f"{tp}.{name}.0", t, f"{tp}.{name}.0", per_frame=False, eps=1e-5, silu=True)
             if t is not h2:
                 P.free(t)
-            t = P.alloc(h2.rows, cout, "f32")
+            t = P.alloc(h2.rows, cout, "f32" if name == "conv4" else self.net.norm_input_dtype)
             key = f"{tp}.{name}.{idx}"
             P.gemm(key, nrm, self.w_tconv(key), cout, 3 * cout, t, bias=self.vec(key + ".bias"),
                    gather=L.GATHER_TCONV3, conv=dict(F=self.F, HW=h * w, Cin=cout),

@@ -97,7 +97,8 @@ def test_gemm_geglu_epilogue():
 def test_gemm_split_k(split):
     M, N, K = 96, 1280, 5760
     P = Program()
-    P.target_blocks = 10 * split * 2 + 1          # steer the heuristic
+    P.force_tile = 0
+    P.target_cus = 10 * split                     # steer the heuristic: 10 output tiles
     g = _g(4)
     a, out, res = P.alloc(M, K, "f16"), P.alloc(M, N, "f32"), P.alloc(M, N, "f32")
     w = {"w": (torch.randn(N, K, generator=g) / math.sqrt(K)).half(), "b": torch.randn(N, generator=g)}
@@ -294,3 +295,81 @@ def test_layout_time_embed_copy_ddim():
     assert rel_l2(ext_got[L.EXT_OUT].float(), ext_ref[L.EXT_OUT].float()) < 1e-3
     assert rel_l2(read(got, te).float(), read(it, te).float()) < 2e-3
     assert rel_l2(ext_got[L.EXT_XT_OUT], ext_ref[L.EXT_XT_OUT]) < 1e-6
+
+
+# ---- second-generation GEMM (csrc/gemm2.hip): 256/128 x 256/320 tiles, 4-/3-stage DMA ring --------
+@pytest.mark.parametrize("tile", [1, 2, 3, 4])
+@pytest.mark.parametrize("M,N,K", [(512, 640, 320), (300, 320, 96), (1000, 960, 1280), (256, 512, 32), (77, 1280, 64),
+                                   (2304, 320, 2880)])
+def test_gemm2_plain_tiles(tile, M, N, K):
+    P = Program()
+    P.force_tile = tile
+    a, out = P.alloc(M, K, "f16"), P.alloc(M, N, "f32")
+    g = _g(21)
+    w = {"w": (torch.randn(N, K, generator=g) / math.sqrt(K)).half(), "b": torch.randn(N, generator=g)}
+    op = P.gemm("g", a, Ref("weight", 0, "w"), N, K, out, bias=Ref("weight", 0, "b"), allow_splitk=False)
+    assert op.i[22] == tile
+    it, got, _, _ = run_both(P, w, {}, lambda it: fill(it, a, g))
+    _check(it, got, out, 2e-5, f"gemm2 tile {tile} {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3, 4])
+def test_gemm2_epilogues_and_geglu(tile):
+    M, C, rpb = 384, 320, 96
+    P = Program()
+    P.force_tile = tile
+    g = _g(22)
+    a = P.alloc(M, C, "f16")
+    out16, res, rb = P.alloc(M, C, "f16"), P.alloc(M, C, "f32"), P.alloc(M // rpb, C, "f32")
+    gout = P.alloc(M, 4 * C, "f16")
+    wsrc, bsrc = torch.randn(8 * C, C, generator=g) / math.sqrt(C), torch.randn(8 * C, generator=g) * 0.1
+    perm = pk.geglu_perm(4 * C)
+    w = {"w": (torch.randn(C, C, generator=g) / math.sqrt(C)).half(), "b": torch.randn(C, generator=g),
+         "wg": wsrc[perm].half(), "bg": bsrc[perm].contiguous()}
+    P.gemm("e", a, Ref("weight", 0, "w"), C, C, out16, bias=Ref("weight", 0, "b"), act=1, residual=res, rowbias=rb,
+           rows_per_batch=rpb, allow_splitk=False)
+    P.gemm("g", a, Ref("weight", 0, "wg"), 8 * C, C, gout, bias=Ref("weight", 0, "bg"), epi=L.EPI_GEGLU, allow_splitk=False)
+
+    def init(it):
+        fill(it, a, g); fill(it, res, g); fill(it, rb, g)
+    it, got, _, _ = run_both(P, w, {}, init)
+    _check(it, got, out16, 1e-3, f"gemm2 epilogue tile {tile}")
+    _check(it, got, gout, 1e-3, f"gemm2 geglu tile {tile}")
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3, 4])
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride,up", [(3, 16, 16, 64, 320, 1, 0), (2, 8, 8, 128, 256, 2, 0),
+                                                      (2, 6, 10, 64, 640, 1, 1)])
+def test_gemm2_conv3x3(tile, B, H, W, Cin, Cout, stride, up):
+    Ho, Wo = (2 * H, 2 * W) if up else ((H + 1) // 2, (W + 1) // 2) if stride == 2 else (H, W)
+    P = Program()
+    P.force_tile = tile
+    g = _g(23)
+    a, out = P.alloc(B * H * W, Cin, "f16"), P.alloc(B * Ho * Wo, Cout, "f32")
+    wt = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    w = {"w": pk.conv3x3(wt).half(), "b": torch.randn(Cout, generator=g)}
+    P.gemm("c", a, Ref("weight", 0, "w"), Cout, 9 * Cin, out, bias=Ref("weight", 0, "b"), gather=L.GATHER_CONV3X3,
+           conv=dict(Hin=H, Win=W, Cin=Cin, stride=stride, up=up, Hout=Ho, Wout=Wo), allow_splitk=False)
+    it, got, _, _ = run_both(P, w, {}, lambda it: fill(it, a, g))
+    _check(it, got, out, 2e-5, f"gemm2 conv3x3 tile {tile}")
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3, 4])
+def test_gemm2_temporal_conv_and_split_k(tile):
+    B, F, HW, C = 2, 5, 16, 640
+    P = Program()
+    P.force_tile = tile
+    P.target_cus = 16                      # 1-4 output tiles -> split-K 2..3
+    g = _g(24)
+    M = B * F * HW
+    a, out, res = P.alloc(M, C, "f16"), P.alloc(M, C, "f32"), P.alloc(M, C, "f32")
+    wt = torch.randn(C, C, 3, 1, 1, generator=g) / math.sqrt(3 * C)
+    w = {"w": pk.tconv3(wt).half(), "b": torch.randn(C, generator=g)}
+    op = P.gemm("t", a, Ref("weight", 0, "w"), C, 3 * C, out, bias=Ref("weight", 0, "b"), gather=L.GATHER_TCONV3,
+                conv=dict(F=F, HW=HW, Cin=C), residual=res)
+    assert op.i[19] > 1
+
+    def init(it):
+        fill(it, a, g); fill(it, res, g)
+    it, got, _, _ = run_both(P, w, {}, init)
+    _check(it, got, out, 2e-5, f"gemm2 tconv split-K tile {tile}")

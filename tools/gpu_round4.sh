@@ -1,0 +1,7 @@
+#!/bin/bash
+set -u
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -x > gpurun_out/pytest_gpu.log 2>&1
+echo "pytest exit $?"; tail -n 30 gpurun_out/pytest_gpu.log
+timeout 600 python tools/profile_unet.py 24 32 32 2 > gpurun_out/profile_unet.log 2>&1; echo "profile exit $?"; tail -n 75 gpurun_out/profile_unet.log
