@@ -48,34 +48,80 @@ def random_weights_(module, seed):
                 p.normal_(0.0, 0.05, generator=g)
 
 
-def cpu_baseline(unet, vae, cfg, ddcfg, frames, ddim_steps, max_seconds=30.0):
-    """Time the oracle port on the host cores: ONE UNet forward (b=1, 2 frames @256x256) and ONE
-    VAE frame decode, fp32.  frames/s for the full workload is extrapolated as
-    F / (2*steps*F*t_unet_per_frame + F*t_vae_frame) (UNet cost is linear in F)."""
-    from oracle import torch_port as tp
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    sd = {k: v.detach().float().cpu() for k, v in unet.state_dict().items() if v.is_floating_point()}
-    fs = 2
+def _usable_cores():
+    """Host cores this process may really use: affinity mask, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline_worker(frames, ddim_steps):
+    """Runs in a child process (bounded by a timeout in the parent): the oracle port
+    (oracle/torch_port.py, fp32) on the host cores — ONE UNet forward (b=1, 2 frames @256x256,
+    0.61 TFLOP) and ONE VAE frame decode (0.62 TFLOP).  frames/s for the whole workload is
+    extrapolated as 1 / (2*steps*t_unet_per_frame + t_vae_frame): UNet cost is linear in F
+    (SURVEY App. B).  Weights are seeded synthetic (timing does not depend on their values)."""
+    from oracle import configs, synth, torch_port as tp
+    from sd_webui_text2video_amd import unet as U, vae as V
+    cores = _usable_cores()
+    threads = min(cores, 64)          # torch CPU ops stop scaling (and can thrash) far beyond this
+    torch.set_num_threads(threads)
+    cfg, ddcfg = configs.MODELSCOPE_UNET, configs.VAE_DDCONFIG
+    t0 = time.time()
+    spec = synth.param_spec(U.UNetSD(**cfg, init_weights=False))
     g = torch.Generator().manual_seed(0)
+    sd = {}
+    for n, shp in spec:
+        if len(shp) > 1:
+            fan_in = 1
+            for d in shp[1:]:
+                fan_in *= d
+            sd[n] = torch.empty(shp).normal_(0, fan_in ** -0.5)
+        else:
+            sd[n] = torch.ones(shp) if n.endswith("weight") else torch.zeros(shp)
+    t_w = time.time() - t0
+    fs = 2
     x = torch.randn(1, 4, fs, 32, 32, generator=g)
     y = torch.randn(1, 77, 1024, generator=g)
-    t0 = time.time()
     with torch.no_grad():
+        t0 = time.time()
         tp.unet_forward(sd, cfg, x, torch.tensor([500]), y)
-    t_unet = time.time() - t0
+        t_unet = time.time() - t0
     del sd
-    vsd = {k: v.detach().float().cpu() for k, v in vae.state_dict().items()}
+    vspec = synth.param_spec(V.AutoencoderKL(ddcfg, 4, init_weights=False))
+    vsd = synth.synth_state_dict(vspec, seed=3)
     z = torch.randn(1, 4, 32, 32, generator=g)
-    t0 = time.time()
     with torch.no_grad():
+        t0 = time.time()
         tp.vae_decode(vsd, ddcfg, z)
-    t_vae = time.time() - t0
+        t_vae = time.time() - t0
     per_frame = 2 * ddim_steps * (t_unet / fs) + t_vae
-    return {"value": round(1.0 / per_frame, 5), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/torch_port.py fp32 on {cores} host threads: 1 UNet forward b=1 {fs}f@256x256 "
-                      f"({t_unet:.2f}s) + 1 VAE frame decode ({t_vae:.2f}s); extrapolated to "
-                      f"{frames}f x {ddim_steps} steps x 2 (CFG) + decode"}
+    print(json.dumps({"value": round(1.0 / per_frame, 5), "unit": "frames/s", "cores": threads, "kind": "port",
+                      "sample": f"oracle/torch_port.py fp32, {threads} torch threads ({cores} usable host cores): 1 UNet forward "
+                                f"b=1 {fs}f@256x256 = {t_unet:.2f}s + 1 VAE frame decode = {t_vae:.2f}s (weights built in "
+                                f"{t_w:.0f}s, untimed); extrapolated to {frames}f x {ddim_steps} steps x 2 (CFG) + decode"}))
+
+
+def cpu_baseline(frames, ddim_steps, timeout_s=240):
+    import subprocess
+    try:
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--frames", str(frames),
+                              "--ddim-steps", str(ddim_steps)], capture_output=True, text=True, timeout=timeout_s,
+                             env={**os.environ, "HIP_VISIBLE_DEVICES": "", "WORLD_SIZE": "1"})
+        for line in reversed(out.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        return {"value": None, "unit": "frames/s", "cores": _usable_cores(), "kind": "port",
+                "sample": "cpu baseline worker failed: " + out.stderr[-300:]}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "frames/s", "cores": _usable_cores(), "kind": "port",
+                "sample": f"cpu baseline worker exceeded {timeout_s}s"}
 
 
 def main():
@@ -88,7 +134,11 @@ def main():
     ap.add_argument("--width", type=int, default=256)
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_baseline_worker:
+        cpu_baseline_worker(args.frames, args.ddim_steps)
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -180,7 +230,7 @@ def main():
             "unet_step_frac_of_peak": round(prog.total_flops() / (step_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
         }
         if not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(net, ae, cfg, ddcfg, args.frames, args.ddim_steps)
+            result["cpu_baseline"] = cpu_baseline(args.frames, args.ddim_steps)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
