@@ -55,7 +55,8 @@ enum t2v_op_kind {
 enum t2v_gather {
   T2V_GATHER_PLAIN = 0,   /* A[m*lda + k]                                   (nn.Linear, 1x1) */
   T2V_GATHER_CONV3X3 = 1, /* 3x3 spatial conv, pad 1, stride 1|2, optional nearest-2x
-                             upsample folded in; K = 9*Cin, Cin % 64 == 0                    */
+                             upsample folded in; K = 9*Cin, Cin % 64 == 0, reduction order
+                             (64-channel chunk, tap, channel)                                */
   T2V_GATHER_TCONV3 = 2,  /* (3,1,1) temporal conv over frames, pad (1,0,0); K = 3*Cin       */
   T2V_GATHER_CONV3X3_C8 = 3 /* 3x3 spatial conv with Cin == 8 (4 real + 4 zero channels)     */
 };
@@ -95,7 +96,7 @@ enum t2v_gather {
  *   i: 0 M, 1 N, 2 K, 3 lda, 4 ldw, 5 ldc, 6 ldr, 7 gather, 8 Hin|F, 9 Win|HW, 10 Cin,
  *      11 stride, 12 upsample, 13 Hout, 14 Wout, 15 rows_per_batch, 16 epilogue,
  *      17 out dtype, 18 act (0 none, 1 SiLU), 19 split_k, 20 bias_along_m, 21 ldrb,
- *      22 tile (0 = 128x128-class kernel; 1 256x256, 2 256x320, 3 128x256, 4 128x320)
+ *      22 tile (0 = 128x128-class kernel; 1 256x256, 2 256x320, 3 128x256)
  *   p: 0 A fp16, 1 W fp16 [N,K], 2 bias fp32 [N] (or [M] if bias_along_m), 3 rowbias fp32
  *      [M/rows_per_batch, ldrb], 4 residual fp32 [M,ldr], 5 out, 6 split-K workspace fp32
  * GROUPNORM: i: 0 n_inst, 1 rows_per_inst, 2 C, 3 ld_in, 4 groups, 5 in dtype, 6 silu,

@@ -9,7 +9,7 @@
 //
 // Data layout: activations are channels-last tokens [(b f) h w, C] (row m = one pixel of one
 // frame, C contiguous) so every reduction index k is memory-contiguous; weights are packed
-// [N, K] with K = tap-major (tap*Cin + ci).  No im2col buffer exists: the A tile of a
+// [N, K] with K ordered (64-channel chunk, tap, channel) for the convolutions.  No im2col buffer exists: the A tile of a
 // convolution is gathered straight from the activation tensor by per-lane source addresses of
 // the LDS-DMA loads, and zero padding / M,N,K tails read a 256-byte zero page.
 //
@@ -158,11 +158,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmParams p) 
     unsigned char* xt = smem + buf * STAGE;
     unsigned char* wt = xt + X_BYTES;
     const int k0 = kt * BK;
-    // tap decode (wave-uniform): a 64-wide k-tile lies inside one tap because Cin % 64 == 0
+    // reduction order is (64-channel chunk, tap, channel): k-tile kt = chunk * TAPS + tap
     int tap = 0, ci0 = k0;
     if (GATHER == T2V_GATHER_CONV3X3 || GATHER == T2V_GATHER_TCONV3) {
-      tap = k0 / p.Cin;
-      ci0 = k0 - tap * p.Cin;
+      const int taps = GATHER == T2V_GATHER_CONV3X3 ? 9 : 3;
+      const int chunk = kt / taps;
+      tap = kt - chunk * taps;
+      ci0 = chunk * BK;
     }
 #pragma unroll
     for (int j = 0; j < XS; ++j) {

@@ -127,24 +127,37 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm2_kernel(const GemmPar
 
   const unsigned char* zero = g2_zero_page;
 
-  // ---- per-lane DMA descriptors --------------------------------------------------------------
+  // ---- per-lane DMA state -------------------------------------------------------------------
+  // Every lane keeps ONE running source pointer per DMA piece; a k-tile costs one 64-bit add per
+  // piece.  Conv gathers recompute the pointers only when the filter tap changes (9 / 3 times per
+  // workgroup); rows that fall into padding, past M / N, or belong to a dummy piece park on the
+  // zero page with step 0.  (K % BK == 0 is guaranteed by the dispatcher.)
   const int lrow = lane / CPR;     // row inside a 1-KiB piece
   const int pchunk = lane % CPR;   // physical 16-B chunk inside the row
-  // chunk swizzle: conflict-free ds_read_b128 fragment reads for 64-B and 128-B rows
   auto swz = [](int r) { return BK == 64 ? ((r >> 1) & 7) : ((r >> 2) & 3); };
+  constexpr int STEP = BK * 2;     // bytes per k-tile along a row
 
+  constexpr int TAPS = GATHER == T2V_GATHER_CONV3X3 ? 9 : (GATHER == T2V_GATHER_TCONV3 ? 3 : 1);
+  const unsigned char* xptr[XPW];  // PLAIN: running pointer; conv: pointer of the CENTRE tap, chunk 0
+  int xstep[XPW];                  // PLAIN only
+  unsigned xmask[XPW];             // conv: bit t set <=> tap t of this row is inside the image / clip
   long xoff[XPW];
-  int xy[XPW], xx[XPW], xlc[XPW];
+  int xy[XPW], xx[XPW];
   bool xvalid[XPW];
+  const bool general = GATHER == T2V_GATHER_CONV3X3 && p.up != 0;   // nearest-2x folded in: no affine tap offset
 #pragma unroll
   for (int j = 0; j < XPW; ++j) {
     const int r = (wave + j * NW) * RPS + lrow;   // row inside the token tile
     const int m = m0 + r;
-    xlc[j] = pchunk ^ swz(r);
+    const int lc = pchunk ^ swz(r);
     xvalid[j] = m < p.M;
-    xoff[j] = 0; xy[j] = 0; xx[j] = 0;
+    xoff[j] = 0; xy[j] = 0; xx[j] = 0; xmask[j] = 0; xstep[j] = 0;
+    xptr[j] = zero;
     if (GATHER == T2V_GATHER_PLAIN) {
-      xoff[j] = (long)m * p.lda;
+      if (xvalid[j]) {
+        xptr[j] = reinterpret_cast<const unsigned char*>(p.A + (long)m * p.lda + (long)kt_begin * BK + lc * 8);
+        xstep[j] = STEP;
+      }
     } else if (GATHER == T2V_GATHER_CONV3X3) {
       const int hw = p.Hout * p.Wout;
       const int img = m / hw, rem = m - img * hw;
@@ -152,65 +165,92 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm2_kernel(const GemmPar
       xoff[j] = (long)img * p.Hin * p.Win;
       xy[j] = yo * p.stride;
       xx[j] = xo * p.stride;
+      xptr[j] = reinterpret_cast<const unsigned char*>(p.A + (xoff[j] + (long)xy[j] * p.Win + xx[j]) * p.lda + lc * 8);
+      for (int t = 0; t < 9; ++t) {
+        const int yv = xy[j] + t / 3 - 1, xv = xx[j] + t % 3 - 1;
+        if (xvalid[j] && yv >= 0 && yv < (p.Hin << p.up) && xv >= 0 && xv < (p.Win << p.up)) xmask[j] |= 1u << t;
+      }
+      xx[j] |= lc << 24;     // keep the chunk for the general path (coordinates are < 2^24)
     } else {  // TCONV3
-      xoff[j] = (long)m;
-      xy[j] = (m / p.HW) % p.F;
+      const int f = (m / p.HW) % p.F;
+      xptr[j] = reinterpret_cast<const unsigned char*>(p.A + (long)m * p.lda + lc * 8);
+      for (int t = 0; t < 3; ++t)
+        if (xvalid[j] && f + t - 1 >= 0 && f + t - 1 < p.F) xmask[j] |= 1u << t;
     }
   }
-  const f16* wrow[WPW];
-  int wlc[WPW];
+  int tap = 0, chunk = 0;          // wave-uniform position of the NEXT k-tile to be staged
+  if (GATHER != T2V_GATHER_PLAIN) {
+    chunk = kt_begin / TAPS;
+    tap = kt_begin - chunk * TAPS;
+  }
+  const unsigned char* wptr[WPW];
+  int wstep[WPW];
   bool wdummy[WPW];
 #pragma unroll
   for (int j = 0; j < WPW; ++j) {
     const int s = wave + j * NW;                 // piece index inside the weight tile
     const int r = s * RPS + lrow;
     const int n = n0 + r;
-    wlc[j] = pchunk ^ swz(r);
     wdummy[j] = s >= WSLABS;                     // wave-uniform
-    wrow[j] = (!wdummy[j] && n < p.N) ? (p.W + (size_t)n * p.ldw) : nullptr;
+    const bool ok = !wdummy[j] && n < p.N;
+    wptr[j] = ok ? reinterpret_cast<const unsigned char*>(p.W + (size_t)n * p.ldw + kt_begin * BK + (pchunk ^ swz(r)) * 8) : zero;
+    wstep[j] = ok ? STEP : 0;
   }
 
-  auto stage = [&](int slot, int kt) {
+  int staged = 0;                  // k-tiles staged so far (wave-uniform)
+  auto stage = [&](int slot) {
     unsigned char* base = smem + slot * STAGE_BYTES;
-    const bool live = kt < kt_end;               // wave-uniform; dead stages read the zero page
-    const int k0 = kt * BK;
-    int tap = 0, ci0 = k0;
-    if (GATHER != T2V_GATHER_PLAIN) {
-      tap = k0 / p.Cin;
-      ci0 = k0 - tap * p.Cin;
-    }
-#pragma unroll
-    for (int j = 0; j < XPW; ++j) {
-      bool ok = live && xvalid[j];
-      long eoff;  // element offset into A
+    if (staged < nkt) {
       if (GATHER == T2V_GATHER_PLAIN) {
-        const int kc = k0 + xlc[j] * 8;
-        ok = ok && kc < p.K;
-        eoff = xoff[j] + kc;
-      } else if (GATHER == T2V_GATHER_CONV3X3) {
-        const int ky = tap / 3, kx = tap - ky * 3;
-        const int yv = xy[j] + ky - 1, xv = xx[j] + kx - 1;
-        const int hv = p.Hin << p.up, wv = p.Win << p.up;
-        ok = ok && yv >= 0 && yv < hv && xv >= 0 && xv < wv;
-        const long row = xoff[j] + (long)(yv >> p.up) * p.Win + (xv >> p.up);
-        eoff = row * p.lda + ci0 + xlc[j] * 8;
-      } else {
-        const int fi = xy[j] + tap - 1;
-        ok = ok && fi >= 0 && fi < p.F;
-        const long row = xoff[j] + (long)(tap - 1) * p.HW;
-        eoff = row * p.lda + ci0 + xlc[j] * 8;
-      }
-      const void* src = ok ? (const void*)(p.A + eoff) : (const void*)zero;
-      glds16(src, base + (wave + j * NW) * 1024);
-    }
 #pragma unroll
-    for (int j = 0; j < WPW; ++j) {
-      const int kc = k0 + wlc[j] * 8;
-      const bool ok = live && wrow[j] != nullptr && kc < p.K;
-      const void* src = ok ? (const void*)(wrow[j] + kc) : (const void*)zero;
-      unsigned char* dst = wdummy[j] ? (smem + DUMMY_OFF) : (base + (XSLABS + wave + j * NW) * 1024);
-      glds16(src, dst);
+        for (int j = 0; j < XPW; ++j) {
+          glds16(xptr[j], base + (wave + j * NW) * 1024);
+          xptr[j] += xstep[j];
+        }
+      } else if (!general) {
+        // k-tile = (chunk, tap): source = centre pointer + a wave-uniform byte offset; the per-lane
+        // part is one bit of the tap-validity mask
+        long delta;   // elements, wave-uniform
+        if (GATHER == T2V_GATHER_CONV3X3) {
+          const int ky = tap / 3, kx = tap - ky * 3;
+          delta = ((long)(ky - 1) * p.Win + (kx - 1)) * p.lda;
+        } else {
+          delta = (long)(tap - 1) * p.HW * p.lda;
+        }
+        const long boff = (delta + (long)chunk * BK) * 2;
+#pragma unroll
+        for (int j = 0; j < XPW; ++j) {
+          const bool ok = (xmask[j] >> tap) & 1u;
+          glds16(ok ? (xptr[j] + boff) : zero, base + (wave + j * NW) * 1024);
+        }
+      } else {
+        // nearest-2x upsample folded into the gather (3 convs per forward): per-lane recompute
+        const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+        for (int j = 0; j < XPW; ++j) {
+          const int lc = xx[j] >> 24, x0 = xx[j] & 0xFFFFFF;
+          const int yv = xy[j] + ky - 1, xv = x0 + kx - 1;
+          const bool ok = (xmask[j] >> tap) & 1u;
+          const long row = xoff[j] + (long)(yv >> 1) * p.Win + (xv >> 1);
+          const void* src = ok ? (const void*)(p.A + row * p.lda + (long)chunk * BK + lc * 8) : (const void*)zero;
+          glds16(src, base + (wave + j * NW) * 1024);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < WPW; ++j) {
+        glds16(wptr[j], wdummy[j] ? (smem + DUMMY_OFF) : (base + (XSLABS + wave + j * NW) * 1024));
+        wptr[j] += wstep[j];
+      }
+      if (GATHER != T2V_GATHER_PLAIN) {
+        if (++tap == TAPS) { tap = 0; ++chunk; }
+      }
+    } else {                       // past the end: keep the outstanding-load count constant
+#pragma unroll
+      for (int j = 0; j < XPW; ++j) glds16(zero, base + (wave + j * NW) * 1024);
+#pragma unroll
+      for (int j = 0; j < WPW; ++j) glds16(zero, wdummy[j] ? (smem + DUMMY_OFF) : (base + (XSLABS + wave + j * NW) * 1024));
     }
+    ++staged;
   };
 
   f32x16 acc[TM][TN];
@@ -223,9 +263,25 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm2_kernel(const GemmPar
 
   // prologue: STAGES-1 k-tiles in flight
 #pragma unroll
-  for (int g = 0; g < STAGES - 1; ++g) stage(g, kt_begin + g);
+  for (int g = 0; g < STAGES - 1; ++g) stage(g);
 
+  // fragment read addressing: lane reads row (tile_row0 + lane&31), logical chunk kk*2 + (lane>>5);
+  // per tile-row keep the byte base and the swizzle term, one xor-add per read
   const int frow = lane & 31, fhalf = lane >> 5;
+  int xbase[TM], xsw[TM], wbase[TN], wsw[TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+    const int r = (wm * TM + a) * 32 + frow;
+    xbase[a] = r * ROW_BYTES;
+    xsw[a] = swz(r) << 4;
+  }
+#pragma unroll
+  for (int b = 0; b < TN; ++b) {
+    const int r = (wn * TN + b) * 32 + frow;
+    wbase[b] = XSLABS * 1024 + r * ROW_BYTES;
+    wsw[b] = swz(r) << 4;
+  }
+
   int slot = 0;
   for (int t = 0; t < nkt; ++t) {
     wait_vmcnt<LPS*(STAGES - 2)>();
@@ -234,24 +290,17 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm2_kernel(const GemmPar
     {
       int fs = slot + STAGES - 1;
       if (fs >= STAGES) fs -= STAGES;
-      stage(fs, kt_begin + t + STAGES - 1);
+      stage(fs);
     }
-    const unsigned char* xt = smem + slot * STAGE_BYTES;
-    const unsigned char* wt = xt + XSLABS * 1024;
+    const unsigned char* st = smem + slot * STAGE_BYTES;
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) {
-      const int lchunk = kk * 2 + fhalf;
+      const int lc4 = (kk * 2 + fhalf) << 4;
       f16x8 xf[TM], wf[TN];
 #pragma unroll
-      for (int a = 0; a < TM; ++a) {
-        const int r = (wm * TM + a) * 32 + frow;
-        xf[a] = *reinterpret_cast<const f16x8*>(xt + r * ROW_BYTES + ((lchunk ^ swz(r)) << 4));
-      }
+      for (int a = 0; a < TM; ++a) xf[a] = *reinterpret_cast<const f16x8*>(st + xbase[a] + (lc4 ^ xsw[a]));
 #pragma unroll
-      for (int b = 0; b < TN; ++b) {
-        const int r = (wn * TN + b) * 32 + frow;
-        wf[b] = *reinterpret_cast<const f16x8*>(wt + r * ROW_BYTES + ((lchunk ^ swz(r)) << 4));
-      }
+      for (int b = 0; b < TN; ++b) wf[b] = *reinterpret_cast<const f16x8*>(st + wbase[b] + (lc4 ^ wsw[b]));
 #pragma unroll
       for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -339,13 +388,12 @@ hipError_t launch_cfg(const GemmParams& pin, hipStream_t s) {
 }  // namespace
 
 // tile ids (t2v_op.i[22]):  1 = 256x256, 2 = 256x320, 3 = 128x256 — all 8 waves, 64-wide k-tiles
-// (full 128-byte lines per row), 2-3 stage ring, one workgroup per CU;  4 = 128x320 (32-wide k-tiles).
+// (full 128-byte lines per row = one conv reduction chunk), 2-3 stage ring, one workgroup per CU.
 hipError_t t2v_launch_gemm2(const GemmParams& p, int tile, hipStream_t s) {
   switch (tile) {
     case 1: return launch_cfg<2, 4, 4, 2, 64, 2, 2>(p, s);   // 2 x 64 KiB
     case 2: return launch_cfg<4, 2, 2, 5, 64, 2, 2>(p, s);   // 2 x 72 KiB
     case 3: return launch_cfg<2, 4, 2, 2, 64, 3, 2>(p, s);   // 3 x 48 KiB
-    case 4: return launch_cfg<2, 2, 2, 5, 32, 3, 1>(p, s);   // 3 x 28 KiB, 4 waves
     default: return hipErrorInvalidValue;
   }
 }

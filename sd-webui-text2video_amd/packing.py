@@ -34,19 +34,30 @@ def linear(w: torch.Tensor) -> torch.Tensor:
     return w.reshape(w.shape[0], -1)
 
 
+KCHUNK = 64   # channels per reduction chunk (= the GEMM k-tile)
+
+
 def conv3x3(w: torch.Tensor, cin_pad: int = 0) -> torch.Tensor:
-    """[Co, Ci, 3, 3] -> [Co, 9*Ci'] with k = (ky*3+kx)*Ci' + ci (Ci' = Ci zero-padded to cin_pad)."""
+    """[Co, Ci, 3, 3] -> [Co, 9*Ci'].  Reduction order for Ci % 64 == 0 (every conv of the UNet/VAE
+    body): k = (ci // 64) * 9*64 + (ky*3+kx) * 64 + ci % 64 — "64-channel chunk, tap, channel" — so
+    that the 9 taps that re-read the same activation cache lines are CONSECUTIVE k-tiles (they hit
+    L1/L2 instead of re-streaming the tensor 9x).  The 4(+4 zero)-channel stem uses k = tap*8 + ci."""
     co, ci = w.shape[0], w.shape[1]
     w = w.permute(0, 2, 3, 1)                      # Co, ky, kx, Ci
     if cin_pad and cin_pad > ci:
         w = torch.cat([w, w.new_zeros(co, 3, 3, cin_pad - ci)], dim=3)
+        ci = cin_pad
+    if ci % KCHUNK == 0:
+        w = w.reshape(co, 9, ci // KCHUNK, KCHUNK).permute(0, 2, 1, 3)   # Co, chunk, tap, 64
     return w.reshape(co, -1)
 
 
 def tconv3(w: torch.Tensor) -> torch.Tensor:
-    """[Co, Ci, 3, 1, 1] -> [Co, 3*Ci] with k = kt*Ci + ci."""
+    """[Co, Ci, 3, 1, 1] -> [Co, 3*Ci] with k = (ci // 64) * 3*64 + kt * 64 + ci % 64 (Ci % 64 == 0)."""
     co, ci = w.shape[0], w.shape[1]
-    return w[:, :, :, 0, 0].permute(0, 2, 1).reshape(co, 3 * ci)
+    w = w[:, :, :, 0, 0].permute(0, 2, 1)          # Co, kt, Ci
+    assert ci % KCHUNK == 0
+    return w.reshape(co, 3, ci // KCHUNK, KCHUNK).permute(0, 2, 1, 3).reshape(co, 3 * ci)
 
 
 def geglu_perm(n_half: int, device=None) -> torch.Tensor:

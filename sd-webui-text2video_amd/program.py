@@ -146,13 +146,13 @@ class Program:
     # ---- GEMM tiling policy ----------------------------------------------------------------
     def choose_tile(self, M: int, n: int, k: int, gather: int, allow_splitk: bool = True):
         """-> (tile id, split_k).  Tile ids as in t2v_op.i[22]: 0 = 128x128-class kernel (any N, the C8
-        stem); 1 256x256, 2 256x320, 3 128x256, 4 128x320 (large-tile kernel, csrc/gemm2.hip).
+        stem); 1 256x256, 2 256x320, 3 128x256 (large-tile kernel, csrc/gemm2.hip).
         Policy for a 256-CU chip: the widest tile whose grid still gives >= ~0.75 wave of
         workgroups; otherwise the 128x256 tile, then split-K over the (long) reduction."""
         cus = self.target_cus
         if self.force_tile is not None:
             tile = self.force_tile
-        elif gather == L.GATHER_CONV3X3_C8 or n < 256 or k < 64:
+        elif gather == L.GATHER_CONV3X3_C8 or n < 256 or k < 64 or k % 64 != 0:
             tile = 0
         elif n % 320 == 0 and M >= 32768:
             tile = 2                                   # 32x32 level: 256x320 tiles, no padded columns
@@ -165,7 +165,7 @@ class Program:
         if tile == 0:
             bm, bn, bk = 128, (64 if (n % 128 != 0 and n % 128 <= 64) else 128), 64
         else:
-            bm, bn, bk = {1: (256, 256, 64), 2: (256, 320, 64), 3: (128, 256, 64), 4: (128, 320, 32)}[tile]
+            bm, bn, bk = {1: (256, 256, 64), 2: (256, 320, 64), 3: (128, 256, 64)}[tile]
         tiles = math.ceil(M / bm) * math.ceil(n / bn)
         kt = math.ceil(k / bk)
         split = 1

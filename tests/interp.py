@@ -78,14 +78,18 @@ class Interp:
             for ky in range(3):
                 for kx in range(3):
                     cols.append(Xp[:, ky:ky + stride * Hout:stride, kx:kx + stride * Wout:stride, :])
-            A = torch.cat(cols, dim=3).reshape(M, 9 * Cin)
+            if gather == L.GATHER_CONV3X3:      # k = (chunk, tap, ci): see packing.conv3x3
+                A = torch.stack(cols, dim=3).reshape(nimg, Hout, Wout, 9, Cin // 64, 64).permute(0, 1, 2, 4, 3, 5).reshape(M, 9 * Cin)
+            else:                               # C8 stem: k = tap*8 + ci
+                A = torch.cat(cols, dim=3).reshape(M, 9 * Cin)
             assert K == 9 * Cin
         elif gather == L.GATHER_TCONV3:
             Fr, HW, Cin = I[8], I[9], I[10]
             nb = M // (Fr * HW)
             X = self.view(op.p[0], (nb, Fr, HW, Cin), (Fr * HW * lda, HW * lda, lda, 1), torch.float16, ext).float()
             Xp = F.pad(X, (0, 0, 0, 0, 1, 1))
-            A = torch.cat([Xp[:, kt:kt + Fr] for kt in range(3)], dim=3).reshape(M, 3 * Cin)
+            A = torch.stack([Xp[:, kt:kt + Fr] for kt in range(3)], dim=3)          # nb, F, HW, 3, Cin
+            A = A.reshape(nb, Fr, HW, 3, Cin // 64, 64).permute(0, 1, 2, 4, 3, 5).reshape(M, 3 * Cin)
         else:
             raise ValueError(gather)
         W = self.mat(op.p[1], N, K, ldw, torch.float16, ext).float()

@@ -298,8 +298,8 @@ def test_layout_time_embed_copy_ddim():
 
 
 # ---- second-generation GEMM (csrc/gemm2.hip): 256/128 x 256/320 tiles, 4-/3-stage DMA ring --------
-@pytest.mark.parametrize("tile", [1, 2, 3, 4])
-@pytest.mark.parametrize("M,N,K", [(512, 640, 320), (300, 320, 96), (1000, 960, 1280), (256, 512, 32), (77, 1280, 64),
+@pytest.mark.parametrize("tile", [1, 2, 3])
+@pytest.mark.parametrize("M,N,K", [(512, 640, 320), (300, 320, 192), (1000, 960, 1280), (256, 512, 64), (77, 1280, 128),
                                    (2304, 320, 2880)])
 def test_gemm2_plain_tiles(tile, M, N, K):
     P = Program()
@@ -313,7 +313,7 @@ def test_gemm2_plain_tiles(tile, M, N, K):
     _check(it, got, out, 2e-5, f"gemm2 tile {tile} {M}x{N}x{K}")
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4])
+@pytest.mark.parametrize("tile", [1, 2, 3])
 def test_gemm2_epilogues_and_geglu(tile):
     M, C, rpb = 384, 320, 96
     P = Program()
@@ -337,7 +337,7 @@ def test_gemm2_epilogues_and_geglu(tile):
     _check(it, got, gout, 1e-3, f"gemm2 geglu tile {tile}")
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4])
+@pytest.mark.parametrize("tile", [1, 2, 3])
 @pytest.mark.parametrize("B,H,W,Cin,Cout,stride,up", [(3, 16, 16, 64, 320, 1, 0), (2, 8, 8, 128, 256, 2, 0),
                                                       (2, 6, 10, 64, 640, 1, 1)])
 def test_gemm2_conv3x3(tile, B, H, W, Cin, Cout, stride, up):
@@ -354,7 +354,7 @@ def test_gemm2_conv3x3(tile, B, H, W, Cin, Cout, stride, up):
     _check(it, got, out, 2e-5, f"gemm2 conv3x3 tile {tile}")
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4])
+@pytest.mark.parametrize("tile", [1, 2, 3])
 def test_gemm2_temporal_conv_and_split_k(tile):
     B, F, HW, C = 2, 5, 16, 640
     P = Program()
