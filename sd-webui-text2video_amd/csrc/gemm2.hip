@@ -29,6 +29,9 @@ namespace {
 
 __device__ __attribute__((aligned(256))) unsigned char g2_zero_page[256];
 
+// internal gather id: 3x3 conv with the nearest-2x upsample folded in (no affine tap offset)
+constexpr int G_CONV_UP = 100;
+
 
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const AS1 void*)gsrc, (AS3 void*)lds_wave_base, 16, 0, 0);
@@ -137,45 +140,47 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm2_kernel(const GemmPar
   auto swz = [](int r) { return BK == 64 ? ((r >> 1) & 7) : ((r >> 2) & 3); };
   constexpr int STEP = BK * 2;     // bytes per k-tile along a row
 
-  constexpr int TAPS = GATHER == T2V_GATHER_CONV3X3 ? 9 : (GATHER == T2V_GATHER_TCONV3 ? 3 : 1);
+  constexpr int TAPS = (GATHER == T2V_GATHER_CONV3X3 || GATHER == G_CONV_UP) ? 9 : (GATHER == T2V_GATHER_TCONV3 ? 3 : 1);
+  constexpr bool general = GATHER == G_CONV_UP;
   const unsigned char* xptr[XPW];  // PLAIN: running pointer; conv: pointer of the CENTRE tap, chunk 0
   int xstep[XPW];                  // PLAIN only
   unsigned xmask[XPW];             // conv: bit t set <=> tap t of this row is inside the image / clip
-  long xoff[XPW];
-  int xy[XPW], xx[XPW];
-  bool xvalid[XPW];
-  const bool general = GATHER == T2V_GATHER_CONV3X3 && p.up != 0;   // nearest-2x folded in: no affine tap offset
+  long xoff[general ? XPW : 1];    // only the upsample path keeps per-row coordinates
+  int xy[general ? XPW : 1], xx[general ? XPW : 1];
 #pragma unroll
   for (int j = 0; j < XPW; ++j) {
     const int r = (wave + j * NW) * RPS + lrow;   // row inside the token tile
     const int m = m0 + r;
     const int lc = pchunk ^ swz(r);
-    xvalid[j] = m < p.M;
-    xoff[j] = 0; xy[j] = 0; xx[j] = 0; xmask[j] = 0; xstep[j] = 0;
+    const bool valid = m < p.M;
+    xmask[j] = 0; xstep[j] = 0;
     xptr[j] = zero;
     if (GATHER == T2V_GATHER_PLAIN) {
-      if (xvalid[j]) {
+      if (valid) {
         xptr[j] = reinterpret_cast<const unsigned char*>(p.A + (long)m * p.lda + (long)kt_begin * BK + lc * 8);
         xstep[j] = STEP;
       }
-    } else if (GATHER == T2V_GATHER_CONV3X3) {
+    } else if (GATHER == T2V_GATHER_CONV3X3 || GATHER == G_CONV_UP) {
       const int hw = p.Hout * p.Wout;
       const int img = m / hw, rem = m - img * hw;
       const int yo = rem / p.Wout, xo = rem - yo * p.Wout;
-      xoff[j] = (long)img * p.Hin * p.Win;
-      xy[j] = yo * p.stride;
-      xx[j] = xo * p.stride;
-      xptr[j] = reinterpret_cast<const unsigned char*>(p.A + (xoff[j] + (long)xy[j] * p.Win + xx[j]) * p.lda + lc * 8);
+      const long ibase = (long)img * p.Hin * p.Win;
+      const int ys = yo * p.stride, xs = xo * p.stride;
+      xptr[j] = reinterpret_cast<const unsigned char*>(p.A + (ibase + (long)ys * p.Win + xs) * p.lda + lc * 8);
       for (int t = 0; t < 9; ++t) {
-        const int yv = xy[j] + t / 3 - 1, xv = xx[j] + t % 3 - 1;
-        if (xvalid[j] && yv >= 0 && yv < (p.Hin << p.up) && xv >= 0 && xv < (p.Win << p.up)) xmask[j] |= 1u << t;
+        const int yv = ys + t / 3 - 1, xv = xs + t % 3 - 1;
+        if (valid && yv >= 0 && yv < (p.Hin << p.up) && xv >= 0 && xv < (p.Win << p.up)) xmask[j] |= 1u << t;
       }
-      xx[j] |= lc << 24;     // keep the chunk for the general path (coordinates are < 2^24)
+      if (general) {
+        xoff[j] = ibase;
+        xy[j] = ys;
+        xx[j] = xs | (lc << 24);     // keep the chunk too (coordinates are < 2^24)
+      }
     } else {  // TCONV3
       const int f = (m / p.HW) % p.F;
       xptr[j] = reinterpret_cast<const unsigned char*>(p.A + (long)m * p.lda + lc * 8);
       for (int t = 0; t < 3; ++t)
-        if (xvalid[j] && f + t - 1 >= 0 && f + t - 1 < p.F) xmask[j] |= 1u << t;
+        if (valid && f + t - 1 >= 0 && f + t - 1 < p.F) xmask[j] |= 1u << t;
     }
   }
   int tap = 0, chunk = 0;          // wave-uniform position of the NEXT k-tile to be staged
@@ -197,58 +202,56 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm2_kernel(const GemmPar
     wstep[j] = ok ? STEP : 0;
   }
 
-  int staged = 0;                  // k-tiles staged so far (wave-uniform)
-  auto stage = [&](int slot) {
-    unsigned char* base = smem + slot * STAGE_BYTES;
-    if (staged < nkt) {
-      if (GATHER == T2V_GATHER_PLAIN) {
-#pragma unroll
-        for (int j = 0; j < XPW; ++j) {
-          glds16(xptr[j], base + (wave + j * NW) * 1024);
-          xptr[j] += xstep[j];
-        }
-      } else if (!general) {
-        // k-tile = (chunk, tap): source = centre pointer + a wave-uniform byte offset; the per-lane
-        // part is one bit of the tap-validity mask
-        long delta;   // elements, wave-uniform
-        if (GATHER == T2V_GATHER_CONV3X3) {
-          const int ky = tap / 3, kx = tap - ky * 3;
-          delta = ((long)(ky - 1) * p.Win + (kx - 1)) * p.lda;
-        } else {
-          delta = (long)(tap - 1) * p.HW * p.lda;
-        }
-        const long boff = (delta + (long)chunk * BK) * 2;
-#pragma unroll
-        for (int j = 0; j < XPW; ++j) {
-          const bool ok = (xmask[j] >> tap) & 1u;
-          glds16(ok ? (xptr[j] + boff) : zero, base + (wave + j * NW) * 1024);
-        }
-      } else {
-        // nearest-2x upsample folded into the gather (3 convs per forward): per-lane recompute
+  // Staging one k-tile = LPS DMA instructions per wave.  They are issued as `pieces` so that the
+  // main loop can spread them between the MFMA k-steps: an LDS-DMA instruction holds the wave's
+  // issue port for ~60+ cycles while the TA walks its 64 addresses, so issuing all of them
+  // back-to-back before the MFMAs (as a monolithic stage() would) serialises DMA issue and MFMA
+  // execution — measured: 27 GB/s/CU of operand delivery, 50 % of wave cycles parked.
+  int staged = 0;                  // k-tiles whose staging has been started (wave-uniform)
+  bool live = true;                // staging position still inside [kt_begin, kt_end)
+  long boff = 0;                   // conv: wave-uniform byte offset of the k-tile being staged
+  int ktap = 0;
+  auto stage_begin = [&]() {
+    live = staged < nkt;
+    if (GATHER != T2V_GATHER_PLAIN) {
+      ktap = tap;
+      long delta = 0;
+      if (GATHER == T2V_GATHER_CONV3X3) {
         const int ky = tap / 3, kx = tap - ky * 3;
-#pragma unroll
-        for (int j = 0; j < XPW; ++j) {
-          const int lc = xx[j] >> 24, x0 = xx[j] & 0xFFFFFF;
-          const int yv = xy[j] + ky - 1, xv = x0 + kx - 1;
-          const bool ok = (xmask[j] >> tap) & 1u;
-          const long row = xoff[j] + (long)(yv >> 1) * p.Win + (xv >> 1);
-          const void* src = ok ? (const void*)(p.A + row * p.lda + (long)chunk * BK + lc * 8) : (const void*)zero;
-          glds16(src, base + (wave + j * NW) * 1024);
-        }
+        delta = ((long)(ky - 1) * p.Win + (kx - 1)) * p.lda;
+      } else if (GATHER == T2V_GATHER_TCONV3) {
+        delta = (long)(tap - 1) * p.HW * p.lda;
       }
-#pragma unroll
-      for (int j = 0; j < WPW; ++j) {
-        glds16(wptr[j], wdummy[j] ? (smem + DUMMY_OFF) : (base + (XSLABS + wave + j * NW) * 1024));
-        wptr[j] += wstep[j];
+      boff = (delta + (long)chunk * BK) * 2;
+    }
+  };
+  auto stage_piece = [&](int slot, int j) {        // j in [0, LPS): token pieces first, then weights
+    unsigned char* base = smem + slot * STAGE_BYTES;
+    if (j < XPW) {
+      const void* src = zero;
+      if (GATHER == T2V_GATHER_PLAIN) {
+        if (live) { src = xptr[j]; xptr[j] += xstep[j]; }
+      } else if (!general) {
+        if (live && ((xmask[j] >> ktap) & 1u)) src = xptr[j] + boff;
+      } else if (general) {
+        // nearest-2x upsample folded into the gather (3 convs per forward): per-lane recompute
+        const int ky = ktap / 3, kx = ktap - ky * 3;
+        const int lc = xx[j] >> 24, x0 = xx[j] & 0xFFFFFF;
+        const int yv = xy[j] + ky - 1, xv = x0 + kx - 1;
+        const long row = xoff[j] + (long)(yv >> 1) * p.Win + (xv >> 1);
+        if (live && ((xmask[j] >> ktap) & 1u)) src = p.A + row * p.lda + (long)chunk * BK + lc * 8;
       }
-      if (GATHER != T2V_GATHER_PLAIN) {
-        if (++tap == TAPS) { tap = 0; ++chunk; }
-      }
-    } else {                       // past the end: keep the outstanding-load count constant
-#pragma unroll
-      for (int j = 0; j < XPW; ++j) glds16(zero, base + (wave + j * NW) * 1024);
-#pragma unroll
-      for (int j = 0; j < WPW; ++j) glds16(zero, wdummy[j] ? (smem + DUMMY_OFF) : (base + (XSLABS + wave + j * NW) * 1024));
+      glds16(src, base + (wave + j * NW) * 1024);
+    } else {
+      const int jw = j - XPW;
+      const void* src = zero;
+      if (live) { src = wptr[jw]; wptr[jw] += wstep[jw]; }
+      glds16(src, wdummy[jw] ? (smem + DUMMY_OFF) : (base + (XSLABS + wave + jw * NW) * 1024));
+    }
+  };
+  auto stage_end = [&]() {
+    if (GATHER != T2V_GATHER_PLAIN && live) {
+      if (++tap == TAPS) { tap = 0; ++chunk; }
     }
     ++staged;
   };
@@ -263,7 +266,12 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm2_kernel(const GemmPar
 
   // prologue: STAGES-1 k-tiles in flight
 #pragma unroll
-  for (int g = 0; g < STAGES - 1; ++g) stage(g);
+  for (int g = 0; g < STAGES - 1; ++g) {
+    stage_begin();
+#pragma unroll
+    for (int j = 0; j < LPS; ++j) stage_piece(g, j);
+    stage_end();
+  }
 
   // fragment read addressing: lane reads row (tile_row0 + lane&31), logical chunk kk*2 + (lane>>5);
   // per tile-row keep the byte base and the swizzle term, one xor-add per read
@@ -282,31 +290,34 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm2_kernel(const GemmPar
     wsw[b] = swz(r) << 4;
   }
 
+  constexpr int KSTEPS = BK / 16;
   int slot = 0;
   for (int t = 0; t < nkt; ++t) {
     wait_vmcnt<LPS*(STAGES - 2)>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    {
-      int fs = slot + STAGES - 1;
-      if (fs >= STAGES) fs -= STAGES;
-      stage(fs);
-    }
+    int fs = slot + STAGES - 1;
+    if (fs >= STAGES) fs -= STAGES;
+    stage_begin();
     const unsigned char* st = smem + slot * STAGE_BYTES;
 #pragma unroll
-    for (int kk = 0; kk < BK / 16; ++kk) {
+    for (int kk = 0; kk < KSTEPS; ++kk) {
       const int lc4 = (kk * 2 + fhalf) << 4;
       f16x8 xf[TM], wf[TN];
 #pragma unroll
       for (int a = 0; a < TM; ++a) xf[a] = *reinterpret_cast<const f16x8*>(st + xbase[a] + (lc4 ^ xsw[a]));
 #pragma unroll
       for (int b = 0; b < TN; ++b) wf[b] = *reinterpret_cast<const f16x8*>(st + wbase[b] + (lc4 ^ wsw[b]));
+      // this k-step's share of the next tile's DMA, issued between the fragment reads and the MFMAs
+#pragma unroll
+      for (int j = (LPS * kk) / KSTEPS; j < (LPS * (kk + 1)) / KSTEPS; ++j) stage_piece(fs, j);
 #pragma unroll
       for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int b = 0; b < TN; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[b], xf[a], acc[a][b], 0, 0, 0);
     }
+    stage_end();
     slot = slot + 1 == STAGES ? 0 : slot + 1;
   }
   wait_vmcnt<0>();   // drain the zero-page loads of the dead stages before the LDS goes away
@@ -376,7 +387,10 @@ hipError_t launch_cfg(const GemmParams& pin, hipStream_t s) {
   hipError_t e;
   switch (p.gather) {
     case T2V_GATHER_PLAIN: e = launch_cfg_gather<WM, WN, TM, TN, BK, STAGES, MINW, T2V_GATHER_PLAIN>(p, s); break;
-    case T2V_GATHER_CONV3X3: e = launch_cfg_gather<WM, WN, TM, TN, BK, STAGES, MINW, T2V_GATHER_CONV3X3>(p, s); break;
+    case T2V_GATHER_CONV3X3:
+      if (p.up) e = launch_cfg_gather<WM, WN, TM, TN, BK, STAGES, MINW, G_CONV_UP>(p, s);
+      else e = launch_cfg_gather<WM, WN, TM, TN, BK, STAGES, MINW, T2V_GATHER_CONV3X3>(p, s);
+      break;
     case T2V_GATHER_TCONV3: e = launch_cfg_gather<WM, WN, TM, TN, BK, STAGES, MINW, T2V_GATHER_TCONV3>(p, s); break;
     default: return hipErrorInvalidValue;
   }
