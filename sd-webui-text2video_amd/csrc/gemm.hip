@@ -332,25 +332,29 @@ hipError_t launch_tile(const GemmParams& p, hipStream_t s) {
   switch (p.gather) {
     case T2V_GATHER_PLAIN: {
       auto k = gemm_kernel<BM, BN, WM, WN, T2V_GATHER_PLAIN>;
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      static bool once0 = false;
+      if (!once0) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds); once0 = true; }
       hipLaunchKernelGGL(k, grid, block, lds, s, p);
       break;
     }
     case T2V_GATHER_CONV3X3: {
       auto k = gemm_kernel<BM, BN, WM, WN, T2V_GATHER_CONV3X3>;
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      static bool once1 = false;
+      if (!once1) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds); once1 = true; }
       hipLaunchKernelGGL(k, grid, block, lds, s, p);
       break;
     }
     case T2V_GATHER_TCONV3: {
       auto k = gemm_kernel<BM, BN, WM, WN, T2V_GATHER_TCONV3>;
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      static bool once2 = false;
+      if (!once2) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds); once2 = true; }
       hipLaunchKernelGGL(k, grid, block, lds, s, p);
       break;
     }
     case T2V_GATHER_CONV3X3_C8: {
       auto k = gemm_kernel<BM, BN, WM, WN, T2V_GATHER_CONV3X3_C8>;
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      static bool once3 = false;
+      if (!once3) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds); once3 = true; }
       hipLaunchKernelGGL(k, grid, block, lds, s, p);
       break;
     }

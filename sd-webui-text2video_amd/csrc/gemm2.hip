@@ -308,9 +308,14 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm2_kernel(const GemmPar
       for (int a = 0; a < TM; ++a) xf[a] = *reinterpret_cast<const f16x8*>(st + xbase[a] + (lc4 ^ xsw[a]));
 #pragma unroll
       for (int b = 0; b < TN; ++b) wf[b] = *reinterpret_cast<const f16x8*>(st + wbase[b] + (lc4 ^ wsw[b]));
-      // this k-step's share of the next tile's DMA, issued between the fragment reads and the MFMAs
+      // this k-step's share of the next tile's DMA, issued between the fragment reads and the MFMAs.
+      // With a 2-deep ring the pieces must land before the next barrier, so they go out in the first
+      // half of the k-tile; with 3 stages they have a whole extra k-tile and are spread over all steps.
+      constexpr int SPREAD = STAGES == 2 ? KSTEPS / 2 : KSTEPS;
+      if (kk < SPREAD) {
 #pragma unroll
-      for (int j = (LPS * kk) / KSTEPS; j < (LPS * (kk + 1)) / KSTEPS; ++j) stage_piece(fs, j);
+        for (int j = (LPS * kk) / SPREAD; j < (LPS * (kk + 1)) / SPREAD; ++j) stage_piece(fs, j);
+      }
 #pragma unroll
       for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -370,8 +375,12 @@ hipError_t launch_cfg_gather(const GemmParams& p, hipStream_t s) {
   constexpr int lds = STAGES * (BM + BN) * BK * 2 + 1024;
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   auto k = gemm2_kernel<WM, WN, TM, TN, BK, STAGES, MINW, GATHER>;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  if (e != hipSuccess) return e;
+  static bool attr_set = false;     // once per instantiation (the call costs microseconds on the host)
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
   hipLaunchKernelGGL(k, dim3(tiles, p.splitk > 1 ? p.splitk : 1), dim3(WM * WN * 64), lds, s, p);
   return hipGetLastError();
 }

@@ -28,6 +28,7 @@ struct GemmParams {
   int rows_per_batch;
   int epi, out_f32, act, splitk, bias_m;
   int kt_per_split;                            // k-tiles (of 64) per split
+  int dbg;                                     // ablation switches (tools only): 1 no DMA, 2 no MFMA, 4 no ds_read
 };
 
 // Each returns hipSuccess or the launch error.
