@@ -134,6 +134,8 @@ def main():
     ap.add_argument("--width", type=int, default=256)
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--parallel", default="auto", choices=["auto", "pairs", "tshard"],
+                    help="N>1 layout: independent CFG pairs, or one T-sharded video (N>=4)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_worker:
@@ -166,7 +168,7 @@ def main():
 
     # weak scaling: every rank group generates its own frames; N=1 is the configs[1] workload.
     runner = parallel.make_runner(pipe, world, rank, frames=args.frames, height=args.height, width=args.width,
-                                  ddim_steps=args.ddim_steps, guidance=9.0)
+                                  ddim_steps=args.ddim_steps, guidance=9.0, mode=args.parallel)
 
     def one_video(seed):
         return runner(cond, uncond, seed)

@@ -83,7 +83,7 @@ enum t2v_gather {
 #define T2V_EXT_EPS 8    /* DDIM: stacked UNet outputs [2,C,F,h,w] (cond, uncond)            */
 
 /* GroupNorm pass-1 granularity: rows of one statistics instance reduced per workgroup.  The
- * caller sizes the scratch as n_inst*ceil(rows/16)*groups*16 + n_inst*groups*8 bytes. */
+ * caller sizes the scratch as nparts*n_inst*ceil(rows/16)*groups*16 + n_inst*groups*8 bytes. */
 #define T2V_GN_ROWS_PER_BLOCK 16
 
 #define T2V_OP_NI 24
@@ -96,11 +96,13 @@ enum t2v_gather {
  *   i: 0 M, 1 N, 2 K, 3 lda, 4 ldw, 5 ldc, 6 ldr, 7 gather, 8 Hin|F, 9 Win|HW, 10 Cin,
  *      11 stride, 12 upsample, 13 Hout, 14 Wout, 15 rows_per_batch, 16 epilogue,
  *      17 out dtype, 18 act (0 none, 1 SiLU), 19 split_k, 20 bias_along_m, 21 ldrb,
- *      22 tile (0 = 128x128-class kernel; 1 256x256, 2 256x320, 3 128x256)
+ *      22 tile (0 = 128x128-class kernel; 1 256x256, 2 256x320, 3 128x256),
+ *      23 tconv halo (input rows are [clip][F+2][HW]: one halo frame either side, T-sharding)
  *   p: 0 A fp16, 1 W fp16 [N,K], 2 bias fp32 [N] (or [M] if bias_along_m), 3 rowbias fp32
  *      [M/rows_per_batch, ldrb], 4 residual fp32 [M,ldr], 5 out, 6 split-K workspace fp32
  * GROUPNORM: i: 0 n_inst, 1 rows_per_inst, 2 C, 3 ld_in, 4 groups, 5 in dtype, 6 silu,
- *      7 ld_out;  f: 0 eps;  p: 0 x, 1 gamma, 2 beta, 3 out fp16, 4 scratch (see above)
+ *      7 ld_out, 8 phase (0 whole op | 1 statistics only | 2 fold gathered parts + normalise),
+ *      9 nparts, 10 this rank's part;  f: 0 eps;  p: 0 x, 1 gamma, 2 beta, 3 out fp16, 4 scratch
  * LAYERNORM: i: 0 M, 1 C, 2 ld_in, 3 ld_out; f: 0 eps; p: 0 x fp32, 1 gamma, 2 beta, 3 out fp16
  * ATTENTION: i: 0 nq, 1 nk, 2 heads, 3 batch_outer, 4 batch_inner, 5..7 q strides (seq,
  *      outer, inner), 8..10 k/v strides, 11..13 out strides (elements; head h at +64h);

@@ -106,7 +106,7 @@ hipError_t launch_op(const t2v_op& op, hipStream_t s) {
       p.res = reinterpret_cast<const float*>(op.p[4]);
       p.out = reinterpret_cast<void*>(op.p[5]);
       p.ws = reinterpret_cast<float*>(op.p[6]);
-      p.dbg = op.i[23];
+      p.halo = op.i[23];
       const int tile = op.i[22];
       // the large-tile kernel advances its source pointers by whole k-tiles: needs K % BK == 0
       if (tile >= 1 && tile <= 3 && p.gather != T2V_GATHER_CONV3X3_C8 && p.K % 64 == 0) return t2v_launch_gemm2(p, tile, s);

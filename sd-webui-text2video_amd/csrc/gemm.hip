@@ -138,9 +138,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmParams p) 
       xoff[j] = (long)img * p.Hin * p.Win;
       xy[j] = yo * p.stride;
       xx[j] = xo * p.stride;
-    } else {  // TCONV3
-      xoff[j] = (long)m;
-      xy[j] = (m / p.HW) % p.F;
+    } else {  // TCONV3 (halo layout: input rows [clip][F+2][HW], every tap in range)
+      const int clip = m / (p.HW * p.F);
+      xoff[j] = p.halo ? (long)m + (long)(2 * clip + 1) * p.HW : (long)m;
+      xy[j] = p.halo ? 1 : (m / p.HW) - clip * p.F;
     }
   }
   // weight rows handled by this lane
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmParams p) 
         }
       } else {  // TCONV3
         const int fi = xy[j] + tap - 1;
-        if (xvalid[j] && fi >= 0 && fi < p.F) {
+        if (xvalid[j] && (p.halo || (fi >= 0 && fi < p.F))) {
           const long row = xoff[j] + (long)(tap - 1) * p.HW;
           src = p.A + row * p.lda + ci0 + xlchunk[j] * 8;
         }

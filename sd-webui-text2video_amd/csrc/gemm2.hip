@@ -177,10 +177,13 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm2_kernel(const GemmPar
         xx[j] = xs | (lc << 24);     // keep the chunk too (coordinates are < 2^24)
       }
     } else {  // TCONV3
-      const int f = (m / p.HW) % p.F;
-      xptr[j] = reinterpret_cast<const unsigned char*>(p.A + (long)m * p.lda + lc * 8);
+      const int clip = m / (p.HW * p.F);
+      const int f = (m / p.HW) - clip * p.F;
+      // halo layout: input rows are [clip][F+2][HW]; output row m reads input frames f, f+1, f+2
+      const long in_row = p.halo ? (long)m + (long)(2 * clip + 1) * p.HW : (long)m;
+      xptr[j] = reinterpret_cast<const unsigned char*>(p.A + in_row * p.lda + lc * 8);
       for (int t = 0; t < 3; ++t)
-        if (valid && f + t - 1 >= 0 && f + t - 1 < p.F) xmask[j] |= 1u << t;
+        if (valid && (p.halo || (f + t - 1 >= 0 && f + t - 1 < p.F))) xmask[j] |= 1u << t;
     }
   }
   int tap = 0, chunk = 0;          // wave-uniform position of the NEXT k-tile to be staged

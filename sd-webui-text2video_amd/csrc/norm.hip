@@ -88,15 +88,18 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* x, double* parti
 }
 
 // Pass 2 — one wave per (instance, group): ordered fold of the block partials -> {mean, rstd}.
+// `nparts` > 1: the partials of all T-shard ranks, gathered as [part][inst][blk][group][2]; the fold
+// order (part-major, then block) is the same on every rank, so all ranks get identical statistics.
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* partials, float* finals, int n_inst, int nblk,
-                                                          int groups, double inv_n, float eps) {
+                                                          int groups, double inv_n, float eps, int nparts) {
   const int lane = threadIdx.x & 63;
   const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);  // (inst, group) pair
   if (idx >= n_inst * groups) return;
   const int inst = idx / groups, g = idx - inst * groups;
   double s = 0.0, q = 0.0;
-  for (int b = lane; b < nblk; b += 64) {
-    const double* st = partials + (((size_t)inst * nblk + b) * groups + g) * 2;
+  for (int u = lane; u < nblk * nparts; u += 64) {
+    const int part = u / nblk, b = u - part * nblk;
+    const double* st = partials + ((((size_t)part * n_inst + inst) * nblk + b) * groups + g) * 2;
     s += st[0];
     q += st[1];
   }
@@ -187,16 +190,21 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
 
 }  // namespace
 
-// Scratch (op.p[4], owned by the caller): fp64 partials [n_inst][nblk][groups][2] followed by
+// Scratch (op.p[4], owned by the caller): fp64 partials [nparts][n_inst][nblk][groups][2] followed by
 // fp32 finals [n_inst][groups][2], nblk = ceil(rows / T2V_GN_ROWS_PER_BLOCK).
+// op.i[8] = phase: 0 = whole op; 1 = statistics only (writes this rank's partials into part op.i[10]);
+//                  2 = fold the op.i[9] gathered parts + normalise (after the partials all-gather).
 hipError_t t2v_launch_groupnorm(const t2v_op& op, hipStream_t s) {
   const int n_inst = op.i[0], rows = op.i[1], C = op.i[2], ld_in = op.i[3], groups = op.i[4];
   const int in_dt = op.i[5], silu = op.i[6], ld_out = op.i[7];
-  if (C % 4 != 0 || C % groups != 0 || groups > 256 || n_inst <= 0 || rows <= 0 || op.p[4] == 0)
+  const int phase = op.i[8], nparts = op.i[9] > 0 ? op.i[9] : 1, part = op.i[10];
+  if (C % 4 != 0 || C % groups != 0 || groups > 256 || n_inst <= 0 || rows <= 0 || op.p[4] == 0 || part < 0 ||
+      part >= nparts || phase < 0 || phase > 2)
     return hipErrorInvalidValue;
   const int nblk = (rows + GN_ROWS_PER_BLOCK - 1) / GN_ROWS_PER_BLOCK;
+  const size_t part_len = (size_t)n_inst * nblk * groups * 2;
   double* partials = reinterpret_cast<double*>(op.p[4]);
-  float* finals = reinterpret_cast<float*>(partials + (size_t)n_inst * nblk * groups * 2);
+  float* finals = reinterpret_cast<float*>(partials + part_len * nparts);
   const dim3 g1(nblk, n_inst);
   const int cv = C / 4;
   const int R = cv <= 256 ? 256 / cv : 1;
@@ -204,22 +212,28 @@ hipError_t t2v_launch_groupnorm(const t2v_op& op, hipStream_t s) {
   const long units = (long)n_inst * rows * cv;
   const int g3 = (int)((units + 255) / 256 < 4096 ? (units + 255) / 256 : 4096);
   const int g2 = (n_inst * groups + 3) / 4;
-  const double inv_n = 1.0 / ((double)rows * (C / groups));
+  const double inv_n = 1.0 / ((double)rows * nparts * (C / groups));
   const float* gamma = reinterpret_cast<const float*>(op.p[1]);
   const float* beta = reinterpret_cast<const float*>(op.p[2]);
   f16* out = reinterpret_cast<f16*>(op.p[3]);
   if (in_dt == T2V_F32) {
     const float* x = reinterpret_cast<const float*>(op.p[0]);
-    hipLaunchKernelGGL(gn_stats_kernel<float>, g1, dim3(256), lds, s, x, partials, rows, C, ld_in, groups);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(g2), dim3(256), 0, s, partials, finals, n_inst, nblk, groups, inv_n, op.f[0]);
-    hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(g3), dim3(256), 0, s, x, finals, gamma, beta, out, n_inst, rows, C,
-                       ld_in, ld_out, groups, silu);
+    if (phase != 2)
+      hipLaunchKernelGGL(gn_stats_kernel<float>, g1, dim3(256), lds, s, x, partials + part_len * part, rows, C, ld_in, groups);
+    if (phase != 1) {
+      hipLaunchKernelGGL(gn_finalize_kernel, dim3(g2), dim3(256), 0, s, partials, finals, n_inst, nblk, groups, inv_n, op.f[0], nparts);
+      hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(g3), dim3(256), 0, s, x, finals, gamma, beta, out, n_inst, rows, C,
+                         ld_in, ld_out, groups, silu);
+    }
   } else {
     const f16* x = reinterpret_cast<const f16*>(op.p[0]);
-    hipLaunchKernelGGL(gn_stats_kernel<f16>, g1, dim3(256), lds, s, x, partials, rows, C, ld_in, groups);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(g2), dim3(256), 0, s, partials, finals, n_inst, nblk, groups, inv_n, op.f[0]);
-    hipLaunchKernelGGL(gn_apply_kernel<f16>, dim3(g3), dim3(256), 0, s, x, finals, gamma, beta, out, n_inst, rows, C,
-                       ld_in, ld_out, groups, silu);
+    if (phase != 2)
+      hipLaunchKernelGGL(gn_stats_kernel<f16>, g1, dim3(256), lds, s, x, partials + part_len * part, rows, C, ld_in, groups);
+    if (phase != 1) {
+      hipLaunchKernelGGL(gn_finalize_kernel, dim3(g2), dim3(256), 0, s, partials, finals, n_inst, nblk, groups, inv_n, op.f[0], nparts);
+      hipLaunchKernelGGL(gn_apply_kernel<f16>, dim3(g3), dim3(256), 0, s, x, finals, gamma, beta, out, n_inst, rows, C,
+                         ld_in, ld_out, groups, silu);
+    }
   }
   return hipGetLastError();
 }

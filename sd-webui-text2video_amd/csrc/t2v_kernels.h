@@ -28,7 +28,8 @@ struct GemmParams {
   int rows_per_batch;
   int epi, out_f32, act, splitk, bias_m;
   int kt_per_split;                            // k-tiles (of 64) per split
-  int dbg;                                     // ablation switches (tools only): 1 no DMA, 2 no MFMA, 4 no ds_read
+  int halo;                                    // tconv3: input has one halo frame before and after each clip
+                                               // ([B][F+2][HW] rows, T-sharded forward); all 3 taps are in range
 };
 
 // Each returns hipSuccess or the launch error.

@@ -14,6 +14,7 @@ from typing import Dict, List, Optional, Tuple
 from . import _lib as L
 
 _ITEM = {"f16": 2, "f32": 4, "f64": 8, "u8": 1}
+OP_COLLECTIVE = 100          # host-side pseudo-op (never handed to the library)
 _DT = {"f16": L.F16, "f32": L.F32}
 
 
@@ -191,7 +192,7 @@ class Program:
              ldw: Optional[int] = None, gather: int = L.GATHER_PLAIN, conv: Optional[dict] = None,
              rowbias: Optional[Buf] = None, rows_per_batch: int = 0, residual: Optional[Buf] = None,
              epi: int = L.EPI_NONE, act: int = 0, bias_along_m: bool = False, m: Optional[int] = None,
-             allow_splitk: bool = True) -> Op:
+             allow_splitk: bool = True, halo: bool = False) -> Op:
         """out[M, n_out] = epi(gather(a)[M, k] @ w[n, k]^T)."""
         conv = conv or {}
         M = out.rows if m is None else m
@@ -214,6 +215,7 @@ class Program:
         I[16], I[17], I[18] = epi, _DT[out.dtype], act
         I[20] = 1 if bias_along_m else 0
         I[21] = rowbias.ld if rowbias is not None else 0
+        I[23] = 1 if halo else 0
         op.p[0], op.p[1], op.p[2] = a.ref, w, bias
         op.p[3] = rowbias.ref if rowbias is not None else NULL
         op.p[4] = residual.ref if residual is not None else NULL
@@ -228,26 +230,59 @@ class Program:
             op.p[6] = ws.ref
         op.flops = 2.0 * M * n * k
         op.out = out
-        op.meta = dict(M=M, N=n, K=k, gather=gather, conv=dict(conv), epi=epi, split=split, tile=tile)
+        op.meta = dict(M=M, N=n, K=k, gather=gather, conv=dict(conv), epi=epi, split=split, tile=tile, halo=halo)
         self._emit(op)
         if ws is not None:
             self.free(ws)     # stream order makes immediate reuse safe
         return op
 
     def groupnorm(self, name: str, x: Buf, gamma: Ref, beta: Ref, out: Buf, *, n_inst: int, eps: float,
-                  silu: bool, groups: int = 32) -> Op:
+                  silu: bool, groups: int = 32, shard: Optional[Tuple[int, int]] = None) -> Op:
+        """GroupNorm(+SiLU).  With shard=(R, r) (cross-frame statistics of a T-sharded clip) the op is split
+        into: statistics (this rank's partials) -> all-gather of the fp64 partials over the T group ->
+        ordered fold of all R parts + normalise; every rank ends up with bit-identical statistics."""
         rows = x.rows // n_inst
         assert rows * n_inst == x.rows and out.dtype == "f16" and x.cols % 4 == 0
-        op = Op(L.OP_GROUPNORM, name)
-        op.i[0:8] = [n_inst, rows, x.cols, x.ld, groups, _DT[x.dtype], int(silu), out.ld]
-        op.f[0] = eps
+        nparts, part = shard if shard is not None else (1, 0)
         nblk = (rows + L.GN_ROWS_PER_BLOCK - 1) // L.GN_ROWS_PER_BLOCK
-        scratch = self.alloc(n_inst * nblk * groups * 16 + n_inst * groups * 8, 1, "u8")
-        op.p[0:5] = [x.ref, gamma, beta, out.ref, scratch.ref]
-        op.out = out
-        self._emit(op)
+        part_bytes = n_inst * nblk * groups * 16
+        scratch = self.alloc(nparts * part_bytes + n_inst * groups * 8, 1, "u8")
+
+        def make(phase, suffix):
+            op = Op(L.OP_GROUPNORM, name + suffix)
+            op.i[0:11] = [n_inst, rows, x.cols, x.ld, groups, _DT[x.dtype], int(silu), out.ld, phase, nparts, part]
+            op.f[0] = eps
+            op.p[0:5] = [x.ref, gamma, beta, out.ref, scratch.ref]
+            return op
+
+        if nparts == 1:
+            op = make(0, "")
+            op.out = out
+            self._emit(op)
+        else:
+            self._emit(make(1, ".stats"))
+            full = Buf(scratch.ref, nparts * part_bytes, 1, 1, "u8", scratch.alloc_off)
+            self.collective(name + ".stats.allgather", "allgather", full=full, part_bytes=part_bytes)
+            op = make(2, ".apply")
+            op.out = out
+            self._emit(op)
         self.free(scratch)      # stream order makes immediate reuse safe
         return op
+
+    def collective(self, name: str, ctype: str, **meta) -> Op:
+        """Pseudo-op: an exchange over the T-shard process group between two program segments.
+        'allgather': full (u8 Buf of nparts*part_bytes bytes, this rank's part already in place);
+        'halo': buf = halo-padded token buffer [(F_local+2)*frame_rows, C] whose interior is filled."""
+        op = Op(OP_COLLECTIVE, name)
+        op.meta = dict(type=ctype, **meta)
+        return self._emit(op)
+
+    def memset(self, name: str, buf: Buf) -> Op:
+        op = Op(L.OP_MEMSET, name)
+        nbytes = ((buf.rows - 1) * buf.ld + buf.cols) * buf.item
+        op.i[0], op.i[1] = nbytes & 0xFFFFFFFF, nbytes >> 32
+        op.p[0] = buf.ref
+        return self._emit(op)
 
     def layernorm(self, name: str, x: Buf, gamma: Ref, beta: Ref, out: Buf, eps: float = 1e-5) -> Op:
         assert x.dtype == "f32" and out.dtype == "f16"
@@ -328,12 +363,15 @@ class BoundProgram:
     """A Program whose symbolic pointers are resolved against a device arena and weight
     tensors, compiled into a `t2v_plan`."""
 
-    def __init__(self, prog: Program, arena_ptr: int, weight_ptrs: Dict[str, int]):
+    def __init__(self, prog: Program, arena_ptr: int, weight_ptrs: Dict[str, int], ops: Optional[List[Op]] = None):
         self.prog = prog
         lib = L.load()
-        n = len(prog.ops)
+        ops = prog.ops if ops is None else ops
+        assert all(op.kind != OP_COLLECTIVE for op in ops), "collectives are executed by parallel.ShardedExecutor"
+        self.ops = ops
+        n = len(ops)
         arr = (L.T2VOp * n)()
-        for idx, op in enumerate(prog.ops):
+        for idx, op in enumerate(ops):
             r = arr[idx]
             r.kind, r.tag = op.kind, idx
             for j, v in enumerate(op.i):
@@ -367,7 +405,7 @@ class BoundProgram:
         e = (ctypes.c_uint64 * L.EXT_SLOTS)()
         for k, v in ext.items():
             e[k] = v
-        ms = (ctypes.c_float * len(self.prog.ops))()
+        ms = (ctypes.c_float * len(self.ops))()
         L.check(self._lib.t2v_plan_run_timed(self.handle, e, L.EXT_SLOTS, ctypes.c_void_p(stream), ms))
         return list(ms)
 

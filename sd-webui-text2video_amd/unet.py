@@ -31,7 +31,7 @@ import torch.nn as nn
 
 from . import _lib as L
 from . import packing as pk
-from .program import NULL, BoundProgram, Buf, Program, Ref
+from .program import NULL, OP_COLLECTIVE, BoundProgram, Buf, Program, Ref
 
 
 # ------------------------------------------------------------------------------------------
@@ -216,6 +216,7 @@ class UNetSD(nn.Module):
         # and the three inner temporal-conv outputs): "f16" halves their HBM traffic (what the
         # reference's .half() path stores everywhere), "f32" keeps them in the fp32 stream.
         self.norm_input_dtype = "f16"
+        self.t_shard = None           # parallel.TShard: this rank holds a contiguous slice of the clip's frames
         self.auto_refresh = True      # re-check parameter versions on every forward (~1 ms); the sampler
                                       # turns this off inside its loop after one explicit refresh
         self.device = torch.device("cpu")
@@ -328,17 +329,23 @@ class UNetSD(nn.Module):
         tf = t.to(device=x.device, dtype=torch.float32).contiguous()
         if tf.ndim == 0:
             tf = tf.expand(B).contiguous()
-        key = (B, F, H, W, y.shape[1], _dt(x.dtype), _dt(y.dtype), _dt(out_dtype))
+        shard = None
+        if self.t_shard is not None and self.t_shard.size > 1:
+            shard = (self.t_shard.size, self.t_shard.index)       # x holds only this rank's frames
+        key = (B, F, H, W, y.shape[1], _dt(x.dtype), _dt(y.dtype), _dt(out_dtype)) + ((shard,) if shard else ())
         comp = self._programs.get(key)
         if comp is None:
-            comp = self._compile(B, F, H, W, y.shape[1], _dt(x.dtype), _dt(out_dtype), _dt(y.dtype))
+            comp = self._compile(B, F, H, W, y.shape[1], _dt(x.dtype), _dt(out_dtype), _dt(y.dtype), shard=shard)
             self._programs[key] = comp
         if self._packed is None or self._packed_device != x.device or self.auto_refresh:
             self.refresh_weights(x.device)
         comp.ensure_bound(self._packed, x.device)
         out = torch.empty((B, self.out_dim, F, H, W), device=x.device, dtype=out_dtype)
         ext = {L.EXT_X: x.data_ptr(), L.EXT_T: tf.data_ptr(), L.EXT_CTX: y.data_ptr(), L.EXT_OUT: out.data_ptr()}
-        comp.bound.run(ext, torch.cuda.current_stream(x.device).cuda_stream)
+        if shard is None:
+            comp.bound.run(ext, torch.cuda.current_stream(x.device).cuda_stream)
+        else:
+            comp.sharded.run(ext, torch.cuda.current_stream(x.device).cuda_stream, self.t_shard)
         comp.keepalive = (x, tf, y)
         return out
 
@@ -354,8 +361,8 @@ class UNetSD(nn.Module):
         return out, ms, comp.prog
 
     # ---- lowering -------------------------------------------------------------------------
-    def _compile(self, B, F, H, W, Lctx, x_dt, out_dt, ctx_dt="f32"):
-        low = _Lowering(self, B, F, H, W, Lctx, x_dt, out_dt, ctx_dt, keep_taps=self.debug_taps)
+    def _compile(self, B, F, H, W, Lctx, x_dt, out_dt, ctx_dt="f32", shard=None):
+        low = _Lowering(self, B, F, H, W, Lctx, x_dt, out_dt, ctx_dt, keep_taps=self.debug_taps, shard=shard)
         prog = low.build()
         return _Compiled(prog, low.packer)
 
@@ -369,6 +376,7 @@ class _Compiled:
         self.prog = prog
         self.packer = packer
         self.bound: Optional[BoundProgram] = None
+        self.sharded = None
         self.arena: Optional[torch.Tensor] = None
         self.keepalive = None
 
@@ -376,14 +384,28 @@ class _Compiled:
         if self.bound is not None and self.arena is not None and self.arena.device == device:
             return
         self.arena = torch.empty(self.prog.arena.high + 256, dtype=torch.uint8, device=device)
-        self.bound = BoundProgram(self.prog, self.arena.data_ptr(), {k: v.data_ptr() for k, v in packed.items()})
+        wptr = {k: v.data_ptr() for k, v in packed.items()}
+        if any(op.kind == OP_COLLECTIVE for op in self.prog.ops):
+            from .parallel import ShardedExecutor
+            self.sharded = ShardedExecutor(self.prog, self.arena,
+                                           lambda ops: BoundProgram(self.prog, self.arena.data_ptr(), wptr, ops=ops))
+            self.bound = self.sharded
+        else:
+            self.bound = BoundProgram(self.prog, self.arena.data_ptr(), wptr)
 
 
 # ------------------------------------------------------------------------------------------
 # lowering: network + geometry -> denoise program
 # ------------------------------------------------------------------------------------------
 class _Lowering:
-    def __init__(self, net: UNetSD, B, F, H, W, Lctx, x_dt, out_dt, ctx_dt, keep_taps=False):
+    def __init__(self, net: UNetSD, B, F, H, W, Lctx, x_dt, out_dt, ctx_dt, keep_taps=False, shard=None):
+        """F = frames held by THIS rank.  shard = (R, r): the clip has R*F frames split contiguously over
+        the R ranks of a T group (this is rank r); temporal ops then exchange data:
+        cross-frame GroupNorm -> all-gather of statistics partials, temporal conv -> +-1 frame halo,
+        temporal attention -> all-gather of K/V.  Everything else is frame-local."""
+        self.shard = shard if (shard is not None and shard[0] > 1) else None
+        if self.shard is not None:
+            assert B == 1, "T-sharded forwards run one sample per rank (the CFG pair is split over ranks)"
         self.net, self.B, self.F, self.H, self.W, self.Lctx = net, B, F, H, W, Lctx
         self.x_dt, self.out_dt, self.ctx_dt = x_dt, out_dt, ctx_dt
         self.P = Program(f"unet b{B} f{F} {H}x{W}")
@@ -407,6 +429,11 @@ class _Lowering:
             return torch.cat([sd[p + ".to_q.weight"], sd[p + ".to_k.weight"], sd[p + ".to_v.weight"]], dim=0)
         return Ref("weight", 0, self.packer.add(prefix + ":qkv", "f16", fn))
 
+    def w_kv(self, prefix) -> Ref:
+        def fn(sd, p=prefix):
+            return torch.cat([sd[p + ".to_k.weight"], sd[p + ".to_v.weight"]], dim=0)
+        return Ref("weight", 0, self.packer.add(prefix + ":kv", "f16", fn))
+
     def w_geglu(self, key) -> Tuple[Ref, Ref]:
         def wfn(sd, k=key):
             w = sd[k + ".weight"]
@@ -426,10 +453,11 @@ class _Lowering:
         return self.B * self.F * h * w
 
     # -- building blocks ------------------------------------------------------------------------
-    def gn(self, name, x: Buf, key, *, per_frame: bool, eps, silu) -> Buf:
-        out = self.P.alloc(x.rows, x.cols, "f16")
+    def gn(self, name, x: Buf, key, *, per_frame: bool, eps, silu, out: Optional[Buf] = None) -> Buf:
+        out = self.P.alloc(x.rows, x.cols, "f16") if out is None else out
         n_inst = self.B * self.F if per_frame else self.B
-        self.P.groupnorm(name, x, self.vec(key + ".weight"), self.vec(key + ".bias"), out, n_inst=n_inst, eps=eps, silu=silu)
+        self.P.groupnorm(name, x, self.vec(key + ".weight"), self.vec(key + ".bias"), out, n_inst=n_inst, eps=eps, silu=silu,
+                         shard=None if per_frame else self.shard)
         return out
 
     def conv3(self, name, a: Buf, key, cout, h, w, *, stride=1, up=0, out_dtype="f32", rowbias=None,
@@ -472,14 +500,28 @@ class _Lowering:
         t = h2
         tp = prefix + ".temopral_conv"
         for name, idx in (("conv1", 2), ("conv2", 3), ("conv3", 3), ("conv4", 3)):
-            nrm = self.gn(f"{tp}.{name}.0", t, f"{tp}.{name}.0", per_frame=False, eps=1e-5, silu=True)
+            if self.shard is None:
+                nrm = self.gn(f"{tp}.{name}.0", t, f"{tp}.{name}.0", per_frame=False, eps=1e-5, silu=True)
+            else:
+                # T-sharded: normalised activations go into a buffer with one halo frame either side;
+                # neighbours fill the halos (zeros at the two ends of the clip = the conv's zero padding)
+                R, r = self.shard
+                hwp = h * w
+                nrm = P.alloc((self.F + 2) * hwp, cout, "f16")
+                if r == 0:
+                    P.memset(f"{tp}.{name}.halo0", nrm.row_slice(0, hwp))
+                if r == R - 1:
+                    P.memset(f"{tp}.{name}.halo1", nrm.row_slice((self.F + 1) * hwp, (self.F + 2) * hwp))
+                self.gn(f"{tp}.{name}.0", t, f"{tp}.{name}.0", per_frame=False, eps=1e-5, silu=True,
+                        out=nrm.row_slice(hwp, (self.F + 1) * hwp))
+                P.collective(f"{tp}.{name}.halo", "halo", buf=nrm, frame_rows=hwp, frames=self.F)
             if t is not h2:
                 P.free(t)
             t = P.alloc(h2.rows, cout, "f32" if name == "conv4" else self.net.norm_input_dtype)
             key = f"{tp}.{name}.{idx}"
             P.gemm(key, nrm, self.w_tconv(key), cout, 3 * cout, t, bias=self.vec(key + ".bias"),
                    gather=L.GATHER_TCONV3, conv=dict(F=self.F, HW=h * w, Cin=cout),
-                   residual=h2 if name == "conv4" else None)
+                   residual=h2 if name == "conv4" else None, halo=self.shard is not None)
             P.free(nrm)
         P.free(h2)
         return t
@@ -489,7 +531,36 @@ class _Lowering:
         P, Mrows, hw, F, B = self.P, x1.rows, h * w, self.F, self.B
         scale = 64 ** -0.5
 
+        def self_attention_sharded(tag, xin: Buf) -> Buf:
+            """Temporal self-attention over a T-sharded clip: queries = local frames, keys/values = ALL
+            frames (K/V projections of the local tokens are all-gathered along T)."""
+            R, r = self.shard
+            n = P.alloc(Mrows, inner, "f16")
+            P.layernorm(f"{prefix}.norm{tag}", xin, self.vec(f"{prefix}.norm{tag}.weight"), self.vec(f"{prefix}.norm{tag}.bias"), n)
+            q = P.alloc(Mrows, inner, "f16")
+            P.gemm(f"{prefix}.attn{tag}.to_q", n, self.w_linear(f"{prefix}.attn{tag}.to_q"), inner, inner, q)
+            kv_all = P.alloc(R * Mrows, 2 * inner, "f16")
+            mine = kv_all.row_slice(r * Mrows, (r + 1) * Mrows)
+            P.gemm(f"{prefix}.attn{tag}.kv", n, self.w_kv(f"{prefix}.attn{tag}"), 2 * inner, inner, mine)
+            P.free(n)
+            full = Buf(kv_all.ref, R * Mrows * 2 * inner * 2, 1, 1, "u8", kv_all.alloc_off)
+            P.collective(f"{prefix}.attn{tag}.kv.allgather", "allgather", full=full, part_bytes=Mrows * 2 * inner * 2)
+            a = P.alloc(Mrows, inner, "f16")
+            ldk = 2 * inner
+            k, v = kv_all.col_slice(0, inner), kv_all.col_slice(inner, 2 * inner)
+            P.attention(f"{prefix}.attn{tag}", q.ref, k.ref, v.ref, a.ref, out_buf=a, nq=F, nk=R * F, heads=heads,
+                        b_outer=1, b_inner=hw, q_strides=(hw * inner, 0, inner), kv_strides=(hw * ldk, 0, ldk),
+                        o_strides=(hw * inner, 0, inner), scale=scale)
+            P.free(q, kv_all)
+            xo = P.alloc(Mrows, inner, "f32")
+            P.gemm(f"{prefix}.attn{tag}.to_out", a, self.w_linear(f"{prefix}.attn{tag}.to_out.0"), inner, inner, xo,
+                   bias=self.vec(f"{prefix}.attn{tag}.to_out.0.bias"), residual=xin)
+            P.free(a, xin)
+            return xo
+
         def self_attention(tag, xin: Buf) -> Buf:
+            if kind == "temporal" and self.shard is not None:
+                return self_attention_sharded(tag, xin)
             n = P.alloc(Mrows, inner, "f16")
             P.layernorm(f"{prefix}.norm{tag}", xin, self.vec(f"{prefix}.norm{tag}.weight"), self.vec(f"{prefix}.norm{tag}.bias"), n)
             qkv = P.alloc(Mrows, 3 * inner, "f16")

@@ -46,3 +46,44 @@ def run_both(prog: Program, weights_cpu: dict, ext_cpu: dict, init):
     got = Interp(prog, weights_cpu, poison=False)
     got.arena = arena_gpu.cpu()
     return it, got, ext_ref, {k: v.cpu() for k, v in ext_gpu.items()}
+
+
+def run_lockstep(executors, exts, stream):
+    """Single-process emulation of a T-shard group (tests on ONE GPU): the executors of all 'ranks' are
+    stepped together; collectives are performed by direct copies between their arenas."""
+    n = len(executors)
+    steps = [ex.steps for ex in executors]
+    assert len({len(s) for s in steps}) == 1
+    for k in range(len(steps[0])):
+        kind = steps[0][k][0]
+        if kind == "seg":
+            for r in range(n):
+                steps[r][k][1].run(exts[r], stream)
+            continue
+        meta = [steps[r][k][1].meta for r in range(n)]
+        if meta[0]["type"] == "allgather":
+            nb = meta[0]["part_bytes"]
+            parts = []
+            for r in range(n):
+                off = meta[r]["full"].ref.off
+                parts.append(executors[r].arena[off + r * nb: off + (r + 1) * nb].clone())
+            for r in range(n):
+                off = meta[r]["full"].ref.off
+                for q in range(n):
+                    executors[r].arena[off + q * nb: off + (q + 1) * nb] = parts[q]
+        else:  # halo
+            firsts, lasts = [], []
+            for r in range(n):
+                buf, fr, nf = meta[r]["buf"], meta[r]["frame_rows"], meta[r]["frames"]
+                fb = fr * buf.ld * buf.item
+                base = buf.ref.off
+                firsts.append(executors[r].arena[base + fb: base + 2 * fb].clone())
+                lasts.append(executors[r].arena[base + nf * fb: base + (nf + 1) * fb].clone())
+            for r in range(n):
+                buf, fr, nf = meta[r]["buf"], meta[r]["frame_rows"], meta[r]["frames"]
+                fb = fr * buf.ld * buf.item
+                base = buf.ref.off
+                if r > 0:
+                    executors[r].arena[base: base + fb] = lasts[r - 1]
+                if r + 1 < n:
+                    executors[r].arena[base + (nf + 1) * fb: base + (nf + 2) * fb] = firsts[r + 1]

@@ -56,8 +56,8 @@ class Interp:
         return self.view(ref, (rows, cols), (ld, 1), dtype, ext)
 
     # ---- execution -----------------------------------------------------------------------------
-    def run(self, ext: Dict[int, torch.Tensor]):
-        for op in self.prog.ops:
+    def run(self, ext: Dict[int, torch.Tensor], ops=None):
+        for op in (self.prog.ops if ops is None else ops):
             getattr(self, f"_op{op.kind}")(op, ext)
 
     # GEMM ------------------------------------------------------------------------------------------
@@ -86,8 +86,11 @@ class Interp:
         elif gather == L.GATHER_TCONV3:
             Fr, HW, Cin = I[8], I[9], I[10]
             nb = M // (Fr * HW)
-            X = self.view(op.p[0], (nb, Fr, HW, Cin), (Fr * HW * lda, HW * lda, lda, 1), torch.float16, ext).float()
-            Xp = F.pad(X, (0, 0, 0, 0, 1, 1))
+            if I[23]:     # halo layout: the input already holds one frame before/after each clip
+                Xp = self.view(op.p[0], (nb, Fr + 2, HW, Cin), ((Fr + 2) * HW * lda, HW * lda, lda, 1), torch.float16, ext).float()
+            else:
+                X = self.view(op.p[0], (nb, Fr, HW, Cin), (Fr * HW * lda, HW * lda, lda, 1), torch.float16, ext).float()
+                Xp = F.pad(X, (0, 0, 0, 0, 1, 1))
             A = torch.stack([Xp[:, kt:kt + Fr] for kt in range(3)], dim=3)          # nb, F, HW, 3, Cin
             A = A.reshape(nb, Fr, HW, 3, Cin // 64, 64).permute(0, 1, 2, 4, 3, 5).reshape(M, 3 * Cin)
         else:
@@ -120,10 +123,26 @@ class Interp:
 
     # GROUPNORM ----------------------------------------------------------------------------------------
     def _op2(self, op, ext):
-        n_inst, rows, C, ld_in, groups, in_dt, silu, ld_out = op.i[0:8]
-        x = self.mat(op.p[0], n_inst * rows, C, ld_in, _TD[in_dt], ext).double().view(n_inst, rows, groups, C // groups)
-        mean = x.mean(dim=(1, 3), keepdim=True)
-        var = (x * x).mean(dim=(1, 3), keepdim=True) - mean * mean
+        n_inst, rows, C, ld_in, groups, in_dt, silu, ld_out, phase, nparts, part = op.i[0:11]
+        nparts = max(nparts, 1)
+        cpg = C // groups
+        x = self.mat(op.p[0], n_inst * rows, C, ld_in, _TD[in_dt], ext).double().view(n_inst, rows, groups, cpg)
+        nblk = (rows + L.GN_ROWS_PER_BLOCK - 1) // L.GN_ROWS_PER_BLOCK
+        part_len = n_inst * nblk * groups * 2
+        if phase == 0:
+            s1, s2, n = x.sum(dim=(1, 3)), (x * x).sum(dim=(1, 3)), rows * cpg
+        else:
+            # scratch: fp64 partials [nparts][n_inst][nblk][groups][2] (device: one entry per 16-row block;
+            # here everything in block 0)
+            pv = self.view(op.p[4], (nparts, n_inst, nblk, groups, 2), (part_len, nblk * groups * 2, groups * 2, 2, 1), torch.float64, ext)
+            if phase == 1:
+                pv[part].zero_()
+                pv[part, :, 0, :, 0] = x.sum(dim=(1, 3))
+                pv[part, :, 0, :, 1] = (x * x).sum(dim=(1, 3))
+                return
+            s1, s2, n = pv[..., 0].sum(dim=(0, 2)), pv[..., 1].sum(dim=(0, 2)), rows * nparts * cpg
+        mean = (s1 / n).view(n_inst, 1, groups, 1)
+        var = (s2 / n).view(n_inst, 1, groups, 1) - mean * mean
         y = ((x - mean) / torch.sqrt(var.clamp_min(0) + op.f[0])).view(n_inst * rows, C).float()
         g = self.view(op.p[1], (C,), (1,), torch.float32, ext)
         b = self.view(op.p[2], (C,), (1,), torch.float32, ext)
@@ -211,6 +230,9 @@ class Interp:
         out.copy_(xn.to(out.dtype))
 
     # MEMSET -------------------------------------------------------------------------------------------
+    def _op100(self, op, ext):
+        raise RuntimeError("collectives are executed by parallel.ShardedExecutor, not the interpreter")
+
     def _op11(self, op, ext):
         nbytes = (op.i[0] & 0xFFFFFFFF) | (op.i[1] << 32)
         assert op.p[0].space == "arena"

@@ -373,3 +373,51 @@ def test_gemm2_temporal_conv_and_split_k(tile):
         fill(it, a, g); fill(it, res, g)
     it, got, _, _ = run_both(P, w, {}, init)
     _check(it, got, out, 2e-5, f"gemm2 tconv split-K tile {tile}")
+
+
+def test_groupnorm_split_phases_two_parts():
+    """T-sharding: statistics partials of two 'ranks' folded in the apply phase (here both parts on one GPU)."""
+    C, rows = 320, 48
+    P = Program()
+    g = _g(31)
+    x0, x1 = P.alloc(rows, C, "f32"), P.alloc(rows, C, "f32")
+    o0, o1 = P.alloc(rows, C, "f16"), P.alloc(rows, C, "f16")
+    w = {"g": 1 + 0.1 * torch.randn(C, generator=g), "b": 0.1 * torch.randn(C, generator=g)}
+    # two programs' worth of ops sharing ONE scratch: emit by hand through the same emitter, then alias the scratch
+    opa = P.groupnorm("a", x0, Ref("weight", 0, "g"), Ref("weight", 0, "b"), o0, n_inst=1, eps=1e-5, silu=True, shard=(2, 0))
+    opb = P.groupnorm("b", x1, Ref("weight", 0, "g"), Ref("weight", 0, "b"), o1, n_inst=1, eps=1e-5, silu=True, shard=(2, 1))
+    ops = [op for op in P.ops if op.kind == L.OP_GROUPNORM]          # a.stats, a.apply, b.stats, b.apply
+    scratch = ops[0].p[4]
+    for op in ops:
+        op.p[4] = scratch
+    P.ops = [ops[0], ops[2], ops[1], ops[3]]                         # both statistics first, then both applies
+
+    def init(it):
+        fill(it, x0, g, 2.0); fill(it, x1, g, 0.5)
+    it, got, _, _ = run_both(P, w, {}, init)
+    _check(it, got, o0, 1e-3, "split GN part 0")
+    _check(it, got, o1, 1e-3, "split GN part 1")
+    # and against one GroupNorm over the concatenation
+    x = torch.cat([read(it, x0), read(it, x1)]).double().view(1, 2 * rows, 32, C // 32)
+    m, v = x.mean(dim=(1, 3), keepdim=True), x.var(dim=(1, 3), unbiased=False, keepdim=True)
+    ref = torch.nn.functional.silu((((x - m) / torch.sqrt(v + 1e-5)).view(2 * rows, C).float() * w["g"] + w["b"]))
+    assert rel_l2(torch.cat([read(got, o0), read(got, o1)]).float(), ref) < 1e-3
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+def test_temporal_conv_halo_layout(tile):
+    B, F, HW, C = 1, 3, 64, 320
+    P = Program()
+    P.force_tile = tile
+    g = _g(32)
+    a = P.alloc((F + 2) * HW, C, "f16")
+    out = P.alloc(F * HW, C, "f32")
+    wt = torch.randn(C, C, 3, 1, 1, generator=g) / math.sqrt(3 * C)
+    w = {"w": pk.tconv3(wt).half(), "b": torch.randn(C, generator=g)}
+    P.gemm("t", a, Ref("weight", 0, "w"), C, 3 * C, out, bias=Ref("weight", 0, "b"), gather=L.GATHER_TCONV3,
+           conv=dict(F=F, HW=HW, Cin=C), halo=True, allow_splitk=False)
+    it, got, _, _ = run_both(P, w, {}, lambda it: fill(it, a, g))
+    _check(it, got, out, 2e-5, f"tconv halo tile {tile}")
+    x = read(it, a).float().view(1, F + 2, HW, 1, C).permute(0, 4, 1, 2, 3)
+    ref = torch.nn.functional.conv3d(x, wt.half().float(), w["b"], padding=(0, 0, 0)).permute(0, 2, 3, 4, 1).reshape(F * HW, C)
+    assert rel_l2(read(got, out), ref) < 1e-4
