@@ -151,18 +151,28 @@ class Program:
         Policy for a 256-CU chip: the widest tile whose grid still gives >= ~0.75 wave of
         workgroups; otherwise the 128x256 tile, then split-K over the (long) reduction."""
         cus = self.target_cus
-        if self.force_tile is not None:
+        forced = self.force_tile is not None
+        conv_like = gather in (L.GATHER_CONV3X3, L.GATHER_TCONV3)
+        if forced:
             tile = self.force_tile
         elif gather == L.GATHER_CONV3X3_C8 or n < 256 or k < 64 or k % 64 != 0:
             tile = 0
-        elif n % 320 == 0 and M >= 32768:
-            tile = 2                                   # 32x32 level: 256x320 tiles, no padded columns
-        elif n >= 2560 and M >= 2048:
-            tile = 2 if (n % 320 == 0 and M >= 8192) else 1    # wide GEGLU / QKV outputs
-        elif gather == L.GATHER_CONV3X3 and k >= 8192 and M <= 4096:
-            tile = 1                                   # deep-level convs: long reduction, few rows
-        else:
-            tile = 0
+        elif M >= 32768:                               # 32x32 level: big tiles, 320-wide when it divides
+            tile = 2 if n % 320 == 0 and n != 960 else 1
+        elif M >= 8192:                                # 16x16 level
+            if gather == L.GATHER_CONV3X3 and k >= 4096 and n % 320 == 0:
+                tile = 2
+            elif n >= 2560:
+                tile = 1
+            else:
+                tile = 0
+        else:                                          # 8x8 / 4x4 levels: few rows, long reductions
+            if n >= 2560:
+                tile = 1 if M >= 2048 else 3
+            elif k >= 2560:
+                tile = 3
+            else:
+                tile = 0
         if tile == 0:
             bm, bn, bk = 128, (64 if (n % 128 != 0 and n % 128 <= 64) else 128), 64
         else:
@@ -171,14 +181,17 @@ class Program:
         kt = math.ceil(k / bk)
         split = 1
         if allow_splitk and kt >= 16:
+            # measured with tools/gemm_sweep.py on MI355X (256 CUs)
             if tile == 0:
-                # measured (tools/gemm_sweep.py): aim for ~2 workgroups per CU when the reduction is long
                 if kt >= 32 and tiles < cus:
                     split = max(1, min(round(2 * cus / tiles), kt // 16, 32))
                 elif tiles < 0.5 * cus:
                     split = max(1, min(round(2 * cus / tiles), kt // 8, 32))
+            elif tile == 3 and not forced:
+                split = max(1, min(cus // tiles, kt // 8, 4))
             elif tiles < 0.6 * cus:
-                split = max(1, min(round(cus / tiles), kt // 8, 32))
+                # one workgroup per CU: keep tiles*split within ONE wave of workgroups
+                split = max(1, min(cus // tiles, kt // 8, 32))
         return tile, split
 
     # ---- ops ------------------------------------------------------------------------------
