@@ -48,7 +48,8 @@ enum t2v_op_kind {
   T2V_OP_COPY2D = 9,      /* strided 2-D copy / cast / SiLU (concat, fp32->fp16 staging)    */
   T2V_OP_DDIM_STEP = 10,  /* DDIM_Gaussian update with half-channel CFG                     */
   T2V_OP_MEMSET = 11,     /* zero a byte range                                              */
-  T2V_OP_KIND_MAX = 12
+  T2V_OP_LINCOMB = 12,    /* out = sum_i c_i * T_i (<= 6 latent-sized tensors): UniPC / DDIM updates */
+  T2V_OP_KIND_MAX = 13
 };
 
 /* GEMM gather modes: how row m / reduction index k of the A operand are addressed          */
@@ -112,9 +113,14 @@ enum t2v_gather {
  * CL_TO_NCTHW: i: 0 B, 1 C, 2 F, 3 HW, 4 ld_in, 5 out dtype; p: 0 in fp32, 1 out
  * TIME_EMBED: i: 0 B, 1 dim; p: 0 t fp32 [B], 1 freqs fp32 [dim/2], 2 out fp16 [B,dim]
  * COPY2D: i: 0 rows, 1 cols, 2 ld_src, 3 ld_dst, 4 src dtype, 5 dst dtype, 6 act; p: 0 src, 1 dst
- * DDIM_STEP: i: 0 C, 1 inner (F*h*w), 2 guided channels, 3 eps dtype, 4 x dtype;
- *      f: 0 sqrt_recip_ac, 1 sqrt_recipm1_ac, 2 sqrt(a_prev), 3 dir coef, 4 sigma (masked),
- *         5 guidance scale; p: 0 xt, 1 eps pair, 2 noise, 3 out
+ * DDIM_STEP: i: 0 C, 1 inner (F*h*w), 2 guided channels, 3 eps dtype, 4 x dtype, 5 mode;
+ *      mode 0 (DDIM_Gaussian, gaussian_sampler.py:103-108,199-211,269-283):
+ *        f: 0 sqrt_recip_ac, 1 sqrt_recipm1_ac, 2 sqrt(a_prev), 3 dir coef, 4 sigma (masked), 5 guidance scale
+ *      mode 1 (LDM DDIM, samplers/ddim/sampler.py:197-219):  x0 = (x - f0*e)/f1;  out = f2*x0 + f3*e + f4*noise
+ *        f: 0 sqrt(1-a_t), 1 sqrt(a_t), 2 sqrt(a_prev), 3 sqrt(1-a_prev-sigma^2), 4 sigma, 5 guidance scale
+ *      p: 0 xt, 1 eps pair, 2 noise, 3 out
+ * LINCOMB: i: 0 n elements, 1 n terms (<= 6), 2 out dtype, 3..8 term dtypes; f: 0..5 coefficients;
+ *      p: 0..5 terms, 6 out
  * MEMSET: i: 0 bytes (lo), 1 bytes (hi); p: 0 dst
  */
 typedef struct t2v_op {

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void copy2d_kernel(const TS* src, TD* dst, int
 
 struct DdimParams {
   const void* xt; const void* eps; const float* noise; void* out;
-  int C, inner, guided, eps_f32, x_f32;
+  int C, inner, guided, eps_f32, x_f32, mode;
   float a_recip, a_recipm1, sqrt_aprev, dir_coef, sigma, gscale;
 };
 
@@ -102,11 +102,41 @@ __global__ __launch_bounds__(256) void ddim_step_kernel(const DdimParams p) {
       o = u + p.gscale * (y - u);
     }
     // same operation order as the reference (all fp32)
-    const float x0 = p.a_recip * x - p.a_recipm1 * o;
-    const float eps = (p.a_recip * x - x0) / p.a_recipm1;
-    float xn = p.sqrt_aprev * x0 + p.dir_coef * eps;
+    float xn;
+    if (p.mode == 0) {                       // DDIM_Gaussian
+      const float x0 = p.a_recip * x - p.a_recipm1 * o;
+      const float eps = (p.a_recip * x - x0) / p.a_recipm1;
+      xn = p.sqrt_aprev * x0 + p.dir_coef * eps;
+    } else {                                 // LDM DDIM: a_recip = sqrt(1-a_t), a_recipm1 = sqrt(a_t)
+      const float x0 = (x - p.a_recip * o) / p.a_recipm1;
+      xn = p.sqrt_aprev * x0 + p.dir_coef * o;
+    }
     if (p.noise != nullptr && p.sigma != 0.f) xn += p.sigma * p.noise[idx];
     out[idx] = (TX)xn;
+  }
+}
+
+struct LinParams {
+  const void* t[6];
+  void* out;
+  float c[6];
+  int f32[6];
+  int n_terms, out_f32;
+  long n;
+};
+
+__global__ __launch_bounds__(256) void lincomb_kernel(const LinParams p) {
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < p.n; idx += (long)gridDim.x * 256) {
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      if (k < p.n_terms) {
+        const float v = p.f32[k] ? reinterpret_cast<const float*>(p.t[k])[idx] : (float)reinterpret_cast<const f16*>(p.t[k])[idx];
+        acc = k == 0 ? p.c[0] * v : acc + p.c[k] * v;
+      }
+    }
+    if (p.out_f32) reinterpret_cast<float*>(p.out)[idx] = acc;
+    else reinterpret_cast<f16*>(p.out)[idx] = (f16)acc;
   }
 }
 
@@ -178,6 +208,7 @@ hipError_t t2v_launch_ddim_step(const t2v_op& op, hipStream_t s) {
   p.noise = reinterpret_cast<const float*>(op.p[2]);
   p.out = reinterpret_cast<void*>(op.p[3]);
   p.C = op.i[0]; p.inner = op.i[1]; p.guided = op.i[2]; p.eps_f32 = op.i[3] == T2V_F32; p.x_f32 = op.i[4] == T2V_F32;
+  p.mode = op.i[5];
   p.a_recip = op.f[0]; p.a_recipm1 = op.f[1]; p.sqrt_aprev = op.f[2]; p.dir_coef = op.f[3]; p.sigma = op.f[4];
   p.gscale = op.f[5];
   const int g = grid_for((long)p.C * p.inner);
@@ -185,5 +216,19 @@ hipError_t t2v_launch_ddim_step(const t2v_op& op, hipStream_t s) {
   else if (p.x_f32) hipLaunchKernelGGL((ddim_step_kernel<float, f16>), dim3(g), dim3(256), 0, s, p);
   else if (p.eps_f32) hipLaunchKernelGGL((ddim_step_kernel<f16, float>), dim3(g), dim3(256), 0, s, p);
   else hipLaunchKernelGGL((ddim_step_kernel<f16, f16>), dim3(g), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
+hipError_t t2v_launch_lincomb(const t2v_op& op, hipStream_t s) {
+  LinParams p;
+  p.n = op.i[0]; p.n_terms = op.i[1]; p.out_f32 = op.i[2] == T2V_F32;
+  if (p.n_terms < 1 || p.n_terms > 6 || p.n <= 0) return hipErrorInvalidValue;
+  for (int k = 0; k < 6; ++k) {
+    p.t[k] = reinterpret_cast<const void*>(op.p[k]);
+    p.c[k] = op.f[k];
+    p.f32[k] = op.i[3 + k] == T2V_F32;
+  }
+  p.out = reinterpret_cast<void*>(op.p[6]);
+  hipLaunchKernelGGL(lincomb_kernel, dim3(grid_for(p.n)), dim3(256), 0, s, p);
   return hipGetLastError();
 }

@@ -358,9 +358,9 @@ class Program:
         op.out = dst
         return self._emit(op)
 
-    def ddim_step(self, name: str, *, C: int, inner: int, guided: int, eps_dtype: str, x_dtype: str) -> Op:
+    def ddim_step(self, name: str, *, C: int, inner: int, guided: int, eps_dtype: str, x_dtype: str, mode: int = 0) -> Op:
         op = Op(L.OP_DDIM_STEP, name)
-        op.i[0:5] = [C, inner, guided, _DT[eps_dtype], _DT[x_dtype]]
+        op.i[0:6] = [C, inner, guided, _DT[eps_dtype], _DT[x_dtype], mode]
         op.p[0:4] = [Ref("ext", L.EXT_XT), Ref("ext", L.EXT_EPS), Ref("ext", L.EXT_NOISE), Ref("ext", L.EXT_XT_OUT)]
         return self._emit(op)
 

@@ -11,8 +11,8 @@ forward (weights stream from HBM once per step), and the whole pointwise update
 (half-channel CFG combine, x0, eps, x_{t-1}) is one HIP kernel (T2V_OP_DDIM_STEP) on the
 same stream — the host only computes five fp32 scalars per step and never synchronises.
 
-Only "DDIM_Gaussian" (the UI default, t2v_helpers/args.py:234) is built in this round; "DDIM"
-and "UniPC" are SURVEY §8(f)-1 and raise a clear error.
+All three samplers of the reference registry are built: "DDIM_Gaussian" (UI default,
+t2v_helpers/args.py:234), "DDIM" (LDM-style, ddim/sampler.py) and "UniPC" (uni_pc/*).
 """
 from __future__ import annotations
 
@@ -233,6 +233,302 @@ class GaussianDiffusion(object):
         return xt
 
 
+# ------------------------------------------------------------------------------------------
+# device helpers shared by the solvers: every latent update is ONE fused kernel launch
+# ------------------------------------------------------------------------------------------
+def _dt_tag(t: torch.Tensor) -> int:
+    return L.F16 if t.dtype == torch.float16 else L.F32
+
+
+def _lincomb(out: torch.Tensor, terms) -> torch.Tensor:
+    """out = sum_i coef_i * tensor_i  (T2V_OP_LINCOMB; <= 6 terms, fp16/fp32 mixed, same numel)."""
+    lib = L.load()
+    op = L.T2VOp()
+    op.kind = L.OP_LINCOMB
+    op.i[0], op.i[1], op.i[2] = out.numel(), len(terms), _dt_tag(out)
+    keep = []
+    for k, (c, t) in enumerate(terms):
+        t = t if t.is_contiguous() else t.contiguous()
+        keep.append(t)
+        assert t.numel() == out.numel() and t.dtype in (torch.float16, torch.float32)
+        op.i[3 + k], op.f[k], op.p[k] = _dt_tag(t), float(c), t.data_ptr()
+    op.p[6] = out.data_ptr()
+    stream = torch.cuda.current_stream(out.device).cuda_stream
+    L.check(lib.t2v_run_ops(ctypes.byref(op), 1, None, 0, ctypes.c_void_p(stream)))
+    return out
+
+
+def _ddim_update(out, xt, eps_pair, noise, coef, guided: int, mode: int):
+    """T2V_OP_DDIM_STEP: CFG combine + x0 + x_{t-1} in one kernel (mode 0 DDIM_Gaussian, 1 LDM DDIM)."""
+    lib = L.load()
+    op = L.T2VOp()
+    op.kind = L.OP_DDIM_STEP
+    C = xt.shape[1]
+    op.i[0], op.i[1], op.i[2] = C, xt.numel() // C, guided
+    op.i[3], op.i[4], op.i[5] = _dt_tag(eps_pair), _dt_tag(xt), mode
+    for k in range(6):
+        op.f[k] = float(coef[k])
+    op.p[0], op.p[1], op.p[3] = xt.data_ptr(), eps_pair.data_ptr(), out.data_ptr()
+    op.p[2] = noise.data_ptr() if (noise is not None and float(coef[4]) != 0.0) else 0
+    stream = torch.cuda.current_stream(xt.device).cuda_stream
+    L.check(lib.t2v_run_ops(ctypes.byref(op), 1, None, 0, ctypes.c_void_p(stream)))
+    return out
+
+
+def _eval_eps_pair(model, x, t_value, c, uc, guide, cfg_parallel=None):
+    """-> (eps [1 or 2, C, F, h, w] (index 0 conditional, 1 unconditional), guided: bool).  One batched
+    b=2 forward when the model supports it; t_value may be fractional (UniPC)."""
+    dev = x.device
+    tt = torch.full((1,), float(t_value), dtype=torch.float32, device=dev)
+    if guide is None or guide == 1.0 or uc is None:
+        return model(x, tt, c).contiguous(), False
+    if cfg_parallel is not None and cfg_parallel.size == 2:
+        mine = c if cfg_parallel.role == 0 else uc
+        return cfg_parallel.exchange_eps(model(x, tt, mine)).contiguous(), True
+    if getattr(model, "supports_cfg_batch", False):
+        return model(torch.cat([x, x], dim=0), torch.cat([tt, tt]), torch.cat([c, uc], dim=0)).contiguous(), True
+    return torch.cat([model(x, tt, c), model(x, tt, uc)], dim=0).contiguous(), True
+
+
+class DDIMSampler(object):
+    """Sampler "DDIM" (LDM-style, full-channel CFG) — reference scripts/samplers/ddim/sampler.py."""
+
+    def __init__(self, model, schedule="linear", device=None, **kwargs):
+        self.model = model
+        self.ddpm_num_timesteps = model.num_timesteps
+        self.schedule = schedule
+        self.device = torch.device(device) if device is not None else torch.device(getattr(model, "device", "cuda"))
+        self.cfg_parallel = None
+
+    def make_schedule(self, ddim_num_steps, ddim_discretize="uniform", ddim_eta=0.0, verbose=False):
+        """sampler.py:24-53 + make_ddim_timesteps / make_ddim_sampling_parameters (lvdm/.../util.py:36-63)."""
+        import numpy as np
+        if ddim_discretize != "uniform":
+            raise NotImplementedError(ddim_discretize)
+        T = self.ddpm_num_timesteps
+        self.ddim_timesteps = np.asarray(list(range(0, T, T // ddim_num_steps))) + 1
+        ac = self.model.alphas_cumprod.detach().cpu()     # float64 after register_buffers_to_model (cumprod of f64 betas)
+        assert ac.shape[0] == T, "alphas have to be defined for each timestep"
+        alphas = ac[self.ddim_timesteps]
+        alphas_prev = torch.cat([ac[0:1], ac[self.ddim_timesteps[:-1]]])
+        sigmas = ddim_eta * torch.sqrt((1 - alphas_prev) / (1 - alphas) * (1 - alphas / alphas_prev))
+        self.alphas_cumprod = ac
+        self.ddim_sigmas, self.ddim_alphas, self.ddim_alphas_prev = sigmas, alphas, alphas_prev
+        self.ddim_sqrt_one_minus_alphas = torch.sqrt(1.0 - alphas)
+
+    def _coef(self, index, guide):
+        f32 = torch.float32
+        a_t, a_prev = self.ddim_alphas[index].to(f32), self.ddim_alphas_prev[index].to(f32)
+        sigma_t, s1m = self.ddim_sigmas[index].to(f32), self.ddim_sqrt_one_minus_alphas[index].to(f32)
+        return [float(s1m), float(a_t.sqrt()), float(a_prev.sqrt()), float((1.0 - a_prev - sigma_t ** 2).sqrt()),
+                float(sigma_t), float(guide) if guide is not None else 1.0]
+
+    def _run(self, img, cond, uncond, time_range, total_steps, guide, callback):
+        model, dev = self.model, img.device
+        C = img.shape[1]
+        nxt = torch.empty_like(img)
+        if hasattr(model, "refresh_weights"):
+            model.refresh_weights(dev)
+        prev_auto = getattr(model, "auto_refresh", None)
+        if prev_auto is not None:
+            model.auto_refresh = False
+        try:
+            for i, step in enumerate(time_range):
+                c, uc = reconstruct_conds(cond, uncond, int(step))
+                index = total_steps - i - 1
+                eps, guided = _eval_eps_pair(model, img, int(step), c, uc, guide, self.cfg_parallel)
+                coef = self._coef(index, guide)
+                noise = torch.randn_like(img, dtype=torch.float32)         # drawn every step, like noise_like()
+                _ddim_update(nxt, img, eps, noise, coef, C if guided else 0, mode=1)
+                img, nxt = nxt, img
+                if callback:
+                    callback(i)
+        finally:
+            if prev_auto is not None:
+                model.auto_refresh = prev_auto
+        return img
+
+    @torch.no_grad()
+    def sample(self, S, batch_size, shape, conditioning=None, callback=None, eta=0.0, mask=None, x0=None, x_T=None,
+               unconditional_guidance_scale=1.0, unconditional_conditioning=None, **kwargs):
+        """sampler.py:56-166."""
+        import numpy as np
+        self.make_schedule(ddim_num_steps=S, ddim_eta=eta)
+        img = torch.randn(tuple(shape), device=self.device) if x_T is None else x_T.clone()
+        img = img.float().contiguous() if img.dtype not in (torch.float16, torch.float32) else img.contiguous()
+        assert img.shape[0] == 1
+        return self._run(img, conditioning, unconditional_conditioning, np.flip(self.ddim_timesteps),
+                         self.ddim_timesteps.shape[0], unconditional_guidance_scale, callback)
+
+    @torch.no_grad()
+    def stochastic_encode(self, x0, t, use_original_steps=False, noise=None):
+        """sampler.py:270-283 — vid2vid noising (fast, not exactly invertible)."""
+        assert not use_original_steps
+        idx = int(t.reshape(-1)[0])
+        a = self.ddim_alphas[idx].to(torch.float32)
+        noise = torch.randn_like(x0) if noise is None else noise
+        out = torch.empty_like(x0)
+        return _lincomb(out, [(float(a.sqrt()), x0), (float(self.ddim_sqrt_one_minus_alphas[idx].to(torch.float32)), noise)])
+
+    @torch.no_grad()
+    def decode(self, x_latent, cond, t_start, unconditional_guidance_scale=1.0, unconditional_conditioning=None,
+               use_original_steps=False, callback=None, *args, **kwargs):
+        """sampler.py:286-306."""
+        import numpy as np
+        assert not use_original_steps
+        timesteps = self.ddim_timesteps[:t_start]
+        return self._run(x_latent.contiguous().clone(), cond, unconditional_conditioning, np.flip(timesteps),
+                         timesteps.shape[0], unconditional_guidance_scale, callback)
+
+
+class _VPSchedule:
+    """Discrete-time VP noise schedule with piecewise-linear log(alpha_t) (NoiseScheduleVP('discrete'),
+    uni_pc/uni_pc.py:8-153), host-side scalars in float64."""
+
+    def __init__(self, alphas_cumprod: torch.Tensor):
+        ac = alphas_cumprod.detach().cpu().to(torch.float32).to(torch.float64)      # the reference keeps fp32 buffers
+        self.log_alpha = 0.5 * torch.log(ac)
+        self.total_N = len(ac)
+        self.T = 1.0
+        self.t = torch.linspace(0.0, 1.0, self.total_N + 1, dtype=torch.float64)[1:]
+
+    def log_alpha_t(self, t: float) -> float:
+        xp, yp = self.t, self.log_alpha
+        k = int(torch.searchsorted(xp, torch.tensor(t, dtype=torch.float64)))
+        k = min(max(k, 1), len(xp) - 1)              # beyond the ends: extend the outermost segment
+        x0, x1, y0, y1 = float(xp[k - 1]), float(xp[k]), float(yp[k - 1]), float(yp[k])
+        return y0 + (t - x0) * (y1 - y0) / (x1 - x0)
+
+    def alpha(self, t):
+        import math
+        return math.exp(self.log_alpha_t(t))
+
+    def std(self, t):
+        import math
+        return math.sqrt(1.0 - math.exp(2.0 * self.log_alpha_t(t)))
+
+    def lam(self, t):
+        import math
+        la = self.log_alpha_t(t)
+        return la - 0.5 * math.log(1.0 - math.exp(2.0 * la))
+
+
+class UniPCSampler(object):
+    """Sampler "UniPC": order-3 multistep unified predictor-corrector, B(h)=h ("bh1"), data prediction,
+    time-uniform steps, lower-order final steps, initial corrector — reference uni_pc/sampler.py:31-90 ->
+    uni_pc/uni_pc.py:683-743, 551-677.  Every latent update is one T2V_OP_LINCOMB launch."""
+
+    def __init__(self, model, device=None, **kwargs):
+        self.model = model
+        self.device = torch.device(device) if device is not None else None
+        self.alphas_cumprod = model.alphas_cumprod.detach().clone().to(torch.float32)
+        self.cfg_parallel = None
+
+    # -- x0 prediction from the (guided) noise prediction: x0 = (x - sigma_t * eps_g) / alpha_t -------------
+    def _data_prediction(self, ns, x, t, cond, uncond, guide):
+        eps, guided = _eval_eps_pair(self.model, x, (t - 1.0 / ns.total_N) * 1000.0, cond, uncond, guide, self.cfg_parallel)
+        a, s = ns.alpha(t), ns.std(t)
+        out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        if guided:
+            g = float(guide)
+            return _lincomb(out, [(1.0 / a, x), (-s * g / a, eps[0:1]), (-s * (1.0 - g) / a, eps[1:2])])
+        return _lincomb(out, [(1.0 / a, x), (-s / a, eps[0:1])])
+
+    def _update(self, ns, x, m_prev, t_prev, t, order, use_corrector, cond, uncond, guide):
+        """multistep_uni_pc_bh_update (predict_x0, bh1): returns (x_t, model_t or None)."""
+        import math
+        lam_t, lam_0 = ns.lam(t), ns.lam(t_prev[-1])
+        h = lam_t - lam_0
+        sigma_t, sigma_0, alpha_t = ns.std(t), ns.std(t_prev[-1]), ns.alpha(t)
+        rks = [(ns.lam(t_prev[-(i + 1)]) - lam_0) / h for i in range(1, order)] + [1.0]
+        hh = -h
+        h_phi_1 = math.expm1(hh)
+        h_phi_k = h_phi_1 / hh - 1.0
+        B_h = hh
+        R, b, fact = [], [], 1
+        for i in range(1, order + 1):
+            R.append([rk ** (i - 1) for rk in rks])
+            b.append(h_phi_k * fact / B_h)
+            fact *= (i + 1)
+            h_phi_k = h_phi_k / hh - 1.0 / fact
+        R64, b64 = torch.tensor(R, dtype=torch.float64), torch.tensor(b, dtype=torch.float64)
+        K = order - 1                                    # number of history differences D1s
+        if K > 0:
+            rhos_p = [0.5] if order == 2 else torch.linalg.solve(R64[:-1, :-1], b64[:-1]).tolist()
+        rhos_c = [0.5] if order == 1 else torch.linalg.solve(R64, b64).tolist()
+        m0 = m_prev[-1]
+        a_x, b0 = sigma_t / sigma_0, -alpha_t * h_phi_1
+        # predictor: x_t = a x + b0 m0 - alpha_t B_h sum_k rho_p[k] (m_{k+1} - m0) / rk_k
+        pk = [-alpha_t * B_h * rhos_p[k] / rks[k] for k in range(K)] if K > 0 else []
+        x_t = torch.empty_like(x)
+        _lincomb(x_t, [(a_x, x), (b0 - sum(pk), m0)] + [(pk[k], m_prev[-(k + 2)]) for k in range(K)])
+        model_t = None
+        if use_corrector:
+            model_t = self._data_prediction(ns, x_t, t, cond, uncond, guide)
+            ck = [-alpha_t * B_h * rhos_c[k] / rks[k] for k in range(K)]
+            cT = -alpha_t * B_h * rhos_c[-1]
+            x_c = torch.empty_like(x)
+            _lincomb(x_c, [(a_x, x), (b0 - sum(ck) - cT, m0)] + [(ck[k], m_prev[-(k + 2)]) for k in range(K)] + [(cT, model_t)])
+            x_t = x_c
+        return x_t, model_t
+
+    @torch.no_grad()
+    def sample(self, S, batch_size, shape, conditioning=None, callback=None, strength=None, eta=0.0, mask=None,
+               x_T=None, unconditional_guidance_scale=1.0, unconditional_conditioning=None, **kwargs):
+        model = self.model
+        dev = x_T.device if x_T is not None else (self.device or torch.device(model.device))
+        x = torch.randn(tuple(shape), device=dev) if x_T is None else x_T
+        x = x.float().contiguous()
+        assert x.shape[0] == 1
+        ns = _VPSchedule(self.alphas_cumprod)
+        order, steps = 3, S
+        assert steps >= order
+        t_T = ns.T if strength is None else strength
+        t_0 = 1.0 / ns.total_N
+        ts = torch.linspace(t_T, t_0, steps + 1, dtype=torch.float32).to(torch.float64).tolist()   # 'time_uniform', fp32 grid
+        guide = unconditional_guidance_scale
+        if hasattr(model, "refresh_weights"):
+            model.refresh_weights(dev)
+        prev_auto = getattr(model, "auto_refresh", None)
+        if prev_auto is not None:
+            model.auto_refresh = False
+
+        def conds():
+            return reconstruct_conds(conditioning, unconditional_conditioning, state.sampling_step)
+
+        try:
+            c, uc = conds()
+            m_prev, t_prev = [self._data_prediction(ns, x, ts[0], c, uc, guide)], [ts[0]]
+            for init_order in range(1, order):                       # warm-up with lower orders + corrector
+                c, uc = conds()
+                x, mx = self._update(ns, x, m_prev, t_prev, ts[init_order], init_order, True, c, uc, guide)
+                m_prev.append(mx)
+                t_prev.append(ts[init_order])
+                if callback is not None:
+                    callback()
+            for step in range(order, steps + 1):
+                c, uc = conds()
+                step_order = min(order, steps + 1 - step)            # lower_order_final
+                use_corr = step != steps                             # no corrector (= no model call) at the last step
+                x, mx = self._update(ns, x, m_prev, t_prev, ts[step], step_order, use_corr, c, uc, guide)
+                m_prev, t_prev = m_prev[1:] + [mx], t_prev[1:] + [ts[step]]
+                if callback is not None:
+                    callback()
+        finally:
+            if prev_auto is not None:
+                model.auto_refresh = prev_auto
+        return x
+
+    @torch.no_grad()
+    def unipc_encode(self, latent, device, strength, steps, noise=None):
+        """vid2vid noising at t = strength (uni_pc/sampler.py:20-29)."""
+        ns = _VPSchedule(self.alphas_cumprod)
+        t = float(strength)
+        noise = torch.randn_like(latent) if noise is None else noise
+        out = torch.empty_like(latent)
+        return _lincomb(out, [(ns.std(t), noise), (ns.alpha(t), latent)])
+
+
 class SamplerBase(object):
     """samplers_common.py:71-87."""
 
@@ -253,18 +549,10 @@ class SamplerBase(object):
         return self.Sampler(sd_model, betas=betas, **kwargs)
 
 
-def _not_built(name):
-    class _Missing(object):
-        def __init__(self, *a, **k):
-            raise NotImplementedError(f"sampler '{name}' is SURVEY §8(f)-1 (next round); use 'DDIM_Gaussian'")
-    _Missing.__name__ = name
-    return _Missing
-
-
 available_samplers = [
     SamplerBase("DDIM_Gaussian", GaussianDiffusion, True),
-    SamplerBase("DDIM", _not_built("DDIM")),
-    SamplerBase("UniPC", _not_built("UniPC")),
+    SamplerBase("DDIM", DDIMSampler),
+    SamplerBase("UniPC", UniPCSampler),
 ]
 
 
@@ -293,10 +581,20 @@ class Txt2VideoSampler(object):
         return latents, noise, shape
 
     def encode_latent(self, latent, noise, strength, steps):
-        """vid2vid noising (:123-145) — DDIM_Gaussian branch (`add_noise`)."""
-        denoise_steps = int(strength * steps)
-        timestep = self.sampler.get_time_steps(denoise_steps, latent.shape[0])
-        encoded_latent = self.sampler.add_noise(latent, noise, timestep[0].cpu())
+        """vid2vid noising (:123-145): dispatch on what the active solver offers."""
+        encoded_latent, denoise_steps = None, None
+        if hasattr(self.sampler, "unipc_encode"):
+            encoded_latent = self.sampler.unipc_encode(latent, self.device, strength, steps, noise=noise)
+        if hasattr(self.sampler, "stochastic_encode"):
+            denoise_steps = int(strength * steps)
+            timestep = torch.tensor([denoise_steps] * int(latent.shape[0]))
+            self.sampler.make_schedule(steps)
+            encoded_latent = self.sampler.stochastic_encode(latent, timestep, noise=noise).to(dtype=latent.dtype)
+            self.sampler.sample = self.sampler.decode
+        if hasattr(self.sampler, "add_noise"):
+            denoise_steps = int(strength * steps)
+            timestep = self.sampler.get_time_steps(denoise_steps, latent.shape[0])
+            encoded_latent = self.sampler.add_noise(latent, noise, timestep[0].cpu())
         return encoded_latent, denoise_steps
 
     def get_sampler(self, sampler_name: str, betas=None, return_sampler=True):

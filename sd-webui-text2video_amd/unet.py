@@ -219,7 +219,7 @@ class UNetSD(nn.Module):
         self.t_shard = None           # parallel.TShard: this rank holds a contiguous slice of the clip's frames
         self.auto_refresh = True      # re-check parameter versions on every forward (~1 ms); the sampler
                                       # turns this off inside its loop after one explicit refresh
-        self.device = torch.device("cpu")
+        self.device = torch.device("cpu")   # SamplerBase.register_buffers_to_model overwrites it (samplers_common.py:82)
 
     # ---- parameter tree -------------------------------------------------------------------
     def _make(self, kind, cin, cout, dropout, decoder, stem=False):

@@ -48,9 +48,45 @@ def tiny():
         x0 = s.sample_loop(steps=4, strength=None, conditioning=c, unconditional_conditioning=uc,
                            batch_size=1, latents=lat, shape=shape, noise=noise, guidance_scale=9.0,
                            eta=0.0, sampler_name="DDIM_Gaussian")
+    extra = other_samplers(ref, unet, betas, lat, noise, shape, c, uc)
     np.savez_compressed(os.path.join(OUT, "tiny.npz"), unet_eps=eps.numpy(), vae_img=img.numpy(),
-                        sampler_x0=x0.numpy())
-    print("tiny done", eps.std().item(), img.std().item(), x0.std().item())
+                        sampler_x0=x0.numpy(), **extra)
+    print("tiny done", eps.std().item(), img.std().item(), x0.std().item(), {k: float(v.std()) for k, v in extra.items()})
+
+
+def other_samplers(ref, unet, betas, lat, noise, shape, c, uc):
+    """"DDIM" and "UniPC" through the reference's own Txt2VideoSampler.  Both reference classes pin
+    their buffers to torch.device("cuda") (ddim/sampler.py:11,18-22; uni_pc/sampler.py:13-17); the only
+    change made here is to point that device at the CPU — the arithmetic is the reference's, untouched."""
+    import samplers.uni_pc.sampler as ups
+    ups.UniPCSampler.register_buffer = lambda self, name, attr: setattr(self, name, attr)
+    out = {}
+    cpu = torch.device("cpu")
+    with torch.no_grad():
+        s = ref.samplers.Txt2VideoSampler(unet, cpu, betas=betas, sampler_name="DDIM")
+        s.sampler.device = cpu
+        out["ddim_x0"] = s.sample_loop(steps=4, strength=None, conditioning=c, unconditional_conditioning=uc,
+                                       batch_size=1, latents=lat, shape=shape, noise=noise, guidance_scale=9.0,
+                                       eta=0.0, sampler_name="DDIM").numpy()
+        s = ref.samplers.Txt2VideoSampler(unet, cpu, betas=betas, sampler_name="UniPC")
+        out["unipc_x0"] = s.sample_loop(steps=6, strength=None, conditioning=c, unconditional_conditioning=uc,
+                                        batch_size=1, latents=lat, shape=shape, noise=noise, guidance_scale=9.0,
+                                        eta=0.0, sampler_name="UniPC").numpy()
+        out["unipc_x0_s07"] = s.sample_loop(steps=4, strength=0.7, conditioning=c, unconditional_conditioning=uc,
+                                            batch_size=1, latents=lat, shape=shape, noise=noise, guidance_scale=7.0,
+                                            eta=0.0, sampler_name="UniPC").numpy()
+        # vid2vid noising helpers (samplers_common.py:123-145)
+        g = torch.Generator().manual_seed(11)
+        z0 = torch.randn(shape, generator=g)
+        out["unipc_encode"] = s.sampler.unipc_encode(z0, cpu, 0.7, 4, noise=noise).numpy()
+        s = ref.samplers.Txt2VideoSampler(unet, cpu, betas=betas, sampler_name="DDIM")
+        s.sampler.device = cpu
+        enc, dsteps = s.encode_latent(z0, noise, 0.75, 4)
+        out["ddim_encode"] = enc.numpy()
+        # after encode_latent `sampler.sample` is `sampler.decode` (samplers_common.py:137); called directly here
+        out["ddim_vid2vid_x0"] = s.sampler.decode(enc, c, dsteps, unconditional_guidance_scale=9.0,
+                                                  unconditional_conditioning=uc).numpy()
+    return out
 
 
 def modelscope(frames=8, steps=5):

@@ -221,15 +221,28 @@ class Interp:
         y, u = e[0], e[1]
         o = y.clone()
         o[:guided] = u[:guided] + gscale * (y[:guided] - u[:guided])
-        x0 = a_recip * xt - a_recipm1 * o
-        eps = (a_recip * xt - x0) / a_recipm1
-        xn = sqrt_aprev * x0 + dir_coef * eps
+        if op.i[5] == 0:
+            x0 = a_recip * xt - a_recipm1 * o
+            eps = (a_recip * xt - x0) / a_recipm1
+            xn = sqrt_aprev * x0 + dir_coef * eps
+        else:
+            x0 = (xt - a_recip * o) / a_recipm1
+            xn = sqrt_aprev * x0 + dir_coef * o
         if op.p[2].space != "null" and sigma != 0.0 and ext.get(L.EXT_NOISE) is not None:
             xn = xn + sigma * self.view(op.p[2], (C, inner), (inner, 1), torch.float32, ext)
         out = self.view(op.p[3], (C, inner), (inner, 1), _TD[xdt], ext)
         out.copy_(xn.to(out.dtype))
 
     # MEMSET -------------------------------------------------------------------------------------------
+    def _op12(self, op, ext):
+        n, k = op.i[0], op.i[1]
+        acc = None
+        for j in range(k):
+            t = self.view(op.p[j], (n,), (1,), _TD[op.i[3 + j]], ext).float()
+            acc = op.f[j] * t if acc is None else acc + op.f[j] * t
+        out = self.view(op.p[6], (n,), (1,), _TD[op.i[2]], ext)
+        out.copy_(acc.to(out.dtype))
+
     def _op100(self, op, ext):
         raise RuntimeError("collectives are executed by parallel.ShardedExecutor, not the interpreter")
 

@@ -125,6 +125,48 @@ def test_tiny_sampler_matches_reference_golden(tiny):
     assert samplers.state.sampling_step == 4
 
 
+def test_tiny_ddim_and_unipc_match_reference_golden(tiny):
+    """"DDIM" (ddim/sampler.py) and "UniPC" (uni_pc/*) through the facade vs the reference's own classes
+    (golden).  The synthetic weights make the trajectories expansive (|x0| grows ~x10-25 under CFG 9), so
+    the fp16-operand error of each UNet call is amplified: tolerance 3e-2 rel-L2 (DDIM_Gaussian: 2e-2)."""
+    net, sd, betas = tiny
+    *_, c, uc = _tiny_inputs()
+    gold = np.load(os.path.join(GOLD, "tiny.npz"))
+    dev = torch.device(DEV)
+    c, uc = c.to(DEV), uc.to(DEV)
+    smp = samplers.Txt2VideoSampler(net, dev, betas=betas, sampler_name="DDIM")
+    smp.progress = False
+    _, noise, shape = smp.get_noise(1, 4, 3, 128, 128, seed=1234)
+    x0 = smp.sample_loop(steps=4, strength=None, conditioning=c, unconditional_conditioning=uc, batch_size=1,
+                         shape=shape, noise=noise, guidance_scale=9.0, eta=0.0, sampler_name="DDIM")
+    r = rel_l2(x0.float().cpu(), torch.from_numpy(gold["ddim_x0"]))
+    assert r < 3e-2, r
+    assert samplers.state.sampling_step == 4
+    # vid2vid: noising + truncated schedule
+    z0 = torch.randn(tuple(shape), generator=torch.Generator().manual_seed(11)).to(DEV)
+    enc, dsteps = smp.encode_latent(z0, noise, 0.75, 4)
+    assert dsteps == 3 and rel_l2(enc.cpu(), torch.from_numpy(gold["ddim_encode"])) < 1e-6
+    x0 = smp.sample_loop(steps=4, strength=0.75, conditioning=c, unconditional_conditioning=uc, batch_size=1,
+                         latents=z0, shape=shape, noise=noise, is_vid2vid=True, guidance_scale=9.0, eta=0.0,
+                         sampler_name="DDIM")
+    r = rel_l2(x0.float().cpu(), torch.from_numpy(gold["ddim_vid2vid_x0"]))
+    assert r < 3e-2, r
+
+    smp = samplers.Txt2VideoSampler(net, dev, betas=betas, sampler_name="UniPC")
+    smp.progress = False
+    x0 = smp.sample_loop(steps=6, strength=None, conditioning=c, unconditional_conditioning=uc, batch_size=1,
+                         shape=shape, noise=noise, guidance_scale=9.0, eta=0.0, sampler_name="UniPC")
+    r = rel_l2(x0.float().cpu(), torch.from_numpy(gold["unipc_x0"]))
+    assert r < 3e-2, r
+    assert samplers.state.sampling_step == 6
+    x0 = smp.sample_loop(steps=4, strength=0.7, conditioning=c, unconditional_conditioning=uc, batch_size=1,
+                         shape=shape, noise=noise, guidance_scale=7.0, eta=0.0, sampler_name="UniPC")
+    r = rel_l2(x0.float().cpu(), torch.from_numpy(gold["unipc_x0_s07"]))
+    assert r < 3e-2, r
+    enc = smp.sampler.unipc_encode(z0, dev, 0.7, 4, noise=noise)
+    assert rel_l2(enc.cpu(), torch.from_numpy(gold["unipc_encode"])) < 1e-6
+
+
 def test_sampler_interrupt_raises(tiny):
     net, sd, betas = tiny
     *_, c, uc = _tiny_inputs()

@@ -421,3 +421,30 @@ def test_temporal_conv_halo_layout(tile):
     x = read(it, a).float().view(1, F + 2, HW, 1, C).permute(0, 4, 1, 2, 3)
     ref = torch.nn.functional.conv3d(x, wt.half().float(), w["b"], padding=(0, 0, 0)).permute(0, 2, 3, 4, 1).reshape(F * HW, C)
     assert rel_l2(read(got, out), ref) < 1e-4
+
+
+def test_lincomb_and_ldm_ddim_update():
+    """T2V_OP_LINCOMB (mixed fp16/fp32 terms, ragged length) and T2V_OP_DDIM_STEP mode 1 (LDM form with
+    eta-noise) against the torch restatement of their documented semantics (include/t2v_hip.h)."""
+    from sd_webui_text2video_amd import samplers as S
+    from test_samplers_cpu import _ddim_update_cpu, _lincomb_cpu
+    g = _g(3)
+    n = 4 * 3 * 16 * 16 + 0
+    for shape, dts in (((1, 4, 3, 16, 16), ["f32", "f16", "f32"]), ((1, 4, 5, 7, 9), ["f32"] * 6), ((1, 4, 1, 3, 3), ["f16", "f16"])):
+        terms = [(float(torch.randn(1, generator=g)), torch.randn(shape, generator=g).to(torch.float16 if d == "f16" else torch.float32))
+                 for d in dts]
+        for odt in (torch.float32, torch.float16):
+            want = _lincomb_cpu(torch.empty(shape, dtype=odt), terms)
+            got = S._lincomb(torch.empty(shape, dtype=odt, device="cuda"), [(c, t.cuda()) for c, t in terms])
+            torch.cuda.synchronize()
+            tol = 2e-3 if odt == torch.float16 else 1e-6
+            assert rel_l2(got.float().cpu(), want.float()) < tol
+    shape = (1, 4, 3, 16, 16)
+    xt, noise = torch.randn(shape, generator=g), torch.randn(shape, generator=g)
+    eps = torch.randn((2,) + shape[1:], generator=g).half()
+    coef = [0.6, 0.8, 0.9, 0.3, 0.25, 7.5]
+    for guided, e in ((4, eps), (0, eps[0:1].contiguous())):
+        want = _ddim_update_cpu(torch.empty(shape), xt, e, noise, coef, guided, 1)
+        got = S._ddim_update(torch.empty(shape, device="cuda"), xt.cuda(), e.cuda(), noise.cuda(), coef, guided, 1)
+        torch.cuda.synchronize()
+        assert rel_l2(got.cpu(), want) < 1e-6

@@ -47,6 +47,31 @@ def test_port_matches_reference_golden_tiny():
     assert np.abs(x0.numpy() - gold["sampler_x0"]).max() < 2e-4 * np.abs(gold["sampler_x0"]).max()
 
 
+def test_port_ddim_and_unipc_match_reference_golden():
+    """oracle restatements of "DDIM" (ddim/sampler.py) and "UniPC" (uni_pc/*) vs outputs of the reference's
+    own sampler classes (tests/golden/make_golden.py:other_samplers)."""
+    gold = np.load(os.path.join(GOLD, "tiny.npz"))
+    _, _, _, _, c, uc = _tiny_inputs()
+    sd = synth.synth_state_dict(_spec_unet(configs.TINY_UNET), seed=0)
+    betas = tp.beta_schedule_linear_sd()
+    noise, _, _ = synth.synth_inputs(3, 128, 128)
+    z0 = torch.randn(noise.shape, generator=torch.Generator().manual_seed(11))
+
+    def f(a, b, cc):
+        return tp.unet_forward(sd, configs.TINY_UNET, a, b, cc)
+
+    def rel(a, k):
+        return np.abs(a.numpy() - gold[k]).max() / np.abs(gold[k]).max()
+
+    assert rel(tp.ddim_ldm_sample(f, betas, noise, 4, c, uc, 9.0), "ddim_x0") < 2e-5
+    assert rel(tp.unipc_sample(f, betas, noise, 6, c, uc, 9.0), "unipc_x0") < 2e-5
+    assert rel(tp.unipc_sample(f, betas, noise, 4, c, uc, 7.0, t_start=0.7), "unipc_x0_s07") < 2e-5
+    assert rel(tp.unipc_encode(betas, z0, 0.7, noise), "unipc_encode") < 1e-6
+    enc = tp.ddim_ldm_encode(betas, 4, z0, 3, noise)
+    assert rel(enc, "ddim_encode") < 1e-6
+    assert rel(tp.ddim_ldm_sample(f, betas, enc, 4, c, uc, 9.0, t_start=3), "ddim_vid2vid_x0") < 2e-5
+
+
 def test_timestep_grid_matches_reference_quirk():
     # SURVEY App. C #2: S=5 -> [801,601,401,201,1]; S=50 -> [981,...,1]
     assert tp.ddim_gaussian_timesteps(1000, 5).tolist() == [801, 601, 401, 201, 1]
