@@ -87,7 +87,7 @@ __device__ __forceinline__ void epi_store_geglu(const GemmParams& p, int m, int 
 }
 
 // WM x WN waves; each wave owns TM x TN MFMA tiles (32 tokens x 32 channels each).
-template <int WM, int WN, int TM, int TN, int BK, int STAGES, int MINW, int GATHER>
+template <int WM, int WN, int TM, int TN, int BK, int STAGES, int MINW, int GATHER, bool PP>
 __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm2_kernel(const GemmParams p) {
   constexpr int NW = WM * WN;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -294,39 +294,119 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm2_kernel(const GemmPar
   }
 
   constexpr int KSTEPS = BK / 16;
-  int slot = 0;
-  for (int t = 0; t < nkt; ++t) {
-    wait_vmcnt<LPS*(STAGES - 2)>();
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    int fs = slot + STAGES - 1;
-    if (fs >= STAGES) fs -= STAGES;
-    stage_begin();
-    const unsigned char* st = smem + slot * STAGE_BYTES;
-#pragma unroll
-    for (int kk = 0; kk < KSTEPS; ++kk) {
-      const int lc4 = (kk * 2 + fhalf) << 4;
-      f16x8 xf[TM], wf[TN];
-#pragma unroll
-      for (int a = 0; a < TM; ++a) xf[a] = *reinterpret_cast<const f16x8*>(st + xbase[a] + (lc4 ^ xsw[a]));
-#pragma unroll
-      for (int b = 0; b < TN; ++b) wf[b] = *reinterpret_cast<const f16x8*>(st + wbase[b] + (lc4 ^ wsw[b]));
-      // this k-step's share of the next tile's DMA, issued between the fragment reads and the MFMAs.
-      // With a 2-deep ring the pieces must land before the next barrier, so they go out in the first
-      // half of the k-tile; with 3 stages they have a whole extra k-tile and are spread over all steps.
-      constexpr int SPREAD = STAGES == 2 ? KSTEPS / 2 : KSTEPS;
-      if (kk < SPREAD) {
-#pragma unroll
-        for (int j = (LPS * kk) / SPREAD; j < (LPS * (kk + 1)) / SPREAD; ++j) stage_piece(fs, j);
+  if constexpr (!PP) {
+    int slot = 0;
+    for (int t = 0; t < nkt; ++t) {
+      wait_vmcnt<LPS*(STAGES - 2)>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      int fs = slot + STAGES - 1;
+      if (fs >= STAGES) fs -= STAGES;
+      stage_begin();
+      const unsigned char* st = smem + slot * STAGE_BYTES;
+  #pragma unroll
+      for (int kk = 0; kk < KSTEPS; ++kk) {
+        const int lc4 = (kk * 2 + fhalf) << 4;
+        f16x8 xf[TM], wf[TN];
+  #pragma unroll
+        for (int a = 0; a < TM; ++a) xf[a] = *reinterpret_cast<const f16x8*>(st + xbase[a] + (lc4 ^ xsw[a]));
+  #pragma unroll
+        for (int b = 0; b < TN; ++b) wf[b] = *reinterpret_cast<const f16x8*>(st + wbase[b] + (lc4 ^ wsw[b]));
+        // this k-step's share of the next tile's DMA, issued between the fragment reads and the MFMAs.
+        // With a 2-deep ring the pieces must land before the next barrier, so they go out in the first
+        // half of the k-tile; with 3 stages they have a whole extra k-tile and are spread over all steps.
+        constexpr int SPREAD = STAGES == 2 ? KSTEPS / 2 : KSTEPS;
+        if (kk < SPREAD) {
+  #pragma unroll
+          for (int j = (LPS * kk) / SPREAD; j < (LPS * (kk + 1)) / SPREAD; ++j) stage_piece(fs, j);
+        }
+  #pragma unroll
+        for (int a = 0; a < TM; ++a)
+  #pragma unroll
+          for (int b = 0; b < TN; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[b], xf[a], acc[a][b], 0, 0, 0);
       }
-#pragma unroll
-      for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[b], xf[a], acc[a][b], 0, 0, 0);
+      stage_end();
+      slot = slot + 1 == STAGES ? 0 : slot + 1;
     }
-    stage_end();
-    slot = slot + 1 == STAGES ? 0 : slot + 1;
+  } else {
+    // ---- ping-pong schedule ---------------------------------------------------------------------
+    // The 8 waves form two groups (waves 0-3 / 4-7: one wave of each group per SIMD).  A k-tile is
+    // cut into P phases of 8 MFMAs (one pair of token sub-tiles x one weight sub-tile x BK); each
+    // phase is  [fragment ds_reads + a share of the next tile's DMA | s_barrier | MFMAs | s_barrier].
+    // Group 1 runs ONE barrier behind group 0, so on every SIMD one wave is in its MFMA segment while
+    // its partner is in its LDS/DMA segment: the LDS pipe (fragment reads + DMA writes ~ the MFMA
+    // time of a 256-wide tile) and the matrix pipe work concurrently instead of alternating.
+    // Hazards (counted by barrier intervals, group 1 = group 0 + 1):
+    //   RAW: every wave retires its DMA pieces of tile t+1 (vmcnt(0)) before barrier #2k'-1, k' = first
+    //        phase of t+1 — group 0 after its last MFMA segment, group 1 after its last read segment —
+    //        and the first read of the slot is after that barrier.
+    //   WAR: a slot is re-staged from phase ISSUE0 of the following k-tile, >= 2 phases after the last
+    //        ds_read of either group from it.
+    static_assert(STAGES == 2 && TM % 2 == 0 && NW == 8, "ping-pong: 2 slots, token sub-tiles in pairs, 8 waves");
+    constexpr int NAP = TM / 2;                       // token sub-tile pairs per wave
+    constexpr int P = NAP * TN;                       // phases per k-tile
+    constexpr bool WCACHE = NAP > 1;                  // weight fragments stay in registers for the 2nd pair
+    constexpr bool LAST_READS = !WCACHE || TN == 1;   // does the last phase read LDS?
+    constexpr int ISSUE0 = LAST_READS ? 1 : 0;
+    static_assert(ISSUE0 + 1 < P - 1 || !LAST_READS, "DMA must be issued at least one phase before its wait");
+    const int grp = wave >> 2;                        // wave-uniform (SGPR)
+    f16x8 xf[2][KSTEPS];
+    f16x8 wf[WCACHE ? TN : 1][KSTEPS];
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (grp) __builtin_amdgcn_s_barrier();
+    int slot = 0;
+    for (int t = 0; t < nkt; ++t) {
+      const unsigned char* st = smem + slot * STAGE_BYTES;
+      const int fs = slot ^ 1;
+#pragma unroll
+      for (int ph = 0; ph < P; ++ph) {
+        const int ap = ph / TN, j = ph % TN;
+        const int b = (ap & 1) ? TN - 1 - j : j;
+        const int wslot = WCACHE ? b : 0;
+        // ---- load segment
+        if (WCACHE ? ap == 0 : true) {
+#pragma unroll
+          for (int kk = 0; kk < KSTEPS; ++kk)
+            wf[wslot][kk] = *reinterpret_cast<const f16x8*>(st + wbase[b] + ((((kk * 2 + fhalf) << 4)) ^ wsw[b]));
+        }
+        if (j == 0) {
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS; ++kk)
+              xf[q][kk] = *reinterpret_cast<const f16x8*>(st + xbase[2 * ap + q] + ((((kk * 2 + fhalf) << 4)) ^ xsw[2 * ap + q]));
+        }
+        if (ph == ISSUE0) stage_begin();
+        if (ph == ISSUE0 || ph == ISSUE0 + 1) {
+          constexpr int HALF = (LPS + 1) / 2;
+#pragma unroll
+          for (int q = 0; q < LPS; ++q)
+            if ((ph == ISSUE0) == (q < HALF)) stage_piece(fs, q);
+        }
+        if (ph == ISSUE0 + 1) stage_end();
+        if (ph == P - 1 && grp) wait_vmcnt<0>();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- MFMA segment
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk)
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+            acc[2 * ap + q][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[wslot][kk], xf[q][kk], acc[2 * ap + q][b], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        if (ph == P - 1 && !grp) wait_vmcnt<0>();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+      }
+      slot ^= 1;
+    }
+    if (!grp) __builtin_amdgcn_s_barrier();
   }
   wait_vmcnt<0>();   // drain the zero-page loads of the dead stages before the LDS goes away
 
@@ -372,12 +452,12 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm2_kernel(const GemmPar
   }
 }
 
-template <int WM, int WN, int TM, int TN, int BK, int STAGES, int MINW, int GATHER>
+template <int WM, int WN, int TM, int TN, int BK, int STAGES, int MINW, int GATHER, bool PP>
 hipError_t launch_cfg_gather(const GemmParams& p, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int lds = STAGES * (BM + BN) * BK * 2 + 1024;
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  auto k = gemm2_kernel<WM, WN, TM, TN, BK, STAGES, MINW, GATHER>;
+  auto k = gemm2_kernel<WM, WN, TM, TN, BK, STAGES, MINW, GATHER, PP>;
   static bool attr_set = false;     // once per instantiation (the call costs microseconds on the host)
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -388,7 +468,7 @@ hipError_t launch_cfg_gather(const GemmParams& p, hipStream_t s) {
   return hipGetLastError();
 }
 
-template <int WM, int WN, int TM, int TN, int BK, int STAGES, int MINW>
+template <int WM, int WN, int TM, int TN, int BK, int STAGES, int MINW, bool PP = false>
 hipError_t launch_cfg(const GemmParams& pin, hipStream_t s) {
   GemmParams p = pin;
   const int KT = (p.K + BK - 1) / BK;
@@ -398,12 +478,12 @@ hipError_t launch_cfg(const GemmParams& pin, hipStream_t s) {
   p.splitk = (KT + p.kt_per_split - 1) / p.kt_per_split;  // no empty splits
   hipError_t e;
   switch (p.gather) {
-    case T2V_GATHER_PLAIN: e = launch_cfg_gather<WM, WN, TM, TN, BK, STAGES, MINW, T2V_GATHER_PLAIN>(p, s); break;
+    case T2V_GATHER_PLAIN: e = launch_cfg_gather<WM, WN, TM, TN, BK, STAGES, MINW, T2V_GATHER_PLAIN, PP>(p, s); break;
     case T2V_GATHER_CONV3X3:
-      if (p.up) e = launch_cfg_gather<WM, WN, TM, TN, BK, STAGES, MINW, G_CONV_UP>(p, s);
-      else e = launch_cfg_gather<WM, WN, TM, TN, BK, STAGES, MINW, T2V_GATHER_CONV3X3>(p, s);
+      if (p.up) e = launch_cfg_gather<WM, WN, TM, TN, BK, STAGES, MINW, G_CONV_UP, PP>(p, s);
+      else e = launch_cfg_gather<WM, WN, TM, TN, BK, STAGES, MINW, T2V_GATHER_CONV3X3, PP>(p, s);
       break;
-    case T2V_GATHER_TCONV3: e = launch_cfg_gather<WM, WN, TM, TN, BK, STAGES, MINW, T2V_GATHER_TCONV3>(p, s); break;
+    case T2V_GATHER_TCONV3: e = launch_cfg_gather<WM, WN, TM, TN, BK, STAGES, MINW, T2V_GATHER_TCONV3, PP>(p, s); break;
     default: return hipErrorInvalidValue;
   }
   if (e != hipSuccess) return e;
@@ -413,13 +493,20 @@ hipError_t launch_cfg(const GemmParams& pin, hipStream_t s) {
 
 }  // namespace
 
-// tile ids (t2v_op.i[22]):  1 = 256x256, 2 = 256x320, 3 = 128x256 — all 8 waves, 64-wide k-tiles
+// tile ids (t2v_op.i[22]):  1 = 256x256, 2 = 256x320, 3 = 128x256 (8 waves), 4 / 5 = 128x128 with a 4-deep ring
+// (few-row levels: latency-bound, keep 96 KiB per CU in flight) — 64-wide k-tiles
 // (full 128-byte lines per row = one conv reduction chunk), 2-3 stage ring, one workgroup per CU.
 hipError_t t2v_launch_gemm2(const GemmParams& p, int tile, hipStream_t s) {
   switch (tile) {
     case 1: return launch_cfg<2, 4, 4, 2, 64, 2, 2>(p, s);   // 2 x 64 KiB
     case 2: return launch_cfg<4, 2, 2, 5, 64, 2, 2>(p, s);   // 2 x 72 KiB
     case 3: return launch_cfg<2, 4, 2, 2, 64, 3, 2>(p, s);   // 3 x 48 KiB
+    case 4: return launch_cfg<2, 2, 2, 2, 64, 4, 1>(p, s);   // 128x128, 4 waves, 4 x 32 KiB: 3 k-tiles in flight
+    case 5: return launch_cfg<2, 4, 2, 1, 64, 4, 2>(p, s);   // 128x128, 8 waves, 4 x 32 KiB
+    case 6: return launch_cfg<2, 4, 4, 2, 64, 2, 2, true>(p, s);   // 256x256 ping-pong (two staggered wave groups)
+    case 7:                                                         // 256x320 ping-pong
+      if (p.gather == T2V_GATHER_CONV3X3 && p.up) return launch_cfg<4, 2, 2, 5, 64, 2, 2>(p, s);   // (upsample gather: register budget)
+      return launch_cfg<4, 2, 2, 5, 64, 2, 2, true>(p, s);
     default: return hipErrorInvalidValue;
   }
 }

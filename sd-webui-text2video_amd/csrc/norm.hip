@@ -10,77 +10,94 @@
 // A statistics "instance" is a contiguous run of `rows` token rows (one frame, or all F frames
 // of one sample) x one of 32 channel groups.  Input is the fp32 (or fp16) residual stream
 // [rows, C]; output is fp16 — the operand format of the following MFMA GEMM.
-//   pass 1: per-thread fp32 partial sums over a 64-row chunk -> LDS -> ordered fp64 fold per
-//           group -> one partial per (instance, block, group); no atomics (bitwise reproducible)
-//   pass 2: one wave per (instance, group): ordered fold of the partials -> {mean, rstd}
-//   pass 3: normalise + affine (+SiLU), 4 channels per thread, 8-byte stores
+//   launch 1: per-thread fp32 partial sums over a chunk of rows (8 rows in flight per thread) -> LDS ->
+//             ordered fp64 fold per group -> one partial per (instance, block, group); no atomics.
+//   launch 2: one wave per (instance, group): ordered fold of the block partials -> {mean, rstd}
+//             (a ticket-elected in-kernel fold was measured: same-line L2 atomics serialise at ~25 ns
+//             each and the fence + fold tail costs as much as this 4-5 us launch — not kept).
+//   launch 3: normalise + affine (+SiLU): scale/shift per channel built once per workgroup in LDS,
+//             then 8 rows x 8 channels per thread, 16-byte loads issued together, 16-byte stores.
+// Bitwise reproducible run to run.
+// (T-sharded clips: statistics / all-gather of the partials / fold + normalise, see phase below.)
 // HBM-bound: 4 B + 4 B read, 2 B written per element.
+#include <type_traits>
+
 #include "t2v_kernels.h"
 
 namespace {
 
-template <typename T> struct Load4;
-template <> struct Load4<float> {
-  static __device__ __forceinline__ f32x4 ld(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+// 8 consecutive channels of one token row as fp32 (one 16-byte load for fp16, two for fp32)
+template <typename T> struct Load8;
+template <> struct Load8<float> {
+  static __device__ __forceinline__ f32x8 ld(const float* __restrict__ p) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+    f32x8 r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return r;
+  }
 };
-template <> struct Load4<f16> {
-  static __device__ __forceinline__ f32x4 ld(const f16* p) {
-    const f16x4 h = *reinterpret_cast<const f16x4*>(p);
-    f32x4 r = {(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+template <> struct Load8<f16> {
+  static __device__ __forceinline__ f32x8 ld(const f16* __restrict__ p) {
+    const f16x8 h = *reinterpret_cast<const f16x8*>(p);
+    f32x8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = (float)h[e];
     return r;
   }
 };
 
-constexpr int GN_ROWS_PER_BLOCK = T2V_GN_ROWS_PER_BLOCK;  // rows of one instance reduced by one workgroup
+constexpr int GN_UNROLL = 8;   // token rows a thread keeps in flight (HBM-bound: ~48 KiB per CU must be outstanding)
 
-// Pass 1 — grid (nblk, n_inst).  Deterministic: per-thread fp32 partials over <= 64 rows are
-// parked in LDS [R][C]; 32 threads then fold replicas + the channels of their group in a fixed
-// order in fp64 and store ONE partial per (instance, block, group).  No atomics anywhere, so
-// results are bitwise reproducible run to run.
+// Launch 1 — grid (nblk, n_inst), nblk = ceil(rows / rpb).  Threads form R row-replicas x TPR column slots of
+// 8 channels.  Deterministic: per-thread fp32 partials are parked in LDS [R][C]; `groups` threads then fold
+// replicas + the channels of their group in a fixed order in fp64 and store ONE partial per (instance,
+// block, group).  No atomics: bitwise reproducible run to run.
 template <typename T>
-__global__ __launch_bounds__(256) void gn_stats_kernel(const T* x, double* partials, int rows, int C, int ld,
-                                                       int groups) {
-  extern __shared__ float sh[];  // [2][R][C]
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, double* partials, int rows, int C,
+                                                       int ld, int groups, int rpb) {
+  extern __shared__ float sh[];  // [2][R][C] floats
   const int tid = threadIdx.x;
   const int inst = blockIdx.y;
-  const int r0 = blockIdx.x * GN_ROWS_PER_BLOCK;
-  const int r1 = min(rows, r0 + GN_ROWS_PER_BLOCK);
+  const int r0 = blockIdx.x * rpb;
+  const int r1 = min(rows, r0 + rpb);
   const T* base = x + ((size_t)inst * rows) * ld;
-  const int cv = C >> 2;  // float4 units per row
-  const int R = cv <= 256 ? 256 / cv : 1;
+  const int cv = C >> 3;                       // 8-channel units per row
+  const int TPR = cv < 256 ? cv : 256;
+  const int R = 256 / TPR;
+  const int cs = tid % TPR, rr = tid / TPR;
   float* psum = sh;
   float* psq = sh + R * C;
-  if (cv <= 256) {
-    if (tid < R * cv) {
-      const int c4 = (tid % cv) * 4, rr = tid / cv;
-      f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
-      for (int r = r0 + rr; r < r1; r += R) {
-        const f32x4 v = Load4<T>::ld(base + (size_t)r * ld + c4);
-        s += v;
-        q += v * v;
+  if (rr < R) {
+    for (int u = cs; u < cv; u += TPR) {
+      const int c8 = u * 8;
+      f32x8 s, q;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+      for (int r = r0 + rr; r < r1; r += R * GN_UNROLL) {
+        f32x8 v[GN_UNROLL];
+#pragma unroll
+        for (int k = 0; k < GN_UNROLL; ++k) {
+          const int rk = r + k * R;
+          if (rk < r1) v[k] = Load8<T>::ld(base + (size_t)rk * ld + c8);
+          else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[k][e] = 0.f;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < GN_UNROLL; ++k) { s += v[k]; q += v[k] * v[k]; }
       }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { psum[rr * C + c4 + e] = s[e]; psq[rr * C + c4 + e] = q[e]; }
-    }
-  } else {
-    for (int u = tid; u < cv; u += 256) {
-      const int c4 = u * 4;
-      f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
-      for (int r = r0; r < r1; ++r) {
-        const f32x4 v = Load4<T>::ld(base + (size_t)r * ld + c4);
-        s += v;
-        q += v * v;
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { psum[c4 + e] = s[e]; psq[c4 + e] = q[e]; }
+      for (int e = 0; e < 8; ++e) { psum[rr * C + c8 + e] = s[e]; psq[rr * C + c8 + e] = q[e]; }
     }
   }
   __syncthreads();
   if (tid < groups) {
     const int cpg = C / groups;
     double s = 0.0, q = 0.0;
-    for (int rr = 0; rr < R; ++rr)
-      for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { s += (double)psum[rr * C + c]; q += (double)psq[rr * C + c]; }
+    for (int k = 0; k < R; ++k)
+      for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { s += (double)psum[k * C + c]; q += (double)psq[k * C + c]; }
     double* st = partials + (((size_t)inst * gridDim.x + blockIdx.x) * groups + tid) * 2;
     st[0] = s;
     st[1] = q;
@@ -113,31 +130,61 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* partials
   }
 }
 
-// Pass 3 — grid-stride over float4 units of the whole [n_inst*rows, C] tensor
+// Launch 2 — grid (ceil(rows / (R*GN_UNROLL)), n_inst), same thread layout.  The workgroup first builds
+// scale[c] = rstd*gamma[c] and shift[c] = beta[c] - mean*scale[c] for the instance in LDS; every thread then
+// normalises GN_UNROLL rows of its 8 channels per column unit (16-byte loads issued together, 16-byte stores).
 template <typename T>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const T* x, const float* finals, const float* gamma,
-                                                       const float* beta, f16* out, int n_inst, int rows, int C,
-                                                       int ld_in, int ld_out, int groups, int silu) {
-  const int cv = C >> 2;
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ finals,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       f16* __restrict__ out, int rows, int C, int ld_in, int ld_out,
+                                                       int groups, int silu) {
+  extern __shared__ float sh[];   // scale[C], shift[C]
+  float* sc = sh;
+  float* sf = sh + C;
+  const int tid = threadIdx.x;
+  const int inst = blockIdx.y;
+  const int cv = C >> 3;
   const int cpg = C / groups;
-  const long total = (long)n_inst * rows * cv;
-  for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < total; u += (long)gridDim.x * 256) {
-    const long row = u / cv;
-    const int c4 = (int)(u - row * cv) * 4;
-    const int inst = (int)(row / rows);
-    const f32x4 v = Load4<T>::ld(x + (size_t)row * ld_in + c4);
-    const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c4);
-    const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c4);
-    f16x4 o;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int grp = (c4 + e) / cpg;
-      const float2 mr = *reinterpret_cast<const float2*>(finals + 2 * ((size_t)inst * groups + grp));
-      float y = (v[e] - mr.x) * mr.y * g[e] + b[e];
-      if (silu) y = t2v_silu(y);
-      o[e] = (f16)y;
+  {
+    const float* fin = finals + (size_t)inst * groups * 2;
+    for (int c = tid; c < C; c += 256) {
+      const int grp = c / cpg;
+      const float a = fin[2 * grp + 1] * gamma[c];
+      sc[c] = a;
+      sf[c] = beta[c] - fin[2 * grp] * a;
     }
-    *reinterpret_cast<f16x4*>(out + (size_t)row * ld_out + c4) = o;
+  }
+  __syncthreads();
+  const int TPR = cv < 256 ? cv : 256;
+  const int R = 256 / TPR;
+  const int cs = tid % TPR, rr = tid / TPR;
+  if (rr >= R) return;
+  const int r0 = blockIdx.x * (R * GN_UNROLL) + rr;
+  const T* xb = x + (size_t)inst * rows * ld_in;
+  f16* ob = out + (size_t)inst * rows * ld_out;
+  for (int u = cs; u < cv; u += TPR) {
+    const int c8 = u * 8;
+    f32x8 v[GN_UNROLL];
+#pragma unroll
+    for (int k = 0; k < GN_UNROLL; ++k) {
+      const int rk = r0 + k * R;
+      if (rk < rows) v[k] = Load8<T>::ld(xb + (size_t)rk * ld_in + c8);
+    }
+    const f32x8 a = Load8<float>::ld(sc + c8), b = Load8<float>::ld(sf + c8);
+#pragma unroll
+    for (int k = 0; k < GN_UNROLL; ++k) {
+      const int rk = r0 + k * R;
+      if (rk < rows) {
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float y = v[k][e] * a[e] + b[e];
+          if (silu) y = t2v_silu(y);
+          o[e] = (f16)y;
+        }
+        *reinterpret_cast<f16x8*>(ob + (size_t)rk * ld_out + c8) = o;
+      }
+    }
   }
 }
 
@@ -191,50 +238,44 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
 }  // namespace
 
 // Scratch (op.p[4], owned by the caller): fp64 partials [nparts][n_inst][nblk][groups][2] followed by
-// fp32 finals [n_inst][groups][2], nblk = ceil(rows / T2V_GN_ROWS_PER_BLOCK).
+// fp32 finals [n_inst][groups][2], nblk = ceil(rows / rpb), rpb = op.i[11] (0: T2V_GN_ROWS_PER_BLOCK).
 // op.i[8] = phase: 0 = whole op; 1 = statistics only (writes this rank's partials into part op.i[10]);
 //                  2 = fold the op.i[9] gathered parts + normalise (after the partials all-gather).
 hipError_t t2v_launch_groupnorm(const t2v_op& op, hipStream_t s) {
   const int n_inst = op.i[0], rows = op.i[1], C = op.i[2], ld_in = op.i[3], groups = op.i[4];
   const int in_dt = op.i[5], silu = op.i[6], ld_out = op.i[7];
   const int phase = op.i[8], nparts = op.i[9] > 0 ? op.i[9] : 1, part = op.i[10];
-  if (C % 4 != 0 || C % groups != 0 || groups > 256 || n_inst <= 0 || rows <= 0 || op.p[4] == 0 || part < 0 ||
-      part >= nparts || phase < 0 || phase > 2)
+  const int rpb = op.i[11] > 0 ? op.i[11] : T2V_GN_ROWS_PER_BLOCK;
+  if (C % 8 != 0 || ld_in % 8 != 0 || ld_out % 8 != 0 || C % groups != 0 || groups > 256 || n_inst <= 0 || rows <= 0 ||
+      op.p[4] == 0 || part < 0 || part >= nparts || phase < 0 || phase > 2)
     return hipErrorInvalidValue;
-  const int nblk = (rows + GN_ROWS_PER_BLOCK - 1) / GN_ROWS_PER_BLOCK;
+  const int nblk = (rows + rpb - 1) / rpb;
   const size_t part_len = (size_t)n_inst * nblk * groups * 2;
   double* partials = reinterpret_cast<double*>(op.p[4]);
   float* finals = reinterpret_cast<float*>(partials + part_len * nparts);
   const dim3 g1(nblk, n_inst);
-  const int cv = C / 4;
-  const int R = cv <= 256 ? 256 / cv : 1;
+  const int cv = C / 8;
+  const int R = cv < 256 ? 256 / cv : 1;
   const size_t lds = 2 * (size_t)R * C * sizeof(float);
-  const long units = (long)n_inst * rows * cv;
-  const int g3 = (int)((units + 255) / 256 < 4096 ? (units + 255) / 256 : 4096);
   const int g2 = (n_inst * groups + 3) / 4;
   const double inv_n = 1.0 / ((double)rows * nparts * (C / groups));
   const float* gamma = reinterpret_cast<const float*>(op.p[1]);
   const float* beta = reinterpret_cast<const float*>(op.p[2]);
   f16* out = reinterpret_cast<f16*>(op.p[3]);
-  if (in_dt == T2V_F32) {
-    const float* x = reinterpret_cast<const float*>(op.p[0]);
+  auto run = [&](auto* x) {
+    using T = typename std::remove_cv<typename std::remove_pointer<decltype(x)>::type>::type;
     if (phase != 2)
-      hipLaunchKernelGGL(gn_stats_kernel<float>, g1, dim3(256), lds, s, x, partials + part_len * part, rows, C, ld_in, groups);
+      hipLaunchKernelGGL(gn_stats_kernel<T>, g1, dim3(256), lds, s, x, partials + part_len * part, rows, C, ld_in, groups, rpb);
     if (phase != 1) {
-      hipLaunchKernelGGL(gn_finalize_kernel, dim3(g2), dim3(256), 0, s, partials, finals, n_inst, nblk, groups, inv_n, op.f[0], nparts);
-      hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(g3), dim3(256), 0, s, x, finals, gamma, beta, out, n_inst, rows, C,
-                         ld_in, ld_out, groups, silu);
+      hipLaunchKernelGGL(gn_finalize_kernel, dim3(g2), dim3(256), 0, s, partials, finals, n_inst, nblk, groups, inv_n,
+                         op.f[0], nparts);
+      const int rpa = R * GN_UNROLL;    // rows per normalise workgroup
+      hipLaunchKernelGGL(gn_apply_kernel<T>, dim3((rows + rpa - 1) / rpa, n_inst), dim3(256), 2 * (size_t)C * sizeof(float), s, x,
+                         finals, gamma, beta, out, rows, C, ld_in, ld_out, groups, silu);
     }
-  } else {
-    const f16* x = reinterpret_cast<const f16*>(op.p[0]);
-    if (phase != 2)
-      hipLaunchKernelGGL(gn_stats_kernel<f16>, g1, dim3(256), lds, s, x, partials + part_len * part, rows, C, ld_in, groups);
-    if (phase != 1) {
-      hipLaunchKernelGGL(gn_finalize_kernel, dim3(g2), dim3(256), 0, s, partials, finals, n_inst, nblk, groups, inv_n, op.f[0], nparts);
-      hipLaunchKernelGGL(gn_apply_kernel<f16>, dim3(g3), dim3(256), 0, s, x, finals, gamma, beta, out, n_inst, rows, C,
-                         ld_in, ld_out, groups, silu);
-    }
-  }
+  };
+  if (in_dt == T2V_F32) run(reinterpret_cast<const float*>(op.p[0]));
+  else run(reinterpret_cast<const f16*>(op.p[0]));
   return hipGetLastError();
 }
 

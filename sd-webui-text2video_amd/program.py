@@ -147,7 +147,8 @@ class Program:
     # ---- GEMM tiling policy ----------------------------------------------------------------
     def choose_tile(self, M: int, n: int, k: int, gather: int, allow_splitk: bool = True):
         """-> (tile id, split_k).  Tile ids as in t2v_op.i[22]: 0 = 128x128-class kernel (any N, the C8
-        stem); 1 256x256, 2 256x320, 3 128x256 (large-tile kernel, csrc/gemm2.hip).
+        stem); 1 256x256, 2 256x320, 3 128x256, 4/5 128x128 with a 4-deep ring (csrc/gemm2.hip); 6/7 = 1/2
+        with the two-group ping-pong schedule (measured equal to 1/2, kept for experiments).
         Policy for a 256-CU chip: the widest tile whose grid still gives >= ~0.75 wave of
         workgroups; otherwise the 128x256 tile, then split-K over the (long) reduction."""
         cus = self.target_cus
@@ -163,20 +164,25 @@ class Program:
             if gather == L.GATHER_CONV3X3 and k >= 4096 and n % 320 == 0:
                 tile = 2
             elif n >= 2560:
-                tile = 1
+                tile = 2 if n % 320 == 0 else 1
+            elif n >= 1536:
+                tile = 3
+            elif gather == L.GATHER_PLAIN and k >= 2048:
+                tile = 5
             else:
                 tile = 0
-        else:                                          # 8x8 / 4x4 levels: few rows, long reductions
+        else:                                          # 8x8 / 4x4 levels: few rows, latency-bound
             if n >= 2560:
-                tile = 1 if M >= 2048 else 3
-            elif k >= 2560:
+                tile = 1 if M >= 2048 else (0 if n >= 8192 else 5)
+            elif gather == L.GATHER_CONV3X3 and k >= 8192:
                 tile = 3
             else:
-                tile = 0
+                tile = 5                               # 128x128, 4-deep ring: 96 KiB per CU in flight
         if tile == 0:
             bm, bn, bk = 128, (64 if (n % 128 != 0 and n % 128 <= 64) else 128), 64
         else:
-            bm, bn, bk = {1: (256, 256, 64), 2: (256, 320, 64), 3: (128, 256, 64)}[tile]
+            bm, bn, bk = {1: (256, 256, 64), 2: (256, 320, 64), 3: (128, 256, 64), 4: (128, 128, 64), 5: (128, 128, 64),
+                          6: (256, 256, 64), 7: (256, 320, 64)}[tile]
         tiles = math.ceil(M / bm) * math.ceil(n / bn)
         kt = math.ceil(k / bk)
         split = 1
@@ -187,8 +193,8 @@ class Program:
                     split = max(1, min(round(2 * cus / tiles), kt // 16, 32))
                 elif tiles < 0.5 * cus:
                     split = max(1, min(round(2 * cus / tiles), kt // 8, 32))
-            elif tile == 3 and not forced:
-                split = max(1, min(cus // tiles, kt // 8, 4))
+            elif tile in (3, 4, 5) and not forced:
+                split = max(1, min(cus // tiles, kt // 8, 8))
             elif tiles < 0.6 * cus:
                 # one workgroup per CU: keep tiles*split within ONE wave of workgroups
                 split = max(1, min(cus // tiles, kt // 8, 32))
@@ -257,13 +263,18 @@ class Program:
         rows = x.rows // n_inst
         assert rows * n_inst == x.rows and out.dtype == "f16" and x.cols % 4 == 0
         nparts, part = shard if shard is not None else (1, 0)
-        nblk = (rows + L.GN_ROWS_PER_BLOCK - 1) // L.GN_ROWS_PER_BLOCK
+        # rows reduced by one statistics workgroup: the smallest power of two >= 4 that keeps the grid within
+        # ~4 workgroups per CU (each thread then has several rows in flight)
+        rpb = 4
+        while n_inst * ((rows + rpb - 1) // rpb) > 4 * self.target_cus:
+            rpb *= 2
+        nblk = (rows + rpb - 1) // rpb
         part_bytes = n_inst * nblk * groups * 16
         scratch = self.alloc(nparts * part_bytes + n_inst * groups * 8, 1, "u8")
 
         def make(phase, suffix):
             op = Op(L.OP_GROUPNORM, name + suffix)
-            op.i[0:11] = [n_inst, rows, x.cols, x.ld, groups, _DT[x.dtype], int(silu), out.ld, phase, nparts, part]
+            op.i[0:12] = [n_inst, rows, x.cols, x.ld, groups, _DT[x.dtype], int(silu), out.ld, phase, nparts, part, rpb]
             op.f[0] = eps
             op.p[0:5] = [x.ref, gamma, beta, out.ref, scratch.ref]
             return op

@@ -127,7 +127,8 @@ class Interp:
         nparts = max(nparts, 1)
         cpg = C // groups
         x = self.mat(op.p[0], n_inst * rows, C, ld_in, _TD[in_dt], ext).double().view(n_inst, rows, groups, cpg)
-        nblk = (rows + L.GN_ROWS_PER_BLOCK - 1) // L.GN_ROWS_PER_BLOCK
+        rpb = op.i[11] if op.i[11] > 0 else L.GN_ROWS_PER_BLOCK
+        nblk = (rows + rpb - 1) // rpb
         part_len = n_inst * nblk * groups * 2
         if phase == 0:
             s1, s2, n = x.sum(dim=(1, 3)), (x * x).sum(dim=(1, 3)), rows * cpg

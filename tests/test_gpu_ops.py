@@ -13,6 +13,8 @@ from sd_webui_text2video_amd.program import Buf, Program, Ref
 
 pytestmark = pytest.mark.gpu
 
+GEMM2_TILES = [1, 2, 3, 4, 5, 6, 7]     # csrc/gemm2.hip configurations (t2v_op.i[22])
+
 
 def _g(seed=0):
     return torch.Generator().manual_seed(seed)
@@ -298,7 +300,7 @@ def test_layout_time_embed_copy_ddim():
 
 
 # ---- second-generation GEMM (csrc/gemm2.hip): 256/128 x 256/320 tiles, 4-/3-stage DMA ring --------
-@pytest.mark.parametrize("tile", [1, 2, 3])
+@pytest.mark.parametrize("tile", GEMM2_TILES)
 @pytest.mark.parametrize("M,N,K", [(512, 640, 320), (300, 320, 192), (1000, 960, 1280), (256, 512, 64), (77, 1280, 128),
                                    (2304, 320, 2880)])
 def test_gemm2_plain_tiles(tile, M, N, K):
@@ -313,7 +315,7 @@ def test_gemm2_plain_tiles(tile, M, N, K):
     _check(it, got, out, 2e-5, f"gemm2 tile {tile} {M}x{N}x{K}")
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3])
+@pytest.mark.parametrize("tile", GEMM2_TILES)
 def test_gemm2_epilogues_and_geglu(tile):
     M, C, rpb = 384, 320, 96
     P = Program()
@@ -337,7 +339,7 @@ def test_gemm2_epilogues_and_geglu(tile):
     _check(it, got, gout, 1e-3, f"gemm2 geglu tile {tile}")
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3])
+@pytest.mark.parametrize("tile", GEMM2_TILES)
 @pytest.mark.parametrize("B,H,W,Cin,Cout,stride,up", [(3, 16, 16, 64, 320, 1, 0), (2, 8, 8, 128, 256, 2, 0),
                                                       (2, 6, 10, 64, 640, 1, 1)])
 def test_gemm2_conv3x3(tile, B, H, W, Cin, Cout, stride, up):
@@ -354,12 +356,12 @@ def test_gemm2_conv3x3(tile, B, H, W, Cin, Cout, stride, up):
     _check(it, got, out, 2e-5, f"gemm2 conv3x3 tile {tile}")
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3])
+@pytest.mark.parametrize("tile", GEMM2_TILES)
 def test_gemm2_temporal_conv_and_split_k(tile):
     B, F, HW, C = 2, 5, 16, 640
     P = Program()
     P.force_tile = tile
-    P.target_cus = 16                      # 1-4 output tiles -> split-K 2..3
+    P.target_cus = 16 if tile <= 3 else 64   # 1-10 output tiles -> split-K 2..3
     g = _g(24)
     M = B * F * HW
     a, out, res = P.alloc(M, C, "f16"), P.alloc(M, C, "f32"), P.alloc(M, C, "f32")
@@ -404,7 +406,7 @@ def test_groupnorm_split_phases_two_parts():
     assert rel_l2(torch.cat([read(got, o0), read(got, o1)]).float(), ref) < 1e-3
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+@pytest.mark.parametrize("tile", [0] + GEMM2_TILES)
 def test_temporal_conv_halo_layout(tile):
     B, F, HW, C = 1, 3, 64, 320
     P = Program()
