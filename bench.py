@@ -124,6 +124,35 @@ def cpu_baseline(frames, ddim_steps, timeout_s=240):
                 "sample": f"cpu baseline worker exceeded {timeout_s}s"}
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the GEMM family from the committed PMC passes (collected with
+    tools/gpu_round16.sh -> tools/pmc_post.py; counters cannot be read from inside this process)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as fh:
+            return round(json.load(fh)["hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def gemm_algorithmic_bytes(op) -> int:
+    """Unique operand + result bytes of one GEMM op: activations once (the 9 / 3 conv taps re-read the same
+    rows), weights once, fp32 residual once, output once; split-K adds its fp32 slabs (written + read)."""
+    i = op.i
+    M, N, K, gather, epi, split = i[0], i[1], i[2], i[7], i[16], max(i[19], 1)
+    if gather == 0:
+        a = M * K * 2
+    elif gather == 2:
+        a = M * i[10] * 2
+    else:
+        a = (M * max(i[11], 1) ** 2 // (4 if i[12] else 1)) * i[10] * 2
+    n_out = N // 2 if epi == 1 else N
+    out = M * n_out * (4 if i[17] == 1 else 2)
+    res = M * n_out * 4 if op.p[4].space != "null" else 0
+    slabs = 2 * split * M * N * 4 if split > 1 else 0
+    return a + N * K * 2 + out + res + slabs
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -231,17 +260,20 @@ def main():
         gemm_ms = sum(m for op, m in zip(prog.ops, ms) if op.kind == 1)
         gemm_fl = sum(op.flops for op in prog.ops if op.kind == 1)
         n_gemm = sum(1 for op in prog.ops if op.kind == 1)
+        alg_bytes = sum(gemm_algorithmic_bytes(op) for op in prog.ops if op.kind == 1)
         step_ms = sum(ms)
         achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12
         result["roofline"] = {
             "bound": "mfma", "kernel": "gemm_kernel<BM,BN,WM,WN,GATHER> (implicit-GEMM conv3x3 / temporal conv / linear)",
             "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
-            "traffic": None,
+            "traffic": pmc_traffic(),
             "launches_per_unet_step": n_gemm, "avg_launch_us": round(gemm_ms / n_gemm * 1e3, 2),
             "flops_per_unet_step_T": round(gemm_fl / 1e12, 3),
             "unet_step_ms_events": round(step_ms, 3),
             "unet_step_tflops_all_kernels": round(prog.total_flops() / (step_ms * 1e-3) / 1e12, 1),
             "unet_step_frac_of_peak": round(prog.total_flops() / (step_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+            "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 --pmc, profiles/r01_pmc_traffic.json)",
+            "algorithmic_bytes_per_launch": round(alg_bytes / n_gemm),
         }
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.frames, args.ddim_steps)

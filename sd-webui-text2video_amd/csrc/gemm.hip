@@ -103,7 +103,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmParams p) 
   const int wm = wave / WN, wn = wave % WN;
 
   const int tiles_n = (p.N + BN - 1) / BN;
-  const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+  int tile_m, tile_n;
+  t2v_tile_of_block(blockIdx.x, (p.M + BM - 1) / BM, tiles_n, p.panel, tile_m, tile_n);   // XCD-aware order
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const int KT = (p.K + BK - 1) / BK;
@@ -325,7 +326,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
 }
 
 template <int BM, int BN, int WM, int WN>
-hipError_t launch_tile(const GemmParams& p, hipStream_t s) {
+hipError_t launch_tile(const GemmParams& pin, hipStream_t s) {
+  GemmParams p = pin;
+  p.panel = t2v_choose_panel(p, (p.M + BM - 1) / BM, (p.N + BN - 1) / BN);
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   const dim3 grid(tiles, p.splitk > 1 ? p.splitk : 1);
   const dim3 block(WM * WN * 64);

@@ -110,17 +110,11 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm2_kernel(const GemmPar
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
 
-  // ---- XCD-aware tile order: blocks of one XCD (id % 8) walk consecutive tiles, n fastest,
-  //      so the activation tile shared by the N-tiles of one M-row stays in that XCD's L2.
+  // ---- XCD-aware tile order (t2v_kernels.h): each XCD walks one contiguous run of the panel numbering
   const int tiles_n = (p.N + BN - 1) / BN;
   const int tiles_m = (p.M + BM - 1) / BM;
-  const int ntiles = tiles_m * tiles_n;
-  int lin;
-  {
-    const int b = blockIdx.x, q = ntiles >> 3, r = ntiles & 7, xcd = b & 7, j = b >> 3;
-    lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-  }
-  const int tile_m = lin / tiles_n, tile_n = lin - tile_m * tiles_n;
+  int tile_m, tile_n;
+  t2v_tile_of_block(blockIdx.x, tiles_m, tiles_n, p.panel, tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const int KT = (p.K + BK - 1) / BK;
@@ -476,6 +470,10 @@ hipError_t launch_cfg(const GemmParams& pin, hipStream_t s) {
   if (p.splitk < 1) p.splitk = 1;
   p.kt_per_split = (KT + p.splitk - 1) / p.splitk;
   p.splitk = (KT + p.kt_per_split - 1) / p.kt_per_split;  // no empty splits
+  {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    p.panel = t2v_choose_panel(p, (p.M + BM - 1) / BM, (p.N + BN - 1) / BN);
+  }
   hipError_t e;
   switch (p.gather) {
     case T2V_GATHER_PLAIN: e = launch_cfg_gather<WM, WN, TM, TN, BK, STAGES, MINW, T2V_GATHER_PLAIN, PP>(p, s); break;

@@ -30,7 +30,41 @@ struct GemmParams {
   int kt_per_split;                            // k-tiles (of 64) per split
   int halo;                                    // tconv3: input has one halo frame before and after each clip
                                                // ([B][F+2][HW] rows, T-sharded forward); all 3 taps are in range
+  int panel;                                   // tile columns per panel of the XCD-aware tile order (set by the launcher)
 };
+
+// ---- XCD-aware tile order -----------------------------------------------------------------------------
+// Workgroup b of a launch runs on XCD b % 8 (round-robin dispatch) and each of the 8 XCDs has a private L2:
+// operand bytes needed on several XCDs are fetched from the fabric once PER XCD (measured with FETCH_SIZE:
+// the 8x8-level convolutions re-fetched their 30-60 MB weight matrices 8 times).  Tiles are therefore
+// numbered panel by panel — a panel = `pw` tile columns, inside it m-major with n fastest — and each XCD
+// takes ONE contiguous run of that numbering.  A run covers ~(tiles_m / xm) x pw tiles with xm * xn = 8,
+// xn = ceil(tiles_n / pw): the chip fetches ~xn * A + xm * W bytes instead of A + 8 W (pw = tiles_n) or
+// 8 A + W (pw = 1).  The launcher picks xn in 1..8 minimising xn * A + (8 / xn) * W.
+__device__ __forceinline__ void t2v_tile_of_block(int b, int tiles_m, int tiles_n, int pw, int& tile_m, int& tile_n) {
+  const int ntiles = tiles_m * tiles_n;
+  const int q = ntiles >> 3, r = ntiles & 7, xcd = b & 7, j = b >> 3;
+  const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;   // bijective for any ntiles
+  const int per_panel = tiles_m * pw;
+  const int pnl = lin / per_panel, rem = lin - pnl * per_panel;
+  const int n_start = pnl * pw;
+  const int w_here = min(pw, tiles_n - n_start);
+  tile_m = rem / w_here;
+  tile_n = n_start + rem - tile_m * w_here;
+}
+
+inline int t2v_choose_panel(const GemmParams& p, int tiles_m, int tiles_n) {
+  const double a_rows = p.gather == T2V_GATHER_CONV3X3 ? (double)p.M * p.stride * p.stride / (p.up ? 4.0 : 1.0) : (double)p.M;
+  const double Ab = a_rows * (p.gather == T2V_GATHER_PLAIN ? p.K : p.Cin) * 2.0;
+  const double Wb = (double)p.N * p.K * 2.0;
+  int best_xn = 1;
+  double best = 1e300;
+  for (int xn = 1; xn <= 8 && xn <= tiles_n; ++xn) {
+    const double cost = xn * Ab + (8.0 / xn) * Wb;
+    if (cost < best) { best = cost; best_xn = xn; }
+  }
+  return (tiles_n + best_xn - 1) / best_xn;
+}
 
 // Each returns hipSuccess or the launch error.
 hipError_t t2v_launch_gemm(const GemmParams& p, hipStream_t s);             // 128x128 / 128x64 tiles (any N, C8 stem)
