@@ -40,7 +40,7 @@ enum t2v_op_kind {
   T2V_OP_GEMM = 1,        /* implicit-GEMM conv / linear on MFMA, fused epilogue            */
   T2V_OP_GROUPNORM = 2,   /* GroupNorm(32) (+SiLU), per-frame or cross-frame statistics     */
   T2V_OP_LAYERNORM = 3,   /* row LayerNorm fp32 -> fp16                                     */
-  T2V_OP_ATTENTION = 4,   /* softmax(QK^T * scale) V, head_dim 64, strided batch            */
+  T2V_OP_ATTENTION = 4,   /* softmax(QK^T * scale) V, head_dim 40|64|80|160, strided batch  */
   T2V_OP_SOFTMAX = 5,     /* row softmax fp32 -> fp16 (VAE single-head attention)           */
   T2V_OP_NCTHW_TO_CL = 6, /* [B,C,F,H,W] -> channels-last fp16 tokens [B*F*H*W, ld]         */
   T2V_OP_CL_TO_NCTHW = 7, /* channels-last fp32 tokens -> [B,C,F,H,W]                       */
@@ -49,7 +49,8 @@ enum t2v_op_kind {
   T2V_OP_DDIM_STEP = 10,  /* DDIM_Gaussian update with half-channel CFG                     */
   T2V_OP_MEMSET = 11,     /* zero a byte range                                              */
   T2V_OP_LINCOMB = 12,    /* out = sum_i c_i * T_i (<= 6 latent-sized tensors): UniPC / DDIM updates */
-  T2V_OP_KIND_MAX = 13
+  T2V_OP_RELPOS_ATTN = 13, /* LVDM temporal attention with relative-position K / V terms (frames <= 32) */
+  T2V_OP_KIND_MAX = 14
 };
 
 /* GEMM gather modes: how row m / reduction index k of the A operand are addressed          */
@@ -107,8 +108,12 @@ enum t2v_gather {
  *      f: 0 eps;  p: 0 x, 1 gamma, 2 beta, 3 out fp16, 4 scratch
  * LAYERNORM: i: 0 M, 1 C, 2 ld_in, 3 ld_out; f: 0 eps; p: 0 x fp32, 1 gamma, 2 beta, 3 out fp16
  * ATTENTION: i: 0 nq, 1 nk, 2 heads, 3 batch_outer, 4 batch_inner, 5..7 q strides (seq,
- *      outer, inner), 8..10 k/v strides, 11..13 out strides (elements; head h at +64h);
- *      f: 0 scale; p: 0 q, 1 k, 2 v, 3 out (all fp16)
+ *      outer, inner), 8..10 k/v strides, 11..13 out strides (elements; head h at +head_dim*h),
+ *      14 head_dim (0 = 64);  f: 0 scale; p: 0 q, 1 k, 2 v, 3 out (all fp16)
+ * RELPOS_ATTN: i: as ATTENTION with nq == nk == frames (<= 32), 14 head_dim (multiple of 8, <= 256),
+ *      15 max relative position R;  f: 0 scale;  p: 0 q, 1 k, 2 v, 3 out (fp16), 4 Ek fp32 [2R+1, head_dim],
+ *      5 Ev fp32 [2R+1, head_dim]:  sim[t,s] = scale * q[t].(k[s] + Ek[clip(s-t)]),
+ *      out[t] = sum_s softmax_s(sim)[t,s] * (v[s] + Ev[clip(s-t)])   (attention_temporal.py:107-144)
  * SOFTMAX: i: 0 rows, 1 cols, 2 ld_in, 3 ld_out; f: 0 scale; p: 0 in fp32, 1 out fp16
  * NCTHW_TO_CL: i: 0 B, 1 C, 2 F, 3 HW, 4 ld_out, 5 in dtype; f: 0 scale; p: 0 in, 1 out fp16
  * CL_TO_NCTHW: i: 0 B, 1 C, 2 F, 3 HW, 4 ld_in, 5 out dtype; p: 0 in fp32, 1 out

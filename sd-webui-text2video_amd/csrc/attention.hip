@@ -1,4 +1,5 @@
-// Fused softmax(Q K^T * scale) V for head_dim 64 on gfx950 MFMA (wave64).
+// Fused softmax(Q K^T * scale) V for head_dim 40 / 64 / 80 / 160 on gfx950 MFMA (wave64), and the
+// relative-position temporal attention of the VideoCrafter LVDM UNet.
 //
 // Replaces CrossAttention.forward's SDPA / einsum-softmax-einsum dispatch
 // (reference scripts/modelscope/t2v_model.py:540-584) for the three call shapes of the UNet
@@ -17,6 +18,9 @@
 // (the key order inside a 16-slot MFMA step is a free permutation as long as V^T uses the
 // same one), so P never goes through LDS.  V is transposed while being written to LDS
 // ([d][key], 136-B rows: conflict-free 8-byte fragment reads).
+// head_dim: ModelScope uses 64 everywhere; the LVDM UNet has 8 heads of C/8 = 40 / 80 / 160 channels
+// (openaimodel3d.py:459-466).  The reduction of Q K^T is zero-padded to a multiple of 16 and the rows of
+// O^T to a multiple of 32 inside LDS / registers only; nothing padded is read from or written to HBM.
 #include "t2v_kernels.h"
 
 namespace {
@@ -33,11 +37,18 @@ struct AttnParams {
 constexpr int KT = 64;         // keys per LDS tile
 constexpr int VT_ROW = 136;    // bytes per V^T row (64 keys * 2 B + 8 B pad)
 
-template <int NW>
+template <int NW, int D>
 __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnParams p) {
   constexpr int NT = NW * 64;
-  __shared__ __attribute__((aligned(16))) unsigned char k_lds[KT * 128];     // [key][64 d], swizzled chunks
-  __shared__ __attribute__((aligned(16))) unsigned char vt_lds[64 * VT_ROW]; // [d][64 keys]
+  constexpr int DK = (D + 15) / 16 * 16;   // Q K^T reduction length (zero-padded in LDS / registers)
+  constexpr int NKK = DK / 16;
+  constexpr int DV = (D + 31) / 32 * 32;   // rows of O^T (zero-padded)
+  constexpr int NDT = DV / 32;
+  constexpr int KCH = DK / 8;              // 16-byte chunks per K row
+  constexpr int K_ROW = DK * 2 + 16;       // padded LDS row: 32 consecutive rows at one chunk hit disjoint banks
+  static_assert(D % 8 == 0, "head_dim must be a multiple of 8");
+  __shared__ __attribute__((aligned(16))) unsigned char k_lds[KT * K_ROW];    // [key][DK]
+  __shared__ __attribute__((aligned(16))) unsigned char vt_lds[DV * VT_ROW];  // [d][64 keys]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -46,50 +57,52 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnParams p) {
   const int q0 = blockIdx.x * (32 * NW) + wave * 32;
   const int frow = lane & 31, fhalf = lane >> 5;
 
-  const f16* qb = p.q + bo * p.sq_out + bi * p.sq_in + head * 64;
-  const f16* kb = p.k + bo * p.sk_out + bi * p.sk_in + head * 64;
-  const f16* vb = p.v + bo * p.sk_out + bi * p.sk_in + head * 64;
-  f16* ob = p.o + bo * p.so_out + bi * p.so_in + head * 64;
+  const f16* qb = p.q + bo * p.sq_out + bi * p.sq_in + head * D;
+  const f16* kb = p.k + bo * p.sk_out + bi * p.sk_in + head * D;
+  const f16* vb = p.v + bo * p.sk_out + bi * p.sk_in + head * D;
+  f16* ob = p.o + bo * p.so_out + bi * p.so_in + head * D;
 
   // Q fragments: query (lane&31), d = kk*16 + 8*fhalf + 0..7
   const int qrow = q0 + frow;
-  f16x8 qf[4];
+  f16x8 qf[NKK];
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk) {
-    if (qrow < p.nq)
-      qf[kk] = *reinterpret_cast<const f16x8*>(qb + (long)qrow * p.sq_seq + kk * 16 + fhalf * 8);
+  for (int kk = 0; kk < NKK; ++kk) {
+    const int d0 = kk * 16 + fhalf * 8;
+    if (qrow < p.nq && d0 < D)
+      qf[kk] = *reinterpret_cast<const f16x8*>(qb + (long)qrow * p.sq_seq + d0);
     else
       for (int e = 0; e < 8; ++e) qf[kk][e] = (f16)0.f;
   }
 
-  f32x16 oacc[2];
+  f32x16 oacc[NDT];
 #pragma unroll
-  for (int d = 0; d < 2; ++d)
+  for (int d = 0; d < NDT; ++d)
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
   for (int kt0 = 0; kt0 < p.nk; kt0 += KT) {
     __syncthreads();  // previous tile fully consumed
-    // ---- K tile: 64 rows x 8 chunks of 16 B ---------------------------------------
-    for (int u = tid; u < KT * 8; u += NT) {
-      const int row = u >> 3, c = u & 7;
+    // ---- K tile: 64 rows x KCH chunks of 16 B -------------------------------------
+    for (int u = tid; u < KT * KCH; u += NT) {
+      const int row = u / KCH, c = u - row * KCH;
       const int key = kt0 + row;
       f16x8 val;
-      if (key < p.nk)
+      if (key < p.nk && c * 8 < D)
         val = *reinterpret_cast<const f16x8*>(kb + (long)key * p.sk_seq + c * 8);
       else
         for (int e = 0; e < 8; ++e) val[e] = (f16)0.f;
-      *reinterpret_cast<f16x8*>(k_lds + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = val;
+      *reinterpret_cast<f16x8*>(k_lds + row * K_ROW + (c << 4)) = val;
     }
     // ---- V tile, transposed: unit = (key pair, 4 d) -> 4 x 32-bit {V[2kp][d], V[2kp+1][d]}
-    for (int u = tid; u < 32 * 16; u += NT) {
-      const int kp = u >> 4, dq = u & 15;
+    for (int u = tid; u < 32 * (DV / 4); u += NT) {
+      const int kp = u / (DV / 4), dq = u - kp * (DV / 4);
       const int key = kt0 + 2 * kp;
+      const bool dok = dq * 4 < D;
       f16x4 a, b;
-      if (key < p.nk) a = *reinterpret_cast<const f16x4*>(vb + (long)key * p.sk_seq + dq * 4);
+      if (dok && key < p.nk) a = *reinterpret_cast<const f16x4*>(vb + (long)key * p.sk_seq + dq * 4);
       else for (int e = 0; e < 4; ++e) a[e] = (f16)0.f;
-      if (key + 1 < p.nk) b = *reinterpret_cast<const f16x4*>(vb + (long)(key + 1) * p.sk_seq + dq * 4);
+      if (dok && key + 1 < p.nk) b = *reinterpret_cast<const f16x4*>(vb + (long)(key + 1) * p.sk_seq + dq * 4);
       else for (int e = 0; e < 4; ++e) b[e] = (f16)0.f;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -110,9 +123,8 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnParams p) {
       if (T == 1 && !t1_live) continue;
       const int row = T * 32 + frow;
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const int chunk = kk * 2 + fhalf;
-        const f16x8 kf = *reinterpret_cast<const f16x8*>(k_lds + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+      for (int kk = 0; kk < NKK; ++kk) {
+        const f16x8 kf = *reinterpret_cast<const f16x8*>(k_lds + row * K_ROW + ((kk * 2 + fhalf) << 4));
         s[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[kk], s[T], 0, 0, 0);
       }
     }
@@ -143,7 +155,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnParams p) {
     l_run = l_run * alpha + psum;
     m_run = m_new;
 #pragma unroll
-    for (int d = 0; d < 2; ++d)
+    for (int d = 0; d < NDT; ++d)
 #pragma unroll
       for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
 
@@ -158,7 +170,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnParams p) {
         for (int e = 0; e < 8; ++e) pf[e] = (f16)s[T][8 * t + e];
         const int kofs = (T * 32 + t * 16 + 4 * fhalf) * 2;  // byte offset of key slot e=0
 #pragma unroll
-        for (int d = 0; d < 2; ++d) {
+        for (int d = 0; d < NDT; ++d) {
           const unsigned char* vrow = vt_lds + (d * 32 + frow) * VT_ROW + kofs;
           const f16x4 lo = *reinterpret_cast<const f16x4*>(vrow);
           const f16x4 hi = *reinterpret_cast<const f16x4*>(vrow + 16);
@@ -173,14 +185,88 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnParams p) {
     const float inv = 1.0f / l_run;
     f16* orow = ob + (long)qrow * p.so_seq;
 #pragma unroll
-    for (int d = 0; d < 2; ++d)
+    for (int d = 0; d < NDT; ++d)
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd) {
-        f16x4 o;
+        const int col = d * 32 + 8 * qd + 4 * fhalf;
+        if (col < D) {
+          f16x4 o;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (f16)(oacc[d][4 * qd + r] * inv);
-        *reinterpret_cast<f16x4*>(orow + d * 32 + 8 * qd + 4 * fhalf) = o;
+          for (int r = 0; r < 4; ++r) o[r] = (f16)(oacc[d][4 * qd + r] * inv);
+          *reinterpret_cast<f16x4*>(orow + col) = o;
+        }
       }
+  }
+}
+
+// ---- temporal attention with relative-position terms (LVDM TemporalCrossAttention.forward,
+//      videocrafter/lvdm/models/modules/attention_temporal.py:107-144, RelativePosition :46-65) ------------
+//   sim[t,s] = scale * q[t] . (k[s] + Ek[clip(s-t)])       p = softmax_s(sim)
+//   out[t]   = sum_s p[t,s] * (v[s] + Ev[clip(s-t)])       clip(x) = clamp(x, -R, R) + R, tables [2R+1, D] fp32
+// Sequences are the T <= 32 frames of one pixel: a memory-bound op (fp32 VALU math, one workgroup per
+// (pixel, head); q/k/v/out addressed by the same (sequence, outer, inner) strides as the MFMA kernel).
+struct RelAttnParams {
+  const f16* q; const f16* k; const f16* v; f16* o;
+  const float* ek; const float* ev;
+  int T, D, heads, b_inner, R;
+  long sq_seq, sq_out, sq_in;
+  long sk_seq, sk_out, sk_in;
+  long so_seq, so_out, so_in;
+  float scale;
+};
+
+__global__ __launch_bounds__(256) void relpos_attn_kernel(const RelAttnParams p) {
+  extern __shared__ float rsh[];           // q[T][D], k[T][D], v[T][D], sim[T][T]
+  const int T = p.T, D = p.D;
+  float* qs = rsh;
+  float* ks = qs + T * D;
+  float* vs = ks + T * D;
+  float* sim = vs + T * D;
+  const int tid = threadIdx.x;
+  const int head = blockIdx.y;
+  const int bo = blockIdx.x / p.b_inner, bi = blockIdx.x % p.b_inner;
+  const f16* qb = p.q + bo * p.sq_out + bi * p.sq_in + head * D;
+  const f16* kb = p.k + bo * p.sk_out + bi * p.sk_in + head * D;
+  const f16* vb = p.v + bo * p.sk_out + bi * p.sk_in + head * D;
+  f16* ob = p.o + bo * p.so_out + bi * p.so_in + head * D;
+  const int d8 = D >> 3;
+  for (int u = tid; u < T * d8; u += 256) {
+    const int t = u / d8, c = (u - t * d8) * 8;
+    const f16x8 a = *reinterpret_cast<const f16x8*>(qb + (long)t * p.sq_seq + c);
+    const f16x8 b = *reinterpret_cast<const f16x8*>(kb + (long)t * p.sk_seq + c);
+    const f16x8 e = *reinterpret_cast<const f16x8*>(vb + (long)t * p.sk_seq + c);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { qs[t * D + c + j] = (float)a[j]; ks[t * D + c + j] = (float)b[j]; vs[t * D + c + j] = (float)e[j]; }
+  }
+  __syncthreads();
+  for (int u = tid; u < T * T; u += 256) {
+    const int t = u / T, s = u - t * T;
+    int r = s - t;
+    r = (r < -p.R ? -p.R : (r > p.R ? p.R : r)) + p.R;
+    const float* er = p.ek + (long)r * D;
+    float acc = 0.f;
+    for (int d = 0; d < D; ++d) acc += qs[t * D + d] * (ks[s * D + d] + er[d]);
+    sim[u] = acc * p.scale;
+  }
+  __syncthreads();
+  if (tid < T) {
+    float mx = -INFINITY;
+    for (int s = 0; s < T; ++s) mx = fmaxf(mx, sim[tid * T + s]);
+    float sum = 0.f;
+    for (int s = 0; s < T; ++s) { const float e = __expf(sim[tid * T + s] - mx); sim[tid * T + s] = e; sum += e; }
+    const float inv = 1.0f / sum;
+    for (int s = 0; s < T; ++s) sim[tid * T + s] *= inv;
+  }
+  __syncthreads();
+  for (int u = tid; u < T * D; u += 256) {
+    const int t = u / D, d = u - t * D;
+    float acc = 0.f;
+    for (int s = 0; s < T; ++s) {
+      int r = s - t;
+      r = (r < -p.R ? -p.R : (r > p.R ? p.R : r)) + p.R;
+      acc += sim[t * T + s] * (vs[s * D + d] + p.ev[(long)r * D + d]);
+    }
+    ob[(long)t * p.so_seq + d] = (f16)acc;
   }
 }
 
@@ -225,11 +311,58 @@ hipError_t t2v_launch_attention(const t2v_op& op, hipStream_t s) {
   p.scale_log2 = op.f[0] * 1.44269504088896340736f;
   if (p.nq <= 0 || p.nk <= 0) return hipErrorInvalidValue;
   const int nbatch = p.b_outer * p.b_inner;
-  if (p.nq <= 32) {
-    hipLaunchKernelGGL(attn_kernel<1>, dim3(1, p.heads, nbatch), dim3(64), 0, s, p);
-  } else {
-    hipLaunchKernelGGL(attn_kernel<4>, dim3((p.nq + 127) / 128, p.heads, nbatch), dim3(256), 0, s, p);
+  const int hd = op.i[14] > 0 ? op.i[14] : 64;
+  const bool small = p.nq <= 32;
+  const dim3 g1(1, p.heads, nbatch), g4((p.nq + 127) / 128, p.heads, nbatch);
+  switch (hd) {
+    case 40:
+      if (small) hipLaunchKernelGGL((attn_kernel<1, 40>), g1, dim3(64), 0, s, p);
+      else hipLaunchKernelGGL((attn_kernel<4, 40>), g4, dim3(256), 0, s, p);
+      break;
+    case 64:
+      if (small) hipLaunchKernelGGL((attn_kernel<1, 64>), g1, dim3(64), 0, s, p);
+      else hipLaunchKernelGGL((attn_kernel<4, 64>), g4, dim3(256), 0, s, p);
+      break;
+    case 80:
+      if (small) hipLaunchKernelGGL((attn_kernel<1, 80>), g1, dim3(64), 0, s, p);
+      else hipLaunchKernelGGL((attn_kernel<4, 80>), g4, dim3(256), 0, s, p);
+      break;
+    case 160:
+      if (small) hipLaunchKernelGGL((attn_kernel<1, 160>), g1, dim3(64), 0, s, p);
+      else hipLaunchKernelGGL((attn_kernel<4, 160>), g4, dim3(256), 0, s, p);
+      break;
+    default:
+      return hipErrorInvalidValue;
   }
+  return hipGetLastError();
+}
+
+hipError_t t2v_launch_relpos_attention(const t2v_op& op, hipStream_t s) {
+  RelAttnParams p;
+  p.q = reinterpret_cast<const f16*>(op.p[0]);
+  p.k = reinterpret_cast<const f16*>(op.p[1]);
+  p.v = reinterpret_cast<const f16*>(op.p[2]);
+  p.o = reinterpret_cast<f16*>(op.p[3]);
+  p.ek = reinterpret_cast<const float*>(op.p[4]);
+  p.ev = reinterpret_cast<const float*>(op.p[5]);
+  p.T = op.i[0]; p.heads = op.i[2]; p.b_inner = op.i[4]; p.D = op.i[14]; p.R = op.i[15];
+  const int b_outer = op.i[3];
+  p.sq_seq = op.i[5]; p.sq_out = op.i[6]; p.sq_in = op.i[7];
+  p.sk_seq = op.i[8]; p.sk_out = op.i[9]; p.sk_in = op.i[10];
+  p.so_seq = op.i[11]; p.so_out = op.i[12]; p.so_in = op.i[13];
+  p.scale = op.f[0];
+  if (p.T <= 0 || p.T > 32 || op.i[1] != p.T || p.D <= 0 || p.D % 8 != 0 || p.D > 256 || p.R < 0 || p.ek == nullptr ||
+      p.ev == nullptr)
+    return hipErrorInvalidValue;
+  const size_t lds = ((size_t)3 * p.T * p.D + (size_t)p.T * p.T) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(relpos_attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (3 * 32 * 256 + 32 * 32) * (int)sizeof(float));
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(relpos_attn_kernel, dim3(b_outer * p.b_inner, p.heads), dim3(256), lds, s, p);
   return hipGetLastError();
 }
 

@@ -73,6 +73,7 @@ hipError_t t2v_launch_splitk_reduce(const GemmParams& p, hipStream_t s);
 hipError_t t2v_launch_groupnorm(const t2v_op& op, hipStream_t s);
 hipError_t t2v_launch_layernorm(const t2v_op& op, hipStream_t s);
 hipError_t t2v_launch_attention(const t2v_op& op, hipStream_t s);
+hipError_t t2v_launch_relpos_attention(const t2v_op& op, hipStream_t s);
 hipError_t t2v_launch_softmax(const t2v_op& op, hipStream_t s);
 hipError_t t2v_launch_ncthw_to_cl(const t2v_op& op, hipStream_t s);
 hipError_t t2v_launch_cl_to_ncthw(const t2v_op& op, hipStream_t s);

@@ -318,9 +318,18 @@ class Program:
         return self._emit(op)
 
     def attention(self, name: str, q: Ref, k: Ref, v: Ref, o: Ref, *, out_buf: Optional[Buf] = None, nq: int, nk: int, heads: int,
-                  b_outer: int, b_inner: int, q_strides, kv_strides, o_strides, scale: float) -> Op:
-        op = Op(L.OP_ATTENTION, name)
+                  b_outer: int, b_inner: int, q_strides, kv_strides, o_strides, scale: float, head_dim: int = 64,
+                  rel_k: Optional[Ref] = None, rel_v: Optional[Ref] = None, max_rel: int = 0) -> Op:
+        """softmax(q k^T scale) v over strided (sequence, outer, inner) batches.  With rel_k / rel_v (fp32
+        [2*max_rel+1, head_dim] tables) the LVDM relative-position temporal attention op is emitted instead."""
+        assert head_dim in (40, 64, 80, 160) or rel_k is not None
+        op = Op(L.OP_ATTENTION if rel_k is None else L.OP_RELPOS_ATTN, name)
         op.i[0:5] = [nq, nk, heads, b_outer, b_inner]
+        op.i[14] = head_dim
+        if rel_k is not None:
+            assert nq == nk <= 32 and head_dim % 8 == 0
+            op.i[15] = max_rel
+            op.p[4], op.p[5] = rel_k, rel_v
         op.i[5:8] = list(q_strides)
         op.i[8:11] = list(kv_strides)
         op.i[11:14] = list(o_strides)
@@ -328,7 +337,7 @@ class Program:
             assert 0 <= s < 2 ** 31
         op.f[0] = scale
         op.p[0:4] = [q, k, v, o]
-        op.flops = 4.0 * nq * nk * 64 * heads * b_outer * b_inner
+        op.flops = 4.0 * nq * nk * head_dim * heads * b_outer * b_inner
         op.out = out_buf
         return self._emit(op)
 

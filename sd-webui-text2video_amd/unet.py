@@ -206,7 +206,10 @@ class UNetSD(nn.Module):
         else:
             self._zero_init()
 
-        # runtime state (not part of the state dict)
+        self._init_runtime()
+
+    def _init_runtime(self):
+        """Runtime state (not part of the state dict); shared with videocrafter.UNetModel."""
         self._programs: Dict[tuple, "_Compiled"] = {}
         self._packed: Optional[Dict[str, torch.Tensor]] = None
         self._packed_sig = None

@@ -126,8 +126,66 @@ def modelscope(frames=8, steps=5):
           eps.std().item(), x0.std().item(), img.std().item())
 
 
+def lvdm_inputs_tiny():
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(2, 4, 5, 8, 8, generator=g)
+    ctx = torch.randn(2, 9, 768, generator=g)
+    x_T = torch.randn(1, 4, 5, 8, 8, generator=g)
+    return x, torch.tensor([801, 401]), ctx, x_T
+
+
+def lvdm(full=True):
+    """VideoCrafter: the reference's own UNetModel (openaimodel3d.py) and DDIMSampler (lvdm/samplers/ddim.py).
+    LatentDiffusion itself needs pytorch_lightning (absent), so the sampler is given a stand-in exposing exactly what
+    it reads from the model: num_timesteps, the DDPM.register_schedule buffers (computed with the reference's
+    make_beta_schedule) and apply_model -> UNetModel.forward.  Its cuda-pinned register_buffer is pointed at the CPU."""
+    import importlib
+    import types
+    rb.bootstrap()
+    om = importlib.import_module("videocrafter.lvdm.models.modules.openaimodel3d")
+    vu = importlib.import_module("videocrafter.lvdm.models.modules.util")
+    dd = importlib.import_module("videocrafter.lvdm.samplers.ddim")
+    dd.DDIMSampler.register_buffer = lambda self, name, attr: setattr(self, name, attr)
+    cfg = configs.TINY_LVDM_UNET
+    net = om.UNetModel(**cfg).eval()
+    synth.load_synth(net, seed=0)
+    x, t, ctx, x_T = lvdm_inputs_tiny()
+    with torch.no_grad():
+        eps = net(x, t, context=ctx)
+    betas = vu.make_beta_schedule("linear", 1000, linear_start=0.00085, linear_end=0.012)
+    ac = np.cumprod(1.0 - betas, axis=0)
+    f32 = lambda a: torch.tensor(a, dtype=torch.float32)
+    model = types.SimpleNamespace(num_timesteps=1000, betas=f32(betas), alphas_cumprod=f32(ac),
+                                  alphas_cumprod_prev=f32(np.append(1.0, ac[:-1])), device=torch.device("cpu"),
+                                  apply_model=lambda xx, tt, c, **kw: net(xx, tt, context=c))
+    smp = dd.DDIMSampler(model)
+    smp.noise_gen.manual_seed(123)
+    with torch.no_grad():
+        x0, _ = smp.sample(S=4, conditioning=ctx[0:1], batch_size=1, shape=list(x_T.shape[1:]), verbose=False,
+                           unconditional_guidance_scale=7.5, unconditional_conditioning=ctx[1:2], eta=0.3, x_T=x_T)
+    np.savez_compressed(os.path.join(OUT, "lvdm_tiny.npz"), unet_eps=eps.numpy(), ddim_x0=x0.numpy())
+    print("lvdm tiny done", eps.std().item(), x0.std().item())
+    if not full:
+        return
+    cfg = configs.LVDM_UNET
+    net = om.UNetModel(**cfg).eval()
+    synth.load_synth(net, seed=0)
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(1, 4, 16, 32, 32, generator=g)
+    ctx = torch.randn(1, 77, 768, generator=g)
+    with torch.no_grad():
+        t0 = time.time()
+        eps = net(x, torch.tensor([500]), context=ctx)
+        t_fwd = time.time() - t0
+    np.savez_compressed(os.path.join(OUT, "lvdm_16f.npz"), unet_eps=eps.numpy(),
+                        timing=np.array([t_fwd, torch.get_num_threads()], dtype=np.float64))
+    print(f"lvdm 16f done fwd {t_fwd:.2f}s", eps.std().item())
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    tiny()
-    if "--tiny-only" not in sys.argv:
-        modelscope()
+    if "--lvdm-only" not in sys.argv:
+        tiny()
+        if "--tiny-only" not in sys.argv:
+            modelscope()
+    lvdm(full="--tiny-only" not in sys.argv)

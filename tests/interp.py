@@ -162,18 +162,31 @@ class Interp:
         self.mat(op.p[3], M, C, ld_out, torch.float16, ext).copy_(y.half())
 
     # ATTENTION ----------------------------------------------------------------------------------------
-    def _op4(self, op, ext):
+    def _op4(self, op, ext, rel=False):
         nq, nk, heads, bo, bi = op.i[0:5]
         sq, sk, so = op.i[5:8], op.i[8:11], op.i[11:14]
+        D = op.i[14] if op.i[14] > 0 else 64
 
         def v(ref, n, s):
-            return self.view(ref, (bo, bi, heads, n, 64), (s[1], s[2], 64, s[0], 1), torch.float16, ext)
+            return self.view(ref, (bo, bi, heads, n, D), (s[1], s[2], D, s[0], 1), torch.float16, ext)
 
         q, k, vv = v(op.p[0], nq, sq).float(), v(op.p[1], nk, sk).float(), v(op.p[2], nk, sk).float()
-        s = torch.einsum("abhid,abhjd->abhij", q, k) * op.f[0]
-        p = torch.softmax(s, dim=-1)
+        s = torch.einsum("abhid,abhjd->abhij", q, k)
+        if rel:
+            # LVDM relative-position terms (attention_temporal.py:46-65,120-140)
+            R = op.i[15]
+            ek = self.view(op.p[4], (2 * R + 1, D), (D, 1), torch.float32, ext)
+            ev = self.view(op.p[5], (2 * R + 1, D), (D, 1), torch.float32, ext)
+            idx = (torch.arange(nk)[None, :] - torch.arange(nq)[:, None]).clamp(-R, R) + R
+            s = s + torch.einsum("abhtd,tsd->abhts", q, ek[idx])
+        p = torch.softmax(s * op.f[0], dim=-1)
         o = torch.einsum("abhij,abhjd->abhid", p, vv)
+        if rel:
+            o = o + torch.einsum("abhts,tsd->abhtd", p, ev[idx])
         v(op.p[3], nq, so).copy_(o.half())
+
+    def _op13(self, op, ext):
+        self._op4(op, ext, rel=True)
 
     # SOFTMAX ------------------------------------------------------------------------------------------
     def _op5(self, op, ext):

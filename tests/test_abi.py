@@ -19,7 +19,7 @@ def test_header_constants_match_binding():
         "T2V_OP_LAYERNORM": L.OP_LAYERNORM, "T2V_OP_ATTENTION": L.OP_ATTENTION, "T2V_OP_SOFTMAX": L.OP_SOFTMAX,
         "T2V_OP_NCTHW_TO_CL": L.OP_NCTHW_TO_CL, "T2V_OP_CL_TO_NCTHW": L.OP_CL_TO_NCTHW,
         "T2V_OP_TIME_EMBED": L.OP_TIME_EMBED, "T2V_OP_COPY2D": L.OP_COPY2D, "T2V_OP_DDIM_STEP": L.OP_DDIM_STEP,
-        "T2V_OP_MEMSET": L.OP_MEMSET, "T2V_OP_LINCOMB": L.OP_LINCOMB, "T2V_GATHER_PLAIN": L.GATHER_PLAIN, "T2V_GATHER_CONV3X3": L.GATHER_CONV3X3,
+        "T2V_OP_MEMSET": L.OP_MEMSET, "T2V_OP_LINCOMB": L.OP_LINCOMB, "T2V_OP_RELPOS_ATTN": L.OP_RELPOS_ATTN, "T2V_GATHER_PLAIN": L.GATHER_PLAIN, "T2V_GATHER_CONV3X3": L.GATHER_CONV3X3,
         "T2V_GATHER_TCONV3": L.GATHER_TCONV3, "T2V_GATHER_CONV3X3_C8": L.GATHER_CONV3X3_C8,
         "T2V_EPI_NONE": L.EPI_NONE, "T2V_EPI_GEGLU": L.EPI_GEGLU, "T2V_F16": L.F16, "T2V_F32": L.F32,
         "T2V_EXT_SLOTS": L.EXT_SLOTS, "T2V_EXT_X": L.EXT_X, "T2V_EXT_T": L.EXT_T, "T2V_EXT_CTX": L.EXT_CTX,

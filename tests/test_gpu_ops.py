@@ -248,6 +248,67 @@ def test_attention(kind, B, F, hw, heads, Lc):
     _check(it, got, o, 3e-3, f"attention {kind}")
 
 
+@pytest.mark.parametrize("D", [40, 80, 160])
+@pytest.mark.parametrize("kind,B,F,hw,Lc", [("spatial", 1, 2, 256, 0), ("spatial", 1, 3, 20, 0), ("cross", 2, 2, 64, 77),
+                                             ("cross", 1, 1, 1024, 9)])
+def test_attention_lvdm_head_dims(D, kind, B, F, hw, Lc):
+    """8 heads of C/8 channels (VideoCrafter LVDM: head_dim 40 / 80 / 160); the zero-padding to the MFMA
+    granularity must stay inside the kernel (the neighbouring head's columns are live data)."""
+    heads = 8 if D < 160 else 3
+    inner = heads * D
+    M = B * F * hw
+    P = Program()
+    g = _g(40 + D)
+    scale = D ** -0.5
+    if kind == "cross":
+        q, kv, o = P.alloc(M, inner, "f16"), P.alloc(B * Lc, 2 * inner + 8, "f16"), P.alloc(M, inner, "f16")
+        k, v = kv.col_slice(8, 8 + inner), kv.col_slice(8 + inner, 8 + 2 * inner)
+        P.attention("a", q.ref, k.ref, v.ref, o.ref, nq=hw, nk=Lc, heads=heads, b_outer=B, b_inner=F,
+                    q_strides=(inner, F * hw * inner, hw * inner), kv_strides=(kv.ld, Lc * kv.ld, 0),
+                    o_strides=(inner, F * hw * inner, hw * inner), scale=scale, head_dim=D)
+        bufs = [q, kv]
+    else:
+        qkv, o = P.alloc(M, 3 * inner, "f16"), P.alloc(M, inner, "f16")
+        ld = 3 * inner
+        q, k, v = qkv.col_slice(0, inner), qkv.col_slice(inner, 2 * inner), qkv.col_slice(2 * inner, 3 * inner)
+        P.attention("a", q.ref, k.ref, v.ref, o.ref, nq=hw, nk=hw, heads=heads, b_outer=B * F, b_inner=1,
+                    q_strides=(ld, hw * ld, 0), kv_strides=(ld, hw * ld, 0), o_strides=(inner, hw * inner, 0), scale=scale,
+                    head_dim=D)
+        bufs = [qkv]
+
+    def init(it):
+        for b in bufs:
+            fill(it, b, g, 1.5)
+        fill(it, o, g, 3.0)          # poison: every output column must be overwritten exactly once
+    it, got, _, _ = run_both(P, {}, {}, init)
+    _check(it, got, o, 3e-3, f"attention {kind} d={D}")
+
+
+@pytest.mark.parametrize("D,T,R", [(40, 16, 16), (80, 16, 16), (160, 16, 16), (40, 24, 16), (64, 5, 2), (160, 32, 16)])
+def test_relpos_temporal_attention(D, T, R):
+    """LVDM TemporalCrossAttention with relative-position K / V terms (attention_temporal.py:107-144)."""
+    heads, B, hw = 8 if D < 160 else 2, 2, 12
+    inner = heads * D
+    M = B * T * hw
+    P = Program()
+    g = _g(50 + D + T)
+    qkv, o = P.alloc(M, 3 * inner, "f16"), P.alloc(M, inner, "f16")
+    ld = 3 * inner
+    q, k, v = qkv.col_slice(0, inner), qkv.col_slice(inner, 2 * inner), qkv.col_slice(2 * inner, 3 * inner)
+    w = {"ek": torch.randn(2 * R + 1, D, generator=g) * 0.5, "ev": torch.randn(2 * R + 1, D, generator=g) * 0.5}
+    P.attention("a", q.ref, k.ref, v.ref, o.ref, nq=T, nk=T, heads=heads, b_outer=B, b_inner=hw,
+                q_strides=(hw * ld, T * hw * ld, ld), kv_strides=(hw * ld, T * hw * ld, ld),
+                o_strides=(hw * inner, T * hw * inner, inner), scale=D ** -0.5, head_dim=D,
+                rel_k=Ref("weight", 0, "ek"), rel_v=Ref("weight", 0, "ev"), max_rel=R)
+    assert P.ops[0].kind == L.OP_RELPOS_ATTN
+
+    def init(it):
+        fill(it, qkv, g, 1.2)
+        fill(it, o, g, 3.0)
+    it, got, _, _ = run_both(P, w, {}, init)
+    _check(it, got, o, 2e-3, f"relpos attention d={D} T={T}")
+
+
 def test_attention_peaked_softmax():
     """Large logits: exercises the running-max rescale path of the online softmax."""
     hw, heads = 300, 1
