@@ -99,7 +99,8 @@ enum t2v_gather {
  *      11 stride, 12 upsample, 13 Hout, 14 Wout, 15 rows_per_batch, 16 epilogue,
  *      17 out dtype, 18 act (0 none, 1 SiLU), 19 split_k, 20 bias_along_m, 21 ldrb,
  *      22 tile (0 = 128x128-class kernel; 1 256x256, 2 256x320, 3 128x256),
- *      23 tconv halo (input rows are [clip][F+2][HW]: one halo frame either side, T-sharding)
+ *      23 tconv halo (input rows are [clip][F+2][HW]: one halo frame either side, T-sharding);
+ *         for CONV3X3: 1 = zero padding (0,1,0,1) instead of (1,1,1,1) (LDM encoder Downsample, taps at +0..+2)
  *   p: 0 A fp16, 1 W fp16 [N,K], 2 bias fp32 [N] (or [M] if bias_along_m), 3 rowbias fp32
  *      [M/rows_per_batch, ldrb], 4 residual fp32 [M,ldr], 5 out, 6 split-K workspace fp32
  * GROUPNORM: i: 0 n_inst, 1 rows_per_inst, 2 C, 3 ld_in, 4 groups, 5 in dtype, 6 silu,

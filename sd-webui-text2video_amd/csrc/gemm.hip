@@ -176,7 +176,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmParams p) 
         if (xvalid[j] && kc < p.K) src = p.A + xoff[j] + kc;
       } else if (GATHER == T2V_GATHER_CONV3X3) {
         const int ky = tap / 3, kx = tap - ky * 3;
-        const int yv = xy[j] + ky - 1, xv = xx[j] + kx - 1;
+        const int pl = p.halo ? 0 : 1;       // conv3x3: halo = 1 selects the (0,1,0,1) padding of the LDM encoder Downsample
+        const int yv = xy[j] + ky - pl, xv = xx[j] + kx - pl;
         const int hv = p.Hin << p.up, wv = p.Win << p.up;
         if (xvalid[j] && yv >= 0 && yv < hv && xv >= 0 && xv < wv) {
           const long row = xoff[j] + (long)(yv >> p.up) * p.Win + (xv >> p.up);

@@ -161,8 +161,9 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm2_kernel(const GemmPar
       const long ibase = (long)img * p.Hin * p.Win;
       const int ys = yo * p.stride, xs = xo * p.stride;
       xptr[j] = reinterpret_cast<const unsigned char*>(p.A + (ibase + (long)ys * p.Win + xs) * p.lda + lc * 8);
+      const int pl = p.halo ? 0 : 1;     // conv3x3: halo = 1 -> taps at +0..+2 (LDM encoder Downsample pads only bottom / right)
       for (int t = 0; t < 9; ++t) {
-        const int yv = ys + t / 3 - 1, xv = xs + t % 3 - 1;
+        const int yv = ys + t / 3 - pl, xv = xs + t % 3 - pl;
         if (valid && yv >= 0 && yv < (p.Hin << p.up) && xv >= 0 && xv < (p.Win << p.up)) xmask[j] |= 1u << t;
       }
       if (general) {
@@ -215,7 +216,8 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm2_kernel(const GemmPar
       long delta = 0;
       if (GATHER == T2V_GATHER_CONV3X3) {
         const int ky = tap / 3, kx = tap - ky * 3;
-        delta = ((long)(ky - 1) * p.Win + (kx - 1)) * p.lda;
+        const int pl = p.halo ? 0 : 1;
+        delta = ((long)(ky - pl) * p.Win + (kx - pl)) * p.lda;
       } else if (GATHER == T2V_GATHER_TCONV3) {
         delta = (long)(tap - 1) * p.HW * p.lda;
       }
@@ -234,7 +236,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm2_kernel(const GemmPar
         // nearest-2x upsample folded into the gather (3 convs per forward): per-lane recompute
         const int ky = ktap / 3, kx = ktap - ky * 3;
         const int lc = xx[j] >> 24, x0 = xx[j] & 0xFFFFFF;
-        const int yv = xy[j] + ky - 1, xv = x0 + kx - 1;
+        const int yv = xy[j] + ky - 1, xv = x0 + kx - 1;      // (upsample path: symmetric padding only)
         const long row = xoff[j] + (long)(yv >> 1) * p.Win + (xv >> 1);
         if (live && ((xmask[j] >> ktap) & 1u)) src = p.A + row * p.lda + (long)chunk * BK + lc * 8;
       }

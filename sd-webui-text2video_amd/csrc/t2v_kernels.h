@@ -29,7 +29,8 @@ struct GemmParams {
   int epi, out_f32, act, splitk, bias_m;
   int kt_per_split;                            // k-tiles (of 64) per split
   int halo;                                    // tconv3: input has one halo frame before and after each clip
-                                               // ([B][F+2][HW] rows, T-sharded forward); all 3 taps are in range
+                                               // ([B][F+2][HW] rows, T-sharded forward); all 3 taps are in range.
+                                               // conv3x3: 1 = asymmetric (0,1,0,1) zero padding (taps at +0..+2)
   int panel;                                   // tile columns per panel of the XCD-aware tile order (set by the launcher)
 };
 

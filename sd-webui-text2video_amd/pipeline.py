@@ -141,6 +141,22 @@ class TextToVideoSynthesis(object):
         return [np.ascontiguousarray(arr[i][:, :, ::-1]) for i in range(arr.shape[0])], x0   # RGB -> BGR
 
     @torch.no_grad()
+    def compute_latents(self, vd_out, cpu_vae="GPU (half precision)", device=torch.device("cuda")):
+        """vid2vid input side (t2v_pipeline.py:148-194): frames [b, 3, F, H, W] in [-1, 1] -> posterior mean x 0.18215,
+        [b, 4, F, H/8, W/8] fp32 on the host.  All frames go through ONE batched encoder program (the reference
+        encodes them one at a time)."""
+        if "CPU" in str(cpu_vae):
+            raise NotImplementedError("CPU VAE modes are host plumbing of the reference; this build encodes on the GPU")
+        self.device = torch.device(device)
+        self.autoencoder.to(self.device)
+        bs, c, F, h, w = vd_out.shape
+        x = vd_out.to(self.device).permute(0, 2, 1, 3, 4).reshape(bs * F, c, h, w).contiguous()
+        if "half precision" in str(cpu_vae):
+            x = x.half()
+        mean = self.autoencoder.encode(x).mean.float() * SCALE_FACTOR
+        return mean.view(bs, F, mean.shape[1], mean.shape[2], mean.shape[3]).permute(0, 2, 1, 3, 4).contiguous().cpu()
+
+    @torch.no_grad()
     def decode_frames(self, x0: torch.Tensor) -> torch.Tensor:
         """latent [b,4,F,h,w] -> uint8 [F,H,(b W),3] RGB on device: ONE batched VAE program over all
         frames of x0/0.18215 (t2v_pipeline.py:329-355 decodes them one at a time) + tensor2vid."""

@@ -212,7 +212,8 @@ class Program:
              rowbias: Optional[Buf] = None, rows_per_batch: int = 0, residual: Optional[Buf] = None,
              epi: int = L.EPI_NONE, act: int = 0, bias_along_m: bool = False, m: Optional[int] = None,
              allow_splitk: bool = True, halo: bool = False) -> Op:
-        """out[M, n_out] = epi(gather(a)[M, k] @ w[n, k]^T)."""
+        """out[M, n_out] = epi(gather(a)[M, k] @ w[n, k]^T).  conv['pad_after_only'] (3x3, stride 2): zero padding
+        (0,1,0,1) instead of 1 on every side."""
         conv = conv or {}
         M = out.rows if m is None else m
         n_out = n // 2 if epi == L.EPI_GEGLU else n
@@ -234,7 +235,8 @@ class Program:
         I[16], I[17], I[18] = epi, _DT[out.dtype], act
         I[20] = 1 if bias_along_m else 0
         I[21] = rowbias.ld if rowbias is not None else 0
-        I[23] = 1 if halo else 0
+        I[23] = 1 if (halo or conv.get("pad_after_only")) else 0
+        assert not (conv.get("pad_after_only") and (gather != L.GATHER_CONV3X3 or conv.get("up")))
         op.p[0], op.p[1], op.p[2] = a.ref, w, bias
         op.p[3] = rowbias.ref if rowbias is not None else NULL
         op.p[4] = residual.ref if residual is not None else NULL

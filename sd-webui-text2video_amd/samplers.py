@@ -135,9 +135,11 @@ class GaussianDiffusion(object):
         return timesteps
 
     def add_noise(self, xt, noise, t):
-        t = t.cpu()
-        dev = self.model.device
-        return self.sqrt_alphas_cumprod[t].to(dev) * xt + noise * self.sqrt_one_minus_alphas_cumprod[t].to(dev)
+        """q(x_t | x_0) for vid2vid (gaussian_sampler.py:87-91): sqrt(ac_t) * x + sqrt(1 - ac_t) * noise, one launch."""
+        t = int(torch.as_tensor(t).reshape(-1)[0])
+        out = torch.empty_like(xt)
+        return _lincomb(out, [(float(self.sqrt_alphas_cumprod[t]), xt.contiguous()),
+                              (float(self.sqrt_one_minus_alphas_cumprod[t]), noise.to(xt.device).contiguous())])
 
     def get_dim(self, y_out):
         return y_out.size(1) if self.var_type.startswith("fixed") else y_out.size(1) // 2

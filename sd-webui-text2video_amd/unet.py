@@ -355,7 +355,7 @@ class UNetSD(nn.Module):
     def forward_timed(self, x, t, y):
         """Like forward, but returns (eps, per-op milliseconds) using HIP events around every op
         on the launch stream (bench.py roofline measurement)."""
-        out = self.forward(x, t, y)
+        out = UNetSD.forward(self, x, t, y)
         comp = self._programs[(x.shape[0], x.shape[2], x.shape[3], x.shape[4], y.shape[1], _dt(x.dtype),
                                _dt(y.dtype), _dt(out.dtype))]
         xs, tf, ys = comp.keepalive

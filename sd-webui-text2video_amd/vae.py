@@ -1,4 +1,4 @@
-"""AutoencoderKL — drop-in for the reference's VAE on the decode side (boundary B5).
+"""AutoencoderKL — drop-in for the reference's VAE (boundary B5): decode (every video) and encode (vid2vid).
 
 Same constructor (`ddconfig`, `embed_dim`, `ckpt_path`), same state-dict keys
 (`post_quant_conv.*`, `decoder.*`, and — as parameter holders only — `encoder.*`,
@@ -10,8 +10,10 @@ scripts/videocrafter/lvdm/models/modules/autoencoder_modules.py:484-596).
 `decode` lowers the decoder into a denoise program executed by libt2v_hip.so: conv 3x3 as
 implicit GEMM (nearest-2x upsample folded into the gather), GroupNorm(eps 1e-6)+swish fused,
 the single-head d=C mid attention as  S = Q K^T (GEMM) -> row softmax -> O = P V (GEMM with
-V^T produced directly by a swapped-operand GEMM).  VAE *encode* (vid2vid) is SURVEY §8(f)-2
-("next") and not built yet: `encode` raises.
+V^T produced directly by a swapped-operand GEMM).  `encode(x[n,3,H,W])` (vid2vid input side,
+t2v_model.py:1640-1644, Encoder autoencoder_modules.py:387-481) lowers the encoder the same way — its
+Downsample pads (0,1,0,1) and convolves with stride 2 — and returns the DiagonalGaussianDistribution of
+`quant_conv`'s moments (distributions.py:5-46).
 """
 from __future__ import annotations
 
@@ -107,6 +109,29 @@ def _encoder_params(ch, ch_mult, num_res_blocks, in_channels, z_channels, double
     return e
 
 
+class DiagonalGaussianDistribution(object):
+    """videocrafter/lvdm/models/modules/distributions.py:5-46 (the ldm class of the same name): `parameters` =
+    [mean | logvar] along channels; latent-sized elementwise plumbing on the moments the encoder program produced."""
+
+    def __init__(self, parameters, deterministic=False):
+        self.parameters = parameters
+        self.mean, self.logvar = torch.chunk(parameters, 2, dim=1)
+        self.logvar = torch.clamp(self.logvar, -30.0, 20.0)
+        self.deterministic = deterministic
+        self.std = torch.exp(0.5 * self.logvar)
+        self.var = torch.exp(self.logvar)
+        if self.deterministic:
+            self.var = self.std = torch.zeros_like(self.mean)
+
+    def sample(self, noise=None):
+        if noise is None:
+            noise = torch.randn(self.mean.shape, device=self.parameters.device, dtype=self.mean.dtype)
+        return self.mean + self.std * noise
+
+    def mode(self):
+        return self.mean
+
+
 class AutoencoderKL(nn.Module):
     def __init__(self, ddconfig, embed_dim, ckpt_path=None, image_key="image", colorize_nlabels=None,
                  monitor=None, ema_decay=None, learn_logvar=False, init_weights=True):
@@ -139,7 +164,29 @@ class AutoencoderKL(nn.Module):
         self.load_state_dict(new, strict=True)
 
     def encode(self, x):
-        raise NotImplementedError("VAE encode (vid2vid input side) is SURVEY §8(f)-2, not built yet")
+        """x [n, 3, H, W] in [-1, 1] -> DiagonalGaussianDistribution over [n, 4, H/8, W/8] (t2v_model.py:1640-1644)."""
+        if not x.is_cuda:
+            raise L.T2VError("AutoencoderKL.encode needs device tensors on an AMD GPU (no CPU fallback)")
+        n, c, h, w = x.shape
+        nlev = len(self.ddconfig["ch_mult"]) - 1
+        assert c == self.ddconfig["in_channels"] and h % (1 << nlev) == 0 and w % (1 << nlev) == 0
+        x = x.contiguous()
+        if x.dtype not in (torch.float16, torch.float32):
+            x = x.float()
+        key = ("enc", n, h, w, _dt(x.dtype))
+        comp = self._programs.get(key)
+        if comp is None:
+            low = _VaeLowering(self, n, h, w, _dt(x.dtype), "f32", self.debug_taps)
+            comp = _Compiled(low.build_encoder(), low.packer)
+            self._programs[key] = comp
+        self._refresh(comp, x.device)
+        comp.ensure_bound(self._packed, x.device)
+        zc2 = 2 * self.embed_dim
+        moments = torch.empty((n, zc2, h >> nlev, w >> nlev), device=x.device, dtype=torch.float32)
+        comp.bound.run({L.EXT_X: x.data_ptr(), L.EXT_OUT: moments.data_ptr()}, torch.cuda.current_stream(x.device).cuda_stream)
+        comp.keepalive = (x,)
+        p0 = next(self.parameters())
+        return DiagonalGaussianDistribution(moments.to(torch.float16 if p0.dtype == torch.float16 else torch.float32))
 
     # ---- weights ------------------------------------------------------------------------------
     def _param_signature(self):
@@ -150,9 +197,13 @@ class AutoencoderKL(nn.Module):
 
     def _refresh(self, comp, device):
         sig = self._param_signature()
-        if self._packed is not None and sig == self._packed_sig and device == self._packed_device:
+        have = self._packed is not None and all(name in self._packed for name, _, _ in comp.packer.recipes)
+        if have and sig == self._packed_sig and device == self._packed_device:
             return
-        self._packed = comp.packer.materialise(self.state_dict(), device)
+        packed = comp.packer.materialise(self.state_dict(), device)
+        if self._packed is not None and sig == self._packed_sig and device == self._packed_device:
+            packed = {**self._packed, **packed}          # decoder and encoder programs pack disjoint weight sets
+        self._packed = packed
         self._packed_sig, self._packed_device = sig, device
         for c in self._programs.values():
             c.bound = None
@@ -207,14 +258,19 @@ class _VaeLowering:
         self.P.groupnorm(key, x, self.vec(key + ".weight"), self.vec(key + ".bias"), out, n_inst=self.n, eps=1e-6, silu=silu)
         return out
 
-    def conv3(self, key, a: Buf, cout, h, w, *, up=0, residual=None, cin=None) -> Buf:
+    def conv3(self, key, a: Buf, cout, h, w, *, up=0, down=False, residual=None, cin=None) -> Buf:
+        """down=True: the encoder's Downsample — F.pad(x, (0,1,0,1)) then 3x3 stride 2 without padding
+        (autoencoder_modules.py:150-166)."""
         cin = a.cols if cin is None else cin
-        ho, wo = (2 * h, 2 * w) if up else (h, w)
+        ho, wo = (2 * h, 2 * w) if up else ((h // 2, w // 2) if down else (h, w))
         nn_ = (cout + 3) // 4 * 4
         out = self.P.alloc(self.n * ho * wo, nn_, "f32")
         gather = L.GATHER_CONV3X3_C8 if cin == 8 else L.GATHER_CONV3X3
+        conv = dict(Hin=h, Win=w, Cin=cin, stride=2 if down else 1, up=up, Hout=ho, Wout=wo)
+        if down:
+            conv["pad_after_only"] = 1
         self.P.gemm(key, a, self.w_conv3(key, 8 if cin == 8 else 0), nn_, 9 * cin, out, bias=self.vec(key + ".bias"),
-                    gather=gather, conv=dict(Hin=h, Win=w, Cin=cin, stride=1, up=up, Hout=ho, Wout=wo), residual=residual)
+                    gather=gather, conv=conv, residual=residual)
         return out
 
     def resnet(self, p, x: Buf, cin, cout, h, w) -> Buf:
@@ -273,6 +329,60 @@ class _VaeLowering:
                residual=x)
         P.free(out_attn)
         return out
+
+    def build_encoder(self) -> Program:
+        """Encoder.forward (autoencoder_modules.py:447-481) + quant_conv: image -> moments [n, 2*z, h/8, w/8]."""
+        P, n, h, w = self.P, self.n, self.h, self.w
+        dd = self.vae.ddconfig
+        ch, ch_mult, nrb = dd["ch"], list(dd["ch_mult"]), dd["num_res_blocks"]
+        nres = len(ch_mult)
+        zc2 = 2 * dd["z_channels"]
+        assert dd["in_channels"] <= 8 and zc2 == 2 * self.vae.embed_dim == 8
+        P.begin()
+        xin = P.alloc(n * h * w, 8, "f16")
+        P.ncthw_to_cl("x.to_tokens", Ref("ext", L.EXT_X), self.z_dt, xin, B=n, C=dd["in_channels"], F=1, HW=h * w)
+        x = self.conv3("encoder.conv_in", xin, ch, h, w, cin=8)
+        P.free(xin)
+        P.tap("encoder.conv_in", x)
+
+        def step(fn, name, *a):
+            nonlocal x
+            y = fn(name, x, *a)
+            P.tap(name, y)
+            P.free(x)
+            x = y
+
+        block_in = ch
+        for lvl in range(nres):
+            block_out = ch * ch_mult[lvl]
+            for j in range(nrb):
+                step(self.resnet, f"encoder.down.{lvl}.block.{j}", block_in, block_out, h, w)
+                block_in = block_out
+            if lvl != nres - 1:
+                x16 = P.alloc(x.rows, block_in, "f16")
+                P.copy2d(f"encoder.down.{lvl}.downsample.cast", x, x16)
+                y = self.conv3(f"encoder.down.{lvl}.downsample.conv", x16, block_in, h, w, down=True)
+                P.free(x16, x)
+                x = y
+                h, w = h // 2, w // 2
+                P.tap(f"encoder.down.{lvl}.downsample", x)
+        step(self.resnet, "encoder.mid.block_1", block_in, block_in, h, w)
+        step(self.attn, "encoder.mid.attn_1", block_in, h, w)
+        step(self.resnet, "encoder.mid.block_2", block_in, block_in, h, w)
+        a = self.gn("encoder.norm_out", x, True)
+        P.free(x)
+        y = self.conv3("encoder.conv_out", a, zc2, h, w)
+        P.free(a)
+        y16 = P.alloc(y.rows, zc2, "f16")
+        P.copy2d("encoder.conv_out.cast", y, y16)
+        P.free(y)
+        m = P.alloc(y16.rows, zc2, "f32")
+        P.gemm("quant_conv", y16, self.w_linear("quant_conv"), zc2, zc2, m, bias=self.vec("quant_conv.bias"))
+        P.free(y16)
+        P.cl_to_ncthw("moments.from_tokens", m, Ref("ext", L.EXT_OUT), "f32", B=n, C=zc2, F=1, HW=h * w)
+        P.free(m)
+        P.finish()
+        return P
 
     def build(self) -> Program:
         P, n, h, w = self.P, self.n, self.h, self.w

@@ -49,6 +49,16 @@ def tiny():
                            batch_size=1, latents=lat, shape=shape, noise=noise, guidance_scale=9.0,
                            eta=0.0, sampler_name="DDIM_Gaussian")
     extra = other_samplers(ref, unet, betas, lat, noise, shape, c, uc)
+    # vid2vid input side: VAE encode of synthetic frames (t2v_model.py:1640-1644) and the DDIM_Gaussian vid2vid loop
+    # (samplers_common.py:165-207 with is_vid2vid=True -> encode_latent -> add_noise, :123-145)
+    frames = torch.rand(3, 3, 64, 48, generator=torch.Generator().manual_seed(9)) * 2 - 1
+    with torch.no_grad():
+        extra["vae_moments"] = vae.encode(frames).parameters.numpy()
+        z0 = torch.randn(shape, generator=torch.Generator().manual_seed(11))
+        s2 = ref.samplers.Txt2VideoSampler(unet, torch.device("cpu"), betas=betas, sampler_name="DDIM_Gaussian")
+        extra["vid2vid_x0"] = s2.sample_loop(steps=4, strength=0.5, conditioning=c, unconditional_conditioning=uc, batch_size=1,
+                                             latents=z0, shape=shape, noise=noise, is_vid2vid=True, guidance_scale=9.0, eta=0.0,
+                                             sampler_name="DDIM_Gaussian").numpy()
     np.savez_compressed(os.path.join(OUT, "tiny.npz"), unet_eps=eps.numpy(), vae_img=img.numpy(),
                         sampler_x0=x0.numpy(), **extra)
     print("tiny done", eps.std().item(), img.std().item(), x0.std().item(), {k: float(v.std()) for k, v in extra.items()})

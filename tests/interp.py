@@ -73,7 +73,7 @@ class Interp:
             X = self.view(op.p[0], (nimg, Hin, Win, Cin), (Hin * Win * lda, Win * lda, lda, 1), torch.float16, ext).float()
             if up:
                 X = X.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
-            Xp = F.pad(X, (0, 0, 1, 1, 1, 1))
+            Xp = F.pad(X, (0, 0, 0, 2, 0, 2)) if (gather == L.GATHER_CONV3X3 and I[23]) else F.pad(X, (0, 0, 1, 1, 1, 1))
             cols = []
             for ky in range(3):
                 for kx in range(3):

@@ -103,6 +103,25 @@ def test_vae_program_matches_oracle_in_interpreter():
     assert rel_l2(out, gold) < 3e-3
 
 
+def test_vae_encoder_program_matches_golden_in_interpreter():
+    """Encoder lowering incl. the (0,1,0,1)-padded stride-2 Downsample, on a non-square input."""
+    from sd_webui_text2video_amd import vae as V
+    dd = configs.TINY_VAE_DDCONFIG
+    ae = V.AutoencoderKL(dd, 4, init_weights=False)
+    ae.load_state_dict(synth.synth_state_dict(synth.param_spec(ae), seed=3), strict=True)
+    frames = torch.rand(3, 3, 64, 48, generator=torch.Generator().manual_seed(9)) * 2 - 1
+    low = V._VaeLowering(ae, 3, 64, 48, "f32", "f32")
+    prog = low.build_encoder()
+    assert any(op.kind == L.OP_GEMM and op.i[7] == L.GATHER_CONV3X3 and op.i[11] == 2 and op.i[23] == 1 for op in prog.ops)
+    out = torch.empty(3, 8, 8, 6)
+    Interp(prog, low.packer.materialise(ae.state_dict(), "cpu")).run({L.EXT_X: frames, L.EXT_OUT: out})
+    gold = torch.from_numpy(np.load(os.path.join(GOLD, "tiny.npz"))["vae_moments"])
+    assert rel_l2(out, gold) < 3e-3
+    d = V.DiagonalGaussianDistribution(gold)
+    assert torch.equal(d.mean, gold[:, :4]) and torch.equal(d.mode(), d.mean)
+    assert torch.allclose(d.std, torch.exp(0.5 * gold[:, 4:].clamp(-30, 20)))
+
+
 def test_ddim_step_op_matches_reference_update():
     """The fused update (interpreter semantics == kernel semantics) against the oracle's loop body."""
     from sd_webui_text2video_amd.program import Program

@@ -72,6 +72,26 @@ def test_port_ddim_and_unipc_match_reference_golden():
     assert rel(tp.ddim_ldm_sample(f, betas, enc, 4, c, uc, 9.0, t_start=3), "ddim_vid2vid_x0") < 2e-5
 
 
+def test_port_vae_encode_and_vid2vid_match_reference_golden():
+    """VAE encode (posterior moments) and the DDIM_Gaussian vid2vid flow: encode_latent noises the input latents at
+    get_time_steps(int(strength*steps))[0] — the step COUNT is passed where a stride is expected, so t = 999 for any
+    strength (samplers_common.py:139-143, gaussian_sampler.py:73-85) — then all S steps run."""
+    gold = np.load(os.path.join(GOLD, "tiny.npz"))
+    _, _, _, _, c, uc = _tiny_inputs()
+    vsd = synth.synth_state_dict(_spec_vae(configs.TINY_VAE_DDCONFIG), seed=3)
+    frames = torch.rand(3, 3, 64, 48, generator=torch.Generator().manual_seed(9)) * 2 - 1
+    m = tp.vae_encode(vsd, configs.TINY_VAE_DDCONFIG, frames)
+    assert np.abs(m.numpy() - gold["vae_moments"]).max() < 2e-5
+    sd = synth.synth_state_dict(_spec_unet(configs.TINY_UNET), seed=0)
+    betas = tp.beta_schedule_linear_sd()
+    noise, _, _ = synth.synth_inputs(3, 128, 128)
+    z0 = torch.randn(noise.shape, generator=torch.Generator().manual_seed(11))
+    ac = torch.cumprod(1 - betas, 0)
+    x_T = torch.sqrt(ac)[999].float() * z0 + noise * torch.sqrt(1 - ac)[999].float()
+    x0 = tp.ddim_gaussian_sample(lambda a, b, cc: tp.unet_forward(sd, configs.TINY_UNET, a, b, cc), betas, x_T, 4, c, uc, 9.0, 0.0)
+    assert np.abs(x0.numpy() - gold["vid2vid_x0"]).max() < 2e-4 * np.abs(gold["vid2vid_x0"]).max()
+
+
 def test_timestep_grid_matches_reference_quirk():
     # SURVEY App. C #2: S=5 -> [801,601,401,201,1]; S=50 -> [981,...,1]
     assert tp.ddim_gaussian_timesteps(1000, 5).tolist() == [801, 601, 401, 201, 1]

@@ -1,5 +1,5 @@
 """Per-op timing of one UNet step on the GPU (HIP events around every op of the denoise program).
-Usage: python tools/profile_unet.py [frames] [latent_h] [latent_w] [batch]"""
+Usage: python tools/profile_unet.py [frames] [latent_h] [latent_w] [batch] [modelscope|lvdm]"""
 import collections
 import json
 import os
@@ -32,29 +32,34 @@ def main():
     H = int(sys.argv[2]) if len(sys.argv) > 2 else 32
     W = int(sys.argv[3]) if len(sys.argv) > 3 else 32
     B = int(sys.argv[4]) if len(sys.argv) > 4 else 2
+    model = sys.argv[5] if len(sys.argv) > 5 else "modelscope"
     dev = torch.device("cuda:0")
     print(L.device_info())
     t0 = time.time()
-    net = U.UNetSD(**configs.MODELSCOPE_UNET, init_weights=False).half().to(dev)
+    if model == "lvdm":
+        from sd_webui_text2video_amd import videocrafter as VC
+        net = VC.UNetModel(**configs.LVDM_UNET, init_weights=False).half().to(dev)
+    else:
+        net = U.UNetSD(**configs.MODELSCOPE_UNET, init_weights=False).half().to(dev)
     random_weights_(net)
-    print(f"model on device in {time.time() - t0:.1f}s")
+    print(f"{model} model on device in {time.time() - t0:.1f}s")
     x = torch.randn(B, 4, F, H, W, device=dev)
-    y = torch.randn(B, 77, 1024, device=dev, dtype=torch.float16)
+    y = torch.randn(B, 77, net.context_dim, device=dev, dtype=torch.float16)
     t = torch.full((B,), 500, device=dev)
     for _ in range(2):
-        out = net(x, t, y)
+        out = net(x, t, context=y) if model == "lvdm" else net(x, t, y)
     torch.cuda.synchronize()
     assert torch.isfinite(out.float()).all()
     n = 5
     t0 = time.time()
     for _ in range(n):
-        out = net(x, t, y)
+        out = net(x, t, context=y) if model == "lvdm" else net(x, t, y)
     torch.cuda.synchronize()
     wall = (time.time() - t0) / n * 1e3
     net.auto_refresh = False
     t0 = time.time()
     for _ in range(n):
-        out = net(x, t, y)
+        out = net(x, t, context=y) if model == "lvdm" else net(x, t, y)
     torch.cuda.synchronize()
     wall2 = (time.time() - t0) / n * 1e3
     _, ms, prog = net.forward_timed(x, t, y)
@@ -67,7 +72,7 @@ def main():
           f"{flops / (tot * 1e-3) / 1e12:.1f} TF/s by events; arena {prog.arena.high / 2**30:.2f} GiB")
     kinds = collections.defaultdict(lambda: [0.0, 0, 0.0])
     names = {1: "gemm", 2: "groupnorm", 3: "layernorm", 4: "attention", 5: "softmax", 6: "to_cl", 7: "from_cl",
-             8: "time_embed", 9: "copy2d", 10: "ddim", 11: "memset"}
+             8: "time_embed", 9: "copy2d", 10: "ddim", 11: "memset", 12: "lincomb", 13: "relpos_attn"}
     for op, m in zip(prog.ops, ms):
         k = names[op.kind]
         if op.kind == 1:
@@ -93,7 +98,7 @@ def main():
     for key, (m, c, fl) in sorted(att.items(), key=lambda kv: -kv[1][0]):
         print(f"  {str(key):32s} {m:8.3f} {c:4d} {fl / max(m, 1e-9) / 1e9:8.1f}")
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", f"unet_ops_b{B}_f{F}_{H}x{W}.json"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", f"unet_ops_b{B}_f{F}_{H}x{W}.json" if model == "modelscope" else f"lvdm_ops_b{B}_f{F}_{H}x{W}.json"), "w") as f:
         json.dump([dict(name=op.name, kind=op.kind, ms=m, flops=op.flops, meta={k: v for k, v in op.meta.items() if k != "conv"})
                    for op, m in zip(prog.ops, ms)], f)
 
