@@ -265,10 +265,12 @@ class _TShardRunner:
 
 
 def make_runner(pipe, world: int, rank: int, *, frames, height, width, ddim_steps, guidance, mode: str = "auto"):
-    """mode 'pairs': independent CFG pairs (one video each); 'tshard': one long video, T-sharded (world >= 4, even);
-    'auto' = tshard when possible."""
+    """mode 'pairs': independent CFG pairs (one video each); 'tshard': one long video, T-sharded (world >= 4, even).
+    'auto' = pairs: the pair layout needs one tiny all-gather per step and has been the measured configuration;
+    the T-sharded forward (validated with gloo and in lock-step on one GPU, 227 host-issued exchanges per forward)
+    stays opt-in until its RCCL timing has been measured on a multi-GPU node."""
     if mode == "auto":
-        mode = "tshard" if (world >= 4 and world % 2 == 0 and frames % 2 == 0) else "pairs"
+        mode = "pairs"
     if mode == "tshard":
         return _TShardRunner(pipe, TShardTopology(world, rank), frames, height, width, ddim_steps, guidance)
     return _Runner(pipe, CfgPair(world, rank), frames, height, width, ddim_steps, guidance)
