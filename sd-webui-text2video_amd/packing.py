@@ -1,6 +1,6 @@
 """Weight plumbing: turns the reference-layout state dict (torch [Cout, Cin, k...] tensors)
-into the GEMM-ready packed images the HIP kernels read ([N, K] fp16, K tap-major /
-channels-last; fp32 bias / affine vectors).  Pure layout work with torch ops, run once per
+into the GEMM-ready packed images the HIP kernels read ([N, K] fp16, reduction ordered (64-channel
+chunk, tap, channel); fp32 bias / affine vectors).  Pure layout work with torch ops, run once per
 weight version (and again after `invalidate()`, e.g. when the LoRA hook of the reference,
 scripts/stable_lora/stable_utils/lora_processor.py:215-246, has mutated `.weight` in place).
 """

@@ -15,7 +15,7 @@ Internal data layout (resident in HBM between kernels):
   * activations: channels-last tokens, row m = ((b*F + f)*H + y)*W + x, C contiguous.
     Residual-stream tensors are fp32, MFMA operands (outputs of norms / activations /
     projections feeding a GEMM or attention) are fp16.
-  * weights: packed once to [N, K] fp16 with K tap-major (packing.py).
+  * weights: packed once to [N, K] fp16, reduction ordered (64-channel chunk, tap, channel) (packing.py).
 Every `rearrange(...).contiguous()` of the reference (t2v_model.py:429,458,648,655,727-761,
 1006-1008) is folded into GEMM addressing or attention strides.
 """
