@@ -160,8 +160,8 @@ class Program:
             tile = 0
         elif M >= 32768:                               # 32x32 level: big tiles, 320-wide when it divides
             tile = 2 if n % 320 == 0 and n != 960 else 1
-        elif M >= 8192:                                # 16x16 level
-            if gather == L.GATHER_CONV3X3 and k >= 4096 and n % 320 == 0:
+        elif M >= 8192:                                # 16x16 level (b=2) / 32x32 level of a single CFG role (b=1)
+            if gather == L.GATHER_CONV3X3 and k >= 2560 and n % 320 == 0:
                 tile = 2
             elif n >= 2560:
                 tile = 2 if n % 320 == 0 else 1
@@ -172,10 +172,12 @@ class Program:
             else:
                 tile = 0
         else:                                          # 8x8 / 4x4 levels: few rows, latency-bound
-            if n >= 2560:
-                tile = 1 if M >= 2048 else (0 if n >= 8192 else 5)
+            if n >= 8192:
+                tile = 1 if M >= 1024 else (0 if M >= 512 else 5)
+            elif n >= 2560:
+                tile = 1 if M >= 2048 else (3 if M >= 1024 else 5)
             elif gather == L.GATHER_CONV3X3 and k >= 8192:
-                tile = 3
+                tile = 2 if (M >= 4096 and n % 320 == 0) else 3
             else:
                 tile = 5                               # 128x128, 4-deep ring: 96 KiB per CU in flight
         if tile == 0:

@@ -13,7 +13,8 @@ from sd_webui_text2video_amd.program import BoundProgram, Program, Ref  # noqa: 
 
 dev = torch.device("cuda:0")
 # (label, gather, M, N, K, conv)
-F, B = 24, 2
+F = 24
+B = int(os.environ.get("SWEEP_BATCH", "2"))      # 2 = cond+uncond batched (1 GPU); 1 = one CFG role per GPU (N >= 2)
 SHAPES = []
 for (C, hw, lvl) in [(320, 32, "L0"), (640, 16, "L1"), (1280, 8, "L2"), (1280, 4, "L3")]:
     M = B * F * hw * hw
