@@ -181,7 +181,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    from oracle import configs            # hyper-parameter dicts only
+    from sd_webui_text2video_amd import configs
     from sd_webui_text2video_amd import parallel, pipeline, unet as U, vae as V
 
     cfg, ddcfg = configs.MODELSCOPE_UNET, configs.VAE_DDCONFIG

@@ -1,4 +1,5 @@
-"""Run a denoise program op by op twice from identical state and report every op whose output
+"""Diagnostic (not collected by pytest; run by hand on the GPU box: python tests/determinism_probe.py [full]).
+Run a denoise program op by op twice from identical state and report every op whose output
 differs between the two runs (in-kernel races / uninitialised reads show up here)."""
 import os
 import sys

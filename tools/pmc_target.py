@@ -7,7 +7,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from oracle import configs  # noqa: E402  (hyper-parameters only)
+from sd_webui_text2video_amd import configs  # noqa: E402
 from sd_webui_text2video_amd import unet as U  # noqa: E402
 from tools.profile_unet import random_weights_  # noqa: E402
 

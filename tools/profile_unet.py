@@ -10,7 +10,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from oracle import configs  # noqa: E402  (hyper-parameters only)
+from sd_webui_text2video_amd import configs  # noqa: E402
 from sd_webui_text2video_amd import _lib as L, unet as U  # noqa: E402
 
 
