@@ -60,3 +60,36 @@ def test_cfg_pair_collectives_gloo_world2():
     ret = mgr.dict()
     mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
     assert dict(ret) == {0: 1, 1: 1}
+
+
+def _worker4(rank, world, port, ret):
+    """Two independent CFG pairs (bench.py --gpus 4 layout): every rank creates every group, exchanges stay inside the pair."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pair = parallel.CfgPair(world, rank)
+        assert (pair.index, pair.role, pair.size) == (rank // 2, rank % 2, 2) and pair.members == [2 * (rank // 2), 2 * (rank // 2) + 1]
+        both = pair.exchange_eps(torch.full((1, 4, 3, 2, 2), float(10 * pair.index + pair.role)))
+        assert both[0].unique().tolist() == [10.0 * pair.index] and both[1].unique().tolist() == [10.0 * pair.index + 1]
+        f0, f1 = pair.my_frames(4)
+        local = (torch.arange(f0, f1, dtype=torch.uint8) + 100 * pair.index).view(-1, 1, 1, 1).expand(-1, 1, 1, 3).contiguous()
+        full = pair.gather_frames(local, 4)
+        assert full[:, 0, 0, 0].tolist() == [100 * pair.index + k for k in range(4)]
+        dist.barrier()
+        ret[rank] = 1
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_cfg_pairs_gloo_world4():
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker4, args=(4, port, ret), nprocs=4, join=True)
+    assert dict(ret) == {0: 1, 1: 1, 2: 1, 3: 1}
+
+
+def test_make_runner_default_is_pairs():
+    import inspect
+    src = inspect.getsource(parallel.make_runner)
+    assert 'mode = "pairs"' in src          # T-sharding is opt-in until measured on a multi-GPU node
