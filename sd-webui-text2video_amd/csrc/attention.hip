@@ -199,74 +199,198 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnParams p) {
   }
 }
 
-// ---- temporal attention with relative-position terms (LVDM TemporalCrossAttention.forward,
-//      videocrafter/lvdm/models/modules/attention_temporal.py:107-144, RelativePosition :46-65) ------------
+// ---- attention over the <= 32 frames of one pixel (ModelScope temporal self-attention, t2v_model.py:716-767, and
+//      LVDM TemporalCrossAttention with relative-position terms, attention_temporal.py:107-144 / RelativePosition :46-65)
 //   sim[t,s] = scale * q[t] . (k[s] + Ek[clip(s-t)])       p = softmax_s(sim)
-//   out[t]   = sum_s p[t,s] * (v[s] + Ev[clip(s-t)])       clip(x) = clamp(x, -R, R) + R, tables [2R+1, D] fp32
-// Sequences are the T <= 32 frames of one pixel: a memory-bound op (fp32 VALU math, one workgroup per
-// (pixel, head); q/k/v/out addressed by the same (sequence, outer, inner) strides as the MFMA kernel).
-struct RelAttnParams {
+//   out[t]   = sum_s p[t,s] * (v[s] + Ev[clip(s-t)])       clip(x) = clamp(x, -R, R) + R; tables [2R+1, D] fp32 (REL only)
+// The relative-position terms make the score of every (t, s) pair a different dot product, so this is a VALU
+// kernel (for plain temporal attention the MFMA kernel above measured faster, 24 frames x d=64): one wave per (pixel, head), four per workgroup.  q/k/v rows are staged once in LDS (fp16, padded pitch);
+// each lane accumulates a TB x TB register block of scores (rows ti + 8a, columns sj + 8b) from 16-byte LDS reads,
+// the row softmax is three xor-shuffles over the 8 lanes that share a row, P goes through LDS and the output is
+// produced 8 channels per lane.  Addressing = the (sequence, outer, inner) strides of the MFMA kernel.
+struct SeqAttnParams {
   const f16* q; const f16* k; const f16* v; f16* o;
   const float* ek; const float* ev;
-  int T, D, heads, b_inner, R;
+  int T, D, heads, b_inner, R, lds_per_wave;
+  long n_items;
   long sq_seq, sq_out, sq_in;
   long sk_seq, sk_out, sk_in;
   long so_seq, so_out, so_in;
   float scale;
 };
 
-__global__ __launch_bounds__(256) void relpos_attn_kernel(const RelAttnParams p) {
-  extern __shared__ float rsh[];           // q[T][D], k[T][D], v[T][D], sim[T][T]
-  const int T = p.T, D = p.D;
-  float* qs = rsh;
-  float* ks = qs + T * D;
-  float* vs = ks + T * D;
-  float* sim = vs + T * D;
-  const int tid = threadIdx.x;
-  const int head = blockIdx.y;
-  const int bo = blockIdx.x / p.b_inner, bi = blockIdx.x % p.b_inner;
+__device__ __forceinline__ f32x8 ld_f32x8(const float* p) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+  f32x8 r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return r;
+}
+
+template <int TB, bool REL>
+__global__ __launch_bounds__(256) void seqattn_kernel(const SeqAttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ssm[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long item = (long)blockIdx.x * 4 + wave;
+  const bool live = item < p.n_items;                      // wave-uniform
+  const int T = p.T, D = p.D, d8 = D >> 3;
+  const int DP = D * 2 + 16;                               // LDS row pitch (bytes): 16-B reads of 8 rows hit disjoint banks
+  unsigned char* qs = ssm + (size_t)wave * p.lds_per_wave;
+  unsigned char* ks = qs + T * DP;
+  unsigned char* vs = ks + T * DP;
+  float* ps = reinterpret_cast<float*>(vs + T * DP);       // [T][T + 1]
+  const int head = live ? (int)(item % p.heads) : 0;
+  const long pos = live ? item / p.heads : 0;
+  const long bo = pos / p.b_inner, bi = pos % p.b_inner;
   const f16* qb = p.q + bo * p.sq_out + bi * p.sq_in + head * D;
   const f16* kb = p.k + bo * p.sk_out + bi * p.sk_in + head * D;
   const f16* vb = p.v + bo * p.sk_out + bi * p.sk_in + head * D;
   f16* ob = p.o + bo * p.so_out + bi * p.so_in + head * D;
-  const int d8 = D >> 3;
-  for (int u = tid; u < T * d8; u += 256) {
-    const int t = u / d8, c = (u - t * d8) * 8;
-    const f16x8 a = *reinterpret_cast<const f16x8*>(qb + (long)t * p.sq_seq + c);
-    const f16x8 b = *reinterpret_cast<const f16x8*>(kb + (long)t * p.sk_seq + c);
-    const f16x8 e = *reinterpret_cast<const f16x8*>(vb + (long)t * p.sk_seq + c);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { qs[t * D + c + j] = (float)a[j]; ks[t * D + c + j] = (float)b[j]; vs[t * D + c + j] = (float)e[j]; }
-  }
-  __syncthreads();
-  for (int u = tid; u < T * T; u += 256) {
-    const int t = u / T, s = u - t * T;
-    int r = s - t;
-    r = (r < -p.R ? -p.R : (r > p.R ? p.R : r)) + p.R;
-    const float* er = p.ek + (long)r * D;
-    float acc = 0.f;
-    for (int d = 0; d < D; ++d) acc += qs[t * D + d] * (ks[s * D + d] + er[d]);
-    sim[u] = acc * p.scale;
-  }
-  __syncthreads();
-  if (tid < T) {
-    float mx = -INFINITY;
-    for (int s = 0; s < T; ++s) mx = fmaxf(mx, sim[tid * T + s]);
-    float sum = 0.f;
-    for (int s = 0; s < T; ++s) { const float e = __expf(sim[tid * T + s] - mx); sim[tid * T + s] = e; sum += e; }
-    const float inv = 1.0f / sum;
-    for (int s = 0; s < T; ++s) sim[tid * T + s] *= inv;
-  }
-  __syncthreads();
-  for (int u = tid; u < T * D; u += 256) {
-    const int t = u / D, d = u - t * D;
-    float acc = 0.f;
-    for (int s = 0; s < T; ++s) {
-      int r = s - t;
-      r = (r < -p.R ? -p.R : (r > p.R ? p.R : r)) + p.R;
-      acc += sim[t * T + s] * (vs[s * D + d] + p.ev[(long)r * D + d]);
+  if (live) {
+    for (int u = lane; u < T * d8; u += 64) {
+      const int t = u / d8, c = u - t * d8;
+      *reinterpret_cast<f16x8*>(qs + t * DP + c * 16) = *reinterpret_cast<const f16x8*>(qb + (long)t * p.sq_seq + c * 8);
+      *reinterpret_cast<f16x8*>(ks + t * DP + c * 16) = *reinterpret_cast<const f16x8*>(kb + (long)t * p.sk_seq + c * 8);
+      *reinterpret_cast<f16x8*>(vs + t * DP + c * 16) = *reinterpret_cast<const f16x8*>(vb + (long)t * p.sk_seq + c * 8);
     }
-    ob[(long)t * p.so_seq + d] = (f16)acc;
+  }
+  __syncthreads();
+  if (live) {
+    const int ti = lane >> 3, sj = lane & 7;
+    float acc[TB][TB];
+#pragma unroll
+    for (int a = 0; a < TB; ++a)
+#pragma unroll
+      for (int b = 0; b < TB; ++b) acc[a][b] = 0.f;
+    int rrow[2 * TB - 1];
+    if (REL) {
+#pragma unroll
+      for (int e = 0; e < 2 * TB - 1; ++e) {
+        int dlt = 8 * (e - (TB - 1)) + sj - ti;
+        dlt = dlt < -p.R ? -p.R : (dlt > p.R ? p.R : dlt);
+        rrow[e] = (dlt + p.R) * D;
+      }
+    }
+    for (int c = 0; c < d8; ++c) {
+      f16x8 qv[TB], kv[TB];
+#pragma unroll
+      for (int a = 0; a < TB; ++a) {
+        const int t = ti + 8 * a;
+        if (t < T) qv[a] = *reinterpret_cast<const f16x8*>(qs + t * DP + c * 16);
+        else for (int j = 0; j < 8; ++j) qv[a][j] = (f16)0.f;
+      }
+#pragma unroll
+      for (int b = 0; b < TB; ++b) {
+        const int sx = sj + 8 * b;
+        if (sx < T) kv[b] = *reinterpret_cast<const f16x8*>(ks + sx * DP + c * 16);
+        else for (int j = 0; j < 8; ++j) kv[b][j] = (f16)0.f;
+      }
+      if (REL) {
+        f32x8 er[2 * TB - 1];
+#pragma unroll
+        for (int e = 0; e < 2 * TB - 1; ++e) er[e] = ld_f32x8(p.ek + rrow[e] + c * 8);
+#pragma unroll
+        for (int a = 0; a < TB; ++a)
+#pragma unroll
+          for (int b = 0; b < TB; ++b)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[a][b] += (float)qv[a][j] * ((float)kv[b][j] + er[b - a + TB - 1][j]);
+      } else {
+#pragma unroll
+        for (int a = 0; a < TB; ++a)
+#pragma unroll
+          for (int b = 0; b < TB; ++b)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[a][b] += (float)qv[a][j] * (float)kv[b][j];
+      }
+    }
+    // row softmax: a row's T scores live in TB registers of the 8 lanes with the same ti
+#pragma unroll
+    for (int a = 0; a < TB; ++a) {
+      const int t = ti + 8 * a;
+      float mx = -INFINITY;
+#pragma unroll
+      for (int b = 0; b < TB; ++b) {
+        acc[a][b] = (sj + 8 * b < T) ? acc[a][b] * p.scale : -INFINITY;
+        mx = fmaxf(mx, acc[a][b]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 1)); mx = fmaxf(mx, __shfl_xor(mx, 2)); mx = fmaxf(mx, __shfl_xor(mx, 4));
+      float sum = 0.f;
+#pragma unroll
+      for (int b = 0; b < TB; ++b) { acc[a][b] = __expf(acc[a][b] - mx); sum += acc[a][b]; }
+      sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4);
+      const float inv = 1.0f / sum;
+      if (t < T) {
+#pragma unroll
+        for (int b = 0; b < TB; ++b)
+          if (sj + 8 * b < T) ps[t * (T + 1) + sj + 8 * b] = acc[a][b] * inv;
+      }
+    }
+  }
+  __syncthreads();
+  if (live) {
+    for (int u = lane; u < T * d8; u += 64) {
+      const int t = u / d8, c = u - t * d8;
+      f32x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = 0.f;
+      for (int sx = 0; sx < T; ++sx) {
+        const float pv = ps[t * (T + 1) + sx];
+        const f16x8 vv = *reinterpret_cast<const f16x8*>(vs + sx * DP + c * 16);
+        if (REL) {
+          int dlt = sx - t;
+          dlt = dlt < -p.R ? -p.R : (dlt > p.R ? p.R : dlt);
+          const f32x8 e = ld_f32x8(p.ev + (long)(dlt + p.R) * D + c * 8);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] += pv * ((float)vv[j] + e[j]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] += pv * (float)vv[j];
+        }
+      }
+      f16x8 oh;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) oh[j] = (f16)o[j];
+      *reinterpret_cast<f16x8*>(ob + (long)t * p.so_seq + c * 8) = oh;
+    }
+  }
+}
+
+template <bool REL>
+hipError_t launch_seqattn(const t2v_op& op, hipStream_t s) {
+  SeqAttnParams p;
+  p.q = reinterpret_cast<const f16*>(op.p[0]);
+  p.k = reinterpret_cast<const f16*>(op.p[1]);
+  p.v = reinterpret_cast<const f16*>(op.p[2]);
+  p.o = reinterpret_cast<f16*>(op.p[3]);
+  p.ek = reinterpret_cast<const float*>(op.p[4]);
+  p.ev = reinterpret_cast<const float*>(op.p[5]);
+  p.T = op.i[0]; p.heads = op.i[2]; p.b_inner = op.i[4]; p.D = op.i[14] > 0 ? op.i[14] : 64; p.R = op.i[15];
+  p.n_items = (long)op.i[3] * op.i[4] * p.heads;
+  p.sq_seq = op.i[5]; p.sq_out = op.i[6]; p.sq_in = op.i[7];
+  p.sk_seq = op.i[8]; p.sk_out = op.i[9]; p.sk_in = op.i[10];
+  p.so_seq = op.i[11]; p.so_out = op.i[12]; p.so_in = op.i[13];
+  p.scale = op.f[0];
+  if (p.T <= 0 || p.T > 32 || op.i[1] != p.T || p.D <= 0 || p.D % 8 != 0 || p.D > 160 || p.n_items <= 0) return hipErrorInvalidValue;
+  if (REL && (p.R < 0 || p.ek == nullptr || p.ev == nullptr)) return hipErrorInvalidValue;
+  p.lds_per_wave = (3 * p.T * (p.D * 2 + 16) + p.T * (p.T + 1) * 4 + 15) / 16 * 16;
+  const int lds = 4 * p.lds_per_wave;
+  const dim3 grid((unsigned)((p.n_items + 3) / 4));
+  const int tb = (p.T + 7) / 8;
+  auto go = [&](auto kern) -> hipError_t {
+    static bool attr_set = false;      // one flag per instantiation (the lambda is instantiated per kernel type)
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return e;
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+    return hipGetLastError();
+  };
+  switch (tb) {
+    case 1: return go(seqattn_kernel<1, REL>);
+    case 2: return go(seqattn_kernel<2, REL>);
+    case 3: return go(seqattn_kernel<3, REL>);
+    default: return go(seqattn_kernel<4, REL>);
   }
 }
 
@@ -337,34 +461,7 @@ hipError_t t2v_launch_attention(const t2v_op& op, hipStream_t s) {
   return hipGetLastError();
 }
 
-hipError_t t2v_launch_relpos_attention(const t2v_op& op, hipStream_t s) {
-  RelAttnParams p;
-  p.q = reinterpret_cast<const f16*>(op.p[0]);
-  p.k = reinterpret_cast<const f16*>(op.p[1]);
-  p.v = reinterpret_cast<const f16*>(op.p[2]);
-  p.o = reinterpret_cast<f16*>(op.p[3]);
-  p.ek = reinterpret_cast<const float*>(op.p[4]);
-  p.ev = reinterpret_cast<const float*>(op.p[5]);
-  p.T = op.i[0]; p.heads = op.i[2]; p.b_inner = op.i[4]; p.D = op.i[14]; p.R = op.i[15];
-  const int b_outer = op.i[3];
-  p.sq_seq = op.i[5]; p.sq_out = op.i[6]; p.sq_in = op.i[7];
-  p.sk_seq = op.i[8]; p.sk_out = op.i[9]; p.sk_in = op.i[10];
-  p.so_seq = op.i[11]; p.so_out = op.i[12]; p.so_in = op.i[13];
-  p.scale = op.f[0];
-  if (p.T <= 0 || p.T > 32 || op.i[1] != p.T || p.D <= 0 || p.D % 8 != 0 || p.D > 256 || p.R < 0 || p.ek == nullptr ||
-      p.ev == nullptr)
-    return hipErrorInvalidValue;
-  const size_t lds = ((size_t)3 * p.T * p.D + (size_t)p.T * p.T) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(relpos_attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (3 * 32 * 256 + 32 * 32) * (int)sizeof(float));
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(relpos_attn_kernel, dim3(b_outer * p.b_inner, p.heads), dim3(256), lds, s, p);
-  return hipGetLastError();
-}
+hipError_t t2v_launch_relpos_attention(const t2v_op& op, hipStream_t s) { return launch_seqattn<true>(op, s); }
 
 hipError_t t2v_launch_softmax(const t2v_op& op, hipStream_t s) {
   hipLaunchKernelGGL(softmax_rows_kernel, dim3(op.i[0]), dim3(256), 0, s,

@@ -26,8 +26,6 @@
 
 namespace {
 
-typedef float f32x8 __attribute__((ext_vector_type(8)));
-
 // 8 consecutive channels of one token row as fp32 (one 16-byte load for fp16, two for fp32)
 template <typename T> struct Load8;
 template <> struct Load8<float> {

@@ -10,6 +10,7 @@ typedef _Float16 f16;
 typedef f16 f16x4 __attribute__((ext_vector_type(4)));
 typedef f16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct GemmParams {
