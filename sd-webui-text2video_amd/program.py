@@ -44,6 +44,7 @@ class Buf:
     ld: int
     dtype: str
     alloc_off: int = -1   # arena allocation this view belongs to (for free())
+    owns: bool = True     # False: a borrowed window of another buffer — free() ignores it
 
     @property
     def item(self) -> int:
@@ -51,6 +52,12 @@ class Buf:
 
     def col_slice(self, c0: int, c1: int) -> "Buf":
         return Buf(self.ref.shifted(c0 * self.item), self.rows, c1 - c0, self.ld, self.dtype, self.alloc_off)
+
+    def borrow_cols(self, c0: int, c1: int) -> "Buf":
+        """Non-owning column window (a producer writes half of a concat buffer in place)."""
+        b = self.col_slice(c0, c1)
+        b.owns = False
+        return b
 
     def row_slice(self, r0: int, r1: int) -> "Buf":
         return Buf(self.ref.shifted(r0 * self.ld * self.item), r1 - r0, self.cols, self.ld, self.dtype, self.alloc_off)
@@ -130,7 +137,7 @@ class Program:
 
     def free(self, *bufs: Buf):
         for b in bufs:
-            if b is None or b.alloc_off < 0:
+            if b is None or b.alloc_off < 0 or not b.owns:
                 continue
             if self.keep_taps and any(t.alloc_off == b.alloc_off for t in self.taps.values()):
                 continue

@@ -464,12 +464,14 @@ class _Lowering:
         return out
 
     def conv3(self, name, a: Buf, key, cout, h, w, *, stride=1, up=0, out_dtype="f32", rowbias=None,
-              residual=None, cin=None) -> Buf:
+              residual=None, cin=None, dest: Optional[Buf] = None) -> Buf:
+        """`dest`: write the result into this (sub-)buffer instead of a fresh allocation — the producers of the two
+        halves of a skip-connection concat write straight into the concat buffer (no copy ops)."""
         cin = a.cols if cin is None else cin
         ho, wo = (h * 2, w * 2) if up else ((h + 1) // 2 if stride == 2 else h, (w + 1) // 2 if stride == 2 else w)
         Mo = self.B * self.F * ho * wo
         n = (cout + 3) // 4 * 4
-        out = self.P.alloc(Mo, n, out_dtype)
+        out = self._dest(dest, Mo, n, out_dtype)
         gather = L.GATHER_CONV3X3_C8 if cin == 8 else L.GATHER_CONV3X3
         self.P.gemm(name, a, self.w_conv3(key, 8 if cin == 8 else 0), n, 9 * cin, out, bias=self.vec(key + ".bias"),
                     gather=gather, conv=dict(Hin=h, Win=w, Cin=cin, stride=stride, up=up, Hout=ho, Wout=wo),
@@ -477,7 +479,13 @@ class _Lowering:
                     residual=residual)
         return out
 
-    def res_block(self, prefix, x: Buf, cin, cout, h, w) -> Buf:
+    def _dest(self, dest: Optional[Buf], rows, cols, dtype) -> Buf:
+        if dest is None:
+            return self.P.alloc(rows, cols, dtype)
+        assert (dest.rows, dest.cols, dest.dtype) == (rows, cols, dtype), (dest, rows, cols, dtype)
+        return dest
+
+    def res_block(self, prefix, x: Buf, cin, cout, h, w, dest: Optional[Buf] = None) -> Buf:
         P = self.P
         a = self.gn(prefix + ".in_layers.0", x, prefix + ".in_layers.0", per_frame=True, eps=1e-5, silu=True)
         e0, e1 = self.emb_slices[prefix]
@@ -520,7 +528,7 @@ class _Lowering:
                 P.collective(f"{tp}.{name}.halo", "halo", buf=nrm, frame_rows=hwp, frames=self.F)
             if t is not h2:
                 P.free(t)
-            t = P.alloc(h2.rows, cout, "f32" if name == "conv4" else self.net.norm_input_dtype)
+            t = self._dest(dest, h2.rows, cout, "f32") if name == "conv4" else P.alloc(h2.rows, cout, self.net.norm_input_dtype)
             key = f"{tp}.{name}.{idx}"
             P.gemm(key, nrm, self.w_tconv(key), cout, 3 * cout, t, bias=self.vec(key + ".bias"),
                    gather=L.GATHER_TCONV3, conv=dict(F=self.F, HW=h * w, Cin=cout),
@@ -623,7 +631,7 @@ class _Lowering:
         P.free(g, x3)
         return x4
 
-    def spatial_transformer(self, prefix, x: Buf, c, h, w) -> Buf:
+    def spatial_transformer(self, prefix, x: Buf, c, h, w, dest: Optional[Buf] = None) -> Buf:
         P = self.P
         heads = c // 64
         n = self.gn(prefix + ".norm", x, prefix + ".norm", per_frame=True, eps=1e-6, silu=False)
@@ -631,13 +639,13 @@ class _Lowering:
         P.gemm(prefix + ".proj_in", n, self.w_linear(prefix + ".proj_in"), c, c, x1, bias=self.vec(prefix + ".proj_in.bias"))
         P.free(n)
         x4 = self.transformer_block(prefix + ".transformer_blocks.0", x1, c, heads, "spatial", h, w)
-        out = P.alloc(x.rows, c, "f32")
+        out = self._dest(dest, x.rows, c, "f32")
         P.gemm(prefix + ".proj_out", x4, self.w_linear(prefix + ".proj_out"), c, c, out,
                bias=self.vec(prefix + ".proj_out.bias"), residual=x)
         P.free(x4)
         return out
 
-    def temporal_transformer(self, prefix, x: Buf, c, heads, h, w) -> Buf:
+    def temporal_transformer(self, prefix, x: Buf, c, heads, h, w, dest: Optional[Buf] = None) -> Buf:
         P = self.P
         inner = heads * 64
         n = self.gn(prefix + ".norm", x, prefix + ".norm", per_frame=False, eps=1e-6, silu=False)
@@ -645,17 +653,17 @@ class _Lowering:
         P.gemm(prefix + ".proj_in", n, self.w_linear(prefix + ".proj_in"), inner, c, x1, bias=self.vec(prefix + ".proj_in.bias"))
         P.free(n)
         x4 = self.transformer_block(prefix + ".transformer_blocks.0", x1, inner, heads, "temporal", h, w)
-        out = P.alloc(x.rows, c, "f32")
+        out = self._dest(dest, x.rows, c, "f32")
         P.gemm(prefix + ".proj_out", x4, self.w_linear(prefix + ".proj_out"), c, inner, out,
                bias=self.vec(prefix + ".proj_out.bias"), residual=x)
         P.free(x4)
         return out
 
-    def resample(self, prefix, attr, x: Buf, c, h, w, *, up) -> Buf:
+    def resample(self, prefix, attr, x: Buf, c, h, w, *, up, dest: Optional[Buf] = None) -> Buf:
         P = self.P
         x16 = P.alloc(x.rows, c, "f16")
         P.copy2d(prefix + ".cast", x, x16)
-        out = self.conv3(f"{prefix}.{attr}", x16, f"{prefix}.{attr}", c, h, w, stride=1 if up else 2, up=1 if up else 0)
+        out = self.conv3(f"{prefix}.{attr}", x16, f"{prefix}.{attr}", c, h, w, stride=1 if up else 2, up=1 if up else 0, dest=dest)
         P.free(x16)
         return out
 
@@ -720,47 +728,60 @@ class _Lowering:
         xin = P.alloc(self.M(h, w), 8, "f16")
         P.ncthw_to_cl("x.to_tokens", Ref("ext", L.EXT_X), self.x_dt, xin, B=B, C=net.in_dim, F=F, HW=h * w)
 
-        def run_parts(prefix, parts, bare, x, h, w):
+        def run_parts(prefix, parts, bare, x, h, w, dest=None):
             for i, (kind, cin, cout) in enumerate(parts):
                 p = prefix if bare else f"{prefix}.{i}"
+                d = dest if i == len(parts) - 1 else None         # the block's result goes straight into a concat buffer
                 if kind == "stem":
-                    y = self.conv3(p, x, p, cout, h, w, cin=8)
+                    y = self.conv3(p, x, p, cout, h, w, cin=8, dest=d)
                 elif kind == "res":
-                    y = self.res_block(p, x, cin, cout, h, w)
+                    y = self.res_block(p, x, cin, cout, h, w, dest=d)
                 elif kind == "st":
-                    y = self.spatial_transformer(p, x, cout, h, w)
+                    y = self.spatial_transformer(p, x, cout, h, w, dest=d)
                 elif kind == "tt":
                     heads = net.num_heads if p == "input_blocks.0.1" else cout // 64
-                    y = self.temporal_transformer(p, x, cout, heads, h, w)
+                    y = self.temporal_transformer(p, x, cout, heads, h, w, dest=d)
                 elif kind == "down":
-                    y = self.resample(p, "op", x, cout, h, w, up=False)
+                    y = self.resample(p, "op", x, cout, h, w, up=False, dest=d)
                     h, w = (h + 1) // 2, (w + 1) // 2
                 elif kind == "up":
-                    y = self.resample(p, "conv", x, cout, h, w, up=True)
+                    y = self.resample(p, "conv", x, cout, h, w, up=True, dest=d)
                     h, w = h * 2, w * 2
                 else:
                     raise ValueError(kind)
                 P.tap(p, y)
-                if not any(x is sk for sk in skips):
-                    P.free(x)
+                P.free(x)              # borrowed windows of a concat buffer are ignored by free()
                 x = y
             return x, h, w
 
-        skips: List[Buf] = []
+        def out_hw(parts, h, w):
+            for kind, _, _ in parts:
+                if kind == "down":
+                    h, w = (h + 1) // 2, (w + 1) // 2
+                elif kind == "up":
+                    h, w = h * 2, w * 2
+            return h, w
+
+        # Skip connections (t2v_model.py:447-452 `torch.cat([x, xs.pop()], dim=1)`): the concat buffer of decoder block j
+        # is allocated when its encoder half is produced; encoder block k writes the right window, the op that produces
+        # the decoder stream (middle block / previous decoder block) writes the left one — no copy kernels.
+        n_skip = len(inputs)
+        cats: List[Buf] = []
         x = xin
-        for prefix, parts, bare in inputs:
-            x, h, w = run_parts(prefix, parts, bare, x, h, w)
-            skips.append(x)
-        x, h, w = run_parts("middle_block", middle, False, x, h, w)
-        for prefix, parts, bare in outputs:
-            s = skips.pop()
-            cat = P.alloc(x.rows, x.cols + s.cols, "f32")
-            P.copy2d(prefix + ".cat.x", x, cat.col_slice(0, x.cols))
-            P.copy2d(prefix + ".cat.skip", s, cat.col_slice(x.cols, x.cols + s.cols))
-            if x is not s:
-                P.free(x)
-            P.free(s)
-            x, h, w = run_parts(prefix, parts, bare, cat, h, w)
+        for k, (prefix, parts, bare) in enumerate(inputs):
+            sc = parts[-1][2]
+            cin_total = outputs[n_skip - 1 - k][1][0][1]            # input channels of the consuming decoder ResBlock
+            ho, wo = out_hw(parts, h, w)
+            cat = P.alloc(self.M(ho, wo), cin_total, "f32")
+            cats.append(cat)
+            x, h, w = run_parts(prefix, parts, bare, x, h, w, dest=cat.borrow_cols(cin_total - sc, cin_total))
+        cat = cats.pop()
+        x, h, w = run_parts("middle_block", middle, False, x, h, w, dest=cat.borrow_cols(0, cat.cols - inputs[-1][1][-1][2]))
+        for j, (prefix, parts, bare) in enumerate(outputs):
+            nxt = cats.pop() if cats else None
+            dest = nxt.borrow_cols(0, nxt.cols - inputs[n_skip - 2 - j][1][-1][2]) if nxt is not None else None
+            x, h, w = run_parts(prefix, parts, bare, cat, h, w, dest=dest)
+            cat = nxt
 
         # ---- head: GN + SiLU + conv 3x3 -> out_dim, then tokens -> b c f h w
         a = self.gn("out.0", x, "out.0", per_frame=True, eps=1e-5, silu=True)

@@ -249,18 +249,19 @@ class _LvdmLowering(_Lowering):
     def table(self, key) -> Ref:
         return Ref("weight", 0, self.packer.add(key + ":tab", "f32", lambda sd, k=key: sd[k]))
 
-    def conv133(self, name, a: Buf, key, cout, h, w, *, stride=1, up=0, out_dtype="f32", rowbias=None, residual=None, cin=None) -> Buf:
+    def conv133(self, name, a: Buf, key, cout, h, w, *, stride=1, up=0, out_dtype="f32", rowbias=None, residual=None, cin=None,
+                dest: Optional[Buf] = None) -> Buf:
         cin = a.cols if cin is None else cin
         ho, wo = (h * 2, w * 2) if up else ((h + 1) // 2 if stride == 2 else h, (w + 1) // 2 if stride == 2 else w)
         n = (cout + 3) // 4 * 4
-        out = self.P.alloc(self.B * self.F * ho * wo, n, out_dtype)
+        out = self._dest(dest, self.B * self.F * ho * wo, n, out_dtype)
         gather = L.GATHER_CONV3X3_C8 if cin == 8 else L.GATHER_CONV3X3
         self.P.gemm(name, a, self.w_conv133(key, 8 if cin == 8 else 0), n, 9 * cin, out, bias=self.vec(key + ".bias"),
                     gather=gather, conv=dict(Hin=h, Win=w, Cin=cin, stride=stride, up=up, Hout=ho, Wout=wo),
                     rowbias=rowbias, rows_per_batch=self.F * ho * wo if rowbias is not None else 0, residual=residual)
         return out
 
-    def res_block(self, prefix, x: Buf, cin, cout, h, w) -> Buf:
+    def res_block(self, prefix, x: Buf, cin, cout, h, w, dest: Optional[Buf] = None) -> Buf:
         """ResBlock._forward (openaimodel3d.py:244-271): GroupNorm32 statistics span all frames of a sample."""
         P = self.P
         a = self.gn(prefix + ".in_layers.0", x, prefix + ".in_layers.0", per_frame=False, eps=1e-5, silu=True)
@@ -279,13 +280,13 @@ class _LvdmLowering(_Lowering):
             P.free(x16)
         else:
             skip = x
-        out = self.conv133(prefix + ".out_layers.3", b, prefix + ".out_layers.3", cout, h, w, residual=skip)
+        out = self.conv133(prefix + ".out_layers.3", b, prefix + ".out_layers.3", cout, h, w, residual=skip, dest=dest)
         P.free(b)
         if skip is not x:
             P.free(skip)
         return out
 
-    def st_transformer(self, prefix, x: Buf, c, h, w) -> Buf:
+    def st_transformer(self, prefix, x: Buf, c, h, w, dest: Optional[Buf] = None) -> Buf:
         """SpatialTemporalTransformer.forward + BasicTransformerBlockST._forward (attention_temporal.py:301-335,
         386-399): s-self, t-self (rel-pos), s-cross (text), t-self (rel-pos), GEGLU feed-forward."""
         P, net, B, F, hw = self.P, self.net, self.B, self.F, h * w
@@ -357,7 +358,7 @@ class _LvdmLowering(_Lowering):
         x4 = P.alloc(M, c, "f16")
         P.gemm(f"{tb}.ff.net.2", g, self.w_linear(f"{tb}.ff.net.2"), c, 4 * c, x4, bias=self.vec(f"{tb}.ff.net.2.bias"), residual=cur)
         P.free(g, cur)
-        out = P.alloc(M, c, "f32")
+        out = self._dest(dest, M, c, "f32")
         P.gemm(prefix + ".proj_out", x4, self.w_linear(prefix + ".proj_out"), c, c, out, bias=self.vec(prefix + ".proj_out.bias"),
                residual=x)
         P.free(x4)
@@ -415,46 +416,57 @@ class _LvdmLowering(_Lowering):
         xin = P.alloc(self.M(h, w), 8, "f16")
         P.ncthw_to_cl("x.to_tokens", Ref("ext", L.EXT_X), self.x_dt, xin, B=B, C=net.in_dim, F=F, HW=h * w)
 
-        def run_parts(prefix, parts, x, h, w, keep):
+        def run_parts(prefix, parts, x, h, w, dest=None):
             for j, (kind, cin, cout) in enumerate(parts):
                 p = f"{prefix}.{j}"
+                d = dest if j == len(parts) - 1 else None
                 if kind == "stem":
-                    y = self.conv133(p, x, p, cout, h, w, cin=8)
+                    y = self.conv133(p, x, p, cout, h, w, cin=8, dest=d)
                 elif kind == "res":
-                    y = self.res_block(p, x, cin, cout, h, w)
+                    y = self.res_block(p, x, cin, cout, h, w, dest=d)
                 elif kind == "st":
-                    y = self.st_transformer(p, x, cout, h, w)
+                    y = self.st_transformer(p, x, cout, h, w, dest=d)
                 elif kind in ("down", "up"):
                     x16 = P.alloc(x.rows, cin, "f16")
                     P.copy2d(p + ".cast", x, x16)
                     attr = "op" if kind == "down" else "conv"
                     y = self.conv133(f"{p}.{attr}", x16, f"{p}.{attr}", cout, h, w, stride=2 if kind == "down" else 1,
-                                     up=1 if kind == "up" else 0)
+                                     up=1 if kind == "up" else 0, dest=d)
                     P.free(x16)
                     h, w = ((h + 1) // 2, (w + 1) // 2) if kind == "down" else (h * 2, w * 2)
                 else:
                     raise ValueError(kind)
                 P.tap(p, y)
-                if not any(x is s for s in keep):
-                    P.free(x)
+                P.free(x)              # borrowed windows of a concat buffer are ignored by free()
                 x = y
             return x, h, w
 
-        skips: List[Buf] = []
+        def out_hw(parts, h, w):
+            for kind, _, _ in parts:
+                if kind == "down":
+                    h, w = (h + 1) // 2, (w + 1) // 2
+                elif kind == "up":
+                    h, w = h * 2, w * 2
+            return h, w
+
+        # `th.cat([h, hs.pop()], dim=1)` (openaimodel3d.py:665): both halves are written in place by their producers
+        n_skip = len(inputs)
+        cats: List[Buf] = []
         x = xin
-        for prefix, parts in inputs:
-            x, h, w = run_parts(prefix, parts, x, h, w, skips)
-            skips.append(x)
-        x, h, w = run_parts("middle_block", middle, x, h, w, skips)
-        for prefix, parts in outputs:
-            s = skips.pop()
-            cat = P.alloc(x.rows, x.cols + s.cols, "f32")
-            P.copy2d(prefix + ".cat.x", x, cat.col_slice(0, x.cols))
-            P.copy2d(prefix + ".cat.skip", s, cat.col_slice(x.cols, x.cols + s.cols))
-            if x is not s:
-                P.free(x)
-            P.free(s)
-            x, h, w = run_parts(prefix, parts, cat, h, w, skips)
+        for k, (prefix, parts) in enumerate(inputs):
+            sc = parts[-1][2]
+            cin_total = outputs[n_skip - 1 - k][1][0][1]
+            ho, wo = out_hw(parts, h, w)
+            cat = P.alloc(self.M(ho, wo), cin_total, "f32")
+            cats.append(cat)
+            x, h, w = run_parts(prefix, parts, x, h, w, dest=cat.borrow_cols(cin_total - sc, cin_total))
+        cat = cats.pop()
+        x, h, w = run_parts("middle_block", middle, x, h, w, dest=cat.borrow_cols(0, cat.cols - inputs[-1][1][-1][2]))
+        for j, (prefix, parts) in enumerate(outputs):
+            nxt = cats.pop() if cats else None
+            dest = nxt.borrow_cols(0, nxt.cols - inputs[n_skip - 2 - j][1][-1][2]) if nxt is not None else None
+            x, h, w = run_parts(prefix, parts, cat, h, w, dest=dest)
+            cat = nxt
 
         a = self.gn("out.0", x, "out.0", per_frame=False, eps=1e-5, silu=True)
         P.free(x)
