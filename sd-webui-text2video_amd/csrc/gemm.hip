@@ -256,6 +256,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmParams p) 
   }
 
   // ---- epilogue: lane holds token (lane & 31), channels 8q + 4*(lane>>5) + {0..3} -------
+  if (p.epi == T2V_EPI_NONE) {      // row-coalesced through a per-wave LDS buffer (t2v_kernels.h); also the split-K slabs
+    __syncthreads();                // every wave is done reading the operand stages
+    t2v_epilogue_rows<TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wave * (32 * T2V_EPI_SP), lane, m0 + wm * TM * 32,
+                              n0 + wn * TN * 32, blockIdx.y);
+    return;
+  }
   const int mlane = lane & 31, nhalf = (lane >> 5) * 4;
 #pragma unroll
   for (int a = 0; a < TM; ++a) {

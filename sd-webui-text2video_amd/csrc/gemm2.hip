@@ -407,6 +407,12 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm2_kernel(const GemmPar
   wait_vmcnt<0>();   // drain the zero-page loads of the dead stages before the LDS goes away
 
   // ---- epilogue ---------------------------------------------------------------------------------
+  if (p.epi == T2V_EPI_NONE) {      // row-coalesced through a per-wave LDS buffer (t2v_kernels.h); also the split-K slabs
+    __builtin_amdgcn_s_barrier();   // every wave is done reading the operand stages
+    t2v_epilogue_rows<TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wave * (32 * T2V_EPI_SP), lane, m0 + wm * TM * 32,
+                              n0 + wn * TN * 32, blockIdx.y);
+    return;
+  }
   const int mlane = lane & 31, nhalf = (lane >> 5) * 4;
 #pragma unroll
   for (int a = 0; a < TM; ++a) {
