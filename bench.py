@@ -163,8 +163,8 @@ def main():
     ap.add_argument("--width", type=int, default=256)
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--parallel", default="auto", choices=["auto", "pairs", "tshard"],
-                    help="N>1 layout: independent CFG pairs, or one T-sharded video (N>=4)")
+    ap.add_argument("--parallel", default="auto", choices=["auto", "replicas", "pairs", "tshard"],
+                    help="N>1 layout: one video per GPU (default), one video per CFG pair, or one T-sharded video (N>=4)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_worker:
@@ -275,7 +275,7 @@ def main():
             "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 --pmc, profiles/r01_pmc_traffic.json)",
             "algorithmic_bytes_per_launch": round(alg_bytes / n_gemm),
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:       # the CPU leg is reported at N=1 only
             result["cpu_baseline"] = cpu_baseline(args.frames, args.ddim_steps)
         print(json.dumps(result), flush=True)
     if world > 1:

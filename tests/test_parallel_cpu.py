@@ -89,7 +89,12 @@ def test_two_cfg_pairs_gloo_world4():
     assert dict(ret) == {0: 1, 1: 1, 2: 1, 3: 1}
 
 
-def test_make_runner_default_is_pairs():
-    import inspect
-    src = inspect.getsource(parallel.make_runner)
-    assert 'mode = "pairs"' in src          # T-sharding is opt-in until measured on a multi-GPU node
+def test_make_runner_default_layouts():
+    """N > 1 defaults to independent videos per GPU (no data-path collective); pairs / tshard are explicit choices."""
+    class Pipe:          # the runner only stores it
+        pass
+    kw = dict(frames=24, height=256, width=256, ddim_steps=50, guidance=9.0)
+    r = parallel.make_runner(Pipe(), 8, 3, **kw)
+    assert isinstance(r, parallel._ReplicaRunner) and r.frames_per_video_all_ranks == 24 * 8 and r.unet_batch == 2
+    r1 = parallel.make_runner(Pipe(), 1, 0, **kw)
+    assert type(r1) is parallel._Runner and r1.frames_per_video_all_ranks == 24 and r1.unet_batch == 2
