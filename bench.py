@@ -264,7 +264,7 @@ def main():
         step_ms = sum(ms)
         achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12
         result["roofline"] = {
-            "bound": "mfma", "kernel": "gemm_kernel<BM,BN,WM,WN,GATHER> (implicit-GEMM conv3x3 / temporal conv / linear)",
+            "bound": "mfma", "kernel": "gemm2_kernel<WM,WN,TM,TN,BK,STAGES,MINW,GATHER,PP> + gemm_kernel<BM,BN,WM,WN,GATHER> (one implicit-GEMM family: conv3x3 / temporal conv / linear)",
             "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
             "traffic": pmc_traffic(),
             "launches_per_unet_step": n_gemm, "avg_launch_us": round(gemm_ms / n_gemm * 1e3, 2),
