@@ -71,12 +71,36 @@ def geglu_perm(n_half: int, device=None) -> torch.Tensor:
     return (g * n_half + 8 * u + j).reshape(-1)
 
 
+class _ReadLog:
+    """Read-only view of a state dict that notes which keys a recipe touches."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor]):
+        self.sd, self.read = sd, set()
+
+    def __getitem__(self, k):
+        self.read.add(k)
+        return self.sd[k]
+
+    def __contains__(self, k):
+        self.read.add(k)
+        return k in self.sd
+
+    def get(self, k, default=None):
+        self.read.add(k)
+        return self.sd.get(k, default)
+
+
 class WeightPacker:
-    """Collects (name -> recipe) pairs during lowering and materialises them on a device."""
+    """Collects (name -> recipe) pairs during lowering and materialises them on a device.
+    `materialise` packs everything and learns which state-dict keys each recipe reads; `update` re-packs, in
+    place, only the images that depend on changed keys — the LoRA merge of the reference
+    (scripts/stable_lora/stable_utils/lora_processor.py:202-246) rewrites some hundred attention / conv weights
+    out of ~2600 tensors, and the device addresses bound into the denoise programs stay valid."""
 
     def __init__(self):
         self.recipes: List[Tuple[str, str, Recipe]] = []   # (name, 'f16'|'f32', fn)
         self._names = set()
+        self.deps: Dict[str, frozenset] = {}                # packed name -> state-dict keys its recipe read
 
     def add(self, name: str, dtype: str, fn: Recipe) -> str:
         if name not in self._names:
@@ -84,9 +108,35 @@ class WeightPacker:
             self.recipes.append((name, dtype, fn))
         return name
 
+    @staticmethod
+    def _cast(t: torch.Tensor, dtype: str, device) -> torch.Tensor:
+        return _f16(t, device) if dtype == "f16" else _f32(t, device)
+
     def materialise(self, sd: Dict[str, torch.Tensor], device) -> Dict[str, torch.Tensor]:
         out = {}
         for name, dtype, fn in self.recipes:
-            t = fn(sd)
-            out[name] = _f16(t, device) if dtype == "f16" else _f32(t, device)
+            log = _ReadLog(sd)
+            out[name] = self._cast(fn(log), dtype, device)
+            self.deps[name] = frozenset(log.read)
         return out
+
+    def update(self, packed: Dict[str, torch.Tensor], sd: Dict[str, torch.Tensor], device, changed, deps=None) -> int:
+        """Re-pack the images whose recipes read any key in `changed`, writing through the existing device
+        tensors.  `deps` = the key sets learnt by the `materialise` that produced `packed` (default: this
+        packer's own).  Returns the number of images rewritten, or -1 if an image or its key set is missing, or
+        its shape changed (the caller then falls back to `materialise` and re-binds its programs)."""
+        changed = set(changed)
+        deps = self.deps if deps is None else deps
+        todo = [(n, d, f) for n, d, f in self.recipes if n not in deps or (deps[n] & changed)]
+        for name, dtype, fn in todo:
+            if name not in packed or name not in deps:
+                return -1
+        fresh = []
+        for name, dtype, fn in todo:
+            t = self._cast(fn(sd), dtype, device)
+            if t.shape != packed[name].shape:
+                return -1
+            fresh.append((name, t))
+        for name, t in fresh:
+            packed[name].copy_(t)
+        return len(fresh)

@@ -214,6 +214,8 @@ class UNetSD(nn.Module):
         self._packed: Optional[Dict[str, torch.Tensor]] = None
         self._packed_sig = None
         self._packed_device = None
+        self._packed_deps = None
+        self.last_repack = None       # images rewritten by the last refresh_weights (-1 = full pack)
         self.debug_taps = False
         # Storage type of tensors that are consumed ONLY by a GroupNorm (ResBlock's first conv output
         # and the three inner temporal-conv outputs): "f16" halves their HBM traffic (what the
@@ -284,7 +286,7 @@ class UNetSD(nn.Module):
 
     # ---- weights --------------------------------------------------------------------------
     def _param_signature(self):
-        return tuple((id(p), p._version, p.device.type, p.dtype) for p in self.parameters())
+        return {n: (id(p), p._version, p.device.type, p.dtype, tuple(p.shape)) for n, p in self.named_parameters()}
 
     def invalidate(self):
         """Drop the packed weight images (call after mutating parameters in place)."""
@@ -292,24 +294,44 @@ class UNetSD(nn.Module):
         self._packed_sig = None
 
     def refresh_weights(self, device=None):
-        """(Re)pack weights if any parameter object / version changed since the last pack."""
+        """(Re)pack weights if any parameter object / version changed since the last pack.  When only some
+        parameters changed (the LoRA merge / un-merge of lora_processor.py:202-246 replaces `.weight` of the
+        matched Linear / Conv modules), only the packed images that read them are rewritten, in place
+        (`last_repack` = number of images, -1 for a full pack)."""
         device = torch.device(device) if device is not None else self._packed_device
         if device is None:
             return
         sig = self._param_signature()
-        if self._packed is not None and sig == self._packed_sig and device == self._packed_device:
+        same_dev = self._packed is not None and device == self._packed_device
+        if same_dev and sig == self._packed_sig:
             return
         comp = self._get_compiled_any()
         sd = {k: v for k, v in self.state_dict().items()}
+        if same_dev and sig.keys() == self._packed_sig.keys():
+            changed = [n for n, v in sig.items() if self._packed_sig[n] != v]
+            n = comp.packer.update(self._packed, sd, device, changed, deps=self._packed_deps)
+            if n >= 0:
+                self._packed_sig, self.last_repack = sig, n
+                return
+        elif same_dev:
+            extra = sorted(set(sig) - set(self._packed_sig))
+            if extra:
+                # e.g. a LoRA file with bias terms for bias-free projections (lora_processor.py:219-222): the
+                # compiled programs have no slot for them; refuse rather than silently ignore
+                raise L.T2VError("parameters were added after the denoise programs were built: "
+                                 f"{extra[:4]}{' ...' if len(extra) > 4 else ''} — not supported")
         self._packed = comp.packer.materialise(sd, device)
-        self._packed_sig, self._packed_device = sig, device
+        self._packed_deps = dict(comp.packer.deps)
+        self._packed_sig, self._packed_device, self.last_repack = sig, device, -1
         for c in self._programs.values():
             c.bound = None
 
     def _get_compiled_any(self):
         if self._programs:
             return next(iter(self._programs.values()))
-        return self._compile(1, 1, 8, 8, 77, "f32", "f32")
+        key = (1, 1, 8, 8, 77, "f32", "f32", "f32")          # same layout as forward()'s keys
+        self._programs[key] = self._compile(1, 1, 8, 8, 77, "f32", "f32")
+        return self._programs[key]
 
     # ---- forward --------------------------------------------------------------------------
     def forward(self, x, t, y, fps=None, video_mask=None, focus_present_mask=None, prob_focus_present=0.0,

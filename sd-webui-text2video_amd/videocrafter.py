@@ -226,11 +226,6 @@ class UNetModel(UNetSD):
             raise NotImplementedError("time_emb_replace / adapter features / class labels are not on the hot path")
         return UNetSD.forward(self, x, timesteps, context)
 
-    def _get_compiled_any(self):
-        if self._programs:
-            return next(iter(self._programs.values()))
-        return self._compile(1, 1, 8, 8, 77, "f32", "f32")
-
     def _compile(self, B, F, H, W, Lctx, x_dt, out_dt, ctx_dt="f32", shard=None):
         if shard is not None:
             raise NotImplementedError("T-sharding of the LVDM UNet")

@@ -106,6 +106,36 @@ def test_weight_mutation_is_picked_up(tiny):
     assert torch.equal(a, c)
 
 
+def test_lora_merge_and_unmerge_repack_in_place(tiny):
+    """§8(f)-4: the reference's LoRA merge replaces `.weight` Parameters (lora_processor.py:202-246).  Only the
+    touched packed images are rewritten (same device addresses, programs stay bound), the forward equals the
+    oracle on the merged weights, and the un-merge restores the original output bit for bit."""
+    net, sd, _ = tiny
+    x, t, y, *_ = _tiny_inputs()
+    base = net(x.to(DEV), t.to(DEV), y.to(DEV)).float().cpu()
+    ptrs = {k: v.data_ptr() for k, v in net._packed.items()}
+    g = torch.Generator().manual_seed(3)
+    saved = {}
+    for name, mod in net.named_modules():
+        if isinstance(mod, torch.nn.Linear) and name.endswith(("attn1.to_q", "attn2.to_k", "attn2.to_v", "attn1.to_out.0")):
+            a = torch.randn(4, mod.weight.shape[1], generator=g) * 0.2
+            b = torch.randn(mod.weight.shape[0], 4, generator=g) * 0.2
+            saved[name] = mod.weight
+            mod.weight = torch.nn.Parameter(mod.weight.detach() + 0.5 * (b @ a))
+    merged = net(x.to(DEV), t.to(DEV), y.to(DEV)).float().cpu()
+    assert 0 < net.last_repack < len(ptrs) // 2
+    assert {k: v.data_ptr() for k, v in net._packed.items()} == ptrs
+    ref = tp.unet_forward({k: v.detach() for k, v in net.state_dict().items()}, configs.TINY_UNET, x, t, y)
+    assert rel_l2(merged, ref) < 4e-3
+    assert rel_l2(merged, base) > 1e-2
+    for name, mod in net.named_modules():
+        if name in saved:
+            mod.weight = saved[name]
+    again = net(x.to(DEV), t.to(DEV), y.to(DEV)).float().cpu()
+    assert 0 < net.last_repack < len(ptrs) // 2
+    assert torch.equal(again, base)
+
+
 def test_tiny_sampler_matches_reference_golden(tiny):
     net, sd, betas = tiny
     *_, c, uc = _tiny_inputs()

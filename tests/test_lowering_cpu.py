@@ -143,3 +143,47 @@ def test_ddim_step_op_matches_reference_update():
     out = torch.empty(1, C, inner)
     Interp(prog, {}).run({L.EXT_XT: xt, L.EXT_EPS: eps, L.EXT_XT_OUT: out})
     assert rel_l2(out.view(-1), out_ref.reshape(-1)) < 1e-6
+
+
+def test_lora_style_merge_repacks_only_the_touched_images():
+    """§8(f)-4: the reference's LoRA processor replaces `.weight` of matched Linear / Conv2d / Conv3d modules
+    (lora_processor.py:202-246: `m.weight = Parameter(W + alpha * B @ A)`).  refresh_weights must rewrite, in
+    place, exactly the packed images that read those tensors and leave the same bytes as a full pack."""
+    cfg, m, sd, x, t, y = _tiny()
+    m.refresh_weights("cpu")
+    assert m.last_repack == -1
+    n_images = len(m._packed)
+    ptrs = {k: v.data_ptr() for k, v in m._packed.items()}
+    m.refresh_weights("cpu")                                  # nothing changed: no work
+    assert m.last_repack == -1
+
+    g = torch.Generator().manual_seed(11)
+    touched = []
+    for name, mod in m.named_modules():
+        if isinstance(mod, torch.nn.Linear) and name.endswith(("attn1.to_q", "attn2.to_v")):
+            r = 2
+            a = torch.randn(r, mod.weight.shape[1], generator=g) * 0.1
+            b = torch.randn(mod.weight.shape[0], r, generator=g) * 0.1
+            mod.weight = torch.nn.Parameter(mod.weight.detach() + 0.7 * (b @ a))      # new Parameter object
+            touched.append(name)
+        if isinstance(mod, torch.nn.Conv3d) and name.endswith("temopral_conv.conv2.3"):
+            with torch.no_grad():
+                mod.weight.add_(0.01)                                               # in-place version bump
+            touched.append(name)
+    assert touched
+    m.refresh_weights("cpu")
+    assert 0 < m.last_repack < n_images // 2, (m.last_repack, n_images)
+    assert {k: v.data_ptr() for k, v in m._packed.items()} == ptrs          # bound programs stay valid
+
+    comp = m._get_compiled_any()
+    full = comp.packer.materialise(m.state_dict(), "cpu")
+    assert full.keys() == m._packed.keys()
+    for k in full:
+        assert torch.equal(full[k], m._packed[k]), k
+
+    # a parameter that appears after the programs were built cannot be honoured: fail loudly
+    some = next(mod for n, mod in m.named_modules() if n.endswith("attn1.to_k"))
+    some.bias = torch.nn.Parameter(torch.zeros(some.weight.shape[0]))
+    import pytest
+    with pytest.raises(L.T2VError):
+        m.refresh_weights("cpu")
