@@ -50,7 +50,8 @@ enum t2v_op_kind {
   T2V_OP_MEMSET = 11,     /* zero a byte range                                              */
   T2V_OP_LINCOMB = 12,    /* out = sum_i c_i * T_i (<= 6 latent-sized tensors): UniPC / DDIM updates */
   T2V_OP_RELPOS_ATTN = 13, /* LVDM temporal attention with relative-position K / V terms (frames <= 32) */
-  T2V_OP_KIND_MAX = 14
+  T2V_OP_EMBED_ROWS = 14,  /* token + positional embedding lookup (CLIP text towers) */
+  T2V_OP_KIND_MAX = 15
 };
 
 /* GEMM gather modes: how row m / reduction index k of the A operand are addressed          */
@@ -110,7 +111,7 @@ enum t2v_gather {
  * LAYERNORM: i: 0 M, 1 C, 2 ld_in, 3 ld_out; f: 0 eps; p: 0 x fp32, 1 gamma, 2 beta, 3 out fp16
  * ATTENTION: i: 0 nq, 1 nk, 2 heads, 3 batch_outer, 4 batch_inner, 5..7 q strides (seq,
  *      outer, inner), 8..10 k/v strides, 11..13 out strides (elements; head h at +head_dim*h),
- *      14 head_dim (0 = 64);  f: 0 scale; p: 0 q, 1 k, 2 v, 3 out (all fp16)
+ *      14 head_dim (0 = 64), 15 causal (1: key s visible to query t iff s <= t);  f: 0 scale; p: 0 q, 1 k, 2 v, 3 out (all fp16)
  * RELPOS_ATTN: i: as ATTENTION with nq == nk == frames (<= 32), 14 head_dim (multiple of 8, <= 256),
  *      15 max relative position R;  f: 0 scale;  p: 0 q, 1 k, 2 v, 3 out (fp16), 4 Ek fp32 [2R+1, head_dim],
  *      5 Ev fp32 [2R+1, head_dim]:  sim[t,s] = scale * q[t].(k[s] + Ek[clip(s-t)]),
@@ -119,7 +120,8 @@ enum t2v_gather {
  * NCTHW_TO_CL: i: 0 B, 1 C, 2 F, 3 HW, 4 ld_out, 5 in dtype; f: 0 scale; p: 0 in, 1 out fp16
  * CL_TO_NCTHW: i: 0 B, 1 C, 2 F, 3 HW, 4 ld_in, 5 out dtype; p: 0 in fp32, 1 out
  * TIME_EMBED: i: 0 B, 1 dim; p: 0 t fp32 [B], 1 freqs fp32 [dim/2], 2 out fp16 [B,dim]
- * COPY2D: i: 0 rows, 1 cols, 2 ld_src, 3 ld_dst, 4 src dtype, 5 dst dtype, 6 act; p: 0 src, 1 dst
+ * COPY2D: i: 0 rows, 1 cols, 2 ld_src, 3 ld_dst, 4 src dtype, 5 dst dtype, 6 act (0 none, 1 SiLU, 2 GELU(erf),
+ *      3 quick-GELU x*sigmoid(1.702x)); p: 0 src, 1 dst
  * DDIM_STEP: i: 0 C, 1 inner (F*h*w), 2 guided channels, 3 eps dtype, 4 x dtype, 5 mode;
  *      mode 0 (DDIM_Gaussian, gaussian_sampler.py:103-108,199-211,269-283):
  *        f: 0 sqrt_recip_ac, 1 sqrt_recipm1_ac, 2 sqrt(a_prev), 3 dir coef, 4 sigma (masked), 5 guidance scale
@@ -129,6 +131,8 @@ enum t2v_gather {
  * LINCOMB: i: 0 n elements, 1 n terms (<= 6), 2 out dtype, 3..8 term dtypes; f: 0..5 coefficients;
  *      p: 0..5 terms, 6 out
  * MEMSET: i: 0 bytes (lo), 1 bytes (hi); p: 0 dst
+ * EMBED_ROWS: out[r,:] = table[ids[r],:] + pos[r % L,:]   i: 0 rows, 1 width, 2 L, 3 vocab, 4 table dtype;
+ *      p: 0 ids int32 [rows], 1 table [vocab,width], 2 pos fp32 [L,width], 3 out fp32 [rows,width]
  */
 typedef struct t2v_op {
   int32_t kind;

@@ -32,6 +32,7 @@ struct AttnParams {
   long sk_seq, sk_out, sk_in;
   long so_seq, so_out, so_in;
   float scale_log2;
+  int causal;   // 1: key s is visible to query t only if s <= t (CLIP text towers)
 };
 
 constexpr int KT = 64;         // keys per LDS tile
@@ -80,6 +81,8 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
+  // last visible key of this lane's query; key 0 is visible to every query, so m_run is finite after the first tile
+  const int key_end = p.causal ? min(p.nk, qrow + 1) : p.nk;
 
   for (int kt0 = 0; kt0 < p.nk; kt0 += KT) {
     __syncthreads();  // previous tile fully consumed
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = kt0 + T * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
-        const float x = (key < p.nk) ? s[T][r] * p.scale_log2 : -INFINITY;
+        const float x = (key < key_end) ? s[T][r] * p.scale_log2 : -INFINITY;
         s[T][r] = x;
         mx = fmaxf(mx, x);
       }
@@ -433,6 +436,7 @@ hipError_t t2v_launch_attention(const t2v_op& op, hipStream_t s) {
   p.sk_seq = op.i[8]; p.sk_out = op.i[9]; p.sk_in = op.i[10];
   p.so_seq = op.i[11]; p.so_out = op.i[12]; p.so_in = op.i[13];
   p.scale_log2 = op.f[0] * 1.44269504088896340736f;
+  p.causal = op.i[15] != 0;
   if (p.nq <= 0 || p.nk <= 0) return hipErrorInvalidValue;
   const int nbatch = p.b_outer * p.b_inner;
   const int hd = op.i[14] > 0 ? op.i[14] : 64;

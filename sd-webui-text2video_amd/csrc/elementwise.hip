@@ -72,10 +72,29 @@ __global__ __launch_bounds__(256) void copy2d_kernel(const TS* src, TD* dst, int
     if (act == 1) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = t2v_silu(v[e]);
+    } else if (act == 2) {            // nn.GELU (erf): OpenCLIP ViT-H text MLP
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = t2v_gelu_erf(v[e]);
+    } else if (act == 3) {            // quick GELU x * sigmoid(1.702 x): OpenAI CLIP-L text MLP
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = v[e] / (1.0f + __expf(-1.702f * v[e]));
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) d[e] = (TD)v[e];
   }
+}
+
+// out[r, :] = table[ids[r], :] + pos[r % L, :]   (token + positional embedding of the CLIP text towers);
+// ids outside [0, vocab) write zeros + pos so that a bad token cannot read out of bounds
+template <typename TT>
+__global__ __launch_bounds__(256) void embed_rows_kernel(const int* ids, const TT* table, const float* pos, float* out,
+                                                         int rows, int W, int L, int vocab) {
+  const int r = blockIdx.x;
+  const int id = ids[r];
+  const bool ok = id >= 0 && id < vocab;
+  const TT* t = table + (size_t)(ok ? id : 0) * W;
+  const float* pr = pos + (size_t)(r % L) * W;
+  for (int c = threadIdx.x; c < W; c += 256) out[(size_t)r * W + c] = (ok ? (float)t[c] : 0.f) + pr[c];
 }
 
 struct DdimParams {
@@ -198,6 +217,21 @@ hipError_t t2v_launch_copy2d(const t2v_op& op, hipStream_t s) {
   else
     hipLaunchKernelGGL((copy2d_kernel<f16, float>), dim3(g), dim3(256), 0, s, reinterpret_cast<const f16*>(op.p[0]),
                        reinterpret_cast<float*>(op.p[1]), rows, cols, lds_, ldd, act);
+  return hipGetLastError();
+}
+
+hipError_t t2v_launch_embed_rows(const t2v_op& op, hipStream_t s) {
+  const int rows = op.i[0], W = op.i[1], L = op.i[2], vocab = op.i[3];
+  if (rows <= 0 || W <= 0 || L <= 0 || vocab <= 0) return hipErrorInvalidValue;
+  const int* ids = reinterpret_cast<const int*>(op.p[0]);
+  const float* pos = reinterpret_cast<const float*>(op.p[2]);
+  float* out = reinterpret_cast<float*>(op.p[3]);
+  if (op.i[4] == T2V_F32)
+    hipLaunchKernelGGL((embed_rows_kernel<float>), dim3(rows), dim3(256), 0, s, ids, reinterpret_cast<const float*>(op.p[1]), pos,
+                       out, rows, W, L, vocab);
+  else
+    hipLaunchKernelGGL((embed_rows_kernel<f16>), dim3(rows), dim3(256), 0, s, ids, reinterpret_cast<const f16*>(op.p[1]), pos,
+                       out, rows, W, L, vocab);
   return hipGetLastError();
 }
 

@@ -80,6 +80,7 @@ int validate_op(const t2v_op& op, int idx) {
     case T2V_OP_MEMSET:
     case T2V_OP_LINCOMB:
     case T2V_OP_RELPOS_ATTN:
+    case T2V_OP_EMBED_ROWS:
       return 0;
     default:
       return bad("unknown op kind");
@@ -125,6 +126,7 @@ hipError_t launch_op(const t2v_op& op, hipStream_t s) {
     case T2V_OP_DDIM_STEP: return t2v_launch_ddim_step(op, s);
     case T2V_OP_LINCOMB: return t2v_launch_lincomb(op, s);
     case T2V_OP_RELPOS_ATTN: return t2v_launch_relpos_attention(op, s);
+    case T2V_OP_EMBED_ROWS: return t2v_launch_embed_rows(op, s);
     case T2V_OP_MEMSET: {
       const size_t bytes = (size_t)(uint32_t)op.i[0] | ((size_t)(uint32_t)op.i[1] << 32);
       return hipMemsetAsync(reinterpret_cast<void*>(op.p[0]), 0, bytes, s);

@@ -83,6 +83,7 @@ hipError_t t2v_launch_time_embed(const t2v_op& op, hipStream_t s);
 hipError_t t2v_launch_copy2d(const t2v_op& op, hipStream_t s);
 hipError_t t2v_launch_ddim_step(const t2v_op& op, hipStream_t s);
 hipError_t t2v_launch_lincomb(const t2v_op& op, hipStream_t s);
+hipError_t t2v_launch_embed_rows(const t2v_op& op, hipStream_t s);
 
 __device__ __forceinline__ float t2v_silu(float x) { return x / (1.0f + __expf(-x)); }
 

@@ -330,7 +330,7 @@ class Program:
 
     def attention(self, name: str, q: Ref, k: Ref, v: Ref, o: Ref, *, out_buf: Optional[Buf] = None, nq: int, nk: int, heads: int,
                   b_outer: int, b_inner: int, q_strides, kv_strides, o_strides, scale: float, head_dim: int = 64,
-                  rel_k: Optional[Ref] = None, rel_v: Optional[Ref] = None, max_rel: int = 0) -> Op:
+                  rel_k: Optional[Ref] = None, rel_v: Optional[Ref] = None, max_rel: int = 0, causal: bool = False) -> Op:
         """softmax(q k^T scale) v over strided (sequence, outer, inner) batches.  With rel_k / rel_v (fp32
         [2*max_rel+1, head_dim] tables) the LVDM relative-position temporal attention op is emitted instead."""
         assert head_dim in (40, 64, 80, 160) or rel_k is not None
@@ -341,6 +341,10 @@ class Program:
             assert nq == nk <= 32 and head_dim % 8 == 0
             op.i[15] = max_rel
             op.p[4], op.p[5] = rel_k, rel_v
+            assert not causal
+        elif causal:
+            assert nq == nk
+            op.i[15] = 1
         op.i[5:8] = list(q_strides)
         op.i[8:11] = list(kv_strides)
         op.i[11:14] = list(o_strides)
@@ -387,6 +391,15 @@ class Program:
         op.i[0:7] = [src.rows, src.cols, src.ld, dst.ld, _DT[src.dtype], _DT[dst.dtype], act]
         op.p[0:2] = [src.ref, dst.ref]
         op.out = dst
+        return self._emit(op)
+
+    def embed_rows(self, name: str, ids: Ref, table: Ref, table_dtype: str, pos: Ref, out: Buf, *, L_pos: int, vocab: int) -> Op:
+        """out[r,:] = table[ids[r],:] + pos[r % L_pos,:]  (fp32 out; ids int32)."""
+        assert out.dtype == "f32" and out.ld == out.cols
+        op = Op(L.OP_EMBED_ROWS, name)
+        op.i[0:5] = [out.rows, out.cols, L_pos, vocab, _DT[table_dtype]]
+        op.p[0:4] = [ids, table, pos, out.ref]
+        op.out = out
         return self._emit(op)
 
     def ddim_step(self, name: str, *, C: int, inner: int, guided: int, eps_dtype: str, x_dtype: str, mode: int = 0) -> Op:

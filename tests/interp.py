@@ -179,6 +179,8 @@ class Interp:
             ev = self.view(op.p[5], (2 * R + 1, D), (D, 1), torch.float32, ext)
             idx = (torch.arange(nk)[None, :] - torch.arange(nq)[:, None]).clamp(-R, R) + R
             s = s + torch.einsum("abhtd,tsd->abhts", q, ek[idx])
+        if not rel and op.i[15]:
+            s = s.masked_fill(torch.arange(nk)[None, :] > torch.arange(nq)[:, None], float("-inf"))
         p = torch.softmax(s * op.f[0], dim=-1)
         o = torch.einsum("abhij,abhjd->abhid", p, vv)
         if rel:
@@ -223,8 +225,22 @@ class Interp:
         x = self.mat(op.p[0], rows, cols, lds, _TD[sdt], ext).float()
         if act == 1:
             x = F.silu(x)
+        elif act == 2:
+            x = F.gelu(x)
+        elif act == 3:
+            x = x * torch.sigmoid(1.702 * x)
         out = self.mat(op.p[1], rows, cols, ldd, _TD[ddt], ext)
         out.copy_(x.to(out.dtype))
+
+    # EMBED_ROWS ---------------------------------------------------------------------------------------
+    def _op14(self, op, ext):
+        rows, W, Lp, vocab, tdt = op.i[0:5]
+        ids = self.view(op.p[0], (rows,), (1,), torch.int32, ext).long()
+        table = self.mat(op.p[1], vocab, W, W, _TD[tdt], ext).float()
+        pos = self.mat(op.p[2], Lp, W, W, torch.float32, ext)
+        ok = (ids >= 0) & (ids < vocab)
+        val = table[ids.clamp(0, vocab - 1)] * ok[:, None]
+        self.mat(op.p[3], rows, W, W, torch.float32, ext).copy_(val + pos[torch.arange(rows) % Lp])
 
     # DDIM_STEP ----------------------------------------------------------------------------------------
     def _op10(self, op, ext):

@@ -511,3 +511,55 @@ def test_lincomb_and_ldm_ddim_update():
         got = S._ddim_update(torch.empty(shape, device="cuda"), xt.cuda(), e.cuda(), noise.cuda(), coef, guided, 1)
         torch.cuda.synchronize()
         assert rel_l2(got.cpu(), want) < 1e-6
+
+
+# ---- CLIP text tower ops ---------------------------------------------------------------------
+@pytest.mark.parametrize("B,Lseq,heads", [(2, 77, 16), (3, 20, 2), (1, 200, 3), (2, 64, 1), (1, 129, 2)])
+def test_attention_causal(B, Lseq, heads):
+    """i[15] = 1: key s contributes to query t only if s <= t (one- and four-wave kernels, several key tiles)."""
+    inner = heads * 64
+    M = B * Lseq
+    P = Program()
+    g = _g(40)
+    qkv, o = P.alloc(M, 3 * inner, "f16"), P.alloc(M, inner, "f16")
+    ld = 3 * inner
+    q, k, v = qkv.col_slice(0, inner), qkv.col_slice(inner, 2 * inner), qkv.col_slice(2 * inner, 3 * inner)
+    P.attention("a", q.ref, k.ref, v.ref, o.ref, nq=Lseq, nk=Lseq, heads=heads, b_outer=B, b_inner=1,
+                q_strides=(ld, Lseq * ld, 0), kv_strides=(ld, Lseq * ld, 0), o_strides=(inner, Lseq * inner, 0),
+                scale=64 ** -0.5, causal=True)
+    it, got, _, _ = run_both(P, {}, {}, lambda it: fill(it, qkv, g, 1.5))
+    _check(it, got, o, 3e-3, "causal attention")
+    # row 0 attends to key 0 only: out[0] == v[0] exactly
+    a = read(got, o)
+    v0 = read(got, qkv)[:, 2 * inner:]
+    for b in range(B):
+        assert torch.equal(a[b * Lseq], v0[b * Lseq])
+
+
+def test_copy2d_gelu_variants_and_embed_rows():
+    P = Program()
+    g = _g(41)
+    rows, cols = 154, 512
+    src = P.alloc(rows, cols, "f16")
+    d2, d3 = P.alloc(rows, cols, "f16"), P.alloc(rows, cols, "f32")
+    P.copy2d("gelu", src, d2, act=2)
+    P.copy2d("quick", src, d3, act=3)
+    inplace = P.alloc(rows, cols, "f16")
+    P.copy2d("cp", src, inplace)
+    P.copy2d("gelu.inplace", inplace, inplace, act=2)
+    vocab, W, Lp = 300, 128, 77
+    emb = P.alloc(2 * Lp, W, "f32")
+    P.embed_rows("emb", Ref("ext", L.EXT_X), Ref("weight", 0, "tab"), "f32", Ref("weight", 0, "pos"), emb, L_pos=Lp, vocab=vocab)
+    emb16 = P.alloc(2 * Lp, W, "f32")
+    P.embed_rows("emb16", Ref("ext", L.EXT_X), Ref("weight", 0, "tab16"), "f16", Ref("weight", 0, "pos"), emb16, L_pos=Lp, vocab=vocab)
+    tab = torch.randn(vocab, W, generator=g)
+    w = {"tab": tab, "tab16": tab.half(), "pos": torch.randn(Lp, W, generator=g)}
+    ids = torch.randint(0, vocab, (2 * Lp,), generator=g).to(torch.int32)
+    ids[5], ids[9] = vocab + 3, -1                      # out of range: zeros + positional, never an OOB read
+    it, got, _, _ = run_both(P, w, {L.EXT_X: ids}, lambda it: fill(it, src, g, 3.0))
+    _check(it, got, d2, 1e-3, "gelu")
+    _check(it, got, d3, 1e-5, "quick gelu")
+    assert torch.equal(read(got, inplace), read(got, d2))
+    assert torch.equal(read(got, emb), read(it, emb))
+    assert torch.equal(read(got, emb16), read(it, emb16))
+    assert torch.equal(read(got, emb)[5], w["pos"][5])
