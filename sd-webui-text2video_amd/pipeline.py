@@ -68,9 +68,11 @@ def create_infotext(vars_: dict) -> str:
 class TextToVideoSynthesis(object):
     def __init__(self, model_dir: Optional[str] = None, *, sd_model: Optional[UNetSD] = None,
                  autoencoder: Optional[AutoencoderKL] = None, clip_encoder=None, betas=None,
-                 device=None):
+                 device=None, tokenizer=None):
         """Either `model_dir` (configuration.json + checkpoints, as t2v_pipeline.py:45-146) or
-        ready-made `sd_model` / `autoencoder` modules."""
+        ready-made `sd_model` / `autoencoder` modules.  With a `model_dir` and no `clip_encoder`, the OpenCLIP text
+        tower is built from `ckpt_clip` (t2v_pipeline.py:137-141) and runs on the GPU (text_encoder.py); `tokenizer` =
+        open_clip's `_tokenizer` (BPE vocabulary; not part of this package)."""
         self.model_dir = model_dir
         self.device = torch.device(device) if device is not None else torch.device("cuda")
         self.keep_in_vram = "All"
@@ -92,6 +94,11 @@ class TextToVideoSynthesis(object):
             sd_model.eval().half()
             betas = beta_schedule("linear_sd", cfg["num_timesteps"], init_beta=0.00085, last_beta=0.0120)
             autoencoder = AutoencoderKL(VAE_DDCONFIG, 4, os.path.join(model_dir, args["ckpt_autoencoder"]), init_weights=False)
+            clip_path = os.path.join(model_dir, args.get("ckpt_clip", ""))
+            if clip_encoder is None and os.path.isfile(clip_path):
+                from .text_encoder import FrozenOpenCLIPEmbedder
+                self.clip_encoder = FrozenOpenCLIPEmbedder(version=clip_path, device=self.device, layer="penultimate",
+                                                           tokenizer=tokenizer)
         if betas is None:
             betas = beta_schedule("linear_sd", 1000, init_beta=0.00085, last_beta=0.0120)
         self.sd_model = sd_model
