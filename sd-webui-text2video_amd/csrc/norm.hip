@@ -112,9 +112,19 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* partials
   if (idx >= n_inst * groups) return;
   const int inst = idx / groups, g = idx - inst * groups;
   double s = 0.0, q = 0.0;
-  for (int u = lane; u < nblk * nparts; u += 64) {
+  const int total = nblk * nparts;
+  auto at = [&](int u) {
     const int part = u / nblk, b = u - part * nblk;
-    const double* st = partials + ((((size_t)part * n_inst + inst) * nblk + b) * groups + g) * 2;
+    return partials + ((((size_t)part * n_inst + inst) * nblk + b) * groups + g) * 2;
+  };
+  int u = lane;
+  for (; u + 192 < total; u += 256) {   // four strided (one cache line each) loads in flight; same summation order
+    const double *p0 = at(u), *p1 = at(u + 64), *p2 = at(u + 128), *p3 = at(u + 192);
+    const double a0 = p0[0], b0 = p0[1], a1 = p1[0], b1 = p1[1], a2 = p2[0], b2 = p2[1], a3 = p3[0], b3 = p3[1];
+    s += a0; q += b0; s += a1; q += b1; s += a2; q += b2; s += a3; q += b3;
+  }
+  for (; u < total; u += 64) {
+    const double* st = at(u);
     s += st[0];
     q += st[1];
   }
@@ -181,6 +191,106 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
           o[e] = (f16)y;
         }
         *reinterpret_cast<f16x8*>(ob + (size_t)rk * ld_out + c8) = o;
+      }
+    }
+  }
+}
+
+// Single-launch GroupNorm for small statistics slices (op.i[12] = 1; the 16x16 / 8x8 / 4x4 levels, where the three
+// launches above cost more than the data movement): one workgroup per (instance, group), XCD-contiguous, streams its
+// [rows x C/groups] slice twice — sums, then normalise; the second pass hits L2.  4-channel units (C/groups % 4 == 0),
+// 4 rows in flight per thread, fp32 per-thread sums folded in fp64 in a fixed order (wave xor-tree, then waves in
+// order): bitwise reproducible.
+constexpr int GNF_THREADS = 512;
+constexpr int GNF_UNROLL = 4;
+
+template <typename T> struct Load4;
+template <> struct Load4<float> {
+  static __device__ __forceinline__ f32x4 ld(const float* __restrict__ p) { return *reinterpret_cast<const f32x4*>(p); }
+};
+template <> struct Load4<f16> {
+  static __device__ __forceinline__ f32x4 ld(const f16* __restrict__ p) {
+    const f16x4 h = *reinterpret_cast<const f16x4*>(p);
+    f32x4 r = {(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+    return r;
+  }
+};
+
+template <typename T>
+__global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, f16* __restrict__ out, int rows,
+                                                               int C, int ld_in, int ld_out, int groups, float eps, int silu) {
+  __shared__ double red[2 * (GNF_THREADS / 64)];
+  __shared__ float stat[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // Workgroup i runs on XCD i % 8 and neighbouring groups share 128-byte lines of every row: give each XCD (= each
+  // private L2) a contiguous range of (instance, group) pairs.
+  const int nwg = gridDim.x;
+  const int pair = (nwg % 8 == 0) ? (int)(blockIdx.x % 8) * (nwg / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+  const int inst = pair / groups, g = pair - inst * groups;
+  const int cpg = C / groups;
+  const int nu = cpg >> 2;                    // 4-channel units per row of this group
+  const int R = GNF_THREADS / nu;             // row replicas
+  const int cs = tid % nu, rr = tid / nu;
+  const bool live = rr < R;
+  const int c0 = g * cpg + cs * 4;
+  const T* xb = x + (size_t)inst * rows * ld_in + c0;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+  if (live) {
+    for (int r = rr; r < rows; r += R * GNF_UNROLL) {
+      f32x4 v[GNF_UNROLL];
+#pragma unroll
+      for (int k = 0; k < GNF_UNROLL; ++k) {
+        const int rk = r + k * R;
+        if (rk < rows) v[k] = Load4<T>::ld(xb + (size_t)rk * ld_in);
+        else v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int k = 0; k < GNF_UNROLL; ++k) { s += v[k]; q += v[k] * v[k]; }
+    }
+  }
+  double ds = (double)s[0] + (double)s[1] + (double)s[2] + (double)s[3];
+  double dq = (double)q[0] + (double)q[1] + (double)q[2] + (double)q[3];
+  for (int o = 32; o > 0; o >>= 1) { ds += __shfl_xor(ds, o); dq += __shfl_xor(dq, o); }
+  if (lane == 0) { red[2 * wave] = ds; red[2 * wave + 1] = dq; }
+  __syncthreads();
+  if (tid == 0) {
+    double a = 0.0, b = 0.0;
+    for (int w = 0; w < GNF_THREADS / 64; ++w) { a += red[2 * w]; b += red[2 * w + 1]; }
+    const double inv_n = 1.0 / ((double)rows * cpg);
+    const double m = a * inv_n;
+    double var = b * inv_n - m * m;
+    var = var < 0.0 ? 0.0 : var;
+    stat[0] = (float)m;
+    stat[1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  if (!live) return;
+  const float mean = stat[0], rstd = stat[1];
+  const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c0), bt = *reinterpret_cast<const f32x4*>(beta + c0);
+  f32x4 sc, sf;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { sc[e] = rstd * gm[e]; sf[e] = bt[e] - mean * sc[e]; }
+  f16* ob = out + (size_t)inst * rows * ld_out + c0;
+  for (int r = rr; r < rows; r += R * GNF_UNROLL) {
+    f32x4 v[GNF_UNROLL];
+#pragma unroll
+    for (int k = 0; k < GNF_UNROLL; ++k) {
+      const int rk = r + k * R;
+      if (rk < rows) v[k] = Load4<T>::ld(xb + (size_t)rk * ld_in);
+    }
+#pragma unroll
+    for (int k = 0; k < GNF_UNROLL; ++k) {
+      const int rk = r + k * R;
+      if (rk < rows) {
+        f16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float y = v[k][e] * sc[e] + sf[e];
+          if (silu) y = t2v_silu(y);
+          o[e] = (f16)y;
+        }
+        *reinterpret_cast<f16x4*>(ob + (size_t)rk * ld_out) = o;
       }
     }
   }
@@ -260,8 +370,15 @@ hipError_t t2v_launch_groupnorm(const t2v_op& op, hipStream_t s) {
   const float* gamma = reinterpret_cast<const float*>(op.p[1]);
   const float* beta = reinterpret_cast<const float*>(op.p[2]);
   f16* out = reinterpret_cast<f16*>(op.p[3]);
+  const bool fused = op.i[12] != 0;
+  if (fused && (phase != 0 || (C / groups) % 4 != 0 || (C / groups) / 4 > GNF_THREADS)) return hipErrorInvalidValue;
   auto run = [&](auto* x) {
     using T = typename std::remove_cv<typename std::remove_pointer<decltype(x)>::type>::type;
+    if (fused) {
+      hipLaunchKernelGGL(gn_fused_kernel<T>, dim3(groups * n_inst), dim3(GNF_THREADS), 0, s, x, gamma, beta, out, rows, C, ld_in,
+                         ld_out, groups, op.f[0], silu);
+      return;
+    }
     if (phase != 2)
       hipLaunchKernelGGL(gn_stats_kernel<T>, g1, dim3(256), lds, s, x, partials + part_len * part, rows, C, ld_in, groups, rpb);
     if (phase != 1) {

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
 
@@ -128,6 +129,11 @@ class Program:
         self.keep_taps = False
         self.target_cus = 256                   # MI355X compute units (tile / split-K policy)
         self.force_tile = None                  # tests: pin a tile id
+        # GroupNorm as ONE launch when a statistics slice (rows x C/groups) is small (bytes; tools/gn_bench.py: the
+        # per-frame instances of the 16x16 and lower levels and the cross-frame ones of the 4x4 level gain 8-19 us each,
+        # larger slices on only 64 workgroups do not)
+        self.gn_fused_slice_bytes = int(os.environ.get("T2V_GN_FUSED_SLICE", 64 * 1024))
+        self.gn_fused_total_bytes = int(os.environ.get("T2V_GN_FUSED_TOTAL", 128 * 1024 * 1024))
 
     # ---- memory ---------------------------------------------------------------------------
     def alloc(self, rows: int, cols: int, dtype: str, ld: Optional[int] = None) -> Buf:
@@ -292,6 +298,13 @@ class Program:
 
         if nparts == 1:
             op = make(0, "")
+            # small statistics slices (16x16 / 8x8 / 4x4 levels): one launch, one workgroup per (instance, group)
+            cpg = x.cols // groups
+            item = 2 if x.dtype == "f16" else 4
+            if self.gn_fused_slice_bytes and x.cols % groups == 0 and cpg % 4 == 0 and rows * cpg * item <= self.gn_fused_slice_bytes \
+                    and x.rows * x.cols * item <= self.gn_fused_total_bytes:
+                op.i[12] = 1
+            op.meta = dict(n_inst=n_inst, rows=rows, C=x.cols, dt=x.dtype, fused=int(op.i[12]))
             op.out = out
             self._emit(op)
         else:

@@ -180,8 +180,13 @@ def test_temporal_conv_gather(B, F, HW, C):
 @pytest.mark.parametrize("n_inst,rows,C,dt,silu", [(6, 256, 320, "f32", True), (2, 24 * 64, 640, "f32", True),
                                                    (4, 16, 1280, "f32", False), (3, 64, 64, "f16", True),
                                                    (2, 100, 2560, "f32", True), (2, 4096, 128, "f32", True)])
-def test_groupnorm(n_inst, rows, C, dt, silu):
+@pytest.mark.parametrize("variant", ["three_launch", "single_launch"])
+def test_groupnorm(n_inst, rows, C, dt, silu, variant):
+    if variant == "single_launch" and (C // 32) % 4 != 0:
+        pytest.skip("single-launch GroupNorm needs (C/groups) % 4 == 0")
     P = Program()
+    P.gn_fused_slice_bytes = 0 if variant == "three_launch" else 1 << 30
+    P.gn_fused_total_bytes = 1 << 30
     P.begin()
     g = _g(8)
     x, out = P.alloc(n_inst * rows, C, dt), P.alloc(n_inst * rows, C, "f16")
@@ -190,6 +195,7 @@ def test_groupnorm(n_inst, rows, C, dt, silu):
     P.groupnorm("gn", x, Ref("weight", 0, "g"), Ref("weight", 0, "b"), out, n_inst=n_inst, eps=1e-5, silu=silu)
     P.groupnorm("gn2", x, Ref("weight", 0, "g"), Ref("weight", 0, "b"), out2, n_inst=n_inst, eps=1e-6, silu=silu)   # ping-pong buffer
     P.finish()
+    assert all(op.i[12] == (variant == "single_launch") for op in P.ops if op.kind == L.OP_GROUPNORM)
 
     def init(it):
         v = fill(it, x, g, scale=2.0)
