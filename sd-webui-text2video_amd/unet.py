@@ -215,6 +215,7 @@ class UNetSD(nn.Module):
         self._packed_sig = None
         self._packed_device = None
         self._packed_deps = None
+        self._param_slots = None
         self.last_repack = None       # images rewritten by the last refresh_weights (-1 = full pack)
         self.debug_taps = False
         # Storage type of tensors that are consumed ONLY by a GroupNorm (ResBlock's first conv output
@@ -286,7 +287,17 @@ class UNetSD(nn.Module):
 
     # ---- weights --------------------------------------------------------------------------
     def _param_signature(self):
-        return {n: (id(p), p._version, p.device.type, p.dtype, tuple(p.shape)) for n, p in self.named_parameters()}
+        """name -> (identity, version, device, dtype, shape) of every parameter.  Walks the cached per-module
+        `_parameters` dicts (the module tree is fixed; re-assigned or added Parameters are still seen) instead of
+        `named_parameters()`: this runs before every forward when `auto_refresh` is on."""
+        if self._param_slots is None:
+            self._param_slots = [(n + "." if n else "", m._parameters) for n, m in self.named_modules() if m._parameters]
+        sig = {}
+        for prefix, pd in self._param_slots:
+            for k, p in pd.items():
+                if p is not None:
+                    sig[prefix + k] = (id(p), p._version, p.device.type, p.dtype, p.shape)
+        return sig
 
     def invalidate(self):
         """Drop the packed weight images (call after mutating parameters in place)."""
