@@ -35,12 +35,13 @@ struct AttnParams {
   int causal;   // 1: key s is visible to query t only if s <= t (CLIP text towers)
 };
 
-constexpr int KT = 64;         // keys per LDS tile
-constexpr int VT_ROW = 136;    // bytes per V^T row (64 keys * 2 B + 8 B pad)
-
-template <int NW, int D>
+// KT = keys per LDS tile: 64, or 32 for sequences of <= 32 keys (temporal attention over the frames of one pixel:
+// half the LDS per workgroup, twice the workgroups per CU for a kernel that is bound by memory latency).
+template <int NW, int D, int KT = 64>
 __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnParams p) {
   constexpr int NT = NW * 64;
+  constexpr int NKT = KT / 32;             // 32-key MFMA tiles per LDS tile
+  constexpr int VT_ROW = KT * 2 + 8;       // bytes per V^T row (KT keys * 2 B + 8 B pad)
   constexpr int DK = (D + 15) / 16 * 16;   // Q K^T reduction length (zero-padded in LDS / registers)
   constexpr int NKK = DK / 16;
   constexpr int DV = (D + 31) / 32 * 32;   // rows of O^T (zero-padded)
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnParams p) {
   constexpr int K_ROW = DK * 2 + 16;       // padded LDS row: 32 consecutive rows at one chunk hit disjoint banks
   static_assert(D % 8 == 0, "head_dim must be a multiple of 8");
   __shared__ __attribute__((aligned(16))) unsigned char k_lds[KT * K_ROW];    // [key][DK]
-  __shared__ __attribute__((aligned(16))) unsigned char vt_lds[DV * VT_ROW];  // [d][64 keys]
+  __shared__ __attribute__((aligned(16))) unsigned char vt_lds[DV * VT_ROW];  // [d][KT keys]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnParams p) {
       *reinterpret_cast<f16x8*>(k_lds + row * K_ROW + (c << 4)) = val;
     }
     // ---- V tile, transposed: unit = (key pair, 4 d) -> 4 x 32-bit {V[2kp][d], V[2kp+1][d]}
-    for (int u = tid; u < 32 * (DV / 4); u += NT) {
+    for (int u = tid; u < (KT / 2) * (DV / 4); u += NT) {
       const int kp = u / (DV / 4), dq = u - kp * (DV / 4);
       const int key = kt0 + 2 * kp;
       const bool dok = dq * 4 < D;
@@ -116,11 +117,11 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnParams p) {
     }
     __syncthreads();
 
-    // ---- S^T = K Q^T : two 32-key tiles -------------------------------------------
+    // ---- S^T = K Q^T : NKT 32-key tiles --------------------------------------------
     const bool t1_live = (kt0 + 32) < p.nk;   // wave-uniform
-    f32x16 s[2];
+    f32x16 s[NKT];
 #pragma unroll
-    for (int T = 0; T < 2; ++T) {
+    for (int T = 0; T < NKT; ++T) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[T][r] = 0.f;
       if (T == 1 && !t1_live) continue;
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnParams p) {
     // ---- online softmax for this lane's query -------------------------------------
     float mx = -INFINITY;
 #pragma unroll
-    for (int T = 0; T < 2; ++T)
+    for (int T = 0; T < NKT; ++T)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = kt0 + T * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnParams p) {
     const float alpha = exp2f(m_run - m_new);      // exp2(-inf) = 0 on the first tile
     float psum = 0.f;
 #pragma unroll
-    for (int T = 0; T < 2; ++T)
+    for (int T = 0; T < NKT; ++T)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float pv = exp2f(s[T][r] - m_new);
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnParams p) {
 
     // ---- O^T += V^T P^T -----------------------------------------------------------
 #pragma unroll
-    for (int T = 0; T < 2; ++T) {
+    for (int T = 0; T < NKT; ++T) {
       if (T == 1 && !t1_live) continue;
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
@@ -444,19 +445,23 @@ hipError_t t2v_launch_attention(const t2v_op& op, hipStream_t s) {
   const dim3 g1(1, p.heads, nbatch), g4((p.nq + 127) / 128, p.heads, nbatch);
   switch (hd) {
     case 40:
-      if (small) hipLaunchKernelGGL((attn_kernel<1, 40>), g1, dim3(64), 0, s, p);
+      if (small && p.nk <= 32) hipLaunchKernelGGL((attn_kernel<1, 40, 32>), g1, dim3(64), 0, s, p);
+      else if (small) hipLaunchKernelGGL((attn_kernel<1, 40>), g1, dim3(64), 0, s, p);
       else hipLaunchKernelGGL((attn_kernel<4, 40>), g4, dim3(256), 0, s, p);
       break;
     case 64:
-      if (small) hipLaunchKernelGGL((attn_kernel<1, 64>), g1, dim3(64), 0, s, p);
+      if (small && p.nk <= 32) hipLaunchKernelGGL((attn_kernel<1, 64, 32>), g1, dim3(64), 0, s, p);
+      else if (small) hipLaunchKernelGGL((attn_kernel<1, 64>), g1, dim3(64), 0, s, p);
       else hipLaunchKernelGGL((attn_kernel<4, 64>), g4, dim3(256), 0, s, p);
       break;
     case 80:
-      if (small) hipLaunchKernelGGL((attn_kernel<1, 80>), g1, dim3(64), 0, s, p);
+      if (small && p.nk <= 32) hipLaunchKernelGGL((attn_kernel<1, 80, 32>), g1, dim3(64), 0, s, p);
+      else if (small) hipLaunchKernelGGL((attn_kernel<1, 80>), g1, dim3(64), 0, s, p);
       else hipLaunchKernelGGL((attn_kernel<4, 80>), g4, dim3(256), 0, s, p);
       break;
     case 160:
-      if (small) hipLaunchKernelGGL((attn_kernel<1, 160>), g1, dim3(64), 0, s, p);
+      if (small && p.nk <= 32) hipLaunchKernelGGL((attn_kernel<1, 160, 32>), g1, dim3(64), 0, s, p);
+      else if (small) hipLaunchKernelGGL((attn_kernel<1, 160>), g1, dim3(64), 0, s, p);
       else hipLaunchKernelGGL((attn_kernel<4, 160>), g4, dim3(256), 0, s, p);
       break;
     default:
