@@ -21,6 +21,8 @@
 // head_dim: ModelScope uses 64 everywhere; the LVDM UNet has 8 heads of C/8 = 40 / 80 / 160 channels
 // (openaimodel3d.py:459-466).  The reduction of Q K^T is zero-padded to a multiple of 16 and the rows of
 // O^T to a multiple of 32 inside LDS / registers only; nothing padded is read from or written to HBM.
+#include <cstdlib>
+
 #include "t2v_kernels.h"
 
 namespace {
@@ -37,7 +39,8 @@ struct AttnParams {
 
 // KT = keys per LDS tile: 64, or 32 for sequences of <= 32 keys (temporal attention over the frames of one pixel:
 // half the LDS per workgroup, twice the workgroups per CU for a kernel that is bound by memory latency).
-template <int NW, int D, int KT = 64>
+constexpr int KT_MAIN = 64;
+template <int NW, int D, int KT = 64, bool PREFETCH = false>
 __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnParams p) {
   constexpr int NT = NW * 64;
   constexpr int NKT = KT / 32;             // 32-key MFMA tiles per LDS tile
@@ -85,83 +88,156 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnParams p) {
   // last visible key of this lane's query; key 0 is visible to every query, so m_run is finite after the first tile
   const int key_end = p.causal ? min(p.nk, qrow + 1) : p.nk;
 
-  for (int kt0 = 0; kt0 < p.nk; kt0 += KT) {
-    __syncthreads();  // previous tile fully consumed
-    // ---- K tile: 64 rows x KCH chunks of 16 B -------------------------------------
-    for (int u = tid; u < KT * KCH; u += NT) {
+  // PREFETCH (experiment, env T2V_ATTN_PREFETCH=1, 4-wave variants with head_dim <= 80): the K / V tile of the next
+  // iteration is fetched into registers while the current one is processed.  Measured equal-to-slower (66.5 vs 66.0 ms
+  // on the 9216-token level, 24 more VGPRs): the kernel is bound by the softmax VALU work, not by load latency.
+  constexpr bool PF = PREFETCH;
+  constexpr int KI = (KT * KCH + NT - 1) / NT;                 // 16-byte K chunks per thread
+  constexpr int VI = ((KT / 2) * (DV / 4) + NT - 1) / NT;      // (key pair, 4 d) V units per thread
+  f16x8 kreg[KI];
+  f16x4 vra[VI], vrb[VI];
+  auto gload = [&](int kt0) {
+#pragma unroll
+    for (int i = 0; i < KI; ++i) {
+      const int u = tid + i * NT;
       const int row = u / KCH, c = u - row * KCH;
       const int key = kt0 + row;
-      f16x8 val;
-      if (key < p.nk && c * 8 < D)
-        val = *reinterpret_cast<const f16x8*>(kb + (long)key * p.sk_seq + c * 8);
+      if (u < KT * KCH && key < p.nk && c * 8 < D)
+        kreg[i] = *reinterpret_cast<const f16x8*>(kb + (long)key * p.sk_seq + c * 8);
       else
-        for (int e = 0; e < 8; ++e) val[e] = (f16)0.f;
-      *reinterpret_cast<f16x8*>(k_lds + row * K_ROW + (c << 4)) = val;
+        for (int e = 0; e < 8; ++e) kreg[i][e] = (f16)0.f;
     }
-    // ---- V tile, transposed: unit = (key pair, 4 d) -> 4 x 32-bit {V[2kp][d], V[2kp+1][d]}
-    for (int u = tid; u < (KT / 2) * (DV / 4); u += NT) {
+#pragma unroll
+    for (int i = 0; i < VI; ++i) {
+      const int u = tid + i * NT;
       const int kp = u / (DV / 4), dq = u - kp * (DV / 4);
       const int key = kt0 + 2 * kp;
-      const bool dok = dq * 4 < D;
-      f16x4 a, b;
-      if (dok && key < p.nk) a = *reinterpret_cast<const f16x4*>(vb + (long)key * p.sk_seq + dq * 4);
-      else for (int e = 0; e < 4; ++e) a[e] = (f16)0.f;
-      if (dok && key + 1 < p.nk) b = *reinterpret_cast<const f16x4*>(vb + (long)(key + 1) * p.sk_seq + dq * 4);
-      else for (int e = 0; e < 4; ++e) b[e] = (f16)0.f;
+      const bool dok = u < (KT / 2) * (DV / 4) && dq * 4 < D;
+      if (dok && key < p.nk) vra[i] = *reinterpret_cast<const f16x4*>(vb + (long)key * p.sk_seq + dq * 4);
+      else for (int e = 0; e < 4; ++e) vra[i][e] = (f16)0.f;
+      if (dok && key + 1 < p.nk) vrb[i] = *reinterpret_cast<const f16x4*>(vb + (long)(key + 1) * p.sk_seq + dq * 4);
+      else for (int e = 0; e < 4; ++e) vrb[i][e] = (f16)0.f;
+    }
+  };
+  auto lstore = [&]() {
+    // K tile: KT rows x KCH chunks of 16 B;  V tile, transposed: unit = (key pair, 4 d) -> 4 x 32-bit {V[2kp][d], V[2kp+1][d]}
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        typedef f16 f16x2 __attribute__((ext_vector_type(2)));
-        f16x2 w = {a[e], b[e]};
-        *reinterpret_cast<f16x2*>(vt_lds + (dq * 4 + e) * VT_ROW + kp * 4) = w;
+    for (int i = 0; i < KI; ++i) {
+      const int u = tid + i * NT;
+      const int row = u / KCH, c = u - row * KCH;
+      if (u < KT * KCH) *reinterpret_cast<f16x8*>(k_lds + row * K_ROW + (c << 4)) = kreg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < VI; ++i) {
+      const int u = tid + i * NT;
+      const int kp = u / (DV / 4), dq = u - kp * (DV / 4);
+      if (u < (KT / 2) * (DV / 4)) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          typedef f16 f16x2 __attribute__((ext_vector_type(2)));
+          f16x2 w = {vra[i][e], vrb[i][e]};
+          *reinterpret_cast<f16x2*>(vt_lds + (dq * 4 + e) * VT_ROW + kp * 4) = w;
+        }
+      }
+    }
+  };
+  if (PF) gload(0);
+
+  for (int kt0 = 0; kt0 < p.nk; kt0 += KT) {
+    __syncthreads();  // previous tile fully consumed
+    if constexpr (PF) {
+      lstore();
+    } else {
+      // straight global -> LDS (few registers: the single-wave variants live on occupancy)
+      for (int u = tid; u < KT * KCH; u += NT) {
+        const int row = u / KCH, c = u - row * KCH;
+        const int key = kt0 + row;
+        f16x8 val;
+        if (key < p.nk && c * 8 < D)
+          val = *reinterpret_cast<const f16x8*>(kb + (long)key * p.sk_seq + c * 8);
+        else
+          for (int e = 0; e < 8; ++e) val[e] = (f16)0.f;
+        *reinterpret_cast<f16x8*>(k_lds + row * K_ROW + (c << 4)) = val;
+      }
+      for (int u = tid; u < (KT / 2) * (DV / 4); u += NT) {
+        const int kp = u / (DV / 4), dq = u - kp * (DV / 4);
+        const int key = kt0 + 2 * kp;
+        const bool dok = dq * 4 < D;
+        f16x4 a, b;
+        if (dok && key < p.nk) a = *reinterpret_cast<const f16x4*>(vb + (long)key * p.sk_seq + dq * 4);
+        else for (int e = 0; e < 4; ++e) a[e] = (f16)0.f;
+        if (dok && key + 1 < p.nk) b = *reinterpret_cast<const f16x4*>(vb + (long)(key + 1) * p.sk_seq + dq * 4);
+        else for (int e = 0; e < 4; ++e) b[e] = (f16)0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          typedef f16 f16x2 __attribute__((ext_vector_type(2)));
+          f16x2 w = {a[e], b[e]};
+          *reinterpret_cast<f16x2*>(vt_lds + (dq * 4 + e) * VT_ROW + kp * 4) = w;
+        }
       }
     }
     __syncthreads();
+    if (PF && kt0 + KT < p.nk) gload(kt0 + KT);
 
     // ---- S^T = K Q^T : NKT 32-key tiles --------------------------------------------
     const bool t1_live = (kt0 + 32) < p.nk;   // wave-uniform
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     f32x16 s[NKT];
 #pragma unroll
     for (int T = 0; T < NKT; ++T) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[T][r] = 0.f;
+      s[T] = zero16;
       if (T == 1 && !t1_live) continue;
       const int row = T * 32 + frow;
 #pragma unroll
       for (int kk = 0; kk < NKK; ++kk) {
         const f16x8 kf = *reinterpret_cast<const f16x8*>(k_lds + row * K_ROW + ((kk * 2 + fhalf) << 4));
-        s[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[kk], s[T], 0, 0, 0);
+        s[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[kk], kk == 0 ? zero16 : s[T], 0, 0, 0);
       }
     }
     // ---- online softmax for this lane's query -------------------------------------
+    // The softmax is the VALU-bound part of this kernel (32 scores per lane and tile against 16 MFMAs), so it is kept
+    // to max / fma / exp2 / add per score: keys are masked only in tiles that need it (ragged end, causal diagonal),
+    // the scale is folded into the exponent's fma, exp2 is the bare v_exp_f32 (arguments <= 8, flushed denormals are
+    // zeros of the sum anyway), and the running maximum is only advanced when it grows by more than 2^8 — O and l
+    // carry the same stale factor, so the result is exact and the accumulator rescale (AGPR round trips) is rare.
+    if (kt0 + KT > p.nk || (p.causal && kt0 + KT - 1 > q0)) {     // wave-uniform
+#pragma unroll
+      for (int T = 0; T < NKT; ++T)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt0 + T * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+          if (key >= key_end) s[T][r] = -INFINITY;
+        }
+    }
     float mx = -INFINITY;
 #pragma unroll
     for (int T = 0; T < NKT; ++T)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kt0 + T * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
-        const float x = (key < key_end) ? s[T][r] * p.scale_log2 : -INFINITY;
-        s[T][r] = x;
-        mx = fmaxf(mx, x);
-      }
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[T][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m_run, mx);          // finite: key kt0 is always valid
-    const float alpha = exp2f(m_run - m_new);      // exp2(-inf) = 0 on the first tile
+    const float m_tile = mx * p.scale_log2;                 // scale > 0 (checked at launch)
+    const bool grow = m_tile - m_run > 8.0f;                // first tile: m_run = -inf (key kt0 = 0 is always visible)
+    if (__builtin_amdgcn_ballot_w64(grow) != 0) {           // wave-uniform
+      const float alpha = grow ? __builtin_amdgcn_exp2f(m_run - m_tile) : 1.0f;   // exp2(-inf) = 0 on the first tile
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < NDT; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+      m_run = grow ? m_tile : m_run;
+    }
     float psum = 0.f;
+    const float neg_m = -m_run;
 #pragma unroll
     for (int T = 0; T < NKT; ++T)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pv = exp2f(s[T][r] - m_new);
+        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[T][r], p.scale_log2, neg_m));
         s[T][r] = pv;
         psum += pv;
       }
     psum += __shfl_xor(psum, 32);
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
-#pragma unroll
-    for (int d = 0; d < NDT; ++d)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+    l_run += psum;
 
     // ---- O^T += V^T P^T -----------------------------------------------------------
 #pragma unroll
@@ -438,25 +514,30 @@ hipError_t t2v_launch_attention(const t2v_op& op, hipStream_t s) {
   p.so_seq = op.i[11]; p.so_out = op.i[12]; p.so_in = op.i[13];
   p.scale_log2 = op.f[0] * 1.44269504088896340736f;
   p.causal = op.i[15] != 0;
-  if (p.nq <= 0 || p.nk <= 0) return hipErrorInvalidValue;
+  if (p.nq <= 0 || p.nk <= 0 || !(op.f[0] > 0.f)) return hipErrorInvalidValue;
   const int nbatch = p.b_outer * p.b_inner;
   const int hd = op.i[14] > 0 ? op.i[14] : 64;
   const bool small = p.nq <= 32;
+  static const bool prefetch_env = [] { const char* e = getenv("T2V_ATTN_PREFETCH"); return e ? atoi(e) != 0 : false; }();
+  const bool prefetch = prefetch_env && p.nk > KT_MAIN;
   const dim3 g1(1, p.heads, nbatch), g4((p.nq + 127) / 128, p.heads, nbatch);
   switch (hd) {
     case 40:
       if (small && p.nk <= 32) hipLaunchKernelGGL((attn_kernel<1, 40, 32>), g1, dim3(64), 0, s, p);
       else if (small) hipLaunchKernelGGL((attn_kernel<1, 40>), g1, dim3(64), 0, s, p);
+      else if (prefetch) hipLaunchKernelGGL((attn_kernel<4, 40, 64, true>), g4, dim3(256), 0, s, p);
       else hipLaunchKernelGGL((attn_kernel<4, 40>), g4, dim3(256), 0, s, p);
       break;
     case 64:
       if (small && p.nk <= 32) hipLaunchKernelGGL((attn_kernel<1, 64, 32>), g1, dim3(64), 0, s, p);
       else if (small) hipLaunchKernelGGL((attn_kernel<1, 64>), g1, dim3(64), 0, s, p);
+      else if (prefetch) hipLaunchKernelGGL((attn_kernel<4, 64, 64, true>), g4, dim3(256), 0, s, p);
       else hipLaunchKernelGGL((attn_kernel<4, 64>), g4, dim3(256), 0, s, p);
       break;
     case 80:
       if (small && p.nk <= 32) hipLaunchKernelGGL((attn_kernel<1, 80, 32>), g1, dim3(64), 0, s, p);
       else if (small) hipLaunchKernelGGL((attn_kernel<1, 80>), g1, dim3(64), 0, s, p);
+      else if (prefetch) hipLaunchKernelGGL((attn_kernel<4, 80, 64, true>), g4, dim3(256), 0, s, p);
       else hipLaunchKernelGGL((attn_kernel<4, 80>), g4, dim3(256), 0, s, p);
       break;
     case 160:
