@@ -85,7 +85,10 @@ hipError_t t2v_launch_ddim_step(const t2v_op& op, hipStream_t s);
 hipError_t t2v_launch_lincomb(const t2v_op& op, hipStream_t s);
 hipError_t t2v_launch_embed_rows(const t2v_op& op, hipStream_t s);
 
-__device__ __forceinline__ float t2v_silu(float x) { return x / (1.0f + __expf(-x)); }
+// x * sigmoid(x) as 5 VALU instructions (v_exp_f32 and v_rcp_f32 are 1-ulp; an IEEE divide would be ~12 more)
+__device__ __forceinline__ float t2v_silu(float x) {
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f));
+}
 
 // ---- row-coalesced GEMM epilogue (shared by gemm.hip and gemm2.hip) -----------------------------------
 // In the MFMA accumulator layout a lane owns 4 consecutive channels of ONE token row, so a wave-wide store (or
