@@ -91,8 +91,26 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
     }
   }
   __syncthreads();
-  if (tid < groups) {
-    const int cpg = C / groups;
+  const int cpg = C / groups;
+  if (groups * 8 <= 256) {
+    // 8 adjacent lanes per group: each folds a fixed strided subset of the R x cpg parked sums, then a fixed xor-tree
+    const int g = tid >> 3, sub = tid & 7;
+    double s = 0.0, q = 0.0;
+    if (g < groups) {
+      const int n = R * cpg;
+      for (int i = sub; i < n; i += 8) {
+        const int k = i / cpg, c = g * cpg + (i - k * cpg);
+        s += (double)psum[k * C + c];
+        q += (double)psq[k * C + c];
+      }
+    }
+    for (int o = 1; o < 8; o <<= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+    if (g < groups && sub == 0) {
+      double* st = partials + (((size_t)inst * gridDim.x + blockIdx.x) * groups + g) * 2;
+      st[0] = s;
+      st[1] = q;
+    }
+  } else if (tid < groups) {
     double s = 0.0, q = 0.0;
     for (int k = 0; k < R; ++k)
       for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { s += (double)psum[k * C + c]; q += (double)psq[k * C + c]; }
@@ -141,11 +159,11 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* partials
 // Launch 2 — grid (ceil(rows / (R*GN_UNROLL)), n_inst), same thread layout.  The workgroup first builds
 // scale[c] = rstd*gamma[c] and shift[c] = beta[c] - mean*scale[c] for the instance in LDS; every thread then
 // normalises GN_UNROLL rows of its 8 channels per column unit (16-byte loads issued together, 16-byte stores).
-template <typename T>
+template <typename T, bool SILU>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ finals,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        f16* __restrict__ out, int rows, int C, int ld_in, int ld_out,
-                                                       int groups, int silu) {
+                                                       int groups) {
   extern __shared__ float sh[];   // scale[C], shift[C]
   float* sc = sh;
   float* sf = sh + C;
@@ -187,7 +205,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           float y = v[k][e] * a[e] + b[e];
-          if (silu) y = t2v_silu(y);
+          if (SILU) y = t2v_silu(y);
           o[e] = (f16)y;
         }
         *reinterpret_cast<f16x8*>(ob + (size_t)rk * ld_out + c8) = o;
@@ -216,10 +234,10 @@ template <> struct Load4<f16> {
   }
 };
 
-template <typename T>
+template <typename T, bool SILU>
 __global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, f16* __restrict__ out, int rows,
-                                                               int C, int ld_in, int ld_out, int groups, float eps, int silu) {
+                                                               int C, int ld_in, int ld_out, int groups, float eps) {
   __shared__ double red[2 * (GNF_THREADS / 64)];
   __shared__ float stat[2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -287,7 +305,7 @@ __global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(const T* __restri
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float y = v[k][e] * sc[e] + sf[e];
-          if (silu) y = t2v_silu(y);
+          if (SILU) y = t2v_silu(y);
           o[e] = (f16)y;
         }
         *reinterpret_cast<f16x4*>(ob + (size_t)rk * ld_out) = o;
@@ -375,8 +393,10 @@ hipError_t t2v_launch_groupnorm(const t2v_op& op, hipStream_t s) {
   auto run = [&](auto* x) {
     using T = typename std::remove_cv<typename std::remove_pointer<decltype(x)>::type>::type;
     if (fused) {
-      hipLaunchKernelGGL(gn_fused_kernel<T>, dim3(groups * n_inst), dim3(GNF_THREADS), 0, s, x, gamma, beta, out, rows, C, ld_in,
-                         ld_out, groups, op.f[0], silu);
+      if (silu) hipLaunchKernelGGL((gn_fused_kernel<T, true>), dim3(groups * n_inst), dim3(GNF_THREADS), 0, s, x, gamma, beta, out, rows,
+                                   C, ld_in, ld_out, groups, op.f[0]);
+      else hipLaunchKernelGGL((gn_fused_kernel<T, false>), dim3(groups * n_inst), dim3(GNF_THREADS), 0, s, x, gamma, beta, out, rows, C,
+                              ld_in, ld_out, groups, op.f[0]);
       return;
     }
     if (phase != 2)
@@ -385,8 +405,10 @@ hipError_t t2v_launch_groupnorm(const t2v_op& op, hipStream_t s) {
       hipLaunchKernelGGL(gn_finalize_kernel, dim3(g2), dim3(256), 0, s, partials, finals, n_inst, nblk, groups, inv_n,
                          op.f[0], nparts);
       const int rpa = R * GN_UNROLL;    // rows per normalise workgroup
-      hipLaunchKernelGGL(gn_apply_kernel<T>, dim3((rows + rpa - 1) / rpa, n_inst), dim3(256), 2 * (size_t)C * sizeof(float), s, x,
-                         finals, gamma, beta, out, rows, C, ld_in, ld_out, groups, silu);
+      const dim3 g3((rows + rpa - 1) / rpa, n_inst);
+      const size_t lds3 = 2 * (size_t)C * sizeof(float);
+      if (silu) hipLaunchKernelGGL((gn_apply_kernel<T, true>), g3, dim3(256), lds3, s, x, finals, gamma, beta, out, rows, C, ld_in, ld_out, groups);
+      else hipLaunchKernelGGL((gn_apply_kernel<T, false>), g3, dim3(256), lds3, s, x, finals, gamma, beta, out, rows, C, ld_in, ld_out, groups);
     }
   };
   if (in_dt == T2V_F32) run(reinterpret_cast<const float*>(op.p[0]));
