@@ -24,7 +24,7 @@ from __future__ import annotations
 
 import os
 from collections import OrderedDict
-from typing import Callable, Dict, List, Optional, Sequence
+from typing import Dict, Optional, Sequence
 
 import torch
 from torch import nn

@@ -4,7 +4,6 @@ import torch
 
 from harness import rel_l2
 from oracle import torch_port as tp
-from sd_webui_text2video_amd import _lib as L
 from sd_webui_text2video_amd import text_encoder as TE
 from test_text_encoder_cpu import TINY, _seed_params, _tokens
 

@@ -2,10 +2,8 @@
 (open_clip's block, the published architecture) and against transformers' own CLIPTextModel (what the VideoCrafter
 embedder calls); (2) the product lowering, executed by the CPU interpreter, matches the oracle; (3) host logic of the
 embedder mirror (chunking, padding after <end>, emphasis multipliers)."""
-import numpy as np
 import pytest
 import torch
-import torch.nn.functional as F
 
 from harness import rel_l2
 from interp import Interp
