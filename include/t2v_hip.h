@@ -76,10 +76,10 @@ enum t2v_gather {
 /* external pointer slots: a pointer field whose value is < T2V_EXT_SLOTS is replaced at run
  * time by ext[value] (value 0 = null). */
 #define T2V_EXT_SLOTS 16
-#define T2V_EXT_X 1      /* UNet: x [B,4,F,h,w]   | VAE: z [n,4,h,w]                         */
+#define T2V_EXT_X 1      /* UNet: x [B,4,F,h,w]   | VAE: z [n,4,h,w]   | text tower: token ids int32 [B,L] */
 #define T2V_EXT_T 2      /* UNet: timesteps, float32 [B]                                     */
 #define T2V_EXT_CTX 3    /* UNet: context [B,L,ctx_dim]                                      */
-#define T2V_EXT_OUT 4    /* UNet: eps [B,4,F,h,w] | VAE: image [n,3,8h,8w]                   */
+#define T2V_EXT_OUT 4    /* UNet: eps [B,4,F,h,w] | VAE: image [n,3,8h,8w] | text tower: z fp32 [B,L,width] */
 #define T2V_EXT_XT 5     /* DDIM: x_t in                                                     */
 #define T2V_EXT_XT_OUT 6 /* DDIM: x_{t-1} out                                                */
 #define T2V_EXT_NOISE 7  /* DDIM: eta-noise (may be null when sigma == 0)                    */
