@@ -162,6 +162,9 @@ def main():
     ap.add_argument("--height", type=int, default=256)
     ap.add_argument("--width", type=int, default=256)
     ap.add_argument("--ddim-steps", type=int, default=50)
+    ap.add_argument("--videos", type=int, default=1,
+                    help="independent videos per batch and GPU (default 1 = the reference's one-video pipeline; the UNet step "
+                         "becomes one b=2*videos forward)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--parallel", default="auto", choices=["auto", "replicas", "pairs", "tshard"],
                     help="N>1 layout: one video per GPU (default), one video per CFG pair, or one T-sharded video (N>=4)")
@@ -197,7 +200,7 @@ def main():
 
     # weak scaling: every rank group generates its own frames; N=1 is the configs[1] workload.
     runner = parallel.make_runner(pipe, world, rank, frames=args.frames, height=args.height, width=args.width,
-                                  ddim_steps=args.ddim_steps, guidance=9.0, mode=args.parallel)
+                                  ddim_steps=args.ddim_steps, guidance=9.0, mode=args.parallel, videos=args.videos)
 
     def one_video(seed):
         return runner(cond, uncond, seed)
@@ -245,15 +248,17 @@ def main():
         "dtype": "f16", "data": "synthetic",
         "config": {"workload": f"ModelScope t2v fp16 (random-init 1.41B UNetSD + VAE decoder), {args.frames} frames @ "
                                f"{args.width}x{args.height}, {args.ddim_steps} DDIM_Gaussian steps, CFG 9.0 "
-                               f"(BASELINE.json configs[1]); one step = one whole video",
-                   "frames_per_video": runner.frames_per_video_all_ranks, "parallelism": runner.describe},
+                               f"(BASELINE.json configs[1]); one step = one whole video" + ("" if args.videos == 1 else f" x {args.videos} per batch"),
+                   "frames_per_video": runner.frames_per_video_all_ranks, "videos_per_batch": args.videos,
+                   "parallelism": runner.describe},
     }
 
     if rank == 0:
         # ---- live roofline of the dominant kernel (HIP events on the launch stream) -------------
         F_loc = runner.unet_frames
         x = torch.randn(runner.unet_batch, 4, F_loc, args.height // 8, args.width // 8, device=dev)
-        y = torch.cat([cond, uncond], 0)[: runner.unet_batch].contiguous()
+        nv = max(1, runner.unet_batch // 2)
+        y = torch.cat([cond.expand(nv, -1, -1), uncond.expand(nv, -1, -1)], 0)[: runner.unet_batch].contiguous()
         t = torch.full((runner.unet_batch,), 500, device=dev)
         net.forward_timed(x, t, y)
         _, ms, prog = net.forward_timed(x, t, y)
@@ -266,7 +271,7 @@ def main():
         result["roofline"] = {
             "bound": "mfma", "kernel": "gemm2_kernel<WM,WN,TM,TN,BK,STAGES,MINW,GATHER,PP> + gemm_kernel<BM,BN,WM,WN,GATHER> (one implicit-GEMM family: conv3x3 / temporal conv / linear)",
             "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
-            "traffic": pmc_traffic(),
+            "traffic": pmc_traffic() if args.videos == 1 else None,      # the committed PMC passes are of the b=2 step
             "launches_per_unet_step": n_gemm, "avg_launch_us": round(gemm_ms / n_gemm * 1e3, 2),
             "flops_per_unet_step_T": round(gemm_fl / 1e12, 3),
             "unet_step_ms_events": round(step_ms, 3),

@@ -123,7 +123,8 @@ enum t2v_gather {
  * TIME_EMBED: i: 0 B, 1 dim; p: 0 t fp32 [B], 1 freqs fp32 [dim/2], 2 out fp16 [B,dim]
  * COPY2D: i: 0 rows, 1 cols, 2 ld_src, 3 ld_dst, 4 src dtype, 5 dst dtype, 6 act (0 none, 1 SiLU, 2 GELU(erf),
  *      3 quick-GELU x*sigmoid(1.702x)); p: 0 src, 1 dst
- * DDIM_STEP: i: 0 C, 1 inner (F*h*w), 2 guided channels, 3 eps dtype, 4 x dtype, 5 mode;
+ * DDIM_STEP: i: 0 C (= samples * channels), 1 inner (F*h*w), 2 guided channels (per sample), 3 eps dtype, 4 x dtype, 5 mode,
+ *      6 channels per sample (0 = C: one video per batch); x [samples, channels, inner], eps [2, samples, channels, inner];
  *      mode 0 (DDIM_Gaussian, gaussian_sampler.py:103-108,199-211,269-283):
  *        f: 0 sqrt_recip_ac, 1 sqrt_recipm1_ac, 2 sqrt(a_prev), 3 dir coef, 4 sigma (masked), 5 guidance scale
  *      mode 1 (LDM DDIM, samplers/ddim/sampler.py:197-219):  x0 = (x - f0*e)/f1;  out = f2*x0 + f3*e + f4*noise

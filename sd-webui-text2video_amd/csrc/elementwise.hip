@@ -99,13 +99,13 @@ __global__ __launch_bounds__(256) void embed_rows_kernel(const int* ids, const T
 
 struct DdimParams {
   const void* xt; const void* eps; const float* noise; void* out;
-  int C, inner, guided, eps_f32, x_f32, mode;
+  int C, inner, guided, eps_f32, x_f32, mode, cps;
   float a_recip, a_recipm1, sqrt_aprev, dir_coef, sigma, gscale;
 };
 
 template <typename TX, typename TE>
 __global__ __launch_bounds__(256) void ddim_step_kernel(const DdimParams p) {
-  // x_t [1,C,inner]; eps pair [2,C,inner] (0 = conditional, 1 = unconditional)
+  // x_t [S,Cs,inner] with C = S*Cs rows; eps [2,S,Cs,inner] (0 = conditional, 1 = unconditional); S videos per batch
   const TX* xt = reinterpret_cast<const TX*>(p.xt);
   const TE* ec = reinterpret_cast<const TE*>(p.eps);
   const TE* eu = ec + (size_t)p.C * p.inner;
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void ddim_step_kernel(const DdimParams p) {
     const float x = (float)xt[idx];
     const float y = (float)ec[idx];
     float o = y;
-    if (c < p.guided) {
+    if (c % p.cps < p.guided) {
       const float u = (float)eu[idx];
       o = u + p.gscale * (y - u);
     }
@@ -243,6 +243,8 @@ hipError_t t2v_launch_ddim_step(const t2v_op& op, hipStream_t s) {
   p.out = reinterpret_cast<void*>(op.p[3]);
   p.C = op.i[0]; p.inner = op.i[1]; p.guided = op.i[2]; p.eps_f32 = op.i[3] == T2V_F32; p.x_f32 = op.i[4] == T2V_F32;
   p.mode = op.i[5];
+  p.cps = op.i[6] > 0 ? op.i[6] : p.C;       // channels per sample (several videos per batch: C = samples * cps)
+  if (p.C % p.cps != 0) return hipErrorInvalidValue;
   p.a_recip = op.f[0]; p.a_recipm1 = op.f[1]; p.sqrt_aprev = op.f[2]; p.dir_coef = op.f[3]; p.sigma = op.f[4];
   p.gscale = op.f[5];
   const int g = grid_for((long)p.C * p.inner);

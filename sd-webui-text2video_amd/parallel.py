@@ -167,14 +167,17 @@ class CfgPair:
 
 
 class _Runner:
-    def __init__(self, pipe, pair: CfgPair, frames, height, width, ddim_steps, guidance):
+    def __init__(self, pipe, pair: CfgPair, frames, height, width, ddim_steps, guidance, videos: int = 1):
         self.pipe, self.pair = pipe, pair
         self.frames, self.height, self.width, self.ddim_steps, self.guidance = frames, height, width, ddim_steps, guidance
+        assert videos == 1 or pair.size == 1, "several videos per batch only in the one-GPU-per-video layouts"
+        self.videos = videos
         n_videos = (pair.world + 1) // 2 if pair.world > 1 else 1
-        self.frames_per_video_all_ranks = frames * n_videos
-        self.unet_batch = 2 if pair.size == 1 else 1
+        self.frames_per_video_all_ranks = frames * n_videos * videos
+        self.unet_batch = 2 * videos if pair.size == 1 else 1
         self.unet_frames = frames
-        self.describe = ("1 GPU: cond+uncond batched as b=2" if pair.world == 1 else
+        self.describe = ((f"1 GPU: cond+uncond batched as b=2" if videos == 1 else
+                          f"1 GPU: {videos} videos per batch, cond+uncond batched as b={2 * videos}") if pair.world == 1 else
                          f"{n_videos} video(s) in parallel, each on a CFG pair (cond | uncond UNet forwards on 2 GPUs, "
                          f"eps all-gather per step over RCCL), VAE frames split over the pair")
 
@@ -184,7 +187,7 @@ class _Runner:
         seed = seed + 1000 * pair.index            # every pair makes its own video
         if pair.size == 1:
             rgb, _ = pipe.infer_conditioned(cond, uncond, self.ddim_steps, self.frames, seed, self.guidance,
-                                            self.width, self.height, 0.0, to_host=False)
+                                            self.width, self.height, 0.0, to_host=False, videos=self.videos)
             return rgb
         pipe.diffusion.get_sampler("DDIM_Gaussian", return_sampler=False)
         pipe.diffusion.sampler.cfg_parallel = pair
@@ -268,17 +271,19 @@ class _ReplicaRunner(_Runner):
     """Throughput layout: every GPU generates its own videos (cond + uncond batched as b=2, exactly the 1-GPU
     workload) — videos are independent objects, so there is no data-path collective at all."""
 
-    def __init__(self, pipe, world, rank, frames, height, width, ddim_steps, guidance):
-        super().__init__(pipe, CfgPair(1, 0), frames, height, width, ddim_steps, guidance)
+    def __init__(self, pipe, world, rank, frames, height, width, ddim_steps, guidance, videos: int = 1):
+        super().__init__(pipe, CfgPair(1, 0), frames, height, width, ddim_steps, guidance, videos=videos)
         self.rank = rank
-        self.frames_per_video_all_ranks = frames * world
-        self.describe = f"{world} independent videos in flight, one per GPU (cond+uncond batched as b=2, no data-path collective)"
+        self.frames_per_video_all_ranks = frames * world * videos
+        self.describe = (f"{world * videos} independent videos in flight, {videos} per GPU (cond+uncond batched as "
+                         f"b={2 * videos}, no data-path collective)")
 
     def __call__(self, cond, uncond, seed):
         return super().__call__(cond, uncond, seed + 1000 * self.rank)
 
 
-def make_runner(pipe, world: int, rank: int, *, frames, height, width, ddim_steps, guidance, mode: str = "auto"):
+def make_runner(pipe, world: int, rank: int, *, frames, height, width, ddim_steps, guidance, mode: str = "auto",
+                videos: int = 1):
     """'replicas': one video per GPU (throughput; no collective).  'pairs': one video per CFG pair — cond | uncond UNet
     forwards on 2 GPUs, one eps all-gather per step (latency: 1.65x faster per video).  'tshard': one long video on
     2 x R GPUs, T-sharded inside the UNet (world >= 4, even; statistics / halo / K-V exchanges before the temporal ops).
@@ -288,7 +293,8 @@ def make_runner(pipe, world: int, rank: int, *, frames, height, width, ddim_step
     if mode == "auto":
         mode = "replicas" if world > 1 else "pairs"
     if mode == "replicas":
-        return _ReplicaRunner(pipe, world, rank, frames, height, width, ddim_steps, guidance)
+        return _ReplicaRunner(pipe, world, rank, frames, height, width, ddim_steps, guidance, videos=videos)
     if mode == "tshard":
+        assert videos == 1
         return _TShardRunner(pipe, TShardTopology(world, rank), frames, height, width, ddim_steps, guidance)
-    return _Runner(pipe, CfgPair(world, rank), frames, height, width, ddim_steps, guidance)
+    return _Runner(pipe, CfgPair(world, rank), frames, height, width, ddim_steps, guidance, videos=videos)

@@ -123,10 +123,14 @@ class TextToVideoSynthesis(object):
     @torch.no_grad()
     def infer_conditioned(self, c, uc, steps, frames, seed, scale, width=256, height=256, eta=0.0,
                           device=None, latents=None, strength=None, mask=None, is_vid2vid=False,
-                          sampler=available_samplers[0].name, decode=True, to_host=True, _keep_sampler=False):
+                          sampler=available_samplers[0].name, decode=True, to_host=True, _keep_sampler=False,
+                          videos: int = 1):
         """Stages 2-4 of `infer` for given conditioning tensors c, uc [1, 77k, 1024].
         Returns (frames, last_tensor): frames = list of HxWx3 uint8 BGR arrays (to_host) or a
-        uint8 device tensor [F,H,W,3] RGB (to_host=False), or None when decode=False."""
+        uint8 device tensor [F,H,W,3] RGB (to_host=False), or None when decode=False.
+        `videos` > 1 (DDIM_Gaussian, txt2vid): that many independent videos of the same prompt in ONE batch — every
+        UNet step is a single 2*videos forward; the frames come back side by side ([F, H, videos*W, 3], the layout
+        `tensor2vid` gives a batch, t2v_pipeline.py:447-460).  The reference generates one video at a time."""
         dev = torch.device(device) if device is not None else self.device
         self.device = dev
         self.diffusion.device = dev
@@ -134,9 +138,15 @@ class TextToVideoSynthesis(object):
         if not _keep_sampler:
             self.diffusion.get_sampler(sampler, return_sampler=False)
         latents, noise, shape = self.diffusion.get_noise(1, 4, frames, height, width, seed=seed, latents=latents)
+        if videos > 1:
+            if sampler != "DDIM_Gaussian" or latents is not None or is_vid2vid:
+                raise NotImplementedError("several videos per batch: DDIM_Gaussian text-to-video only")
+            shape = (videos,) + tuple(shape[1:])
+            self.diffusion.noise_gen.manual_seed(seed)
+            noise = torch.randn(shape, generator=self.diffusion.noise_gen).to(dev)     # video 0 = the single-video noise
         x0 = self.diffusion.sample_loop(
             steps=steps, strength=strength, eta=eta, conditioning=c.to(dev), unconditional_conditioning=uc.to(dev),
-            batch_size=1, guidance_scale=scale, latents=latents, shape=shape, noise=noise, is_vid2vid=is_vid2vid,
+            batch_size=videos, guidance_scale=scale, latents=latents, shape=shape, noise=noise, is_vid2vid=is_vid2vid,
             sampler_name=sampler, mask=mask)
         self.last_tensor = x0
         if not decode:

@@ -415,9 +415,11 @@ class Program:
         op.out = out
         return self._emit(op)
 
-    def ddim_step(self, name: str, *, C: int, inner: int, guided: int, eps_dtype: str, x_dtype: str, mode: int = 0) -> Op:
+    def ddim_step(self, name: str, *, C: int, inner: int, guided: int, eps_dtype: str, x_dtype: str, mode: int = 0,
+                  samples: int = 1) -> Op:
+        """C channels per video, `samples` videos per batch (x [samples, C, inner], eps [2, samples, C, inner])."""
         op = Op(L.OP_DDIM_STEP, name)
-        op.i[0:6] = [C, inner, guided, _DT[eps_dtype], _DT[x_dtype], mode]
+        op.i[0:7] = [C * samples, inner, guided, _DT[eps_dtype], _DT[x_dtype], mode, C]
         op.p[0:4] = [Ref("ext", L.EXT_XT), Ref("ext", L.EXT_EPS), Ref("ext", L.EXT_NOISE), Ref("ext", L.EXT_XT_OUT)]
         return self._emit(op)
 

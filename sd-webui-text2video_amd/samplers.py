@@ -148,12 +148,12 @@ class GaussianDiffusion(object):
         return guide_scale is None or guide_scale == 1
 
     # -- fused update kernel -------------------------------------------------------------------
-    def _step_plan(self, C, inner, guided, eps_dtype, x_dtype):
-        key = (C, inner, guided, eps_dtype, x_dtype)
+    def _step_plan(self, C, inner, guided, eps_dtype, x_dtype, samples=1):
+        key = (C, inner, guided, eps_dtype, x_dtype, samples)
         plan = self._step_plans.get(key)
         if plan is None:
             prog = Program("ddim_step")
-            prog.ddim_step("ddim.step", C=C, inner=inner, guided=guided, eps_dtype=eps_dtype, x_dtype=x_dtype)
+            prog.ddim_step("ddim.step", C=C, inner=inner, guided=guided, eps_dtype=eps_dtype, x_dtype=x_dtype, samples=samples)
             plan = BoundProgram(prog, 0, {})
             self._step_plans[key] = plan
         return plan
@@ -177,7 +177,8 @@ class GaussianDiffusion(object):
         if xt.dtype not in (torch.float16, torch.float32):
             xt = xt.float()
         xt = xt.contiguous()
-        assert xt.shape[0] == 1, "the reference pipeline samples one video at a time (num_sample = 1)"
+        # the reference pipeline samples one video at a time (num_sample = 1, samplers_common.py:108); Bx > 1 = several
+        # independent videos per batch (same conditioning), evaluated as ONE 2*Bx forward per step
         x_next = torch.empty_like(xt)
         Bx, C, Fr, Hh, Ww = xt.shape
         inner = Fr * Hh * Ww
@@ -196,12 +197,17 @@ class GaussianDiffusion(object):
             for step in range(steps):
                 c, uc = reconstruct_conds(conditioning, unconditional_conditioning, step)
                 t = int(all_t[step])
-                tt = torch.full((1,), t, dtype=torch.long, device=dev)
+                tt = torch.full((Bx,), t, dtype=torch.long, device=dev)
+                if Bx > 1:
+                    c = c.expand(Bx, *c.shape[1:]) if c.shape[0] == 1 else c
+                    if uc is not None:
+                        uc = uc.expand(Bx, *uc.shape[1:]) if uc.shape[0] == 1 else uc
                 if self.is_unconditional(guide):
                     eps = model(xt, tt, c)
                     guided, gscale = 0, 1.0
                 elif self.cfg_parallel is not None and self.cfg_parallel.size == 2:
                     # CFG pair: this rank evaluates ONE of the two forwards; one eps all-gather per step
+                    assert Bx == 1, "the CFG-pair layout runs one video per pair"
                     mine = c if self.cfg_parallel.role == 0 else uc
                     eps = self.cfg_parallel.exchange_eps(model(xt, tt, mine))
                     guided, gscale = C // 2 if not self.var_type.startswith("fixed") else C, float(guide)
@@ -222,7 +228,7 @@ class GaussianDiffusion(object):
                     float(sigma) if t != 0 else 0.0, gscale)
                 noise = torch.randn_like(xt, dtype=f32)     # drawn every step, like the reference (global RNG)
                 _ = torch.randn_like(xt, dtype=f32)         # the (inert) inpaint hook's draw, gaussian_sampler.py:288
-                plan = self._step_plan(C, inner, guided, "f16" if eps.dtype == torch.float16 else "f32", x_dt)
+                plan = self._step_plan(C, inner, guided, "f16" if eps.dtype == torch.float16 else "f32", x_dt, samples=Bx)
                 L.check(lib.t2v_ddim_step(plan.handle, xt.data_ptr(), eps.data_ptr(),
                                           noise.data_ptr() if float(sigma) != 0.0 else None,
                                           x_next.data_ptr(), coef, ctypes.c_void_p(stream)))

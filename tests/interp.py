@@ -50,7 +50,7 @@ class Interp:
 
     def view(self, ref: Ref, shape, strides, dtype, ext):
         flat, off = self._flat(ref, dtype, ext)
-        return torch.as_strided(flat, tuple(shape), tuple(strides), off)
+        return torch.as_strided(flat, tuple(shape), tuple(strides), flat.storage_offset() + off)   # (ext tensors may be views)
 
     def mat(self, ref: Ref, rows, cols, ld, dtype, ext):
         return self.view(ref, (rows, cols), (ld, 1), dtype, ext)
@@ -245,12 +245,14 @@ class Interp:
     # DDIM_STEP ----------------------------------------------------------------------------------------
     def _op10(self, op, ext):
         C, inner, guided, edt, xdt = op.i[0:5]
+        cps = op.i[6] if op.i[6] > 0 else C
         a_recip, a_recipm1, sqrt_aprev, dir_coef, sigma, gscale = op.f[0:6]
         xt = self.view(op.p[0], (C, inner), (inner, 1), _TD[xdt], ext).float()
         e = self.view(op.p[1], (2, C, inner), (C * inner, inner, 1), _TD[edt], ext).float()
         y, u = e[0], e[1]
         o = y.clone()
-        o[:guided] = u[:guided] + gscale * (y[:guided] - u[:guided])
+        g = (torch.arange(C) % cps) < guided
+        o[g] = u[g] + gscale * (y[g] - u[g])
         if op.i[5] == 0:
             x0 = a_recip * xt - a_recipm1 * o
             eps = (a_recip * xt - x0) / a_recipm1

@@ -187,3 +187,24 @@ def test_lora_style_merge_repacks_only_the_touched_images():
     import pytest
     with pytest.raises(L.T2VError):
         m.refresh_weights("cpu")
+
+
+def test_ddim_step_op_with_several_videos_per_batch():
+    """i[6] = channels per sample: x [S, C, inner], eps [2, S, C, inner]; identical to S single-video updates."""
+    from sd_webui_text2video_amd.program import Program
+    C, inner, S = 4, 48, 3
+    coef = [1.3, 0.83, 0.9, 0.43, 0.2, 9.0]
+    P = Program()
+    P.ddim_step("s", C=C, inner=inner, guided=2, eps_dtype="f32", x_dtype="f32", samples=S)
+    P.ops[-1].f[0:6] = coef
+    g = torch.Generator().manual_seed(0)
+    xt, eps, nz = torch.randn(S, C, inner, generator=g), torch.randn(2, S, C, inner, generator=g), torch.randn(S, C, inner, generator=g)
+    out = torch.zeros(S, C, inner)
+    Interp(P, {}).run({L.EXT_XT: xt, L.EXT_EPS: eps, L.EXT_NOISE: nz, L.EXT_XT_OUT: out})
+    P1 = Program()
+    P1.ddim_step("s", C=C, inner=inner, guided=2, eps_dtype="f32", x_dtype="f32")
+    P1.ops[-1].f[0:6] = coef
+    for s in range(S):
+        o1 = torch.zeros(1, C, inner)
+        Interp(P1, {}).run({L.EXT_XT: xt[s:s + 1], L.EXT_EPS: torch.stack([eps[0, s], eps[1, s]]), L.EXT_NOISE: nz[s:s + 1], L.EXT_XT_OUT: o1})
+        assert torch.equal(o1[0], out[s]), s
