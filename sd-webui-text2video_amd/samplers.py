@@ -271,8 +271,9 @@ def _ddim_update(out, xt, eps_pair, noise, coef, guided: int, mode: int):
     lib = L.load()
     op = L.T2VOp()
     op.kind = L.OP_DDIM_STEP
-    C = xt.shape[1]
-    op.i[0], op.i[1], op.i[2] = C, xt.numel() // C, guided
+    B, C = xt.shape[0], xt.shape[1]              # B videos per batch: eps_pair = [cond (B), uncond (B)]
+    op.i[0], op.i[1], op.i[2] = B * C, xt.numel() // (B * C), guided
+    op.i[6] = C
     op.i[3], op.i[4], op.i[5] = _dt_tag(eps_pair), _dt_tag(xt), mode
     for k in range(6):
         op.f[k] = float(coef[k])

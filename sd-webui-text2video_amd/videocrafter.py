@@ -611,7 +611,7 @@ class DDIMSampler(object):
             raise NotImplementedError("mask blending / quantisation / noise dropout / score correctors are not on the hot path")
         self.make_schedule(ddim_num_steps=S, ddim_eta=eta, verbose=schedule_verbose)
         size = (batch_size, *shape)
-        assert batch_size == 1 and len(size) == 5, "the fused update handles one video per call (the webui path)"
+        assert len(size) == 5
         return self.ddim_sampling(conditioning, size, callback=callback, img_callback=img_callback, temperature=temperature,
                                   x_T=x_T, log_every_t=log_every_t, unconditional_guidance_scale=unconditional_guidance_scale,
                                   unconditional_conditioning=unconditional_conditioning, sample_noise=sample_noise, verbose=verbose)
@@ -642,7 +642,7 @@ class DDIMSampler(object):
         unet.refresh_weights(device)
         prev_auto, unet.auto_refresh = unet.auto_refresh, False
         nxt = torch.empty_like(img)
-        C = img.shape[1]
+        nb, C = img.shape[0], img.shape[1]          # nb videos per batch (sample_text2video's batch_size)
         f32 = torch.float32
         S.state.sampling_steps = total_steps
         iterator = np.flip(timesteps)
@@ -654,7 +654,7 @@ class DDIMSampler(object):
                 if S.state.interrupted:
                     raise S.InterruptedException
                 index = total_steps - i - 1
-                ts = torch.full((1,), int(step), device=device, dtype=torch.long)
+                ts = torch.full((nb,), int(step), device=device, dtype=torch.long)
                 if guided:
                     eps = self.model.apply_model(torch.cat([img, img]), torch.cat([ts, ts]), torch.cat([c, uc])).contiguous()
                 else:
@@ -673,9 +673,9 @@ class DDIMSampler(object):
                     ia = 1.0 / coef[1]
                     if guided:
                         g = float(guide)
-                        S._lincomb(px0, [(ia, img), (-coef[0] * g * ia, eps[0:1]), (-coef[0] * (1.0 - g) * ia, eps[1:2])])
+                        S._lincomb(px0, [(ia, img), (-coef[0] * g * ia, eps[0:nb]), (-coef[0] * (1.0 - g) * ia, eps[nb:2 * nb])])
                     else:
-                        S._lincomb(px0, [(ia, img), (-coef[0] * ia, eps[0:1])])
+                        S._lincomb(px0, [(ia, img), (-coef[0] * ia, eps[0:nb])])
                 S._ddim_update(nxt, img, eps, noise, coef, C if guided else 0, mode=1)
                 img, nxt = nxt, img
                 if callback:

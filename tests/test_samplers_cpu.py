@@ -27,9 +27,10 @@ def _lincomb_cpu(out, terms):
 
 def _ddim_update_cpu(out, xt, eps_pair, noise, coef, guided, mode):
     f = [torch.tensor(c, dtype=torch.float32) for c in coef]
-    e = eps_pair[0:1].float()
+    nb = xt.shape[0]                                     # videos per batch: eps_pair = [cond (nb), uncond (nb)]
+    e = eps_pair[0:nb].float()
     if guided:
-        u = eps_pair[1:2].float()
+        u = eps_pair[nb:2 * nb].float()
         e = torch.cat([u[:, :guided] + f[5] * (e[:, :guided] - u[:, :guided]), e[:, guided:]], dim=1)
     assert mode == 1
     x0 = (xt.float() - f[0] * e) / f[1]

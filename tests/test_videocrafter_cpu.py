@@ -115,6 +115,18 @@ def test_ddim_sampler_host_logic(tiny, monkeypatch):
     assert len(inter["x_inter"]) == len(inter["pred_x0"]) == 3 and samplers.state.sampling_step == 3
     with pytest.raises(NotImplementedError):
         smp.sample(S=4, conditioning=ctx[0:1], batch_size=1, shape=list(x_T.shape[1:]), mask=torch.ones(1), x0=x_T)
+    # batch_size = 2 (sample_text2video's batch): video 0 of the batch = the single-video result (eta = 0: no noise draw)
+    x1, _ = smp.sample(S=4, conditioning={"c_crossattn": [ctx[0:1]]}, batch_size=1, shape=list(x_T.shape[1:]), verbose=False,
+                       unconditional_guidance_scale=7.5, unconditional_conditioning={"c_crossattn": [ctx[1:2]]}, eta=0.0, x_T=x_T)
+    g = torch.Generator().manual_seed(9)
+    xT2 = torch.cat([x_T, torch.randn(x_T.shape, generator=g)], dim=0)
+    calls.clear()
+    x2, _ = smp.sample(S=4, conditioning={"c_crossattn": [ctx[0:1].repeat(2, 1, 1)]}, batch_size=2, shape=list(x_T.shape[1:]),
+                       verbose=False, unconditional_guidance_scale=7.5,
+                       unconditional_conditioning={"c_crossattn": [ctx[1:2].repeat(2, 1, 1)]}, eta=0.0, x_T=xT2)
+    assert x2.shape[0] == 2 and all(c[0] == 4 and len(c[1]) == 4 for c in calls)
+    assert (x2[0:1] - x1).abs().max() < 1e-5 * x1.abs().max()
+    assert (x2[1] - x2[0]).abs().max() > 0.1
 
 
 def test_entry_point_helpers():
