@@ -130,7 +130,8 @@ class TextToVideoSynthesis(object):
         uint8 device tensor [F,H,W,3] RGB (to_host=False), or None when decode=False.
         `videos` > 1 (DDIM_Gaussian, txt2vid): that many independent videos of the same prompt in ONE batch — every
         UNet step is a single 2*videos forward; the frames come back side by side ([F, H, videos*W, 3], the layout
-        `tensor2vid` gives a batch, t2v_pipeline.py:447-460).  The reference generates one video at a time."""
+        `tensor2vid` gives a batch, t2v_pipeline.py:447-460).  Video v starts from the noise of seed + v, i.e. the batch is
+        the reference's `batch_count` loop (process_modelscope.py:152-221: one video at a time, seed + batch) in one pass."""
         dev = torch.device(device) if device is not None else self.device
         self.device = dev
         self.diffusion.device = dev
@@ -141,9 +142,13 @@ class TextToVideoSynthesis(object):
         if videos > 1:
             if sampler != "DDIM_Gaussian" or latents is not None or is_vid2vid:
                 raise NotImplementedError("several videos per batch: DDIM_Gaussian text-to-video only")
+            one = (1,) + tuple(shape[1:])
+            draws = []
+            for v in range(videos):                      # each video from its own seed, as the batch_count loop draws them
+                self.diffusion.noise_gen.manual_seed(seed + v)
+                draws.append(torch.randn(one, generator=self.diffusion.noise_gen))
+            noise = torch.cat(draws, dim=0).to(dev)
             shape = (videos,) + tuple(shape[1:])
-            self.diffusion.noise_gen.manual_seed(seed)
-            noise = torch.randn(shape, generator=self.diffusion.noise_gen).to(dev)     # video 0 = the single-video noise
         x0 = self.diffusion.sample_loop(
             steps=steps, strength=strength, eta=eta, conditioning=c.to(dev), unconditional_conditioning=uc.to(dev),
             batch_size=videos, guidance_scale=scale, latents=latents, shape=shape, noise=noise, is_vid2vid=is_vid2vid,
@@ -209,7 +214,9 @@ def process_modelscope(args_dict: dict, extra_args=None):
     """Entry-point name kept (process_modelscope.py:34).  The reference body is webui file / ffmpeg /
     Gradio plumbing and is out of scope; this minimal form runs the hot path for
     args_dict = {model_dir | pipe, prompt, n_prompt, steps, frames, seed, cfg_scale, width, height,
-    eta, sampler, clip_encoder | (cond, uncond)} and returns the list of BGR uint8 frames."""
+    eta, sampler, clip_encoder | (cond, uncond), batch_count} and returns the list of BGR uint8 frames
+    (batch_count > 1 with given (cond, uncond): the videos of seeds seed .. seed + batch_count - 1 in one batched pass,
+    frames side by side)."""
     global pipe
     a = SimpleNamespace(**args_dict)
     if getattr(a, "pipe", None) is not None:
@@ -220,7 +227,7 @@ def process_modelscope(args_dict: dict, extra_args=None):
                   height=getattr(a, "height", 256), eta=getattr(a, "eta", 0.0),
                   sampler=getattr(a, "sampler", available_samplers[0].name))
     if getattr(a, "cond", None) is not None:
-        frames, _ = pipe.infer_conditioned(a.cond, a.uncond, **common)
+        frames, _ = pipe.infer_conditioned(a.cond, a.uncond, videos=int(getattr(a, "batch_count", 1)), **common)
         return frames
     frames, _, _ = pipe.infer(a.prompt, getattr(a, "n_prompt", ""), **common)
     return frames
