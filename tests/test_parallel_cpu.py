@@ -98,3 +98,16 @@ def test_make_runner_default_layouts():
     assert isinstance(r, parallel._ReplicaRunner) and r.frames_per_video_all_ranks == 24 * 8 and r.unet_batch == 2
     r1 = parallel.make_runner(Pipe(), 1, 0, **kw)
     assert type(r1) is parallel._Runner and r1.frames_per_video_all_ranks == 24 and r1.unet_batch == 2
+    # several videos per batch and GPU (bench.py --videos V): frame accounting and the UNet batch follow
+    r4 = parallel.make_runner(Pipe(), 1, 0, videos=4, **kw)
+    assert r4.frames_per_video_all_ranks == 96 and r4.unet_batch == 8 and "4 videos per batch" in r4.describe
+    r8 = parallel.make_runner(Pipe(), 8, 5, videos=2, **kw)
+    assert r8.frames_per_video_all_ranks == 24 * 8 * 2 and r8.unet_batch == 4 and "16 independent videos" in r8.describe
+    calls = []
+
+    class P2:
+        def infer_conditioned(self, *a, **k):
+            calls.append((a[4], k.get("videos")))
+            return "rgb", None
+    r8.pipe = P2()
+    assert r8(None, None, 100) == "rgb" and calls == [(100 + 1000 * 5, 2)]      # every rank draws its own seeds
