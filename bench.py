@@ -165,6 +165,9 @@ def main():
     ap.add_argument("--videos", type=int, default=1,
                     help="independent videos per batch and GPU (default 1 = the reference's one-video pipeline; the UNet step "
                          "becomes one b=2*videos forward)")
+    ap.add_argument("--also-batched", type=int, default=4,
+                    help="at N=1 with --videos 1: also time one pass with this many videos per batch and report it as "
+                         "`batched` beside the headline (0 / 1 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--parallel", default="auto", choices=["auto", "replicas", "pairs", "tshard"],
                     help="N>1 layout: one video per GPU (default), one video per CFG pair, or one T-sharded video (N>=4)")
@@ -280,6 +283,20 @@ def main():
             "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 --pmc, profiles/r01_pmc_traffic.json)",
             "algorithmic_bytes_per_launch": round(alg_bytes / n_gemm),
         }
+        if world == 1 and args.videos == 1 and args.also_batched > 1:
+            # Reported beside the headline, never as `value`: the same workload with several videos per batch (the
+            # reference's batch_count loop in one pass) — one warm-up pass, one timed pass.
+            nv = args.also_batched
+            r2 = parallel.make_runner(pipe, 1, 0, frames=args.frames, height=args.height, width=args.width,
+                                      ddim_steps=args.ddim_steps, guidance=9.0, videos=nv)
+            r2(cond, uncond, 4321)
+            torch.cuda.synchronize(dev)
+            tb = time.perf_counter()
+            r2(cond, uncond, 4322)
+            torch.cuda.synchronize(dev)
+            tb = time.perf_counter() - tb
+            result["batched"] = {"videos_per_batch": nv, "value": round(nv * args.frames / tb, 4), "unit": "frames/s",
+                                 "ms_per_step": round(tb * 1e3, 2), "note": "same workload, several videos per batch; not the headline"}
         if not args.no_cpu_baseline and world == 1:       # the CPU leg is reported at N=1 only
             result["cpu_baseline"] = cpu_baseline(args.frames, args.ddim_steps)
         print(json.dumps(result), flush=True)
