@@ -274,7 +274,8 @@ def main():
         result["roofline"] = {
             "bound": "mfma", "kernel": "gemm2_kernel<WM,WN,TM,TN,BK,STAGES,MINW,GATHER,PP> + gemm_kernel<BM,BN,WM,WN,GATHER> (one implicit-GEMM family: conv3x3 / temporal conv / linear)",
             "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
-            "traffic": pmc_traffic() if args.videos == 1 else None,      # the committed PMC passes are of the b=2 step
+            # the committed PMC passes are of the b=2, 24-frame, 256x256 step
+            "traffic": pmc_traffic() if (args.videos, args.frames, args.height, args.width) == (1, 24, 256, 256) else None,
             "launches_per_unet_step": n_gemm, "avg_launch_us": round(gemm_ms / n_gemm * 1e3, 2),
             "flops_per_unet_step_T": round(gemm_fl / 1e12, 3),
             "unet_step_ms_events": round(step_ms, 3),
