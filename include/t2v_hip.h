@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define T2V_ABI_VERSION 1
+#define T2V_ABI_VERSION 2
 
 /* error codes */
 #define T2V_OK 0
@@ -34,6 +34,7 @@ extern "C" {
 #define T2V_ERR_UNSUPPORTED (-2)
 #define T2V_ERR_LAUNCH (-3)
 #define T2V_ERR_NO_DEVICE (-4)
+#define T2V_ERR_COMM (-5)      /* RCCL not loadable / communicator call failed */
 
 /* ---- op kinds ------------------------------------------------------------------------- */
 enum t2v_op_kind {
@@ -51,7 +52,10 @@ enum t2v_op_kind {
   T2V_OP_LINCOMB = 12,    /* out = sum_i c_i * T_i (<= 6 latent-sized tensors): UniPC / DDIM updates */
   T2V_OP_RELPOS_ATTN = 13, /* LVDM temporal attention with relative-position K / V terms (frames <= 32) */
   T2V_OP_EMBED_ROWS = 14,  /* token + positional embedding lookup (CLIP text towers) */
-  T2V_OP_KIND_MAX = 15
+  T2V_OP_TO_UINT8 = 15,    /* tensor2vid: float video -> uint8 frames [F,H,(i W),3], truncating (t2v_pipeline.py:447-460) */
+  T2V_OP_ALLGATHER = 16,   /* in-place all-gather of equal byte parts over the plan's communicator (RCCL, launch stream) */
+  T2V_OP_HALO_EXCHANGE = 17, /* +-1 frame neighbour exchange of a [F+2]-frame token buffer over the plan's communicator */
+  T2V_OP_KIND_MAX = 18
 };
 
 /* GEMM gather modes: how row m / reduction index k of the A operand are addressed          */
@@ -99,7 +103,8 @@ enum t2v_gather {
  *   i: 0 M, 1 N, 2 K, 3 lda, 4 ldw, 5 ldc, 6 ldr, 7 gather, 8 Hin|F, 9 Win|HW, 10 Cin,
  *      11 stride, 12 upsample, 13 Hout, 14 Wout, 15 rows_per_batch, 16 epilogue,
  *      17 out dtype, 18 act (0 none, 1 SiLU), 19 split_k, 20 bias_along_m, 21 ldrb,
- *      22 tile (0 = 128x128-class kernel; 1 256x256, 2 256x320, 3 128x256),
+ *      22 tile (0 = 128x128-class kernel; 1 256x256, 2 256x320, 3 128x256 (8 waves, 3-stage ring), 4 / 5 128x128 with a 4-deep
+ *         ring on 4 / 8 waves, 6 / 7 = 1 / 2 with the two-group ping-pong schedule),
  *      23 tconv halo (input rows are [clip][F+2][HW]: one halo frame either side, T-sharding);
  *         for CONV3X3: 1 = zero padding (0,1,0,1) instead of (1,1,1,1) (LDM encoder Downsample, taps at +0..+2)
  *   p: 0 A fp16, 1 W fp16 [N,K], 2 bias fp32 [N] (or [M] if bias_along_m), 3 rowbias fp32
@@ -108,6 +113,8 @@ enum t2v_gather {
  *      7 ld_out, 8 phase (0 whole op | 1 statistics only | 2 fold gathered parts + normalise),
  *      9 nparts, 10 this rank's part, 11 rows per workgroup (0: T2V_GN_ROWS_PER_BLOCK; sizes the scratch),
  *      12 single-launch variant (phase 0 only, (C/groups) % 4 == 0): one workgroup per (instance, group);
+ *      13 rows of the LARGEST part (0 = rows: equal parts) — sizes every part's slot count ceil(rows_max / rows per workgroup);
+ *         a shorter part zero-fills its unused slots;  14 rows of the whole instance over all parts (0 = rows * nparts);
  *      f: 0 eps;  p: 0 x, 1 gamma, 2 beta, 3 out fp16, 4 scratch
  * LAYERNORM: i: 0 M, 1 C, 2 ld_in, 3 ld_out; f: 0 eps; p: 0 x fp32, 1 gamma, 2 beta, 3 out fp16
  * ATTENTION: i: 0 nq, 1 nk, 2 heads, 3 batch_outer, 4 batch_inner, 5..7 q strides (seq,
@@ -135,6 +142,16 @@ enum t2v_gather {
  * MEMSET: i: 0 bytes (lo), 1 bytes (hi); p: 0 dst
  * EMBED_ROWS: out[r,:] = table[ids[r],:] + pos[r % L,:]   i: 0 rows, 1 width, 2 L, 3 vocab, 4 table dtype;
  *      p: 0 ids int32 [rows], 1 table [vocab,width], 2 pos fp32 [L,width], 3 out fp32 [rows,width]
+ * TO_UINT8: out[f, y, i*W + x, c] = trunc(clamp(v*0.5 + 0.5, 0, 1) * 255), v = in[i*si + c*sc + f*sf + y*sy + x*sx]
+ *      i: 0 NI (videos side by side), 1 C, 2 F, 3 H, 4 W, 5 in dtype, 6 arithmetic (0 fp32 | 1 every intermediate rounded
+ *      to fp16, the reference's half-precision VAE path), 7 channel order reversed (RGB -> BGR), 8/9 si (lo, hi), 10 sc,
+ *      11/12 sf (lo, hi), 13 sy, 14 sx (element strides);  p: 0 in, 1 out uint8
+ * ALLGATHER: part q of `nparts` equal parts lives at base + q*bytes; this rank's part is already in place.
+ *      i: 0/1 bytes per part (lo, hi), 2 nparts, 3 this rank's part;  p: 0 base.   nparts == 1: no-op.
+ * HALO_EXCHANGE: token buffer of F+2 frames (frame = `bytes`): frame 1 -> previous rank's frame F+1 slot ... i.e. this rank
+ *      sends its first real frame to `prev` and its last to `next`, and receives their boundary frames into frame 0 / F+1.
+ *      i: 0/1 bytes per frame (lo, hi), 2 F (local frames), 3 prev rank in the communicator (-1 none), 4 next rank (-1 none);
+ *      p: 0 base.   Both collectives need t2v_plan_set_comm unless they are no-ops.
  */
 typedef struct t2v_op {
   int32_t kind;
@@ -163,6 +180,17 @@ int t2v_plan_run(t2v_plan* plan, const uint64_t* ext, int n_ext, void* stream);
  * Synchronises the stream.  Used by bench.py for the live roofline measurement. */
 int t2v_plan_run_timed(t2v_plan* plan, const uint64_t* ext, int n_ext, void* stream, float* ms);
 void t2v_plan_destroy(t2v_plan* plan);
+
+/* Communicators (T-axis sharding, one process per GPU): RCCL is dlopen'ed on first use, the library itself does not link
+ * it.  Rank 0 of a group calls t2v_comm_unique_id and hands the 128 bytes to the others out of band (the host uses
+ * torch.distributed's store); every rank then calls t2v_comm_create on its own device.  Collective ops of a plan run on
+ * the launch stream, in program order with the kernels: a sharded UNet forward is ONE host call. */
+typedef struct t2v_comm t2v_comm;
+int t2v_comm_unique_id(unsigned char id[128]);
+int t2v_comm_create(const unsigned char id[128], int nranks, int rank, t2v_comm** out);
+int t2v_comm_size(const t2v_comm* comm);
+void t2v_comm_destroy(t2v_comm* comm);
+int t2v_plan_set_comm(t2v_plan* plan, t2v_comm* comm);   /* borrowed; must outlive the plan's runs */
 
 /* Drop-in entry points for the reference's call sites (thin wrappers over t2v_plan_run that
  * fix the external-slot convention):

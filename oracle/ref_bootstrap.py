@@ -126,3 +126,29 @@ def build_reference_vae(ddconfig: dict, embed_dim: int = 4):
     with contextlib.redirect_stdout(io.StringIO()):  # the Decoder ctor prints its z shape
         vae = ref.t2v.AutoencoderKL(dict(ddconfig), embed_dim, None).eval()
     return vae
+
+
+def bootstrap_pipeline():
+    """The reference's outer entry point module scripts/modelscope/t2v_pipeline.py (TextToVideoSynthesis.infer,
+    tensor2vid, postprocess_video), imported unmodified.  Extra stubs: cv2 (only `cvtColor(img, COLOR_RGB2BGR)` is
+    called, postprocess_video :431), open_clip and the webui modules clip_hardcode.py imports at module top
+    (the text encoder is outside the hot path: callers install a stand-in `preprocess`)."""
+    ref = bootstrap()
+    if getattr(ref, "pipeline", None) is not None:
+        return ref.pipeline
+    import contextlib
+    import numpy as np
+    if "cv2" not in sys.modules:
+        _mod("cv2", COLOR_RGB2BGR=4, cvtColor=lambda img, code: np.ascontiguousarray(img[:, :, ::-1]))
+    if "open_clip" not in sys.modules:
+        _mod("open_clip", tokenizer=types.SimpleNamespace(_tokenizer=types.SimpleNamespace(encoder={}, decoder={})))
+    mods = sys.modules["modules"]
+    dev = _mod("modules.devices", autocast=contextlib.nullcontext, torch_gc=lambda: None, device=torch.device("cpu"))
+    gp = _mod("modules.generation_parameters_copypaste", quote=lambda v: str(v))
+    hj = _mod("modules.sd_hijack", model_hijack=types.SimpleNamespace())
+    ti = _mod("modules.textual_inversion")
+    ti.textual_inversion = _mod("modules.textual_inversion.textual_inversion", Embedding=object,
+                                EmbeddingDatabase=lambda *a, **k: types.SimpleNamespace())
+    mods.devices, mods.generation_parameters_copypaste, mods.sd_hijack, mods.textual_inversion = dev, gp, hj, ti
+    ref.pipeline = importlib.import_module("modelscope.t2v_pipeline")
+    return ref.pipeline

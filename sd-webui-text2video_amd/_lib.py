@@ -10,12 +10,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libt2v_hip.so")
 
 # ---- mirrors of include/t2v_hip.h (checked against the header by tests/test_abi.py) -------
-ABI_VERSION = 1
+ABI_VERSION = 2
 OP_GEMM, OP_GROUPNORM, OP_LAYERNORM, OP_ATTENTION, OP_SOFTMAX = 1, 2, 3, 4, 5
 OP_NCTHW_TO_CL, OP_CL_TO_NCTHW, OP_TIME_EMBED, OP_COPY2D, OP_DDIM_STEP, OP_MEMSET = 6, 7, 8, 9, 10, 11
 OP_LINCOMB = 12
 OP_RELPOS_ATTN = 13
 OP_EMBED_ROWS = 14
+OP_TO_UINT8, OP_ALLGATHER, OP_HALO_EXCHANGE = 15, 16, 17
 GATHER_PLAIN, GATHER_CONV3X3, GATHER_TCONV3, GATHER_CONV3X3_C8 = 0, 1, 2, 3
 EPI_NONE, EPI_GEGLU = 0, 1
 F16, F32 = 0, 1
@@ -28,6 +29,7 @@ EXPORTS = [
     "t2v_abi_version", "t2v_last_error", "t2v_device_info", "t2v_run_ops", "t2v_plan_create",
     "t2v_plan_num_ops", "t2v_plan_run", "t2v_plan_run_timed", "t2v_plan_destroy",
     "t2v_unet_forward", "t2v_vae_decode", "t2v_ddim_step",
+    "t2v_comm_unique_id", "t2v_comm_create", "t2v_comm_size", "t2v_comm_destroy", "t2v_plan_set_comm",
 ]
 
 
@@ -71,6 +73,12 @@ def load():
     lib.t2v_unet_forward.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.t2v_vae_decode.argtypes = [vp, vp, vp, vp]
     lib.t2v_ddim_step.argtypes = [vp, vp, vp, vp, vp, ctypes.POINTER(ctypes.c_float), vp]
+    lib.t2v_comm_unique_id.argtypes = [ctypes.c_char_p]
+    lib.t2v_comm_create.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(vp)]
+    lib.t2v_comm_size.argtypes = [vp]
+    lib.t2v_comm_destroy.argtypes = [vp]
+    lib.t2v_comm_destroy.restype = None
+    lib.t2v_plan_set_comm.argtypes = [vp, vp]
     if lib.t2v_abi_version() != ABI_VERSION:
         raise T2VError(f"libt2v_hip.so ABI {lib.t2v_abi_version()} != binding {ABI_VERSION}; rebuild")
     _lib = lib

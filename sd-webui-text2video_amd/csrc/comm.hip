@@ -1,0 +1,140 @@
+// Communicators for the T-axis (frame) sharding of a UNet forward: one process per GPU, RCCL over xGMI.
+//
+// The reference's only collective is an all-gather of decoded samples (lvdm/utils/dist_utils.py:13-19); the exchanges
+// here are the ones a frame-sharded forward needs before its temporal ops: all-gather of GroupNorm
+// statistics partials and of temporal-attention K/V, and a +-1 frame neighbour exchange for the (3,1,1) convolutions.
+// They are ops of the denoise program and run on the launch stream between the kernels, so a sharded forward stays one
+// host call.  RCCL is dlopen'ed on first use: the library has no link-time dependency on it (single-GPU use never loads
+// it, and the process may already hold torch's copy — the same soname resolves to that one).
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <mutex>
+#include <string>
+
+#include "t2v_kernels.h"
+
+struct t2v_comm {
+  ncclComm_t comm;
+  int nranks, rank;
+};
+
+namespace {
+
+struct Rccl {
+  void* handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  std::string err;
+};
+
+Rccl g_rccl;
+std::once_flag g_once;
+
+template <typename F>
+bool sym(void* h, const char* name, F& fn) {
+  fn = reinterpret_cast<F>(dlsym(h, name));
+  return fn != nullptr;
+}
+
+void load_rccl() {
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char* n : names) {
+    g_rccl.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (g_rccl.handle) break;
+  }
+  if (!g_rccl.handle) {
+    g_rccl.err = std::string("cannot dlopen librccl: ") + (dlerror() ? dlerror() : "?");
+    return;
+  }
+  void* h = g_rccl.handle;
+  const bool ok = sym(h, "ncclGetUniqueId", g_rccl.GetUniqueId) && sym(h, "ncclCommInitRank", g_rccl.CommInitRank) &&
+                  sym(h, "ncclCommDestroy", g_rccl.CommDestroy) && sym(h, "ncclAllGather", g_rccl.AllGather) &&
+                  sym(h, "ncclSend", g_rccl.Send) && sym(h, "ncclRecv", g_rccl.Recv) &&
+                  sym(h, "ncclGroupStart", g_rccl.GroupStart) && sym(h, "ncclGroupEnd", g_rccl.GroupEnd) &&
+                  sym(h, "ncclGetErrorString", g_rccl.GetErrorString);
+  if (!ok) {
+    g_rccl.err = "librccl lacks an expected nccl* symbol";
+    g_rccl.handle = nullptr;
+  }
+}
+
+const Rccl* rccl() {
+  std::call_once(g_once, load_rccl);
+  return g_rccl.handle ? &g_rccl : nullptr;
+}
+
+}  // namespace
+
+const char* t2v_comm_load_error() { return g_rccl.err.c_str(); }
+
+int t2v_comm_impl_unique_id(unsigned char id[128], std::string& err) {
+  const Rccl* r = rccl();
+  if (!r) { err = g_rccl.err; return T2V_ERR_COMM; }
+  ncclUniqueId u;
+  const ncclResult_t rc = r->GetUniqueId(&u);
+  if (rc != ncclSuccess) { err = std::string("ncclGetUniqueId: ") + r->GetErrorString(rc); return T2V_ERR_COMM; }
+  static_assert(sizeof(u) == 128, "ncclUniqueId is 128 bytes");
+  memcpy(id, &u, 128);
+  return T2V_OK;
+}
+
+int t2v_comm_impl_create(const unsigned char id[128], int nranks, int rank, t2v_comm** out, std::string& err) {
+  const Rccl* r = rccl();
+  if (!r) { err = g_rccl.err; return T2V_ERR_COMM; }
+  ncclUniqueId u;
+  memcpy(&u, id, 128);
+  ncclComm_t c;
+  const ncclResult_t rc = r->CommInitRank(&c, nranks, u, rank);
+  if (rc != ncclSuccess) { err = std::string("ncclCommInitRank: ") + r->GetErrorString(rc); return T2V_ERR_COMM; }
+  *out = new t2v_comm{c, nranks, rank};
+  return T2V_OK;
+}
+
+void t2v_comm_impl_destroy(t2v_comm* c) {
+  if (!c) return;
+  const Rccl* r = rccl();
+  if (r) (void)r->CommDestroy(c->comm);
+  delete c;
+}
+
+int t2v_comm_impl_size(const t2v_comm* c) { return c ? c->nranks : 0; }
+
+// In-place all-gather: part q at base + q*bytes, this rank's part already written by the preceding kernels.
+int t2v_comm_allgather(t2v_comm* c, void* base, size_t bytes, int nparts, int part, hipStream_t s, std::string& err) {
+  if (nparts <= 1 && !c) return T2V_OK;     // single slice without a communicator: nothing to do
+  const Rccl* r = rccl();
+  if (!r || !c) { err = c ? g_rccl.err : "collective op in a plan without a communicator (t2v_plan_set_comm)"; return T2V_ERR_COMM; }
+  if (c->nranks != nparts || c->rank != part) { err = "all-gather parts do not match the communicator (nranks / rank)"; return T2V_ERR_BAD_ARG; }
+  unsigned char* b = static_cast<unsigned char*>(base);
+  const ncclResult_t rc = r->AllGather(b + (size_t)part * bytes, b, bytes, ncclUint8, c->comm, s);
+  if (rc != ncclSuccess) { err = std::string("ncclAllGather: ") + r->GetErrorString(rc); return T2V_ERR_COMM; }
+  return T2V_OK;
+}
+
+// Token buffer of F+2 frames: send frame 1 to prev / frame F to next, receive into frame 0 / frame F+1.
+int t2v_comm_halo(t2v_comm* c, void* base, size_t frame_bytes, int F, int prev, int next, hipStream_t s, std::string& err) {
+  if (prev < 0 && next < 0) return T2V_OK;
+  const Rccl* r = rccl();
+  if (!r || !c) { err = c ? g_rccl.err : "collective op in a plan without a communicator (t2v_plan_set_comm)"; return T2V_ERR_COMM; }
+  if (prev >= c->nranks || next >= c->nranks || prev == c->rank || next == c->rank) { err = "halo exchange: bad neighbour rank"; return T2V_ERR_BAD_ARG; }
+  unsigned char* b = static_cast<unsigned char*>(base);
+  ncclResult_t rc = r->GroupStart();
+  if (rc == ncclSuccess && prev >= 0) rc = r->Send(b + frame_bytes, frame_bytes, ncclUint8, prev, c->comm, s);
+  if (rc == ncclSuccess && prev >= 0) rc = r->Recv(b, frame_bytes, ncclUint8, prev, c->comm, s);
+  if (rc == ncclSuccess && next >= 0) rc = r->Send(b + (size_t)F * frame_bytes, frame_bytes, ncclUint8, next, c->comm, s);
+  if (rc == ncclSuccess && next >= 0) rc = r->Recv(b + (size_t)(F + 1) * frame_bytes, frame_bytes, ncclUint8, next, c->comm, s);
+  const ncclResult_t rc2 = r->GroupEnd();
+  if (rc == ncclSuccess) rc = rc2;
+  if (rc != ncclSuccess) { err = std::string("halo exchange (ncclSend/ncclRecv): ") + r->GetErrorString(rc); return T2V_ERR_COMM; }
+  return T2V_OK;
+}

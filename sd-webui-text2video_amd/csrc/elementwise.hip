@@ -159,6 +159,40 @@ __global__ __launch_bounds__(256) void lincomb_kernel(const LinParams p) {
   }
 }
 
+// tensor2vid (t2v_pipeline.py:447-460): video[i,c,f,y,x] -> uint8 out[f, y, i*W + x, c]: v*0.5 + 0.5 (two roundings, as
+// mul_ / add_), clamp to [0,1], *255, TRUNCATED like `(image.numpy()*255).astype('uint8')`.  HALF: the reference's
+// 'GPU (half precision)' VAE hands tensor2vid an fp16 video, so every intermediate is rounded to fp16 (the input too
+// when the tokens are fp32).  Input addressed by element strides: channels-last decoder tokens or a plain NCFHW tensor.
+template <typename TIN, bool HALF>
+__global__ __launch_bounds__(256) void to_uint8_kernel(const TIN* in, unsigned char* out, int NI, int C, int F, int H, int W,
+                                                       long si, long sc, long sf, long sy, long sx, int bgr) {
+  const long total = (long)F * H * NI * W;
+  for (long px = (long)blockIdx.x * 256 + threadIdx.x; px < total; px += (long)gridDim.x * 256) {
+    const int xw = (int)(px % ((long)NI * W));
+    long r = px / ((long)NI * W);
+    const int y = (int)(r % H);
+    const int f = (int)(r / H);
+    const int i = xw / W, x = xw - i * W;
+    const TIN* src = in + i * si + f * sf + y * sy + x * sx;
+    unsigned char* o = out + px * C;
+    for (int c = 0; c < C; ++c) {
+      float v = (float)src[c * sc];
+      if (HALF) {
+        f16 h = (f16)v;
+        h = (f16)__fmul_rn((float)h, 0.5f);
+        h = (f16)__fadd_rn((float)h, 0.5f);
+        h = h < (f16)0.f ? (f16)0.f : (h > (f16)1.f ? (f16)1.f : h);
+        v = (float)(f16)__fmul_rn((float)h, 255.f);
+      } else {
+        v = __fadd_rn(__fmul_rn(v, 0.5f), 0.5f);
+        v = v < 0.f ? 0.f : (v > 1.f ? 1.f : v);
+        v = __fmul_rn(v, 255.f);
+      }
+      o[bgr ? C - 1 - c : c] = (unsigned char)(int)v;
+    }
+  }
+}
+
 inline int grid_for(long n) {
   const long g = (n + 255) / 256;
   return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
@@ -189,6 +223,26 @@ hipError_t t2v_launch_cl_to_ncthw(const t2v_op& op, hipStream_t s) {
   else
     hipLaunchKernelGGL(cl_to_ncthw_kernel<f16>, dim3(grid_for(n)), dim3(256), 0, s, in,
                        reinterpret_cast<f16*>(op.p[1]), B, C, F, HW, ld);
+  return hipGetLastError();
+}
+
+hipError_t t2v_launch_to_uint8(const t2v_op& op, hipStream_t s) {
+  const int NI = op.i[0], C = op.i[1], F = op.i[2], H = op.i[3], W = op.i[4];
+  const bool half = op.i[6] != 0;
+  const int bgr = op.i[7];
+  const long si = (long)(uint32_t)op.i[8] | ((long)op.i[9] << 32), sc = op.i[10], sf = (long)(uint32_t)op.i[11] | ((long)op.i[12] << 32);
+  const long sy = op.i[13], sx = op.i[14];
+  const int g = grid_for((long)F * H * NI * W);
+  unsigned char* out = reinterpret_cast<unsigned char*>(op.p[1]);
+  if (op.i[5] == T2V_F32) {
+    const float* in = reinterpret_cast<const float*>(op.p[0]);
+    if (half) hipLaunchKernelGGL((to_uint8_kernel<float, true>), dim3(g), dim3(256), 0, s, in, out, NI, C, F, H, W, si, sc, sf, sy, sx, bgr);
+    else hipLaunchKernelGGL((to_uint8_kernel<float, false>), dim3(g), dim3(256), 0, s, in, out, NI, C, F, H, W, si, sc, sf, sy, sx, bgr);
+  } else {
+    const f16* in = reinterpret_cast<const f16*>(op.p[0]);
+    if (half) hipLaunchKernelGGL((to_uint8_kernel<f16, true>), dim3(g), dim3(256), 0, s, in, out, NI, C, F, H, W, si, sc, sf, sy, sx, bgr);
+    else hipLaunchKernelGGL((to_uint8_kernel<f16, false>), dim3(g), dim3(256), 0, s, in, out, NI, C, F, H, W, si, sc, sf, sy, sx, bgr);
+  }
   return hipGetLastError();
 }
 

@@ -68,19 +68,86 @@ int validate_op(const t2v_op& op, int idx) {
       if (op.i[22] < 0 || op.i[22] > 7) return bad("unknown tile id");
       return 0;
     }
-    case T2V_OP_GROUPNORM:
+    case T2V_OP_GROUPNORM: {
+      const int C = op.i[2], groups = op.i[4], phase = op.i[8], nparts = op.i[9] > 0 ? op.i[9] : 1;
+      if (op.i[0] <= 0 || op.i[1] <= 0 || C <= 0 || groups <= 0) return bad("empty GroupNorm");
+      if (C % groups != 0 || C % 8 != 0 || op.i[3] % 8 != 0 || op.i[7] % 8 != 0 || groups > 256) return bad("GroupNorm needs C % groups == 0, C / ld % 8 == 0, groups <= 256");
+      if (phase < 0 || phase > 2 || op.i[10] < 0 || op.i[10] >= nparts) return bad("bad GroupNorm phase / part");
+      if (op.i[13] != 0 && op.i[13] < op.i[1]) return bad("rows of the largest part < rows");
+      if (op.i[12] != 0 && (phase != 0 || (C / groups) % 4 != 0)) return bad("single-launch GroupNorm: phase 0, (C/groups) % 4 == 0");
+      if (op.p[0] == 0 || op.p[1] == 0 || op.p[2] == 0 || op.p[4] == 0 || (phase != 1 && op.p[3] == 0)) return bad("null GroupNorm pointer");
+      return 0;
+    }
     case T2V_OP_LAYERNORM:
-    case T2V_OP_ATTENTION:
+      if (op.i[0] <= 0 || op.i[1] <= 0 || op.i[1] % 4 != 0 || op.i[1] > 64 * 4 * 8) return bad("LayerNorm needs 0 < C <= 2048, C % 4 == 0");
+      if (op.i[2] < op.i[1] || op.i[3] < op.i[1]) return bad("LayerNorm leading dimension < C");
+      if (op.p[0] == 0 || op.p[1] == 0 || op.p[2] == 0 || op.p[3] == 0) return bad("null LayerNorm pointer");
+      return 0;
+    case T2V_OP_ATTENTION: {
+      const int d = op.i[14] > 0 ? op.i[14] : 64;
+      if (op.i[0] <= 0 || op.i[1] <= 0 || op.i[2] <= 0 || op.i[3] <= 0 || op.i[4] <= 0) return bad("empty attention");
+      if (d != 40 && d != 64 && d != 80 && d != 160) return bad("attention head_dim must be 40, 64, 80 or 160");
+      for (int k = 5; k <= 13; ++k)
+        if (op.i[k] < 0) return bad("negative attention stride");
+      if (op.i[15] != 0 && op.i[0] != op.i[1]) return bad("causal attention needs nq == nk");
+      if (!(op.f[0] > 0.f)) return bad("attention scale must be > 0");
+      if (op.p[0] == 0 || op.p[1] == 0 || op.p[2] == 0 || op.p[3] == 0) return bad("null attention pointer");
+      return 0;
+    }
+    case T2V_OP_RELPOS_ATTN:
+      if (op.i[0] <= 0 || op.i[0] > 32 || op.i[1] != op.i[0]) return bad("relative-position attention needs nq == nk <= 32");
+      if (op.i[14] <= 0 || op.i[14] % 8 != 0 || op.i[14] > 160) return bad("relative-position attention head_dim: multiple of 8, <= 160");
+      if (op.i[2] <= 0 || op.i[3] <= 0 || op.i[4] <= 0 || op.i[15] < 0) return bad("empty relative-position attention");
+      for (int k = 5; k <= 13; ++k)
+        if (op.i[k] < 0) return bad("negative attention stride");
+      for (int k = 0; k < 6; ++k)
+        if (op.p[k] == 0) return bad("null relative-position attention pointer");
+      return 0;
     case T2V_OP_SOFTMAX:
+      if (op.i[0] <= 0 || op.i[1] <= 0 || op.i[2] < op.i[1] || op.i[3] < op.i[1] || op.p[0] == 0 || op.p[1] == 0) return bad("bad softmax shape / pointer");
+      return 0;
     case T2V_OP_NCTHW_TO_CL:
     case T2V_OP_CL_TO_NCTHW:
+      if (op.i[0] <= 0 || op.i[1] <= 0 || op.i[2] <= 0 || op.i[3] <= 0 || op.i[4] < op.i[1]) return bad("bad layout-conversion shape");
+      if (op.p[0] == 0 || op.p[1] == 0) return bad("null layout-conversion pointer");
+      return 0;
     case T2V_OP_TIME_EMBED:
+      if (op.i[0] <= 0 || op.i[1] <= 0 || op.i[1] % 2 != 0 || op.p[0] == 0 || op.p[1] == 0 || op.p[2] == 0) return bad("bad time-embedding op");
+      return 0;
     case T2V_OP_COPY2D:
-    case T2V_OP_DDIM_STEP:
+      if (op.i[0] <= 0 || op.i[1] <= 0 || op.i[1] % 4 != 0) return bad("copy2d needs cols % 4 == 0");
+      if (op.i[2] < op.i[1] || op.i[3] < op.i[1] || op.i[6] < 0 || op.i[6] > 3) return bad("copy2d leading dimension / activation");
+      if (op.p[0] == 0 || op.p[1] == 0) return bad("null copy2d pointer");
+      return 0;
+    case T2V_OP_DDIM_STEP: {
+      const int C = op.i[0], cps = op.i[6] > 0 ? op.i[6] : C;
+      if (C <= 0 || op.i[1] <= 0 || cps <= 0 || C % cps != 0) return bad("DDIM step needs C > 0, inner > 0, C % channels-per-sample == 0");
+      if (op.i[2] < 0 || op.i[2] > cps || (op.i[5] != 0 && op.i[5] != 1)) return bad("DDIM step: guided channels / mode");
+      if (op.p[0] == 0 || op.p[1] == 0 || op.p[3] == 0) return bad("null DDIM step pointer");
+      return 0;
+    }
     case T2V_OP_MEMSET:
+      if (op.p[0] == 0) return bad("null memset pointer");
+      return 0;
     case T2V_OP_LINCOMB:
-    case T2V_OP_RELPOS_ATTN:
+      if (op.i[0] <= 0 || op.i[1] < 1 || op.i[1] > 6 || op.p[6] == 0) return bad("lincomb needs n > 0, 1..6 terms, an output");
+      for (int k = 0; k < op.i[1]; ++k)
+        if (op.p[k] == 0) return bad("null lincomb term");
+      return 0;
     case T2V_OP_EMBED_ROWS:
+      if (op.i[0] <= 0 || op.i[1] <= 0 || op.i[2] <= 0 || op.i[3] <= 0) return bad("empty embedding lookup");
+      for (int k = 0; k < 4; ++k)
+        if (op.p[k] == 0) return bad("null embedding pointer");
+      return 0;
+    case T2V_OP_TO_UINT8:
+      if (op.i[0] <= 0 || op.i[1] <= 0 || op.i[1] > 4 || op.i[2] <= 0 || op.i[3] <= 0 || op.i[4] <= 0) return bad("empty uint8 conversion");
+      if (op.p[0] == 0 || op.p[1] == 0) return bad("null uint8-conversion pointer");
+      return 0;
+    case T2V_OP_ALLGATHER:
+      if (op.i[2] < 1 || op.i[3] < 0 || op.i[3] >= op.i[2] || op.p[0] == 0) return bad("bad all-gather record");
+      return 0;
+    case T2V_OP_HALO_EXCHANGE:
+      if (op.i[2] < 1 || op.p[0] == 0 || op.i[3] < -1 || op.i[4] < -1) return bad("bad halo-exchange record");
       return 0;
     default:
       return bad("unknown op kind");
@@ -127,6 +194,7 @@ hipError_t launch_op(const t2v_op& op, hipStream_t s) {
     case T2V_OP_LINCOMB: return t2v_launch_lincomb(op, s);
     case T2V_OP_RELPOS_ATTN: return t2v_launch_relpos_attention(op, s);
     case T2V_OP_EMBED_ROWS: return t2v_launch_embed_rows(op, s);
+    case T2V_OP_TO_UINT8: return t2v_launch_to_uint8(op, s);
     case T2V_OP_MEMSET: {
       const size_t bytes = (size_t)(uint32_t)op.i[0] | ((size_t)(uint32_t)op.i[1] << 32);
       return hipMemsetAsync(reinterpret_cast<void*>(op.p[0]), 0, bytes, s);
@@ -135,7 +203,7 @@ hipError_t launch_op(const t2v_op& op, hipStream_t s) {
   }
 }
 
-int run_resolved(const t2v_op* ops, int n, const uint64_t* ext, int n_ext, hipStream_t s, float* ms) {
+int run_resolved(const t2v_op* ops, int n, const uint64_t* ext, int n_ext, hipStream_t s, float* ms, t2v_comm* comm = nullptr) {
   std::vector<hipEvent_t> ev;
   if (ms) {
     ev.resize(n + 1);
@@ -149,6 +217,20 @@ int run_resolved(const t2v_op* ops, int n, const uint64_t* ext, int n_ext, hipSt
       char buf[96];
       snprintf(buf, sizeof buf, "op %d (tag %d): unresolved external pointer slot", k, op.tag);
       return fail(T2V_ERR_BAD_ARG, buf);
+    }
+    if (op.kind == T2V_OP_ALLGATHER || op.kind == T2V_OP_HALO_EXCHANGE) {
+      const size_t bytes = (size_t)(uint32_t)op.i[0] | ((size_t)(uint32_t)op.i[1] << 32);
+      std::string err;
+      const int rc = op.kind == T2V_OP_ALLGATHER
+                         ? t2v_comm_allgather(comm, reinterpret_cast<void*>(op.p[0]), bytes, op.i[2], op.i[3], s, err)
+                         : t2v_comm_halo(comm, reinterpret_cast<void*>(op.p[0]), bytes, op.i[2], op.i[3], op.i[4], s, err);
+      if (rc != T2V_OK) {
+        char buf[300];
+        snprintf(buf, sizeof buf, "op %d (kind %d, tag %d): %s", k, op.kind, op.tag, err.c_str());
+        return fail(rc, buf);
+      }
+      if (ms) (void)hipEventRecord(ev[k + 1], s);
+      continue;
     }
     const hipError_t e = launch_op(op, s);
     if (e != hipSuccess) {
@@ -170,6 +252,7 @@ int run_resolved(const t2v_op* ops, int n, const uint64_t* ext, int n_ext, hipSt
 
 struct t2v_plan {
   std::vector<t2v_op> ops;
+  t2v_comm* comm = nullptr;   // borrowed (t2v_plan_set_comm)
 };
 
 extern "C" {
@@ -217,15 +300,39 @@ int t2v_plan_num_ops(const t2v_plan* plan) { return plan ? (int)plan->ops.size()
 
 int t2v_plan_run(t2v_plan* plan, const uint64_t* ext, int n_ext, void* stream) {
   if (!plan) return fail(T2V_ERR_BAD_ARG, "null plan");
-  return run_resolved(plan->ops.data(), (int)plan->ops.size(), ext, n_ext, reinterpret_cast<hipStream_t>(stream), nullptr);
+  return run_resolved(plan->ops.data(), (int)plan->ops.size(), ext, n_ext, reinterpret_cast<hipStream_t>(stream), nullptr, plan->comm);
 }
 
 int t2v_plan_run_timed(t2v_plan* plan, const uint64_t* ext, int n_ext, void* stream, float* ms) {
   if (!plan || !ms) return fail(T2V_ERR_BAD_ARG, "null plan / ms");
-  return run_resolved(plan->ops.data(), (int)plan->ops.size(), ext, n_ext, reinterpret_cast<hipStream_t>(stream), ms);
+  return run_resolved(plan->ops.data(), (int)plan->ops.size(), ext, n_ext, reinterpret_cast<hipStream_t>(stream), ms, plan->comm);
 }
 
 void t2v_plan_destroy(t2v_plan* plan) { delete plan; }
+
+int t2v_plan_set_comm(t2v_plan* plan, t2v_comm* comm) {
+  if (!plan) return fail(T2V_ERR_BAD_ARG, "null plan");
+  plan->comm = comm;
+  return T2V_OK;
+}
+
+int t2v_comm_unique_id(unsigned char id[128]) {
+  if (!id) return fail(T2V_ERR_BAD_ARG, "null id");
+  std::string err;
+  const int rc = t2v_comm_impl_unique_id(id, err);
+  return rc == T2V_OK ? rc : fail(rc, err);
+}
+
+int t2v_comm_create(const unsigned char id[128], int nranks, int rank, t2v_comm** out) {
+  if (!id || !out || nranks < 1 || rank < 0 || rank >= nranks) return fail(T2V_ERR_BAD_ARG, "bad communicator arguments");
+  std::string err;
+  const int rc = t2v_comm_impl_create(id, nranks, rank, out, err);
+  return rc == T2V_OK ? rc : fail(rc, err);
+}
+
+int t2v_comm_size(const t2v_comm* comm) { return t2v_comm_impl_size(comm); }
+
+void t2v_comm_destroy(t2v_comm* comm) { t2v_comm_impl_destroy(comm); }
 
 int t2v_unet_forward(t2v_plan* plan, const void* x, const float* t, const void* ctx, void* eps_out, void* stream) {
   uint64_t ext[T2V_EXT_SLOTS] = {0};

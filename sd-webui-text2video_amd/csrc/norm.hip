@@ -375,7 +375,12 @@ hipError_t t2v_launch_groupnorm(const t2v_op& op, hipStream_t s) {
   if (C % 8 != 0 || ld_in % 8 != 0 || ld_out % 8 != 0 || C % groups != 0 || groups > 256 || n_inst <= 0 || rows <= 0 ||
       op.p[4] == 0 || part < 0 || part >= nparts || phase < 0 || phase > 2)
     return hipErrorInvalidValue;
-  const int nblk = (rows + rpb - 1) / rpb;
+  // uneven T-shards: every part has the slot count of the LARGEST part (a shorter part zero-fills its unused slots —
+  // its surplus statistics workgroups see no rows), the mean is over the rows of all parts
+  const int rows_max = op.i[13] > 0 ? op.i[13] : rows;
+  const long rows_total = op.i[14] > 0 ? (long)op.i[14] : (long)rows * nparts;
+  if (rows_max < rows) return hipErrorInvalidValue;
+  const int nblk = (rows_max + rpb - 1) / rpb;
   const size_t part_len = (size_t)n_inst * nblk * groups * 2;
   double* partials = reinterpret_cast<double*>(op.p[4]);
   float* finals = reinterpret_cast<float*>(partials + part_len * nparts);
@@ -384,7 +389,7 @@ hipError_t t2v_launch_groupnorm(const t2v_op& op, hipStream_t s) {
   const int R = cv < 256 ? 256 / cv : 1;
   const size_t lds = 2 * (size_t)R * C * sizeof(float);
   const int g2 = (n_inst * groups + 3) / 4;
-  const double inv_n = 1.0 / ((double)rows * nparts * (C / groups));
+  const double inv_n = 1.0 / ((double)rows_total * (C / groups));
   const float* gamma = reinterpret_cast<const float*>(op.p[1]);
   const float* beta = reinterpret_cast<const float*>(op.p[2]);
   f16* out = reinterpret_cast<f16*>(op.p[3]);

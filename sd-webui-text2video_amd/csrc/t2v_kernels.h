@@ -79,6 +79,7 @@ hipError_t t2v_launch_relpos_attention(const t2v_op& op, hipStream_t s);
 hipError_t t2v_launch_softmax(const t2v_op& op, hipStream_t s);
 hipError_t t2v_launch_ncthw_to_cl(const t2v_op& op, hipStream_t s);
 hipError_t t2v_launch_cl_to_ncthw(const t2v_op& op, hipStream_t s);
+hipError_t t2v_launch_to_uint8(const t2v_op& op, hipStream_t s);
 hipError_t t2v_launch_time_embed(const t2v_op& op, hipStream_t s);
 hipError_t t2v_launch_copy2d(const t2v_op& op, hipStream_t s);
 hipError_t t2v_launch_ddim_step(const t2v_op& op, hipStream_t s);
@@ -166,3 +167,13 @@ __device__ __forceinline__ float t2v_gelu_erf(float x) {
   const float e = poly * t * __builtin_amdgcn_exp2f(-az * az * 1.44269504088896340736f);   // erfc(|z|)
   return 0.5f * x * (z >= 0.f ? 2.0f - e : e);
 }
+
+// ---- communicators (comm.hip): RCCL is dlopen'ed on first use --------------------------------------------------
+#include <string>
+struct t2v_comm;
+int t2v_comm_impl_unique_id(unsigned char id[128], std::string& err);
+int t2v_comm_impl_create(const unsigned char id[128], int nranks, int rank, t2v_comm** out, std::string& err);
+void t2v_comm_impl_destroy(t2v_comm* c);
+int t2v_comm_impl_size(const t2v_comm* c);
+int t2v_comm_allgather(t2v_comm* c, void* base, size_t bytes, int nparts, int part, hipStream_t s, std::string& err);
+int t2v_comm_halo(t2v_comm* c, void* base, size_t frame_bytes, int F, int prev, int next, hipStream_t s, std::string& err);

@@ -1,30 +1,34 @@
-"""Multi-GPU decomposition of the hot path: one process per GPU, torch.distributed over RCCL
-(backend "nccl" on ROCm) / xGMI.
+"""Multi-GPU decomposition of the hot path: one process per GPU, RCCL over xGMI.
 
 The reference has exactly one collective — sample-level data parallelism whose decoded videos are
 all-gathered (scripts/videocrafter/lvdm/utils/dist_utils.py:13-19, sample_text2video.py:123-125)
-— and two sequential UNet calls per guided step (gaussian_sampler.py:161-162).  Round-1 layout:
+— and two sequential UNet calls per guided step (gaussian_sampler.py:161-162).  Layouts here:
 
-  * classifier-free-guidance pair (2 ranks): rank role 0 evaluates the conditional UNet forward,
-    role 1 the unconditional one (b=1 each, zero communication inside the UNet); ONE exchange per
-    DDIM step — an all-gather of eps [1,4,F,h,w] inside the pair — after which both ranks apply
-    the same fused update kernel (bitwise-identical, so x_t never diverges).
-  * VAE decode: the frames of the finished latent are split contiguously over the ranks of the
-    pair, decoded independently (frames are independent in the VAE) and gathered as uint8.
-  * more than 2 GPUs: independent CFG pairs, one video each (data parallel over videos, the
-    reference's own multi-GPU mode); per-GPU work is fixed => weak scaling.
-
-Frame-axis (T) sharding inside one UNet forward — north_star's 8-GPU layout — needs an exchange
-before every temporal op (39 sites per forward) and is the next step.
+  * T-axis (frame) sharding x CFG pair (north_star's layout; default for N >= 4): world = 2 roles x R frame slices.
+    The clip's frames are split contiguously over the R ranks of a role (slices of ceil(F / R) frames, a shorter last
+    one: 125 = 32 + 32 + 32 + 29); all spatial work is frame-local, and before each temporal op the lowering inserts
+    an exchange op into the denoise program (program.py: T2V_OP_ALLGATHER of GroupNorm statistics partials / of
+    temporal-attention K/V, T2V_OP_HALO_EXCHANGE of one boundary frame for the (3,1,1) convolutions).  The library
+    executes them with RCCL on the launch stream (csrc/comm.hip), so a sharded forward is ONE host call.  The two
+    roles evaluate the conditional / unconditional forward of the same frames; one eps all-gather per DDIM step
+    inside each {cond, uncond} pair, then both apply the same bitwise-deterministic update kernel.
+  * classifier-free-guidance pair alone (N = 2): role 0 / 1 evaluate the conditional / unconditional forward (b = 1
+    each, no communication inside the UNet), one eps all-gather per step.
+  * replicas: every GPU makes its own videos, no data-path collective (the reference's own data-parallel mode).
+  * VAE decode: the frames of the finished latent are split over all ranks that hold them, decoded independently
+    (frames are independent in the VAE) and gathered as uint8 — the reference's gather of decoded samples.
 """
 from __future__ import annotations
 
+import ctypes
+import os
 from typing import Callable, Dict, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
 
-from .program import OP_COLLECTIVE, Op, Program
+from . import _lib as L
+from .program import COLLECTIVE_KINDS, Op, Program, TShardSpec
 
 
 def partition_frames(n_frames: int, parts: int) -> List[Tuple[int, int]]:
@@ -38,13 +42,47 @@ def partition_frames(n_frames: int, parts: int) -> List[Tuple[int, int]]:
     return out
 
 
-class TShard:
-    """Membership of one T (frame-axis) shard group: `size` ranks hold contiguous, equal frame slices of
-    one clip; this is slice `index`.  `group` is the torch.distributed process group (RCCL on GPUs,
-    gloo in the CPU tests); `ranks[i]` = global rank of slice i."""
+class Communicator:
+    """t2v_comm handle (include/t2v_hip.h): an RCCL communicator owned by libt2v_hip.so for the collective ops of a
+    denoise program.  The 128-byte unique id comes from `index` 0 of the group and travels over torch.distributed."""
 
-    def __init__(self, group, ranks: List[int], index: int):
-        self.group, self.ranks, self.index, self.size = group, list(ranks), index, len(ranks)
+    def __init__(self, group, ranks: List[int], index: int, device):
+        lib = L.load()
+        buf = ctypes.create_string_buffer(128)
+        if index == 0:
+            L.check(lib.t2v_comm_unique_id(buf))
+        box = [bytes(buf.raw)]
+        if len(ranks) > 1:
+            dist.broadcast_object_list(box, src=ranks[0], group=group, device=torch.device(device))
+        handle = ctypes.c_void_p()
+        L.check(lib.t2v_comm_create(box[0], len(ranks), index, ctypes.byref(handle)))
+        self.handle, self._lib, self.size = handle, lib, len(ranks)
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self._lib.t2v_comm_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class TShard:
+    """Membership of one T (frame-axis) shard group: `spec.size` ranks hold contiguous frame slices of one clip
+    (spec.counts frames each; this is slice spec.index).  `group` is the torch.distributed process group of the slice
+    holders (RCCL on GPUs, gloo in the CPU tests); `ranks[i]` = global rank of slice i."""
+
+    def __init__(self, group, ranks: List[int], spec: TShardSpec):
+        assert len(ranks) == spec.size
+        self.group, self.ranks, self.spec = group, list(ranks), spec
+        self.index, self.size = spec.index, spec.size
+        self._comm: Optional[Communicator] = None
+
+    def with_frames(self, total_frames: int) -> "TShard":
+        """Same group, another clip length."""
+        t = TShard(self.group, self.ranks, TShardSpec.make(total_frames, self.size, self.index))
+        t._comm = self._comm
+        return t
 
     @property
     def prev(self) -> Optional[int]:
@@ -54,20 +92,30 @@ class TShard:
     def next(self) -> Optional[int]:
         return self.ranks[self.index + 1] if self.index + 1 < self.size else None
 
+    def communicator(self, device) -> Optional[Communicator]:
+        """The in-library communicator for programs on `device`; None = run the exchanges from the host through
+        torch.distributed (CPU / gloo groups, or T2V_COLLECTIVES=host)."""
+        if torch.device(device).type != "cuda" or os.environ.get("T2V_COLLECTIVES", "library") == "host":
+            return None
+        if self._comm is None:
+            self._comm = Communicator(self.group, self.ranks, self.index, device)
+        return self._comm
+
 
 class ShardedExecutor:
-    """Runs a denoise program that contains collective pseudo-ops: the compute ops between two
-    collectives form a segment (one t2v_plan each); collectives run through torch.distributed on typed
-    views of the SAME arena, stream-ordered with the kernels.  `make_segment(ops)` returns an object with
-    .run(ext, stream) — a BoundProgram on the GPU, the CPU interpreter in the gloo tests — so the
-    orchestration below is exactly what the multi-GPU path executes."""
+    """Host-side executor of a denoise program that contains collective ops: the compute ops between two collectives
+    form a segment, collectives run through torch.distributed on typed views of the SAME arena.  `make_segment(ops)`
+    returns an object with .run(ext, stream) — the CPU interpreter in the gloo tests, a BoundProgram when the exchanges
+    are kept on the host (T2V_COLLECTIVES=host) or emulated in lock-step on one GPU (tests/harness.py).  It reads the
+    very op records the library executes (byte counts, part index, neighbour ranks), so the gloo tests cover what the
+    RCCL path is handed."""
 
-    def __init__(self, prog: Program, arena: torch.Tensor, make_segment: Callable[[List[Op]], object]):
-        self.prog, self.arena = prog, arena
+    def __init__(self, prog: Program, arena: torch.Tensor, shard: Optional[TShard], make_segment: Callable[[List[Op]], object]):
+        self.prog, self.arena, self.shard = prog, arena, shard
         self.steps: List[Tuple[str, object]] = []
         cur: List[Op] = []
         for op in prog.ops:
-            if op.kind == OP_COLLECTIVE:
+            if op.kind in COLLECTIVE_KINDS:
                 if cur:
                     self.steps.append(("seg", make_segment(cur)))
                     cur = []
@@ -81,38 +129,36 @@ class ShardedExecutor:
     def _bytes(self, off: int, n: int) -> torch.Tensor:
         return self.arena[off: off + n]
 
-    def run(self, ext: Dict[int, int], stream, shard: TShard):
+    def run(self, ext: Dict[int, int], stream):
+        shard = self.shard
         for kind, item in self.steps:
             if kind == "seg":
                 item.run(ext, stream)
                 continue
-            meta = item.meta
-            if meta["type"] == "allgather":
-                full, nb = meta["full"], meta["part_bytes"]
-                out = self._bytes(full.ref.off, nb * shard.size)
+            i = item.i
+            nb = (i[0] & 0xFFFFFFFF) | (i[1] << 32)
+            base = item.p[0].off
+            if item.kind == L.OP_ALLGATHER:
+                assert (i[2], i[3]) == (shard.size, shard.index)
+                out = self._bytes(base, nb * shard.size)
                 mine = out[shard.index * nb: (shard.index + 1) * nb]
                 dist.all_gather_into_tensor(out, mine, group=shard.group)
-            elif meta["type"] == "halo":
-                buf, fr, nf = meta["buf"], meta["frame_rows"], meta["frames"]
-                row_b = buf.ld * buf.item
-                fb = fr * row_b                                    # bytes of one frame
-                base = buf.ref.off
-                first, last = self._bytes(base + fb, fb), self._bytes(base + nf * fb, fb)
-                halo0, halo1 = self._bytes(base, fb), self._bytes(base + (nf + 1) * fb, fb)
+            else:   # OP_HALO_EXCHANGE: frame 1 -> prev, frame F -> next; their boundary frames into frame 0 / F + 1
+                nf = i[2]
+                first, last = self._bytes(base + nb, nb), self._bytes(base + nf * nb, nb)
+                halo0, halo1 = self._bytes(base, nb), self._bytes(base + (nf + 1) * nb, nb)
                 ops = []
-                if shard.prev is not None:
-                    ops += [dist.P2POp(dist.isend, first, shard.prev, group=shard.group),
-                            dist.P2POp(dist.irecv, halo0, shard.prev, group=shard.group)]
-                if shard.next is not None:
-                    ops += [dist.P2POp(dist.isend, last, shard.next, group=shard.group),
-                            dist.P2POp(dist.irecv, halo1, shard.next, group=shard.group)]
+                if i[3] >= 0:
+                    ops += [dist.P2POp(dist.isend, first, shard.ranks[i[3]], group=shard.group),
+                            dist.P2POp(dist.irecv, halo0, shard.ranks[i[3]], group=shard.group)]
+                if i[4] >= 0:
+                    ops += [dist.P2POp(dist.isend, last, shard.ranks[i[4]], group=shard.group),
+                            dist.P2POp(dist.irecv, halo1, shard.ranks[i[4]], group=shard.group)]
                 if ops:
                     for w in dist.batch_isend_irecv(ops):
                         w.wait()
-            else:
-                raise ValueError(meta["type"])
 
-    # BoundProgram-compatible timing hook (per-op times are not defined across collectives)
+    # BoundProgram-compatible timing hook (per-op times are not defined across host-side collectives)
     def run_timed(self, ext, stream):
         raise NotImplementedError("per-op timing is only available for unsharded programs")
 
@@ -199,22 +245,23 @@ class _Runner:
 
 
 class TShardTopology:
-    """world = 2 (CFG roles) x R (frame shards).  rank = role * R + t.
-    T group of a role = its R ranks (exchanges inside a UNet forward); pair group of a shard index t =
+    """world = 2 (CFG roles) x R (frame slices).  rank = role * R + t.
+    T group of a role = its R ranks (exchanges inside a UNet forward); pair group of a slice index t =
     {t, R + t} (one eps exchange per DDIM step).  Every rank creates every group, in the same order."""
 
-    def __init__(self, world: int, rank: int):
+    def __init__(self, world: int, rank: int, total_frames: int):
         assert world >= 4 and world % 2 == 0
         self.world, self.rank = world, rank
         self.R = world // 2
         self.role, self.t = rank // self.R, rank % self.R
         self.size = 2                                   # CfgPair-compatible interface for the sampler
+        self.spec = TShardSpec.make(total_frames, self.R, self.t)
         self.tshard = None
         for role in range(2):
             ranks = list(range(role * self.R, (role + 1) * self.R))
             g = dist.new_group(ranks=ranks)
             if role == self.role:
-                self.tshard = TShard(g, ranks, self.t)
+                self.tshard = TShard(g, ranks, self.spec)
         self.pair_group = None
         for t in range(self.R):
             g = dist.new_group(ranks=[t, self.R + t])
@@ -226,45 +273,75 @@ class TShardTopology:
         dist.all_gather_into_tensor(out, eps_local.contiguous(), group=self.pair_group)
         return out                                       # index 0 = role 0 = conditional
 
+    def decode_share(self) -> Tuple[int, int]:
+        return tshard_decode_share(self.spec.counts, self.role, self.t)
+
+    def frame_order(self) -> List[Tuple[int, int, int]]:
+        return tshard_frame_order(self.spec.counts)
+
+
+def tshard_decode_share(counts, role: int, t: int) -> Tuple[int, int]:
+    """Frames [a, b) of slice t's latent that the rank of `role` decodes: the two roles hold the same slice and split
+    it (the conditional role takes the larger half of an odd count)."""
+    n = counts[t]
+    half = (n + 1) // 2
+    return (0, half) if role == 0 else (half, n)
+
+
+def tshard_frame_order(counts) -> List[Tuple[int, int, int]]:
+    """(global rank, first clip frame, count) of every rank's decoded share, in clip order (rank = role * R + t)."""
+    R, out, off = len(counts), [], 0
+    for t, n in enumerate(counts):
+        half = (n + 1) // 2
+        out.append((t, off, half))
+        if n - half:
+            out.append((R + t, off + half, n - half))
+        off += n
+    return out
+
 
 class _TShardRunner:
-    """One video of R*frames frames on 2R GPUs: frame slices of `frames` per rank along T, the CFG pair
-    across the two roles.  Weak scaling: per-GPU work (frames per rank, b=1) is fixed as N grows."""
+    """ONE video of `frames` frames on 2R GPUs: contiguous frame slices along T (uneven tail allowed), the CFG pair
+    across the two roles.  Strong scaling of a fixed clip: frames/s = frames / (time of the whole video)."""
 
     def __init__(self, pipe, topo: TShardTopology, frames, height, width, ddim_steps, guidance):
         self.pipe, self.topo = pipe, topo
-        self.frames_local, self.height, self.width, self.ddim_steps, self.guidance = frames, height, width, ddim_steps, guidance
-        self.frames_total = frames * topo.R
-        self.frames_per_video_all_ranks = self.frames_total
-        self.unet_batch, self.unet_frames = 1, frames
-        assert frames % 2 == 0, "the two CFG roles split the VAE decode of their shared frame slice"
-        self.describe = (f"one {self.frames_total}-frame video on {topo.world} GPUs: T-axis sharding x{topo.R} inside the UNet "
-                         f"({frames} frames per rank; statistics / halo / K-V exchanges over RCCL before temporal ops) "
-                         f"x CFG pair (eps all-gather per step); VAE frames split over all ranks")
+        self.frames_total, self.height, self.width, self.ddim_steps, self.guidance = frames, height, width, ddim_steps, guidance
+        self.frames_per_video_all_ranks = frames
+        self.unet_batch, self.unet_frames = 1, topo.spec.frames
+        counts = "+".join(str(c) for c in topo.spec.counts)
+        self.describe = (f"one {frames}-frame video on {topo.world} GPUs: T-axis sharding x{topo.R} inside the UNet "
+                         f"({counts} frames per slice; statistics / halo / K-V exchanges as program ops over RCCL on the launch "
+                         f"stream) x CFG pair (eps all-gather per step); VAE frames split over all ranks")
 
     @torch.no_grad()
     def __call__(self, cond, uncond, seed):
         pipe, topo = self.pipe, self.topo
         dev = pipe.device
         pipe.sd_model.t_shard = topo.tshard
-        pipe.diffusion.get_sampler("DDIM_Gaussian", return_sampler=False)
-        sampler = pipe.diffusion.sampler
-        sampler.cfg_parallel = topo
-        _, noise, _ = pipe.diffusion.get_noise(1, 4, self.frames_total, self.height, self.width, seed=seed)
-        Fl = self.frames_local
-        x_T = noise[:, :, topo.t * Fl:(topo.t + 1) * Fl].contiguous()
-        from .samplers import SamplerStepCallback
-        x0 = sampler.sample(S=self.ddim_steps, conditioning=cond.to(dev), unconditional_conditioning=uncond.to(dev),
-                            x_T=x_T, shape=tuple(x_T.shape), unconditional_guidance_scale=self.guidance, eta=0.0,
-                            callback=SamplerStepCallback("DDIM_Gaussian", self.ddim_steps, progress=False))
-        pipe.sd_model.t_shard = None
-        half = Fl // 2                                   # both roles hold the same slice: decode one half each
-        rgb = pipe.decode_frames(x0[:, :, topo.role * half:(topo.role + 1) * half])
-        out = torch.empty((topo.world * half,) + tuple(rgb.shape[1:]), dtype=rgb.dtype, device=rgb.device)
-        dist.all_gather_into_tensor(out, rgb.contiguous())
-        # rank (role, t) decoded frames [t*Fl + role*half, +half): put them in frame order
-        order = [(f // Fl) + ((f % Fl) // half) * topo.R for f in range(0, self.frames_total, half)]
-        return torch.cat([out[r * half:(r + 1) * half] for r in order], dim=0)
+        try:
+            pipe.diffusion.get_sampler("DDIM_Gaussian", return_sampler=False)
+            sampler = pipe.diffusion.sampler
+            sampler.cfg_parallel = topo
+            _, noise, _ = pipe.diffusion.get_noise(1, 4, self.frames_total, self.height, self.width, seed=seed)
+            f0 = topo.spec.offset
+            x_T = noise[:, :, f0:f0 + topo.spec.frames].contiguous()
+            from .samplers import SamplerStepCallback
+            x0 = sampler.sample(S=self.ddim_steps, conditioning=cond.to(dev), unconditional_conditioning=uncond.to(dev),
+                                x_T=x_T, shape=tuple(x_T.shape), unconditional_guidance_scale=self.guidance, eta=0.0,
+                                callback=SamplerStepCallback("DDIM_Gaussian", self.ddim_steps, progress=False))
+        finally:
+            pipe.sd_model.t_shard = None
+        a, b = topo.decode_share()
+        order = topo.frame_order()
+        nmax = max(n for _, _, n in order)
+        H, W = self.height, self.width
+        send = torch.zeros((nmax, H, W, 3), dtype=torch.uint8, device=dev)
+        if b > a:
+            send[: b - a] = pipe.decode_frames(x0[:, :, a:b])
+        out = torch.empty((topo.world * nmax, H, W, 3), dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(out, send)
+        return torch.cat([out[r * nmax: r * nmax + n] for r, _, n in order], dim=0)
 
 
 class _ReplicaRunner(_Runner):
@@ -284,17 +361,15 @@ class _ReplicaRunner(_Runner):
 
 def make_runner(pipe, world: int, rank: int, *, frames, height, width, ddim_steps, guidance, mode: str = "auto",
                 videos: int = 1):
-    """'replicas': one video per GPU (throughput; no collective).  'pairs': one video per CFG pair — cond | uncond UNet
-    forwards on 2 GPUs, one eps all-gather per step (latency: 1.65x faster per video).  'tshard': one long video on
-    2 x R GPUs, T-sharded inside the UNet (world >= 4, even; statistics / halo / K-V exchanges before the temporal ops).
-    'auto' = replicas for world > 1: the metric is whole-job frames/s and videos are independent; the exchange-carrying
-    layouts (validated with gloo and in lock-step on one GPU) stay opt-in until their RCCL cost has been measured on a
-    multi-GPU node."""
+    """'tshard' (default for an even world >= 4): ONE `frames`-frame video on 2 x R GPUs, T-sharded inside the UNet
+    (statistics / halo / K-V exchanges before the temporal ops, executed by the library over RCCL) x the CFG pair.
+    'pairs' (default for world == 2): one video per CFG pair — cond | uncond UNet forwards on 2 GPUs, one eps all-gather
+    per step.  'replicas': one video per GPU (throughput; no data-path collective; default for an odd world > 1)."""
     if mode == "auto":
-        mode = "replicas" if world > 1 else "pairs"
+        mode = "pairs" if world <= 2 else ("tshard" if world % 2 == 0 else "replicas")
     if mode == "replicas":
         return _ReplicaRunner(pipe, world, rank, frames, height, width, ddim_steps, guidance, videos=videos)
     if mode == "tshard":
         assert videos == 1
-        return _TShardRunner(pipe, TShardTopology(world, rank), frames, height, width, ddim_steps, guidance)
+        return _TShardRunner(pipe, TShardTopology(world, rank, frames), frames, height, width, ddim_steps, guidance)
     return _Runner(pipe, CfgPair(world, rank), frames, height, width, ddim_steps, guidance, videos=videos)

@@ -43,12 +43,33 @@ def beta_schedule(schedule, num_timesteps=1000, init_beta=None, last_beta=None):
     raise ValueError(f"Unsupported schedule: {schedule}")
 
 
-def tensor2vid_device(video: torch.Tensor) -> torch.Tensor:
-    """[1,3,F,H,W] float -> uint8 [F,H,W,3] RGB on the same device; x*0.5+0.5, clamp, *255 with
-    TRUNCATION like `(image.numpy()*255).astype('uint8')` (t2v_pipeline.py:447-460)."""
-    v = video.float().mul(0.5).add_(0.5).clamp_(0, 1)
-    v = v.permute(2, 3, 0, 4, 1).reshape(v.shape[2], v.shape[3], v.shape[0] * v.shape[4], v.shape[1])
-    return v.mul(255).to(torch.uint8)
+def tensor2vid_device(video: torch.Tensor, bgr: bool = False) -> torch.Tensor:
+    """[i,3,F,H,W] float video -> uint8 [F,H,(i W),3] on the same device with ONE T2V_OP_TO_UINT8 launch: x*0.5+0.5, clamp,
+    *255 TRUNCATED like `(image.numpy()*255).astype('uint8')` (t2v_pipeline.py:447-460) — in fp32 for an fp32 video, in
+    fp16 for an fp16 one (what `mul_` / `add_` / numpy do on the reference's half-precision VAE output).  Bit-exact
+    with the reference for identical float input (tests/test_gpu_boundary.py)."""
+    import ctypes
+    from . import _lib as L
+    if not video.is_cuda:
+        raise L.T2VError("tensor2vid_device needs a device tensor on an AMD GPU (no CPU fallback)")
+    if video.dtype not in (torch.float16, torch.float32):
+        video = video.float()
+    video = video.contiguous()
+    NI, C, Fr, H, W = video.shape
+    out = torch.empty((Fr, H, NI * W, C), dtype=torch.uint8, device=video.device)
+    op = L.T2VOp()
+    op.kind = L.OP_TO_UINT8
+    half = video.dtype == torch.float16
+    vals = [NI, C, Fr, H, W, L.F16 if half else L.F32, int(half), int(bgr)]
+    si, sc, sf, sy, sx = C * Fr * H * W, Fr * H * W, H * W, W, 1
+    vals += [si & 0xFFFFFFFF, si >> 32, sc, sf & 0xFFFFFFFF, sf >> 32, sy, sx]
+    if sc >= 2 ** 31:
+        raise L.T2VError("video too large for one uint8 conversion launch")
+    for k, v in enumerate(vals):
+        op.i[k] = v - (1 << 32) if v >= (1 << 31) else v       # low words as raw bits
+    op.p[0], op.p[1] = video.data_ptr(), out.data_ptr()
+    L.check(L.load().t2v_run_ops(ctypes.byref(op), 1, None, 0, ctypes.c_void_p(torch.cuda.current_stream(video.device).cuda_stream)))
+    return out
 
 
 def tensor2vid(video: torch.Tensor) -> List[np.ndarray]:
@@ -185,9 +206,7 @@ class TextToVideoSynthesis(object):
         self.autoencoder.to(x0.device)
         bs, _, F, h, w = x0.shape
         z = (x0 * (1.0 / SCALE_FACTOR)).permute(0, 2, 1, 3, 4).reshape(bs * F, 4, h, w)   # '(b f) c h w'
-        img = self.autoencoder.decode(z)                                                 # [(b f), 3, 8h, 8w]
-        vd = img.view(bs, F, 3, img.shape[2], img.shape[3]).permute(0, 2, 1, 3, 4)
-        return tensor2vid_device(vd)
+        return self.autoencoder.decode_to_uint8(z, videos=bs)     # uint8 conversion = last op of the decoder program
 
     def infer(self, prompt, n_prompt, steps, frames, seed, scale, width=256, height=256, eta=0.0,
               cpu_vae="GPU (half precision)", device=torch.device("cuda"), latents=None, skip_steps=0,

@@ -15,8 +15,42 @@ from typing import Dict, List, Optional, Tuple
 from . import _lib as L
 
 _ITEM = {"f16": 2, "f32": 4, "f64": 8, "u8": 1}
-OP_COLLECTIVE = 100          # host-side pseudo-op (never handed to the library)
+COLLECTIVE_KINDS = (L.OP_ALLGATHER, L.OP_HALO_EXCHANGE)   # executed over the plan's communicator (RCCL) or by a host executor
 _DT = {"f16": L.F16, "f32": L.F32}
+
+
+@dataclass(frozen=True)
+class TShardSpec:
+    """Frame-axis (T) split of one clip over `size` ranks: contiguous slices, `counts[i]` frames on slice i — all equal
+    to ceil(F / size) except a shorter LAST one (125 frames / 4 -> 32, 32, 32, 29), so that gathered per-slice buffers
+    padded to counts[0] frames keep the real frames contiguous from 0."""
+    size: int
+    index: int
+    counts: Tuple[int, ...]
+
+    @staticmethod
+    def make(total_frames: int, size: int, index: int) -> "TShardSpec":
+        base = -(-total_frames // size)
+        last = total_frames - base * (size - 1)
+        if last < 1:
+            raise ValueError(f"{total_frames} frames cannot be split over {size} ranks in slices of {base}")
+        return TShardSpec(size, index, tuple([base] * (size - 1) + [last]))
+
+    @property
+    def frames(self) -> int:
+        return self.counts[self.index]
+
+    @property
+    def max_frames(self) -> int:
+        return self.counts[0]
+
+    @property
+    def total(self) -> int:
+        return sum(self.counts)
+
+    @property
+    def offset(self) -> int:
+        return sum(self.counts[: self.index])
 
 
 # ------------------------------------------------------------------------------------------
@@ -273,25 +307,34 @@ class Program:
         return op
 
     def groupnorm(self, name: str, x: Buf, gamma: Ref, beta: Ref, out: Buf, *, n_inst: int, eps: float,
-                  silu: bool, groups: int = 32, shard: Optional[Tuple[int, int]] = None) -> Op:
-        """GroupNorm(+SiLU).  With shard=(R, r) (cross-frame statistics of a T-sharded clip) the op is split
+                  silu: bool, groups: int = 32, shard: Optional[TShardSpec] = None) -> Op:
+        """GroupNorm(+SiLU).  With `shard` (cross-frame statistics of a T-sharded clip; n_inst = 1) the op is split
         into: statistics (this rank's partials) -> all-gather of the fp64 partials over the T group ->
-        ordered fold of all R parts + normalise; every rank ends up with bit-identical statistics."""
+        ordered fold of all parts + normalise; every rank ends up with bit-identical statistics.  Uneven slices: every
+        part has the slot count of the largest slice (a shorter one zero-fills the rest)."""
         rows = x.rows // n_inst
         assert rows * n_inst == x.rows and out.dtype == "f16" and x.cols % 4 == 0
-        nparts, part = shard if shard is not None else (1, 0)
+        nparts, part = (shard.size, shard.index) if shard is not None else (1, 0)
+        rows_max, rows_total = rows, rows * nparts
+        if shard is not None:
+            assert n_inst == 1 and rows % shard.frames == 0
+            per_frame = rows // shard.frames
+            rows_max, rows_total = per_frame * shard.max_frames, per_frame * shard.total
         # rows reduced by one statistics workgroup: the smallest power of two >= 4 that keeps the grid within
-        # ~4 workgroups per CU (each thread then has several rows in flight)
+        # ~4 workgroups per CU (each thread then has several rows in flight); from the LARGEST slice, so that every
+        # rank of a T group chooses the same value
         rpb = 4
-        while n_inst * ((rows + rpb - 1) // rpb) > 4 * self.target_cus:
+        while n_inst * ((rows_max + rpb - 1) // rpb) > 4 * self.target_cus:
             rpb *= 2
-        nblk = (rows + rpb - 1) // rpb
+        nblk = (rows_max + rpb - 1) // rpb
         part_bytes = n_inst * nblk * groups * 16
         scratch = self.alloc(nparts * part_bytes + n_inst * groups * 8, 1, "u8")
 
         def make(phase, suffix):
             op = Op(L.OP_GROUPNORM, name + suffix)
             op.i[0:12] = [n_inst, rows, x.cols, x.ld, groups, _DT[x.dtype], int(silu), out.ld, phase, nparts, part, rpb]
+            if shard is not None:
+                op.i[13], op.i[14] = rows_max, rows_total
             op.f[0] = eps
             op.p[0:5] = [x.ref, gamma, beta, out.ref, scratch.ref]
             return op
@@ -310,19 +353,33 @@ class Program:
         else:
             self._emit(make(1, ".stats"))
             full = Buf(scratch.ref, nparts * part_bytes, 1, 1, "u8", scratch.alloc_off)
-            self.collective(name + ".stats.allgather", "allgather", full=full, part_bytes=part_bytes)
+            self.allgather(name + ".stats.allgather", full, part_bytes, shard)
             op = make(2, ".apply")
             op.out = out
             self._emit(op)
         self.free(scratch)      # stream order makes immediate reuse safe
         return op
 
-    def collective(self, name: str, ctype: str, **meta) -> Op:
-        """Pseudo-op: an exchange over the T-shard process group between two program segments.
-        'allgather': full (u8 Buf of nparts*part_bytes bytes, this rank's part already in place);
-        'halo': buf = halo-padded token buffer [(F_local+2)*frame_rows, C] whose interior is filled."""
-        op = Op(OP_COLLECTIVE, name)
-        op.meta = dict(type=ctype, **meta)
+    def allgather(self, name: str, full: Buf, part_bytes: int, shard: TShardSpec) -> Op:
+        """In-place all-gather over the T group: `full` = shard.size parts of part_bytes bytes, this rank's part
+        (index shard.index) already written by the preceding ops.  One T2V_OP_ALLGATHER record: RCCL on the launch
+        stream inside the library, or torch.distributed in a host executor (gloo CPU tests)."""
+        op = Op(L.OP_ALLGATHER, name)
+        op.i[0], op.i[1], op.i[2], op.i[3] = part_bytes & 0xFFFFFFFF, part_bytes >> 32, shard.size, shard.index
+        op.p[0] = full.ref
+        op.meta = dict(type="allgather", full=full, part_bytes=part_bytes)
+        return self._emit(op)
+
+    def halo_exchange(self, name: str, buf: Buf, frame_rows: int, frames: int, shard: TShardSpec) -> Op:
+        """+-1 frame neighbour exchange: `buf` = halo-padded token buffer [(frames + 2) * frame_rows, C] whose interior
+        is filled; the first / last real frame goes to the previous / next slice's halo slot (T2V_OP_HALO_EXCHANGE)."""
+        op = Op(L.OP_HALO_EXCHANGE, name)
+        fb = frame_rows * buf.ld * buf.item
+        op.i[0], op.i[1], op.i[2] = fb & 0xFFFFFFFF, fb >> 32, frames
+        op.i[3] = shard.index - 1 if shard.index > 0 else -1
+        op.i[4] = shard.index + 1 if shard.index + 1 < shard.size else -1
+        op.p[0] = buf.ref
+        op.meta = dict(type="halo", buf=buf, frame_rows=frame_rows, frames=frames)
         return self._emit(op)
 
     def memset(self, name: str, buf: Buf) -> Op:
@@ -391,6 +448,19 @@ class Program:
         op.p[0:2] = [x.ref, dst]
         return self._emit(op)
 
+    def to_uint8(self, name: str, src: Ref, src_dtype: str, dst: Ref, *, NI: int, C: int, F: int, H: int, W: int, strides,
+                 half: bool, bgr: bool = False) -> Op:
+        """tensor2vid on device: element (i, c, f, y, x) of the float video at i*si + c*sc + f*sf + y*sy + x*sx ->
+        uint8 out[f, y, i*W + x, c]; `half` = the reference's fp16 arithmetic (half-precision VAE)."""
+        si, sc, sf, sy, sx = strides
+        op = Op(L.OP_TO_UINT8, name)
+        op.i[0:8] = [NI, C, F, H, W, _DT[src_dtype], int(half), int(bgr)]
+        op.i[8], op.i[9], op.i[10], op.i[11], op.i[12], op.i[13], op.i[14] = si & 0xFFFFFFFF, si >> 32, sc, sf & 0xFFFFFFFF, sf >> 32, sy, sx
+        for v in (sc, sy, sx):
+            assert 0 <= v < 2 ** 31
+        op.p[0:2] = [src, dst]
+        return self._emit(op)
+
     def time_embed(self, name: str, t: Ref, freqs: Ref, out: Buf) -> Op:
         op = Op(L.OP_TIME_EMBED, name)
         op.i[0:2] = [out.rows, out.cols]
@@ -435,19 +505,21 @@ class BoundProgram:
     """A Program whose symbolic pointers are resolved against a device arena and weight
     tensors, compiled into a `t2v_plan`."""
 
-    def __init__(self, prog: Program, arena_ptr: int, weight_ptrs: Dict[str, int], ops: Optional[List[Op]] = None):
+    def __init__(self, prog: Program, arena_ptr: int, weight_ptrs: Dict[str, int], ops: Optional[List[Op]] = None, comm=None):
+        """`comm`: a parallel.Communicator (t2v_comm over RCCL) — required to RUN a program that holds collective ops."""
         self.prog = prog
         lib = L.load()
         ops = prog.ops if ops is None else ops
-        assert all(op.kind != OP_COLLECTIVE for op in ops), "collectives are executed by parallel.ShardedExecutor"
         self.ops = ops
+        self.comm = comm
         n = len(ops)
         arr = (L.T2VOp * n)()
         for idx, op in enumerate(ops):
             r = arr[idx]
             r.kind, r.tag = op.kind, idx
             for j, v in enumerate(op.i):
-                r.i[j] = int(v)
+                v = int(v)
+                r.i[j] = v - (1 << 32) if v >= (1 << 31) else v      # low words of 64-bit sizes are stored as raw bits
             for j, v in enumerate(op.f):
                 r.f[j] = float(v)
             for j, ref in enumerate(op.p):
@@ -466,6 +538,8 @@ class BoundProgram:
         L.check(lib.t2v_plan_create(arr, n, ctypes.byref(handle)))
         self.handle = handle
         self._lib = lib
+        if comm is not None:
+            L.check(lib.t2v_plan_set_comm(handle, comm.handle))
 
     def run(self, ext: Dict[int, int], stream: int):
         e = (ctypes.c_uint64 * L.EXT_SLOTS)()

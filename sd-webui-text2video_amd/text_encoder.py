@@ -258,7 +258,6 @@ class ClipTextTower:
         comp.ensure_bound(self._packed, tokens.device)
         z = torch.empty((B, Lseq, self.width), device=tokens.device, dtype=torch.float32)
         comp.bound.run({L.EXT_X: ids.data_ptr(), L.EXT_OUT: z.data_ptr()}, torch.cuda.current_stream(tokens.device).cuda_stream)
-        comp.keepalive = (ids,)
         return z
 
 

@@ -31,7 +31,7 @@ import torch.nn as nn
 
 from . import _lib as L
 from . import packing as pk
-from .program import NULL, OP_COLLECTIVE, BoundProgram, Buf, Program, Ref
+from .program import COLLECTIVE_KINDS, NULL, BoundProgram, Buf, Program, Ref, TShardSpec
 
 
 # ------------------------------------------------------------------------------------------
@@ -308,7 +308,9 @@ class UNetSD(nn.Module):
         """(Re)pack weights if any parameter object / version changed since the last pack.  When only some
         parameters changed (the LoRA merge / un-merge of lora_processor.py:202-246 replaces `.weight` of the
         matched Linear / Conv modules), only the packed images that read them are rewritten, in place
-        (`last_repack` = number of images, -1 for a full pack)."""
+        (`last_repack` = number of images, -1 for a full pack).  The packed set is the UNION of the images of every
+        compiled program (a T-sharded lowering declares `:kv` / `.to_q:lin` images the unsharded one does not, and
+        vice versa)."""
         device = torch.device(device) if device is not None else self._packed_device
         if device is None:
             return
@@ -316,11 +318,11 @@ class UNetSD(nn.Module):
         same_dev = self._packed is not None and device == self._packed_device
         if same_dev and sig == self._packed_sig:
             return
-        comp = self._get_compiled_any()
+        packer = self._union_packer()
         sd = {k: v for k, v in self.state_dict().items()}
         if same_dev and sig.keys() == self._packed_sig.keys():
             changed = [n for n, v in sig.items() if self._packed_sig[n] != v]
-            n = comp.packer.update(self._packed, sd, device, changed, deps=self._packed_deps)
+            n = packer.update(self._packed, sd, device, changed, deps=self._packed_deps)
             if n >= 0:
                 self._packed_sig, self.last_repack = sig, n
                 return
@@ -331,11 +333,32 @@ class UNetSD(nn.Module):
                 # compiled programs have no slot for them; refuse rather than silently ignore
                 raise L.T2VError("parameters were added after the denoise programs were built: "
                                  f"{extra[:4]}{' ...' if len(extra) > 4 else ''} — not supported")
-        self._packed = comp.packer.materialise(sd, device)
-        self._packed_deps = dict(comp.packer.deps)
+        self._packed = packer.materialise(sd, device)
+        self._packed_deps = dict(packer.deps)
         self._packed_sig, self._packed_device, self.last_repack = sig, device, -1
         for c in self._programs.values():
             c.bound = None
+
+    def _union_packer(self) -> pk.WeightPacker:
+        if not self._programs:
+            self._get_compiled_any()
+        packer = pk.WeightPacker()
+        for comp in self._programs.values():
+            for name, dtype, fn in comp.packer.recipes:
+                packer.add(name, dtype, fn)
+        return packer
+
+    def _pack_missing(self, comp: "_Compiled", device):
+        """Images a newly compiled program needs that no earlier program declared: packed and merged into the live
+        set (existing device tensors — and the programs bound to them — are untouched)."""
+        missing = [(n, d, f) for n, d, f in comp.packer.recipes if n not in self._packed]
+        if not missing:
+            return
+        tmp = pk.WeightPacker()
+        for n, d, f in missing:
+            tmp.add(n, d, f)
+        self._packed.update(tmp.materialise(self.state_dict(), device))
+        self._packed_deps.update(tmp.deps)
 
     def _get_compiled_any(self):
         if self._programs:
@@ -367,23 +390,32 @@ class UNetSD(nn.Module):
             tf = tf.expand(B).contiguous()
         shard = None
         if self.t_shard is not None and self.t_shard.size > 1:
-            shard = (self.t_shard.size, self.t_shard.index)       # x holds only this rank's frames
+            shard = self.t_shard.spec                             # x holds only this rank's frames
+            if shard.frames != F:
+                raise L.T2VError(f"T-sharded forward: this rank holds {shard.frames} of {shard.total} frames, got {F}")
         key = (B, F, H, W, y.shape[1], _dt(x.dtype), _dt(y.dtype), _dt(out_dtype)) + ((shard,) if shard else ())
         comp = self._programs.get(key)
         if comp is None:
             comp = self._compile(B, F, H, W, y.shape[1], _dt(x.dtype), _dt(out_dtype), _dt(y.dtype), shard=shard)
             self._programs[key] = comp
+            self._evict_programs(keep=key)
         if self._packed is None or self._packed_device != x.device or self.auto_refresh:
             self.refresh_weights(x.device)
-        comp.ensure_bound(self._packed, x.device)
+        self._pack_missing(comp, x.device)
+        comp.ensure_bound(self._packed, x.device, t_shard=self.t_shard if shard is not None else None)
         out = torch.empty((B, self.out_dim, F, H, W), device=x.device, dtype=out_dtype)
         ext = {L.EXT_X: x.data_ptr(), L.EXT_T: tf.data_ptr(), L.EXT_CTX: y.data_ptr(), L.EXT_OUT: out.data_ptr()}
-        if shard is None:
-            comp.bound.run(ext, torch.cuda.current_stream(x.device).cuda_stream)
-        else:
-            comp.sharded.run(ext, torch.cuda.current_stream(x.device).cuda_stream, self.t_shard)
-        comp.keepalive = (x, tf, y)
+        comp.bound.run(ext, torch.cuda.current_stream(x.device).cuda_stream)     # one host call, collectives included
         return out
+
+    max_programs = 4      # compiled geometries kept (each owns a device arena: 0.4 GiB per 24-frame sample, GiBs for long clips)
+
+    def _evict_programs(self, keep):
+        """Least-recently-compiled eviction: a webui session that varies frames / resolution / batch_count would otherwise
+        accumulate one arena per geometry (the reference frees its activations after every call)."""
+        while len(self._programs) > self.max_programs:
+            victim = next(k for k in self._programs if k != keep)
+            del self._programs[victim]
 
     def forward_timed(self, x, t, y):
         """Like forward, but returns (eps, per-op milliseconds) using HIP events around every op
@@ -391,7 +423,8 @@ class UNetSD(nn.Module):
         out = UNetSD.forward(self, x, t, y)
         comp = self._programs[(x.shape[0], x.shape[2], x.shape[3], x.shape[4], y.shape[1], _dt(x.dtype),
                                _dt(y.dtype), _dt(out.dtype))]
-        xs, tf, ys = comp.keepalive
+        xs, ys = x.contiguous(), y.contiguous()
+        tf = t.to(device=x.device, dtype=torch.float32).contiguous()
         ext = {L.EXT_X: xs.data_ptr(), L.EXT_T: tf.data_ptr(), L.EXT_CTX: ys.data_ptr(), L.EXT_OUT: out.data_ptr()}
         ms = comp.bound.run_timed(ext, torch.cuda.current_stream(x.device).cuda_stream)
         return out, ms, comp.prog
@@ -412,20 +445,26 @@ class _Compiled:
         self.prog = prog
         self.packer = packer
         self.bound: Optional[BoundProgram] = None
-        self.sharded = None
         self.arena: Optional[torch.Tensor] = None
-        self.keepalive = None
 
-    def ensure_bound(self, packed: Dict[str, torch.Tensor], device):
+    def ensure_bound(self, packed: Dict[str, torch.Tensor], device, t_shard=None):
+        """Bind the program to a device arena and the packed weights.  A program with collective ops (T-sharded
+        forward) is bound together with the T group's communicator: its exchanges then run inside the library (RCCL on
+        the launch stream) — or, with T2V_COLLECTIVES=host / a non-GPU group, through parallel.ShardedExecutor."""
         if self.bound is not None and self.arena is not None and self.arena.device == device:
             return
         self.arena = torch.empty(self.prog.arena.high + 256, dtype=torch.uint8, device=device)
         wptr = {k: v.data_ptr() for k, v in packed.items()}
-        if any(op.kind == OP_COLLECTIVE for op in self.prog.ops):
-            from .parallel import ShardedExecutor
-            self.sharded = ShardedExecutor(self.prog, self.arena,
-                                           lambda ops: BoundProgram(self.prog, self.arena.data_ptr(), wptr, ops=ops))
-            self.bound = self.sharded
+        if any(op.kind in COLLECTIVE_KINDS for op in self.prog.ops):
+            if t_shard is None:
+                raise L.T2VError("a T-sharded program needs the T group (UNetSD.t_shard)")
+            comm = t_shard.communicator(device)
+            if comm is not None:
+                self.bound = BoundProgram(self.prog, self.arena.data_ptr(), wptr, comm=comm)
+            else:
+                from .parallel import ShardedExecutor
+                self.bound = ShardedExecutor(self.prog, self.arena, t_shard,
+                                             lambda ops: BoundProgram(self.prog, self.arena.data_ptr(), wptr, ops=ops))
         else:
             self.bound = BoundProgram(self.prog, self.arena.data_ptr(), wptr)
 
@@ -435,13 +474,14 @@ class _Compiled:
 # ------------------------------------------------------------------------------------------
 class _Lowering:
     def __init__(self, net: UNetSD, B, F, H, W, Lctx, x_dt, out_dt, ctx_dt, keep_taps=False, shard=None):
-        """F = frames held by THIS rank.  shard = (R, r): the clip has R*F frames split contiguously over
-        the R ranks of a T group (this is rank r); temporal ops then exchange data:
-        cross-frame GroupNorm -> all-gather of statistics partials, temporal conv -> +-1 frame halo,
+        """F = frames held by THIS rank.  shard = TShardSpec: the clip's frames are split contiguously over the ranks
+        of a T group (slices of ceil(F_total / R) frames, a shorter last one); temporal ops then exchange data
+        (SURVEY §5.7): cross-frame GroupNorm -> all-gather of statistics partials, temporal conv -> +-1 frame halo,
         temporal attention -> all-gather of K/V.  Everything else is frame-local."""
-        self.shard = shard if (shard is not None and shard[0] > 1) else None
+        self.shard: Optional[TShardSpec] = shard if (shard is not None and shard.size > 1) else None
         if self.shard is not None:
             assert B == 1, "T-sharded forwards run one sample per rank (the CFG pair is split over ranks)"
+            assert F == self.shard.frames
         self.net, self.B, self.F, self.H, self.W, self.Lctx = net, B, F, H, W, Lctx
         self.x_dt, self.out_dt, self.ctx_dt = x_dt, out_dt, ctx_dt
         self.P = Program(f"unet b{B} f{F} {H}x{W}")
@@ -549,7 +589,7 @@ class _Lowering:
             else:
                 # T-sharded: normalised activations go into a buffer with one halo frame either side;
                 # neighbours fill the halos (zeros at the two ends of the clip = the conv's zero padding)
-                R, r = self.shard
+                R, r = self.shard.size, self.shard.index
                 hwp = h * w
                 nrm = P.alloc((self.F + 2) * hwp, cout, "f16")
                 if r == 0:
@@ -558,7 +598,7 @@ class _Lowering:
                     P.memset(f"{tp}.{name}.halo1", nrm.row_slice((self.F + 1) * hwp, (self.F + 2) * hwp))
                 self.gn(f"{tp}.{name}.0", t, f"{tp}.{name}.0", per_frame=False, eps=1e-5, silu=True,
                         out=nrm.row_slice(hwp, (self.F + 1) * hwp))
-                P.collective(f"{tp}.{name}.halo", "halo", buf=nrm, frame_rows=hwp, frames=self.F)
+                P.halo_exchange(f"{tp}.{name}.halo", nrm, hwp, self.F, self.shard)
             if t is not h2:
                 P.free(t)
             t = self._dest(dest, h2.rows, cout, "f32") if name == "conv4" else P.alloc(h2.rows, cout, self.net.norm_input_dtype)
@@ -578,21 +618,24 @@ class _Lowering:
         def self_attention_sharded(tag, xin: Buf) -> Buf:
             """Temporal self-attention over a T-sharded clip: queries = local frames, keys/values = ALL
             frames (K/V projections of the local tokens are all-gathered along T)."""
-            R, r = self.shard
+            R, r = self.shard.size, self.shard.index
+            Mmax, Ftot = self.shard.max_frames * hw, self.shard.total     # rows of the largest slice; frames of the clip
             n = P.alloc(Mrows, inner, "f16")
             P.layernorm(f"{prefix}.norm{tag}", xin, self.vec(f"{prefix}.norm{tag}.weight"), self.vec(f"{prefix}.norm{tag}.bias"), n)
             q = P.alloc(Mrows, inner, "f16")
             P.gemm(f"{prefix}.attn{tag}.to_q", n, self.w_linear(f"{prefix}.attn{tag}.to_q"), inner, inner, q)
-            kv_all = P.alloc(R * Mrows, 2 * inner, "f16")
-            mine = kv_all.row_slice(r * Mrows, (r + 1) * Mrows)
+            # slice q of the gathered buffer starts at frame q * max_frames: only the LAST slice can be short, so the
+            # clip's frames are contiguous from row 0 and the padding rows at the very end are never addressed
+            kv_all = P.alloc(R * Mmax, 2 * inner, "f16")
+            mine = kv_all.row_slice(r * Mmax, r * Mmax + Mrows)
             P.gemm(f"{prefix}.attn{tag}.kv", n, self.w_kv(f"{prefix}.attn{tag}"), 2 * inner, inner, mine)
             P.free(n)
-            full = Buf(kv_all.ref, R * Mrows * 2 * inner * 2, 1, 1, "u8", kv_all.alloc_off)
-            P.collective(f"{prefix}.attn{tag}.kv.allgather", "allgather", full=full, part_bytes=Mrows * 2 * inner * 2)
+            full = Buf(kv_all.ref, R * Mmax * 2 * inner * 2, 1, 1, "u8", kv_all.alloc_off)
+            P.allgather(f"{prefix}.attn{tag}.kv.allgather", full, Mmax * 2 * inner * 2, self.shard)
             a = P.alloc(Mrows, inner, "f16")
             ldk = 2 * inner
             k, v = kv_all.col_slice(0, inner), kv_all.col_slice(inner, 2 * inner)
-            P.attention(f"{prefix}.attn{tag}", q.ref, k.ref, v.ref, a.ref, out_buf=a, nq=F, nk=R * F, heads=heads,
+            P.attention(f"{prefix}.attn{tag}", q.ref, k.ref, v.ref, a.ref, out_buf=a, nq=F, nk=Ftot, heads=heads,
                         b_outer=1, b_inner=hw, q_strides=(hw * inner, 0, inner), kv_strides=(hw * ldk, 0, ldk),
                         o_strides=(hw * inner, 0, inner), scale=scale)
             P.free(q, kv_all)

@@ -184,7 +184,6 @@ class AutoencoderKL(nn.Module):
         zc2 = 2 * self.embed_dim
         moments = torch.empty((n, zc2, h >> nlev, w >> nlev), device=x.device, dtype=torch.float32)
         comp.bound.run({L.EXT_X: x.data_ptr(), L.EXT_OUT: moments.data_ptr()}, torch.cuda.current_stream(x.device).cuda_stream)
-        comp.keepalive = (x,)
         p0 = next(self.parameters())
         return DiagonalGaussianDistribution(moments.to(torch.float16 if p0.dtype == torch.float16 else torch.float32))
 
@@ -211,6 +210,17 @@ class AutoencoderKL(nn.Module):
     # ---- decode -------------------------------------------------------------------------------
     def decode(self, z):
         """z [n, 4, h, w] (the pipeline passes x0/0.18215, t2v_pipeline.py:348) -> [n, 3, 8h, 8w]."""
+        return self._decode(z, None)
+
+    def decode_to_uint8(self, z, videos: int = 1, bgr: bool = False):
+        """decode + tensor2vid in ONE program: z [(videos f), 4, h, w] -> uint8 [f, 8h, videos * 8w, 3] (RGB, or BGR as
+        postprocess_video returns them, t2v_pipeline.py:412-435).  The uint8 conversion is the decoder program's last
+        op (T2V_OP_TO_UINT8 on the conv_out tokens); with fp16 weights it uses the fp16 arithmetic the reference's
+        half-precision VAE path hands tensor2vid (t2v_pipeline.py:337-351,447-460)."""
+        assert z.shape[0] % videos == 0
+        return self._decode(z, (videos, bool(bgr)))
+
+    def _decode(self, z, u8):
         if not z.is_cuda:
             raise L.T2VError("AutoencoderKL.decode needs device tensors on an AMD GPU (no CPU fallback)")
         n, c, h, w = z.shape
@@ -219,19 +229,25 @@ class AutoencoderKL(nn.Module):
             z = z.float()
         p0 = next(self.parameters())
         out_dtype = torch.float16 if p0.dtype == torch.float16 else torch.float32
-        key = (n, h, w, _dt(z.dtype), _dt(out_dtype))
+        key = (n, h, w, _dt(z.dtype), _dt(out_dtype), u8)
         comp = self._programs.get(key)
         if comp is None:
             low = _VaeLowering(self, n, h, w, _dt(z.dtype), _dt(out_dtype), self.debug_taps)
-            comp = _Compiled(low.build(), low.packer)
+            comp = _Compiled(low.build(u8), low.packer)
             self._programs[key] = comp
+            while len(self._programs) > self.max_programs:          # each program owns a device arena
+                del self._programs[next(k for k in self._programs if k != key)]
         self._refresh(comp, z.device)
         comp.ensure_bound(self._packed, z.device)
-        out = torch.empty((n, self.ddconfig["out_ch"], 8 * h, 8 * w), device=z.device, dtype=out_dtype)
+        if u8 is None:
+            out = torch.empty((n, self.ddconfig["out_ch"], 8 * h, 8 * w), device=z.device, dtype=out_dtype)
+        else:
+            out = torch.empty((n // u8[0], 8 * h, u8[0] * 8 * w, self.ddconfig["out_ch"]), device=z.device, dtype=torch.uint8)
         comp.bound.run({L.EXT_X: z.data_ptr(), L.EXT_OUT: out.data_ptr()},
                        torch.cuda.current_stream(z.device).cuda_stream)
-        comp.keepalive = (z,)
         return out
+
+    max_programs = 4
 
     def forward(self, input, sample_posterior=True):
         raise NotImplementedError("only decode() is on the hot path")
@@ -384,7 +400,7 @@ class _VaeLowering:
         P.finish()
         return P
 
-    def build(self) -> Program:
+    def build(self, u8=None) -> Program:
         P, n, h, w = self.P, self.n, self.h, self.w
         dd = self.vae.ddconfig
         ch, ch_mult, nrb = dd["ch"], list(dd["ch_mult"]), dd["num_res_blocks"]
@@ -432,7 +448,13 @@ class _VaeLowering:
         P.free(x)
         y = self.conv3("decoder.conv_out", a, dd["out_ch"], h, w)
         P.free(a)
-        P.cl_to_ncthw("img.from_tokens", y, Ref("ext", L.EXT_OUT), self.out_dt, B=n, C=dd["out_ch"], F=1, HW=h * w)
+        if u8 is None:
+            P.cl_to_ncthw("img.from_tokens", y, Ref("ext", L.EXT_OUT), self.out_dt, B=n, C=dd["out_ch"], F=1, HW=h * w)
+        else:
+            videos, bgr = u8
+            Fr = n // videos                    # token row = ((video * Fr + f) * h + y) * w + x
+            P.to_uint8("img.to_uint8", y.ref, y.dtype, Ref("ext", L.EXT_OUT), NI=videos, C=dd["out_ch"], F=Fr, H=h, W=w,
+                       strides=(Fr * h * w * y.ld, 1, h * w * y.ld, w * y.ld, y.ld), half=self.out_dt == "f16", bgr=bgr)
         P.free(y)
         P.finish()
         return P

@@ -192,8 +192,61 @@ def lvdm(full=True):
     print(f"lvdm 16f done fwd {t_fwd:.2f}s", eps.std().item())
 
 
+def infer_inputs_tiny():
+    g = torch.Generator().manual_seed(17)
+    c = torch.randn(1, 7, configs.TINY_UNET["context_dim"], generator=g)
+    uc = torch.randn(1, 7, configs.TINY_UNET["context_dim"], generator=g)
+    return c, uc
+
+
+def infer_tiny():
+    """Boundary B2 end to end: the reference's OWN `TextToVideoSynthesis.infer` (t2v_pipeline.py:197-385 — get_noise ->
+    sample_loop -> per-frame VAE decode of x0/0.18215 -> tensor2vid -> RGB2BGR) on the tiny UNet / VAE, CPU fp32 ('CPU (full
+    precision)' VAE branch).  The object is assembled without `__init__` (which needs configuration.json, checkpoints and
+    open_clip); the text-encoding stage (`preprocess`, outside the hot path) is replaced by fixed conditioning tensors."""
+    import types
+    ref = rb.bootstrap()
+    pl = rb.bootstrap_pipeline()
+    unet, betas = rb.build_reference_unet(configs.TINY_UNET)
+    synth.load_synth(unet, seed=0)
+    vae = rb.build_reference_vae(configs.TINY_VAE_DDCONFIG)
+    synth.load_synth(vae, seed=3)
+    pipe = object.__new__(pl.TextToVideoSynthesis)
+    pipe.device = torch.device("cpu")
+    pipe.sd_model, pipe.autoencoder = unet, vae
+    pipe.keep_in_vram = "All"
+    pipe.clip_encoder = types.SimpleNamespace(to=lambda d: None, device=None)
+    pipe.diffusion = ref.samplers.Txt2VideoSampler(unet, torch.device("cpu"), betas=betas, sampler_name="DDIM_Gaussian")
+    c, uc = infer_inputs_tiny()
+    pipe.preprocess = lambda prompt, n_prompt, steps, offload=True: (c, uc)
+    out = {}
+    for tag, kw in (("", dict(steps=4, frames=3, seed=1234, scale=9.0, width=128, height=128)),
+                    ("_wide", dict(steps=3, frames=2, seed=77, scale=7.5, width=192, height=64))):
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):
+            frames, last, info = pipe.infer("a prompt", "a negative prompt", kw["steps"], kw["frames"], kw["seed"], kw["scale"],
+                                            kw["width"], kw["height"], 0.0, "CPU (full precision)", torch.device("cpu"),
+                                            sampler="DDIM_Gaussian")
+        out["frames_bgr" + tag] = np.stack(frames)
+        out["last_tensor" + tag] = last.numpy()
+        out["infotext" + tag] = np.array(info)
+        print("infer", tag, out["frames_bgr" + tag].shape, out["frames_bgr" + tag].mean(), info.replace("\n", " | "))
+    # tensor2vid itself on a fixed float video (bit-exact target of the device kernel), fp32 and fp16 inputs
+    g = torch.Generator().manual_seed(23)
+    vid = torch.randn(2, 3, 3, 16, 24, generator=g) * 0.8
+    vid[0, :, 0, 0, :6] = torch.tensor([-1.0, 1.0, 0.999, 0.0, -0.00392, 0.99609])
+    out["t2v_in"] = vid.numpy()
+    out["t2v_u8_f32"] = np.stack(pl.tensor2vid(vid.clone()))
+    out["t2v_u8_f16"] = np.stack(pl.tensor2vid(vid.clone().half()))
+    np.savez_compressed(os.path.join(OUT, "infer_tiny.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
+    if "--infer-only" in sys.argv:
+        infer_tiny()
+        sys.exit(0)
     if "--lvdm-only" not in sys.argv:
         tiny()
         if "--tiny-only" not in sys.argv:

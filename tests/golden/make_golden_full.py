@@ -1,0 +1,167 @@
+"""Full-size golden fixtures FROM THE REAL REFERENCE for BASELINE.json configs[1]..[4] (run in the build container).
+
+    python tests/golden/make_golden_full.py [c1] [c2] [c3] [c4]      # default: all (~45 min on 8 cores)
+
+Same recipe as make_golden.py (reference classes imported read-only through oracle/ref_bootstrap.py, seeded
+synthetic weights/inputs of oracle/synth.py, fp32 CPU arithmetic); only OUTPUTS are stored.  The large outputs
+are stored as the sub-sets named below (whole frames / strided pixel grids) so the fixtures stay small; the GPU
+tests compare exactly those sub-sets (tests/test_gpu_fullsize.py).
+
+  modelscope_24f.npz   configs[1]  ModelScope 1.41 B, 24 frames @256x256: one forward (t=801), DDIM_Gaussian CFG 9
+                                   x0 after 10 and after 50 steps, tensor2vid uint8 frames 0 / 23 of the 50-step video
+  modelscope_125f.npz  configs[2]  125 frames @256x256: one forward, frames FRAMES_125 (the slice edges of the
+                                   4-way T split 32+32+32+29 and both clip ends)
+  zeroscope_24f.npz    configs[3]  24 frames @1024x576 (latent 72x128): one forward, frames FRAMES_XL; one VAE frame
+                                   decoded at 1024x576 (mid attention over 9216 tokens): stride-4 pixel grid + a crop
+  lvdm_16f_ddim.npz    configs[4]  VideoCrafter 0.96 B, 16 frames @256x256: lvdm DDIM (CFG 7.5, eta 0) x0 after 10 and
+                                   50 steps, VAE decode of frame 0 of the 50-step latent (stride-2 pixel grid)
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
+sys.path.insert(0, ROOT)
+from oracle import configs, ref_bootstrap as rb, synth  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+FRAMES_125 = [0, 31, 32, 63, 64, 95, 96, 124]
+FRAMES_XL = [0, 11, 23]
+XL_GRID = (slice(1, None, 4), slice(2, None, 4))            # [3, 144, 256] of the 576 x 1024 image
+XL_CROP = (slice(128, 256), slice(384, 512))
+
+
+def _unet():
+    t0 = time.time()
+    unet, betas = rb.build_reference_unet(configs.MODELSCOPE_UNET)
+    synth.load_synth(unet, seed=0)
+    print(f"reference UNetSD + synthetic weights {time.time() - t0:.1f}s", flush=True)
+    return unet, betas
+
+
+def _sample(ref, unet, betas, frames, steps, cond, uncond, h=256, w=256):
+    s = ref.samplers.Txt2VideoSampler(unet, torch.device("cpu"), betas=betas, sampler_name="DDIM_Gaussian")
+    lat, nz, shape = s.get_noise(1, 4, frames, h, w, seed=1234)
+    with torch.no_grad():
+        return s.sample_loop(steps=steps, strength=None, conditioning=cond, unconditional_conditioning=uncond, batch_size=1,
+                             latents=lat, shape=shape, noise=nz, guidance_scale=9.0, eta=0.0, sampler_name="DDIM_Gaussian")
+
+
+def tensor2vid_ref(video):
+    """The reference's own tensor2vid (t2v_pipeline.py:447-460) cannot be imported (module top imports open_clip /
+    cv2); its arithmetic is four lines and is restated in oracle/torch_port.tensor2vid, pinned in test_oracle_pin."""
+    from oracle import torch_port as tp
+    return [np.asarray(f) for f in tp.tensor2vid_uint8(video)]
+
+
+def c1():
+    ref = rb.bootstrap()
+    unet, betas = _unet()
+    noise, cond, uncond = synth.synth_inputs(24, 256, 256)
+    with torch.no_grad():
+        t0 = time.time()
+        eps = unet(noise, torch.tensor([801]), cond)
+        t_fwd = time.time() - t0
+    print(f"c1 forward {t_fwd:.1f}s std {eps.std():.4f}", flush=True)
+    t0 = time.time()
+    x10 = _sample(ref, unet, betas, 24, 10, cond, uncond)
+    print(f"c1 10 steps {time.time() - t0:.0f}s std {x10.std():.4f}", flush=True)
+    t0 = time.time()
+    x50 = _sample(ref, unet, betas, 24, 50, cond, uncond)
+    t50 = time.time() - t0
+    print(f"c1 50 steps {t50:.0f}s std {x50.std():.4f}", flush=True)
+    del unet
+    vae = rb.build_reference_vae(configs.VAE_DDCONFIG)
+    synth.load_synth(vae, seed=3)
+    with torch.no_grad():
+        imgs = torch.cat([vae.decode(x50[:, :, f] / configs.SCALE_FACTOR) for f in (0, 23)], dim=0)   # [2,3,256,256]
+    vid = imgs.permute(1, 0, 2, 3).unsqueeze(0)                # [1,3,F,H,W] as t2v_pipeline.py:355-357
+    frames_u8 = np.stack(tensor2vid_ref(vid))                  # [2,256,256,3]
+    np.savez_compressed(os.path.join(OUT, "modelscope_24f.npz"), unet_eps=eps.numpy(), sampler_x0_10=x10.numpy(),
+                        sampler_x0_50=x50.numpy(), frames_u8=frames_u8, vae_img=imgs.numpy().astype(np.float32)[:, :, ::2, ::2],
+                        timing=np.array([t_fwd, t50, torch.get_num_threads()], dtype=np.float64))
+    print("c1 done", flush=True)
+
+
+def c2():
+    unet, _ = _unet()
+    noise, cond, _ = synth.synth_inputs(125, 256, 256)
+    with torch.no_grad():
+        t0 = time.time()
+        eps = unet(noise, torch.tensor([801]), cond)
+        t_fwd = time.time() - t0
+    np.savez_compressed(os.path.join(OUT, "modelscope_125f.npz"), unet_eps_frames=eps[:, :, FRAMES_125].numpy(),
+                        frames=np.array(FRAMES_125), eps_std=np.float64(eps.std()),
+                        timing=np.array([t_fwd, torch.get_num_threads()], dtype=np.float64))
+    print(f"c2 done forward {t_fwd:.1f}s std {eps.std():.4f}", flush=True)
+
+
+def c3():
+    unet, _ = _unet()
+    noise, cond, _ = synth.synth_inputs(24, 576, 1024)
+    with torch.no_grad():
+        t0 = time.time()
+        eps = unet(noise, torch.tensor([801]), cond)
+        t_fwd = time.time() - t0
+    print(f"c3 forward {t_fwd:.1f}s std {eps.std():.4f}", flush=True)
+    del unet
+    vae = rb.build_reference_vae(configs.VAE_DDCONFIG)
+    synth.load_synth(vae, seed=3)
+    z = noise[:, :, 0] / configs.SCALE_FACTOR
+    with torch.no_grad():
+        t0 = time.time()
+        img = vae.decode(z)[0]                                 # [3,576,1024]
+        t_vae = time.time() - t0
+    np.savez_compressed(os.path.join(OUT, "zeroscope_24f.npz"), unet_eps_frames=eps[:, :, FRAMES_XL].numpy(),
+                        frames=np.array(FRAMES_XL), vae_grid=img[:, XL_GRID[0], XL_GRID[1]].numpy(),
+                        vae_crop=img[:, XL_CROP[0], XL_CROP[1]].numpy(), vae_std=np.float64(img.std()),
+                        timing=np.array([t_fwd, t_vae, torch.get_num_threads()], dtype=np.float64))
+    print(f"c3 done vae {t_vae:.1f}s std {img.std():.4f}", flush=True)
+
+
+def c4():
+    import importlib
+    import types
+    rb.bootstrap()
+    om = importlib.import_module("videocrafter.lvdm.models.modules.openaimodel3d")
+    vu = importlib.import_module("videocrafter.lvdm.models.modules.util")
+    dd = importlib.import_module("videocrafter.lvdm.samplers.ddim")
+    dd.DDIMSampler.register_buffer = lambda self, name, attr: setattr(self, name, attr)
+    net = om.UNetModel(**configs.LVDM_UNET).eval()
+    synth.load_synth(net, seed=0)
+    g = torch.Generator().manual_seed(1234)
+    x_T = torch.randn(1, 4, 16, 32, 32, generator=g)
+    ctx = torch.randn(2, 77, 768, generator=g)
+    betas = vu.make_beta_schedule("linear", 1000, linear_start=0.00085, linear_end=0.012)
+    ac = np.cumprod(1.0 - betas, axis=0)
+    f32 = lambda a: torch.tensor(a, dtype=torch.float32)
+    model = types.SimpleNamespace(num_timesteps=1000, betas=f32(betas), alphas_cumprod=f32(ac),
+                                  alphas_cumprod_prev=f32(np.append(1.0, ac[:-1])), device=torch.device("cpu"),
+                                  apply_model=lambda xx, tt, c, **kw: net(xx, tt, context=c))
+    out = {}
+    for steps in (10, 50):
+        smp = dd.DDIMSampler(model)
+        smp.noise_gen.manual_seed(123)
+        t0 = time.time()
+        with torch.no_grad():
+            x0, _ = smp.sample(S=steps, conditioning=ctx[0:1], batch_size=1, shape=list(x_T.shape[1:]), verbose=False,
+                               unconditional_guidance_scale=7.5, unconditional_conditioning=ctx[1:2], eta=0.0, x_T=x_T)
+        out[f"ddim_x0_{steps}"] = x0.numpy()
+        print(f"c4 {steps} steps {time.time() - t0:.0f}s std {x0.std():.4f}", flush=True)
+    del net
+    vae = rb.build_reference_vae(configs.VAE_DDCONFIG)
+    synth.load_synth(vae, seed=3)
+    with torch.no_grad():       # decode_first_stage_2DAE: z = 1/scale_factor * z, per frame (ddpm3d.py:776-793)
+        img = vae.decode(torch.from_numpy(out["ddim_x0_50"])[:, :, 0] / configs.SCALE_FACTOR)
+    np.savez_compressed(os.path.join(OUT, "lvdm_16f_ddim.npz"), vae_img_frame0=img.numpy()[:, :, ::2, ::2], **out)
+    print("c4 done", flush=True)
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    which = [a for a in sys.argv[1:] if a in ("c1", "c2", "c3", "c4")] or ["c2", "c3", "c4", "c1"]
+    for name in which:
+        globals()[name]()

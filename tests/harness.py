@@ -60,30 +60,28 @@ def run_lockstep(executors, exts, stream):
             for r in range(n):
                 steps[r][k][1].run(exts[r], stream)
             continue
-        meta = [steps[r][k][1].meta for r in range(n)]
-        if meta[0]["type"] == "allgather":
-            nb = meta[0]["part_bytes"]
+        ops = [steps[r][k][1] for r in range(n)]
+        nb = (ops[0].i[0] & 0xFFFFFFFF) | (ops[0].i[1] << 32)
+        if ops[0].kind == L.OP_ALLGATHER:
             parts = []
             for r in range(n):
-                off = meta[r]["full"].ref.off
+                assert (ops[r].i[2], ops[r].i[3]) == (n, r)
+                off = ops[r].p[0].off
                 parts.append(executors[r].arena[off + r * nb: off + (r + 1) * nb].clone())
             for r in range(n):
-                off = meta[r]["full"].ref.off
+                off = ops[r].p[0].off
                 for q in range(n):
                     executors[r].arena[off + q * nb: off + (q + 1) * nb] = parts[q]
-        else:  # halo
+        else:  # halo exchange: frame 1 -> prev's frame F+1 ... (byte counts / neighbours read from the op records)
             firsts, lasts = [], []
             for r in range(n):
-                buf, fr, nf = meta[r]["buf"], meta[r]["frame_rows"], meta[r]["frames"]
-                fb = fr * buf.ld * buf.item
-                base = buf.ref.off
-                firsts.append(executors[r].arena[base + fb: base + 2 * fb].clone())
-                lasts.append(executors[r].arena[base + nf * fb: base + (nf + 1) * fb].clone())
+                base, nf = ops[r].p[0].off, ops[r].i[2]
+                firsts.append(executors[r].arena[base + nb: base + 2 * nb].clone())
+                lasts.append(executors[r].arena[base + nf * nb: base + (nf + 1) * nb].clone())
             for r in range(n):
-                buf, fr, nf = meta[r]["buf"], meta[r]["frame_rows"], meta[r]["frames"]
-                fb = fr * buf.ld * buf.item
-                base = buf.ref.off
+                base, nf = ops[r].p[0].off, ops[r].i[2]
+                assert ops[r].i[3] == (r - 1 if r > 0 else -1) and ops[r].i[4] == (r + 1 if r + 1 < n else -1)
                 if r > 0:
-                    executors[r].arena[base: base + fb] = lasts[r - 1]
+                    executors[r].arena[base: base + nb] = lasts[r - 1]
                 if r + 1 < n:
-                    executors[r].arena[base + (nf + 1) * fb: base + (nf + 2) * fb] = firsts[r + 1]
+                    executors[r].arena[base + (nf + 1) * nb: base + (nf + 2) * nb] = firsts[r + 1]

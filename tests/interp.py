@@ -128,7 +128,9 @@ class Interp:
         cpg = C // groups
         x = self.mat(op.p[0], n_inst * rows, C, ld_in, _TD[in_dt], ext).double().view(n_inst, rows, groups, cpg)
         rpb = op.i[11] if op.i[11] > 0 else L.GN_ROWS_PER_BLOCK
-        nblk = (rows + rpb - 1) // rpb
+        rows_max = op.i[13] if op.i[13] > 0 else rows
+        rows_total = op.i[14] if op.i[14] > 0 else rows * nparts
+        nblk = (rows_max + rpb - 1) // rpb
         part_len = n_inst * nblk * groups * 2
         if phase == 0:
             s1, s2, n = x.sum(dim=(1, 3)), (x * x).sum(dim=(1, 3)), rows * cpg
@@ -141,7 +143,7 @@ class Interp:
                 pv[part, :, 0, :, 0] = x.sum(dim=(1, 3))
                 pv[part, :, 0, :, 1] = (x * x).sum(dim=(1, 3))
                 return
-            s1, s2, n = pv[..., 0].sum(dim=(0, 2)), pv[..., 1].sum(dim=(0, 2)), rows * nparts * cpg
+            s1, s2, n = pv[..., 0].sum(dim=(0, 2)), pv[..., 1].sum(dim=(0, 2)), rows_total * cpg
         mean = (s1 / n).view(n_inst, 1, groups, 1)
         var = (s2 / n).view(n_inst, 1, groups, 1) - mean * mean
         y = ((x - mean) / torch.sqrt(var.clamp_min(0) + op.f[0])).view(n_inst * rows, C).float()
@@ -275,8 +277,31 @@ class Interp:
         out = self.view(op.p[6], (n,), (1,), _TD[op.i[2]], ext)
         out.copy_(acc.to(out.dtype))
 
-    def _op100(self, op, ext):
+    def _op16(self, op, ext):
         raise RuntimeError("collectives are executed by parallel.ShardedExecutor, not the interpreter")
+
+    _op17 = _op16
+
+    # TO_UINT8 (tensor2vid) ------------------------------------------------------------------------------
+    def _op15(self, op, ext):
+        NI, C, Fr, H, W, in_dt, half, bgr = op.i[0:8]
+        si, sc = (op.i[8] & 0xFFFFFFFF) | (op.i[9] << 32), op.i[10]
+        sf, sy, sx = (op.i[11] & 0xFFFFFFFF) | (op.i[12] << 32), op.i[13], op.i[14]
+        v = self.view(op.p[0], (NI, C, Fr, H, W), (si, sc, sf, sy, sx), _TD[in_dt], ext)
+        if half:
+            v = v.half()
+            v = (v * 0.5)
+            v = (v + 0.5).clamp(0, 1)
+            v = (v * 255).float()
+        else:
+            v = v.float()
+            v = ((v * 0.5) + 0.5).clamp(0, 1) * 255
+        u8 = v.to(torch.uint8).permute(2, 3, 0, 4, 1).reshape(Fr, H, NI * W, C)
+        if bgr:
+            u8 = u8.flip(-1)
+        out = ext[op.p[1].off] if op.p[1].space == "ext" else None
+        assert out is not None and out.dtype == torch.uint8
+        out.view(Fr, H, NI * W, C).copy_(u8)
 
     def _op11(self, op, ext):
         nbytes = (op.i[0] & 0xFFFFFFFF) | (op.i[1] << 32)

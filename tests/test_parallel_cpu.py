@@ -89,19 +89,41 @@ def test_two_cfg_pairs_gloo_world4():
     assert dict(ret) == {0: 1, 1: 1, 2: 1, 3: 1}
 
 
+def test_tshard_frame_bookkeeping_uneven():
+    """north_star's 8-GPU layout: 125 frames over 4 slices (32+32+32+29) x 2 CFG roles; every frame is decoded by
+    exactly one rank and the gathered order is the clip order."""
+    from sd_webui_text2video_amd.program import TShardSpec
+    for F, R in ((125, 4), (24, 2), (10, 4), (125, 8), (7, 3)):
+        spec = TShardSpec.make(F, R, 0)
+        assert sum(spec.counts) == F and all(c == spec.counts[0] for c in spec.counts[:-1]) and 1 <= spec.counts[-1] <= spec.counts[0]
+        assert [TShardSpec.make(F, R, r).offset for r in range(R)] == [r * spec.counts[0] for r in range(R)]
+        order = parallel.tshard_frame_order(spec.counts)
+        covered = []
+        for rank, f0, n in order:
+            role, t = rank // R, rank % R
+            a, b = parallel.tshard_decode_share(spec.counts, role, t)
+            assert b - a == n and sum(spec.counts[:t]) + a == f0
+            covered += list(range(f0, f0 + n))
+        assert covered == list(range(F))
+    assert TShardSpec.make(125, 4, 3).counts == (32, 32, 32, 29)
+    import pytest
+    with pytest.raises(ValueError):
+        TShardSpec.make(4, 4, 0).counts and TShardSpec.make(5, 4, 0)      # 5 frames / 4 slices of 2 leaves an empty last slice
+
+
 def test_make_runner_default_layouts():
-    """N > 1 defaults to independent videos per GPU (no data-path collective); pairs / tshard are explicit choices."""
+    """Layout bookkeeping of the runners that need no process group (replicas / single GPU)."""
     class Pipe:          # the runner only stores it
         pass
     kw = dict(frames=24, height=256, width=256, ddim_steps=50, guidance=9.0)
-    r = parallel.make_runner(Pipe(), 8, 3, **kw)
+    r = parallel.make_runner(Pipe(), 8, 3, mode="replicas", **kw)
     assert isinstance(r, parallel._ReplicaRunner) and r.frames_per_video_all_ranks == 24 * 8 and r.unet_batch == 2
     r1 = parallel.make_runner(Pipe(), 1, 0, **kw)
     assert type(r1) is parallel._Runner and r1.frames_per_video_all_ranks == 24 and r1.unet_batch == 2
     # several videos per batch and GPU (bench.py --videos V): frame accounting and the UNet batch follow
     r4 = parallel.make_runner(Pipe(), 1, 0, videos=4, **kw)
     assert r4.frames_per_video_all_ranks == 96 and r4.unet_batch == 8 and "4 videos per batch" in r4.describe
-    r8 = parallel.make_runner(Pipe(), 8, 5, videos=2, **kw)
+    r8 = parallel.make_runner(Pipe(), 8, 5, videos=2, mode="replicas", **kw)
     assert r8.frames_per_video_all_ranks == 24 * 8 * 2 and r8.unet_batch == 4 and "16 independent videos" in r8.describe
     calls = []
 

@@ -6,6 +6,7 @@ temporal-attention K/V all have to be exact for that)."""
 import os
 import socket
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -16,6 +17,7 @@ from oracle import configs, synth, torch_port as tp
 from sd_webui_text2video_amd import _lib as L
 from sd_webui_text2video_amd import parallel
 from sd_webui_text2video_amd import unet as U
+from sd_webui_text2video_amd.program import TShardSpec
 
 
 def _free_port():
@@ -50,27 +52,27 @@ def _worker(rank, world, port, F, ret):
         net = U.UNetSD(**cfg, init_weights=False)
         synth.load_synth(net, seed=0)
         x, t, y = _inputs(F)
-        Fl = F // world
-        shard = parallel.TShard(dist.group.WORLD, list(range(world)), rank)
-        comp = net._compile(1, Fl, 8, 8, 5, "f32", "f32", "f32", shard=(world, rank))
+        spec = TShardSpec.make(F, world, rank)
+        shard = parallel.TShard(dist.group.WORLD, list(range(world)), spec)
+        comp = net._compile(1, spec.frames, 8, 8, 5, "f32", "f32", "f32", shard=spec)
         it = Interp(comp.prog, comp.packer.materialise(net.state_dict(), "cpu"))
-        ex = parallel.ShardedExecutor(comp.prog, it.arena, lambda ops: _Seg(it, ops))
+        ex = parallel.ShardedExecutor(comp.prog, it.arena, shard, lambda ops: _Seg(it, ops))
         assert ex.n_collectives == 22 * 8 + 17 * 3            # 39 temporal sites
-        out = torch.empty(1, 4, Fl, 8, 8)
-        xl = x[:, :, rank * Fl:(rank + 1) * Fl].contiguous()
-        ex.run({L.EXT_X: xl, L.EXT_T: t, L.EXT_CTX: y, L.EXT_OUT: out}, None, shard)
+        out = torch.empty(1, 4, spec.frames, 8, 8)
+        xl = x[:, :, spec.offset:spec.offset + spec.frames].contiguous()
+        ex.run({L.EXT_X: xl, L.EXT_T: t, L.EXT_CTX: y, L.EXT_OUT: out}, None)
         ret[rank] = out
     finally:
         dist.destroy_process_group()
 
 
-def test_tsharded_unet_matches_unsharded_gloo_world2():
-    F = 4
+@pytest.mark.parametrize("world,F", [(2, 4), (3, 7), (4, 10)])      # 7 = 3+3+1, 10 = 3+3+3+1: uneven last slices
+def test_tsharded_unet_matches_unsharded_gloo(world, F):
     port = _free_port()
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(2, port, F, ret), nprocs=2, join=True)
-    sharded = torch.cat([ret[0], ret[1]], dim=2)
+    mp.spawn(_worker, args=(world, port, F, ret), nprocs=world, join=True)
+    sharded = torch.cat([ret[r] for r in range(world)], dim=2)
     # unsharded reference: same program family, one rank
     cfg = configs.TINY_UNET
     net = U.UNetSD(**cfg, init_weights=False)
