@@ -14,17 +14,20 @@ namespace {
 
 template <typename TIN>
 __global__ __launch_bounds__(256) void ncthw_to_cl_kernel(const TIN* in, f16* out, int B, int C, int F, int HW,
-                                                          int ld, float scale) {
-  // one thread per output token; writes ld (>= C, multiple of 4) channels, zero padded
+                                                          int ld, float scale, int Bsrc) {
+  // one thread per output token; writes ld (>= C, multiple of 4) channels, zero padded.  Bsrc < B: the source holds
+  // Bsrc samples and output sample b reads source sample b % Bsrc (the cond | uncond pair of a guided step shares x_t,
+  // gaussian_sampler.py:161-162 — no torch.cat([x, x]) on the host)
   const long total = (long)B * F * HW;
   for (long tkn = (long)blockIdx.x * 256 + threadIdx.x; tkn < total; tkn += (long)gridDim.x * 256) {
     const long bf = tkn / HW;
     const int pix = (int)(tkn - bf * HW);
     const int b = (int)(bf / F), f = (int)(bf - (long)b * F);
+    const int bs = b % Bsrc;
     f16* o = out + tkn * ld;
     for (int c = 0; c < ld; ++c) {
       float v = 0.f;
-      if (c < C) v = (float)in[(((size_t)b * C + c) * F + f) * HW + pix] * scale;
+      if (c < C) v = (float)in[(((size_t)bs * C + c) * F + f) * HW + pix] * scale;
       o[c] = (f16)v;
     }
   }
@@ -203,13 +206,14 @@ inline int grid_for(long n) {
 hipError_t t2v_launch_ncthw_to_cl(const t2v_op& op, hipStream_t s) {
   const int B = op.i[0], C = op.i[1], F = op.i[2], HW = op.i[3], ld = op.i[4];
   const long n = (long)B * F * HW;
+  const int Bsrc = (op.i[6] > 0 && op.i[6] < B) ? op.i[6] : B;
   f16* out = reinterpret_cast<f16*>(op.p[1]);
   if (op.i[5] == T2V_F32)
     hipLaunchKernelGGL(ncthw_to_cl_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s,
-                       reinterpret_cast<const float*>(op.p[0]), out, B, C, F, HW, ld, op.f[0]);
+                       reinterpret_cast<const float*>(op.p[0]), out, B, C, F, HW, ld, op.f[0], Bsrc);
   else
     hipLaunchKernelGGL(ncthw_to_cl_kernel<f16>, dim3(grid_for(n)), dim3(256), 0, s,
-                       reinterpret_cast<const f16*>(op.p[0]), out, B, C, F, HW, ld, op.f[0]);
+                       reinterpret_cast<const f16*>(op.p[0]), out, B, C, F, HW, ld, op.f[0], Bsrc);
   return hipGetLastError();
 }
 

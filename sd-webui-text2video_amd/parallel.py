@@ -31,6 +31,38 @@ from . import _lib as L
 from .program import COLLECTIVE_KINDS, Op, Program, TShardSpec
 
 
+def _host_staged(group) -> bool:
+    """gloo moves host memory only: device tensors are staged through the host (multi-process tests that share one GPU)."""
+    return dist.get_backend(group) == "gloo"
+
+
+def all_gather_into(out: torch.Tensor, mine: torch.Tensor, group=None):
+    """dist.all_gather_into_tensor, also for device tensors over a gloo group."""
+    if out.is_cuda and _host_staged(group):
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(o, mine.cpu().contiguous(), group=group)
+        out.copy_(o)
+    else:
+        dist.all_gather_into_tensor(out, mine, group=group)
+
+
+def exchange_pairs(sends, recvs, group):
+    """sends / recvs: [(tensor, global rank)] — one batched neighbour exchange."""
+    staged = bool(sends or recvs) and (sends + recvs)[0][0].is_cuda and _host_staged(group)
+    if staged:
+        hs = [(t.cpu(), r) for t, r in sends]
+        hr = [(torch.empty(t.shape, dtype=t.dtype), r) for t, r in recvs]
+    else:
+        hs, hr = sends, recvs
+    ops = [dist.P2POp(dist.isend, t, r, group=group) for t, r in hs] + [dist.P2POp(dist.irecv, t, r, group=group) for t, r in hr]
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    if staged:
+        for (dst, _), (src, _) in zip(recvs, hr):
+            dst.copy_(src)
+
+
 def partition_frames(n_frames: int, parts: int) -> List[Tuple[int, int]]:
     """Contiguous, near-equal frame ranges [f0, f1) (uneven tail allowed, e.g. 125 = 7x16 + 13)."""
     base, rem = divmod(n_frames, parts)
@@ -95,7 +127,7 @@ class TShard:
     def communicator(self, device) -> Optional[Communicator]:
         """The in-library communicator for programs on `device`; None = run the exchanges from the host through
         torch.distributed (CPU / gloo groups, or T2V_COLLECTIVES=host)."""
-        if torch.device(device).type != "cuda" or os.environ.get("T2V_COLLECTIVES", "library") == "host":
+        if torch.device(device).type != "cuda" or os.environ.get("T2V_COLLECTIVES", "library") == "host" or _host_staged(self.group):
             return None
         if self._comm is None:
             self._comm = Communicator(self.group, self.ranks, self.index, device)
@@ -142,21 +174,19 @@ class ShardedExecutor:
                 assert (i[2], i[3]) == (shard.size, shard.index)
                 out = self._bytes(base, nb * shard.size)
                 mine = out[shard.index * nb: (shard.index + 1) * nb]
-                dist.all_gather_into_tensor(out, mine, group=shard.group)
+                all_gather_into(out, mine, group=shard.group)
             else:   # OP_HALO_EXCHANGE: frame 1 -> prev, frame F -> next; their boundary frames into frame 0 / F + 1
                 nf = i[2]
                 first, last = self._bytes(base + nb, nb), self._bytes(base + nf * nb, nb)
                 halo0, halo1 = self._bytes(base, nb), self._bytes(base + (nf + 1) * nb, nb)
-                ops = []
+                sends, recvs = [], []
                 if i[3] >= 0:
-                    ops += [dist.P2POp(dist.isend, first, shard.ranks[i[3]], group=shard.group),
-                            dist.P2POp(dist.irecv, halo0, shard.ranks[i[3]], group=shard.group)]
+                    sends.append((first, shard.ranks[i[3]]))
+                    recvs.append((halo0, shard.ranks[i[3]]))
                 if i[4] >= 0:
-                    ops += [dist.P2POp(dist.isend, last, shard.ranks[i[4]], group=shard.group),
-                            dist.P2POp(dist.irecv, halo1, shard.ranks[i[4]], group=shard.group)]
-                if ops:
-                    for w in dist.batch_isend_irecv(ops):
-                        w.wait()
+                    sends.append((last, shard.ranks[i[4]]))
+                    recvs.append((halo1, shard.ranks[i[4]]))
+                exchange_pairs(sends, recvs, shard.group)
 
     # BoundProgram-compatible timing hook (per-op times are not defined across host-side collectives)
     def run_timed(self, ext, stream):
@@ -193,7 +223,7 @@ class CfgPair:
         if self.size == 1:
             return eps_local
         out = torch.empty((2,) + tuple(eps_local.shape[1:]), dtype=eps_local.dtype, device=eps_local.device)
-        dist.all_gather_into_tensor(out, eps_local.contiguous(), group=self.group)
+        all_gather_into(out, eps_local.contiguous(), group=self.group)
         return out
 
     def my_frames(self, n_frames: int) -> Tuple[int, int]:
@@ -208,7 +238,7 @@ class CfgPair:
         send = torch.zeros((nmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         send[: local.shape[0]] = local
         recv = torch.empty((self.size * nmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(recv, send, group=self.group)
+        all_gather_into(recv, send, group=self.group)
         return torch.cat([recv[i * nmax: i * nmax + (b - a)] for i, (a, b) in enumerate(parts)], dim=0)
 
 
@@ -270,7 +300,7 @@ class TShardTopology:
 
     def exchange_eps(self, eps_local: torch.Tensor) -> torch.Tensor:
         out = torch.empty((2,) + tuple(eps_local.shape[1:]), dtype=eps_local.dtype, device=eps_local.device)
-        dist.all_gather_into_tensor(out, eps_local.contiguous(), group=self.pair_group)
+        all_gather_into(out, eps_local.contiguous(), group=self.pair_group)
         return out                                       # index 0 = role 0 = conditional
 
     def decode_share(self) -> Tuple[int, int]:
@@ -340,7 +370,7 @@ class _TShardRunner:
         if b > a:
             send[: b - a] = pipe.decode_frames(x0[:, :, a:b])
         out = torch.empty((topo.world * nmax, H, W, 3), dtype=torch.uint8, device=dev)
-        dist.all_gather_into_tensor(out, send)
+        all_gather_into(out, send)
         return torch.cat([out[r * nmax: r * nmax + n] for r, _, n in order], dim=0)
 
 

@@ -177,11 +177,10 @@ class TextToVideoSynthesis(object):
         self.last_tensor = x0
         if not decode:
             return None, x0
-        rgb = self.decode_frames(x0)
         if not to_host:
-            return rgb, x0
-        arr = rgb.cpu().numpy()
-        return [np.ascontiguousarray(arr[i][:, :, ::-1]) for i in range(arr.shape[0])], x0   # RGB -> BGR
+            return self.decode_frames(x0), x0
+        arr = self.decode_frames(x0, bgr=True).cpu().numpy()          # BGR like postprocess_video (t2v_pipeline.py:430-433)
+        return [arr[i] for i in range(arr.shape[0])], x0
 
     @torch.no_grad()
     def compute_latents(self, vd_out, cpu_vae="GPU (half precision)", device=torch.device("cuda")):
@@ -200,13 +199,13 @@ class TextToVideoSynthesis(object):
         return mean.view(bs, F, mean.shape[1], mean.shape[2], mean.shape[3]).permute(0, 2, 1, 3, 4).contiguous().cpu()
 
     @torch.no_grad()
-    def decode_frames(self, x0: torch.Tensor) -> torch.Tensor:
-        """latent [b,4,F,h,w] -> uint8 [F,H,(b W),3] RGB on device: ONE batched VAE program over all
+    def decode_frames(self, x0: torch.Tensor, bgr: bool = False) -> torch.Tensor:
+        """latent [b,4,F,h,w] -> uint8 [F,H,(b W),3] RGB (or BGR) on device: ONE batched VAE program over all
         frames of x0/0.18215 (t2v_pipeline.py:329-355 decodes them one at a time) + tensor2vid."""
         self.autoencoder.to(x0.device)
         bs, _, F, h, w = x0.shape
         z = (x0 * (1.0 / SCALE_FACTOR)).permute(0, 2, 1, 3, 4).reshape(bs * F, 4, h, w)   # '(b f) c h w'
-        return self.autoencoder.decode_to_uint8(z, videos=bs)     # uint8 conversion = last op of the decoder program
+        return self.autoencoder.decode_to_uint8(z, videos=bs, bgr=bgr)     # uint8 conversion = last op of the decoder program
 
     def infer(self, prompt, n_prompt, steps, frames, seed, scale, width=256, height=256, eta=0.0,
               cpu_vae="GPU (half precision)", device=torch.device("cuda"), latents=None, skip_steps=0,
@@ -218,6 +217,8 @@ class TextToVideoSynthesis(object):
         vars_["seed"] = seed
         if "CPU" in str(cpu_vae):
             raise NotImplementedError("CPU VAE modes are host plumbing of the reference; this build decodes on the GPU")
+        if "half precision" in str(cpu_vae):
+            self.autoencoder.half()                      # t2v_pipeline.py:337-339
         steps = steps - skip_steps
         c, uc = self.preprocess(prompt, n_prompt, steps)
         strength = None if (strength == 0.0 and not is_vid2vid) else strength
@@ -230,23 +231,40 @@ pipe: Optional[TextToVideoSynthesis] = None     # module-global model cache, as 
 
 
 def process_modelscope(args_dict: dict, extra_args=None):
-    """Entry-point name kept (process_modelscope.py:34).  The reference body is webui file / ffmpeg /
-    Gradio plumbing and is out of scope; this minimal form runs the hot path for
-    args_dict = {model_dir | pipe, prompt, n_prompt, steps, frames, seed, cfg_scale, width, height,
-    eta, sampler, clip_encoder | (cond, uncond), batch_count} and returns the list of BGR uint8 frames
-    (batch_count > 1 with given (cond, uncond): the videos of seeds seed .. seed + batch_count - 1 in one batched pass,
-    frames side by side)."""
+    """Entry point B1 (process_modelscope.py:34-266).  The reference body is webui file / ffmpeg / Gradio plumbing around
+    the `batch_count` loop of `pipe.infer(...)` calls (:152-221) and returns `list[str]`: one `data:video/mp4;base64,`
+    URL per video, made from the mp4 that ffmpeg stitched (:248-266).  Here:
+      args_dict = {model_dir | pipe, prompt, n_prompt, steps, frames, seed, cfg_scale, width, height, eta, sampler,
+                   batch_count, clip_encoder | (cond, uncond), stitch}
+    * `stitch(frames_bgr, infotext) -> bytes` (the ffmpeg stage, out of scope — e.g. the reference's own
+      `ffmpeg_stitch_video` behind a temp directory) given: returns the reference's list of data-URLs, video b from
+      seed + b (seed -1 stays random), exactly the reference loop;
+    * no `stitch`: returns the BGR uint8 frames of the (last) video — what the reference writes as PNGs (:225-229);
+      with (cond, uncond) tensors and batch_count > 1 the videos of seeds seed .. seed + batch_count - 1 are made in ONE
+      batched pass, frames side by side."""
     global pipe
     a = SimpleNamespace(**args_dict)
     if getattr(a, "pipe", None) is not None:
         pipe = a.pipe
     elif pipe is None:
         pipe = TextToVideoSynthesis(a.model_dir, clip_encoder=getattr(a, "clip_encoder", None))
-    common = dict(steps=a.steps, frames=a.frames, seed=a.seed, scale=a.cfg_scale, width=getattr(a, "width", 256),
+    common = dict(steps=a.steps, frames=a.frames, scale=a.cfg_scale, width=getattr(a, "width", 256),
                   height=getattr(a, "height", 256), eta=getattr(a, "eta", 0.0),
                   sampler=getattr(a, "sampler", available_samplers[0].name))
-    if getattr(a, "cond", None) is not None:
-        frames, _ = pipe.infer_conditioned(a.cond, a.uncond, videos=int(getattr(a, "batch_count", 1)), **common)
+    batch_count = int(getattr(a, "batch_count", 1))
+    stitch = getattr(a, "stitch", None)
+    if getattr(a, "cond", None) is not None and stitch is None:
+        frames, _ = pipe.infer_conditioned(a.cond, a.uncond, seed=a.seed, videos=batch_count, **common)
         return frames
-    frames, _, _ = pipe.infer(a.prompt, getattr(a, "n_prompt", ""), **common)
-    return frames
+    urls, frames = [], None
+    for batch in range(batch_count):
+        seed = a.seed + batch if a.seed != -1 else -1
+        if getattr(a, "cond", None) is not None:
+            frames, _ = pipe.infer_conditioned(a.cond, a.uncond, seed=seed, **common)
+            info = ""
+        else:
+            frames, _, info = pipe.infer(a.prompt, getattr(a, "n_prompt", ""), seed=seed, **common)
+        if stitch is not None:
+            import base64
+            urls.append("data:video/mp4;base64," + base64.b64encode(stitch(frames, info)).decode())
+    return urls if stitch is not None else frames

@@ -434,9 +434,11 @@ class Program:
         op.out = out
         return self._emit(op)
 
-    def ncthw_to_cl(self, name: str, src: Ref, src_dtype: str, out: Buf, *, B, C, F, HW, scale=1.0) -> Op:
+    def ncthw_to_cl(self, name: str, src: Ref, src_dtype: str, out: Buf, *, B, C, F, HW, scale=1.0, src_batch: int = 0) -> Op:
+        """src_batch (< B): the source holds that many samples, output sample b reads sample b % src_batch."""
+        assert src_batch == 0 or B % src_batch == 0
         op = Op(L.OP_NCTHW_TO_CL, name)
-        op.i[0:6] = [B, C, F, HW, out.ld, _DT[src_dtype]]
+        op.i[0:7] = [B, C, F, HW, out.ld, _DT[src_dtype], src_batch]
         op.f[0] = scale
         op.p[0:2] = [src, out.ref]
         op.out = out
@@ -537,15 +539,29 @@ class BoundProgram:
         handle = ctypes.c_void_p()
         L.check(lib.t2v_plan_create(arr, n, ctypes.byref(handle)))
         self.handle = handle
+        self._skip_handle = None
         self._lib = lib
         if comm is not None:
             L.check(lib.t2v_plan_set_comm(handle, comm.handle))
 
-    def run(self, ext: Dict[int, int], stream: int):
+    def run(self, ext: Dict[int, int], stream: int, skip_invariant: bool = False):
+        """skip_invariant: leave out the program's step-invariant ops (Op.meta['step_invariant'] — the text-context K/V
+        projection): their results are still in the arena from the previous run of this plan with the same context."""
         e = (ctypes.c_uint64 * L.EXT_SLOTS)()
         for k, v in ext.items():
             e[k] = v
-        L.check(self._lib.t2v_plan_run(self.handle, e, L.EXT_SLOTS, ctypes.c_void_p(stream)))
+        handle = self.handle
+        if skip_invariant:
+            if self._skip_handle is None:
+                keep = [k for k, op in enumerate(self.ops) if not op.meta.get("step_invariant")]
+                arr = (L.T2VOp * len(keep))(*[self._arr[k] for k in keep])
+                h = ctypes.c_void_p()
+                L.check(self._lib.t2v_plan_create(arr, len(keep), ctypes.byref(h)))
+                if self.comm is not None:
+                    L.check(self._lib.t2v_plan_set_comm(h, self.comm.handle))
+                self._skip_handle, self._skip_arr = h, arr
+            handle = self._skip_handle
+        L.check(self._lib.t2v_plan_run(handle, e, L.EXT_SLOTS, ctypes.c_void_p(stream)))
 
     def run_timed(self, ext: Dict[int, int], stream: int) -> List[float]:
         e = (ctypes.c_uint64 * L.EXT_SLOTS)()
@@ -560,5 +576,8 @@ class BoundProgram:
             if self.handle:
                 self._lib.t2v_plan_destroy(self.handle)
                 self.handle = None
+            if self._skip_handle:
+                self._lib.t2v_plan_destroy(self._skip_handle)
+                self._skip_handle = None
         except Exception:
             pass

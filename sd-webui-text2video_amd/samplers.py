@@ -192,10 +192,12 @@ class GaussianDiffusion(object):
         if prev_auto is not None:
             model.auto_refresh = False
         stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
+        pair_key = pair_ctx = pair_refs = None      # pair_refs keeps the tensors alive, so their ids stay unique
         try:
             all_t = self.get_time_steps(stride, 1).cpu()
             for step in range(steps):
                 c, uc = reconstruct_conds(conditioning, unconditional_conditioning, step)
+                c0, uc0 = c, uc
                 t = int(all_t[step])
                 tt = torch.full((Bx,), t, dtype=torch.long, device=dev)
                 if Bx > 1:
@@ -208,11 +210,19 @@ class GaussianDiffusion(object):
                 elif self.cfg_parallel is not None and self.cfg_parallel.size == 2:
                     # CFG pair: this rank evaluates ONE of the two forwards; one eps all-gather per step
                     assert Bx == 1, "the CFG-pair layout runs one video per pair"
+                    _require_eta0(eta)
                     mine = c if self.cfg_parallel.role == 0 else uc
                     eps = self.cfg_parallel.exchange_eps(model(xt, tt, mine))
                     guided, gscale = C // 2 if not self.var_type.startswith("fixed") else C, float(guide)
                 else:
-                    if getattr(model, "supports_cfg_batch", False):
+                    if hasattr(model, "forward_cfg_pair"):
+                        # [cond | uncond] built once while the conditioning OBJECTS stay the same (prompt scheduling may
+                        # swap them between steps, reconstruct_cond_batch); x_t is read twice by the entry op
+                        ident = (id(c0), c0._version, id(uc0), uc0._version, Bx)
+                        if pair_key != ident:
+                            pair_key, pair_ctx, pair_refs = ident, torch.cat([c, uc], dim=0), (c0, uc0)
+                        eps = model.forward_cfg_pair(xt, tt, pair_ctx, context_token=pair_key)
+                    elif getattr(model, "supports_cfg_batch", False):
                         eps = model(torch.cat([xt, xt], dim=0), torch.cat([tt, tt]), torch.cat([c, uc], dim=0))
                     else:
                         eps = torch.cat([model(xt, tt, c), model(xt, tt, uc)], dim=0)
@@ -284,9 +294,17 @@ def _ddim_update(out, xt, eps_pair, noise, coef, guided: int, mode: int):
     return out
 
 
-def _eval_eps_pair(model, x, t_value, c, uc, guide, cfg_parallel=None):
+def _require_eta0(eta):
+    """Layouts that split one video over ranks (CFG pair / T shards) rely on every rank applying a bit-identical update;
+    the per-step eta noise is drawn from each rank's own device RNG, so eta > 0 would let x_t diverge."""
+    if float(eta) != 0.0:
+        raise NotImplementedError("eta > 0 with a video split over several GPUs (rank-local RNG): use eta = 0")
+
+
+def _eval_eps_pair(model, x, t_value, c, uc, guide, cfg_parallel=None, cache: Optional[dict] = None):
     """-> (eps [1 or 2, C, F, h, w] (index 0 conditional, 1 unconditional), guided: bool).  One batched
-    b=2 forward when the model supports it; t_value may be fractional (UniPC)."""
+    b=2 forward when the model supports it; t_value may be fractional (UniPC).  `cache` (one dict per sampling run): the
+    [cond | uncond] batch is built once while the conditioning objects stay the same, and the UNet reuses their K/V."""
     dev = x.device
     tt = torch.full((1,), float(t_value), dtype=torch.float32, device=dev)
     if guide is None or guide == 1.0 or uc is None:
@@ -294,6 +312,11 @@ def _eval_eps_pair(model, x, t_value, c, uc, guide, cfg_parallel=None):
     if cfg_parallel is not None and cfg_parallel.size == 2:
         mine = c if cfg_parallel.role == 0 else uc
         return cfg_parallel.exchange_eps(model(x, tt, mine)).contiguous(), True
+    if cache is not None and hasattr(model, "forward_cfg_pair") and c.shape[0] == uc.shape[0] == x.shape[0]:
+        ident = (id(c), c._version, id(uc), uc._version)
+        if cache.get("key") != ident:
+            cache.update(key=ident, ctx=torch.cat([c, uc], dim=0), refs=(c, uc))
+        return model.forward_cfg_pair(x, tt, cache["ctx"], context_token=ident).contiguous(), True
     if getattr(model, "supports_cfg_batch", False):
         return model(torch.cat([x, x], dim=0), torch.cat([tt, tt]), torch.cat([c, uc], dim=0)).contiguous(), True
     return torch.cat([model(x, tt, c), model(x, tt, uc)], dim=0).contiguous(), True
@@ -341,12 +364,15 @@ class DDIMSampler(object):
         prev_auto = getattr(model, "auto_refresh", None)
         if prev_auto is not None:
             model.auto_refresh = False
+        pair_cache = {}
         try:
             for i, step in enumerate(time_range):
                 c, uc = reconstruct_conds(cond, uncond, int(step))
                 index = total_steps - i - 1
-                eps, guided = _eval_eps_pair(model, img, int(step), c, uc, guide, self.cfg_parallel)
+                eps, guided = _eval_eps_pair(model, img, int(step), c, uc, guide, self.cfg_parallel, cache=pair_cache)
                 coef = self._coef(index, guide)
+                if self.cfg_parallel is not None and self.cfg_parallel.size == 2:
+                    _require_eta0(coef[4])                                  # sigma_t == 0 <=> eta == 0
                 noise = torch.randn_like(img, dtype=torch.float32)         # drawn every step, like noise_like()
                 _ddim_update(nxt, img, eps, noise, coef, C if guided else 0, mode=1)
                 img, nxt = nxt, img
@@ -432,10 +458,12 @@ class UniPCSampler(object):
         self.device = torch.device(device) if device is not None else None
         self.alphas_cumprod = model.alphas_cumprod.detach().clone().to(torch.float32)
         self.cfg_parallel = None
+        self._pair_cache = {}
 
     # -- x0 prediction from the (guided) noise prediction: x0 = (x - sigma_t * eps_g) / alpha_t -------------
     def _data_prediction(self, ns, x, t, cond, uncond, guide):
-        eps, guided = _eval_eps_pair(self.model, x, (t - 1.0 / ns.total_N) * 1000.0, cond, uncond, guide, self.cfg_parallel)
+        eps, guided = _eval_eps_pair(self.model, x, (t - 1.0 / ns.total_N) * 1000.0, cond, uncond, guide, self.cfg_parallel,
+                                     cache=self._pair_cache)
         a, s = ns.alpha(t), ns.std(t)
         out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
         if guided:

@@ -222,6 +222,7 @@ class UNetSD(nn.Module):
         # and the three inner temporal-conv outputs): "f16" halves their HBM traffic (what the
         # reference's .half() path stores everywhere), "f32" keeps them in the fp32 stream.
         self.norm_input_dtype = "f16"
+        self.context_token = None     # one-shot hint consumed by the next forward (see forward_cfg_pair)
         self.t_shard = None           # parallel.TShard: this rank holds a contiguous slice of the clip's frames
         self.auto_refresh = True      # re-check parameter versions on every forward (~1 ms); the sampler
                                       # turns this off inside its loop after one explicit refresh
@@ -375,8 +376,10 @@ class UNetSD(nn.Module):
         if not x.is_cuda:
             raise L.T2VError("UNetSD.forward needs device tensors on an AMD GPU (no CPU fallback); "
                              "use oracle/torch_port.py for a CPU reference")
-        B, C, F, H, W = x.shape
-        assert C == self.in_dim and y.shape[0] == B and y.shape[2] == self.context_dim
+        Bx, C, F, H, W = x.shape
+        B = y.shape[0]
+        # x with fewer samples than the context: sample b of the batch reads x[b % Bx] (`forward_cfg_pair`)
+        assert C == self.in_dim and B % Bx == 0 and y.shape[2] == self.context_dim
         x = x.contiguous()
         y = y.contiguous()
         if x.dtype not in (torch.float16, torch.float32):
@@ -393,10 +396,12 @@ class UNetSD(nn.Module):
             shard = self.t_shard.spec                             # x holds only this rank's frames
             if shard.frames != F:
                 raise L.T2VError(f"T-sharded forward: this rank holds {shard.frames} of {shard.total} frames, got {F}")
-        key = (B, F, H, W, y.shape[1], _dt(x.dtype), _dt(y.dtype), _dt(out_dtype)) + ((shard,) if shard else ())
+        key = (B, F, H, W, y.shape[1], _dt(x.dtype), _dt(y.dtype), _dt(out_dtype)) + ((shard,) if shard else ()) + \
+              ((("xb", Bx),) if Bx != B else ())
         comp = self._programs.get(key)
         if comp is None:
-            comp = self._compile(B, F, H, W, y.shape[1], _dt(x.dtype), _dt(out_dtype), _dt(y.dtype), shard=shard)
+            comp = self._compile(B, F, H, W, y.shape[1], _dt(x.dtype), _dt(out_dtype), _dt(y.dtype), shard=shard,
+                                 x_batch=Bx if Bx != B else 0)
             self._programs[key] = comp
             self._evict_programs(keep=key)
         if self._packed is None or self._packed_device != x.device or self.auto_refresh:
@@ -405,8 +410,25 @@ class UNetSD(nn.Module):
         comp.ensure_bound(self._packed, x.device, t_shard=self.t_shard if shard is not None else None)
         out = torch.empty((B, self.out_dim, F, H, W), device=x.device, dtype=out_dtype)
         ext = {L.EXT_X: x.data_ptr(), L.EXT_T: tf.data_ptr(), L.EXT_CTX: y.data_ptr(), L.EXT_OUT: out.data_ptr()}
-        comp.bound.run(ext, torch.cuda.current_stream(x.device).cuda_stream)     # one host call, collectives included
+        # step-invariant prologue: skipped only when the caller passed the token of the previous run of THIS binding
+        token, self.context_token = self.context_token, None
+        reuse = token is not None and comp.ctx_token == token and comp.ctx_bound is comp.bound
+        if isinstance(comp.bound, BoundProgram):
+            comp.bound.run(ext, torch.cuda.current_stream(x.device).cuda_stream, skip_invariant=reuse)   # one host call
+        else:
+            comp.bound.run(ext, torch.cuda.current_stream(x.device).cuda_stream)
+        comp.ctx_token, comp.ctx_bound = token, comp.bound
         return out
+
+    def forward_cfg_pair(self, x, t, ctx_pair, context_token=None):
+        """One guided step's two evaluations (gaussian_sampler.py:161-162) as ONE forward: x [V,4,F,h,w] is read twice by
+        the entry op (no torch.cat([x, x])), ctx_pair = [cond (V) | uncond (V)]; -> eps [2V,...].  `context_token`: any
+        hashable the caller changes whenever ctx_pair's CONTENT changes — equal to the previous call's token, the
+        text-context K/V projections of that call are reused (they do not depend on x or t)."""
+        tt = t.to(device=x.device, dtype=torch.float32).reshape(-1)
+        tt = tt.repeat(ctx_pair.shape[0] // tt.shape[0]) if tt.shape[0] != ctx_pair.shape[0] else tt
+        self.context_token = context_token
+        return UNetSD.forward(self, x, tt, ctx_pair)
 
     max_programs = 4      # compiled geometries kept (each owns a device arena: 0.4 GiB per 24-frame sample, GiBs for long clips)
 
@@ -430,8 +452,8 @@ class UNetSD(nn.Module):
         return out, ms, comp.prog
 
     # ---- lowering -------------------------------------------------------------------------
-    def _compile(self, B, F, H, W, Lctx, x_dt, out_dt, ctx_dt="f32", shard=None):
-        low = _Lowering(self, B, F, H, W, Lctx, x_dt, out_dt, ctx_dt, keep_taps=self.debug_taps, shard=shard)
+    def _compile(self, B, F, H, W, Lctx, x_dt, out_dt, ctx_dt="f32", shard=None, x_batch=0):
+        low = _Lowering(self, B, F, H, W, Lctx, x_dt, out_dt, ctx_dt, keep_taps=self.debug_taps, shard=shard, x_batch=x_batch)
         prog = low.build()
         return _Compiled(prog, low.packer)
 
@@ -446,6 +468,8 @@ class _Compiled:
         self.packer = packer
         self.bound: Optional[BoundProgram] = None
         self.arena: Optional[torch.Tensor] = None
+        self.ctx_token = None          # context token of the last run (step-invariant prologue reuse)
+        self.ctx_bound = None
 
     def ensure_bound(self, packed: Dict[str, torch.Tensor], device, t_shard=None):
         """Bind the program to a device arena and the packed weights.  A program with collective ops (T-sharded
@@ -473,7 +497,7 @@ class _Compiled:
 # lowering: network + geometry -> denoise program
 # ------------------------------------------------------------------------------------------
 class _Lowering:
-    def __init__(self, net: UNetSD, B, F, H, W, Lctx, x_dt, out_dt, ctx_dt, keep_taps=False, shard=None):
+    def __init__(self, net: UNetSD, B, F, H, W, Lctx, x_dt, out_dt, ctx_dt, keep_taps=False, shard=None, x_batch=0):
         """F = frames held by THIS rank.  shard = TShardSpec: the clip's frames are split contiguously over the ranks
         of a T group (slices of ceil(F_total / R) frames, a shorter last one); temporal ops then exchange data
         (SURVEY §5.7): cross-frame GroupNorm -> all-gather of statistics partials, temporal conv -> +-1 frame halo,
@@ -484,6 +508,7 @@ class _Lowering:
             assert F == self.shard.frames
         self.net, self.B, self.F, self.H, self.W, self.Lctx = net, B, F, H, W, Lctx
         self.x_dt, self.out_dt, self.ctx_dt = x_dt, out_dt, ctx_dt
+        self.x_batch = x_batch if 0 < x_batch < B else 0      # x holds fewer samples than the batch: sample b reads x[b % x_batch]
         self.P = Program(f"unet b{B} f{F} {H}x{W}")
         self.P.keep_taps = keep_taps
         self.packer = pk.WeightPacker()
@@ -771,6 +796,12 @@ class _Lowering:
             off += 2 * c
         n_kv = off
 
+        # The text-context K/V projections do not depend on x or t: they are the program's step-invariant prologue
+        # (Op.meta['step_invariant']), skipped when the caller vouches that the context is the one of the previous run
+        # (UNetSD.context_token).  Their buffer is allocated FIRST and freed last, so no other
+        # buffer of the program can alias it between two runs.
+        if n_kv:
+            self.kv_all = P.alloc(B * self.Lctx, n_kv, "f16")
         freqs = Ref("weight", 0, self.packer.add("time_freqs", "f32", lambda sd, d=dim: torch.pow(
             10000, -torch.arange(d // 2).to(torch.float32).div(d // 2))))
         te = P.alloc(B, dim, "f16")
@@ -791,18 +822,17 @@ class _Lowering:
 
         ctx16 = P.alloc(B * self.Lctx, net.context_dim, "f16")
         ctx_src = Buf(Ref("ext", L.EXT_CTX), B * self.Lctx, net.context_dim, net.context_dim, self.ctx_dt)
-        P.copy2d("context.cast", ctx_src, ctx16)
+        P.copy2d("context.cast", ctx_src, ctx16).meta["step_invariant"] = True
         if n_kv:
             w_kv = Ref("weight", 0, self.packer.add("kv_all:lin", "f16", lambda sd, ps=tuple(p for p, _ in st_prefixes): torch.cat(
                 [torch.cat([sd[p + ".transformer_blocks.0.attn2.to_k.weight"], sd[p + ".transformer_blocks.0.attn2.to_v.weight"]], dim=0)
                  for p in ps], dim=0)))
-            self.kv_all = P.alloc(B * self.Lctx, n_kv, "f16")
-            P.gemm("attn2.kv.all", ctx16, w_kv, n_kv, net.context_dim, self.kv_all)
+            P.gemm("attn2.kv.all", ctx16, w_kv, n_kv, net.context_dim, self.kv_all).meta["step_invariant"] = True
         P.free(ctx16)
 
         # ---- entry layout conversion: b c f h w -> tokens x 8 channels (4 real + 4 zero)
         xin = P.alloc(self.M(h, w), 8, "f16")
-        P.ncthw_to_cl("x.to_tokens", Ref("ext", L.EXT_X), self.x_dt, xin, B=B, C=net.in_dim, F=F, HW=h * w)
+        P.ncthw_to_cl("x.to_tokens", Ref("ext", L.EXT_X), self.x_dt, xin, B=B, C=net.in_dim, F=F, HW=h * w, src_batch=self.x_batch)
 
         def run_parts(prefix, parts, bare, x, h, w, dest=None):
             for i, (kind, cin, cout) in enumerate(parts):

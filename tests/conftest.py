@@ -20,3 +20,25 @@ def built_lib():
     ge.build()
     from sd_webui_text2video_amd import _lib
     return _lib.load()
+
+
+@pytest.fixture(scope="session")
+def modelscope_full():
+    """ModelScope configuration (1.41 G parameters), seeded synthetic weights, fp32 (built once per session: ~1 min of CPU)."""
+    from oracle import configs, synth, torch_port as tp
+    from sd_webui_text2video_amd import unet as U
+    net = U.UNetSD(**configs.MODELSCOPE_UNET, init_weights=False)
+    synth.load_synth(net, seed=0)
+    betas = tp.beta_schedule_linear_sd()
+    net.register_schedule(given_betas=betas.numpy())
+    return net, betas
+
+
+@pytest.fixture(scope="session")
+def modelscope_full_fp16(modelscope_full):
+    """The deployed form: `.half()` weights on the device (t2v_pipeline.py:103-104)."""
+    import copy
+    net, betas = modelscope_full
+    net16 = copy.deepcopy(net).half().to("cuda:0")
+    net16._init_runtime()
+    return net16, betas

@@ -11,8 +11,12 @@ tests compare exactly those sub-sets (tests/test_gpu_fullsize.py).
                                    x0 after 10 and after 50 steps, tensor2vid uint8 frames 0 / 23 of the 50-step video
   modelscope_125f.npz  configs[2]  125 frames @256x256: one forward, frames FRAMES_125 (the slice edges of the
                                    4-way T split 32+32+32+29 and both clip ends)
-  zeroscope_24f.npz    configs[3]  24 frames @1024x576 (latent 72x128): one forward, frames FRAMES_XL; one VAE frame
-                                   decoded at 1024x576 (mid attention over 9216 tokens): stride-4 pixel grid + a crop
+  zeroscope_xl.npz     configs[3]  ZeroScope-XL geometry @1024x576 (latent 72x128, spatial attention over 9216 tokens): one
+                                   forward of N_FRAMES_XL = 4 frames, frames FRAMES_XL — the reference's CPU attention
+                                   (F.scaled_dot_product_attention, t2v_model.py:566-569) needs 0.8 GB per (frame, head) at 9216
+                                   tokens, so 24 frames (120 heads-batches) exceed this container's 62 GB; the 24-frame
+                                   count itself is covered by configs[1]; one VAE frame decoded at 1024x576 (mid attention
+                                   over 9216 tokens): stride-4 pixel grid + a crop
   lvdm_16f_ddim.npz    configs[4]  VideoCrafter 0.96 B, 16 frames @256x256: lvdm DDIM (CFG 7.5, eta 0) x0 after 10 and
                                    50 steps, VAE decode of frame 0 of the 50-step latent (stride-2 pixel grid)
 """
@@ -29,7 +33,8 @@ from oracle import configs, ref_bootstrap as rb, synth  # noqa: E402
 
 OUT = os.path.dirname(os.path.abspath(__file__))
 FRAMES_125 = [0, 31, 32, 63, 64, 95, 96, 124]
-FRAMES_XL = [0, 11, 23]
+FRAMES_XL = [0, 1, 3]
+N_FRAMES_XL = 4
 XL_GRID = (slice(1, None, 4), slice(2, None, 4))            # [3, 144, 256] of the 576 x 1024 image
 XL_CROP = (slice(128, 256), slice(384, 512))
 
@@ -101,7 +106,7 @@ def c2():
 
 def c3():
     unet, _ = _unet()
-    noise, cond, _ = synth.synth_inputs(24, 576, 1024)
+    noise, cond, _ = synth.synth_inputs(N_FRAMES_XL, 576, 1024)
     with torch.no_grad():
         t0 = time.time()
         eps = unet(noise, torch.tensor([801]), cond)
@@ -115,7 +120,7 @@ def c3():
         t0 = time.time()
         img = vae.decode(z)[0]                                 # [3,576,1024]
         t_vae = time.time() - t0
-    np.savez_compressed(os.path.join(OUT, "zeroscope_24f.npz"), unet_eps_frames=eps[:, :, FRAMES_XL].numpy(),
+    np.savez_compressed(os.path.join(OUT, "zeroscope_xl.npz"), unet_eps_frames=eps[:, :, FRAMES_XL].numpy(),
                         frames=np.array(FRAMES_XL), vae_grid=img[:, XL_GRID[0], XL_GRID[1]].numpy(),
                         vae_crop=img[:, XL_CROP[0], XL_CROP[1]].numpy(), vae_std=np.float64(img.std()),
                         timing=np.array([t_fwd, t_vae, torch.get_num_threads()], dtype=np.float64))

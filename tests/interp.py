@@ -201,7 +201,9 @@ class Interp:
     # NCTHW_TO_CL --------------------------------------------------------------------------------------
     def _op6(self, op, ext):
         B, C, Fr, HW, ld, in_dt = op.i[0:6]
-        x = self.view(op.p[0], (B, C, Fr, HW), (C * Fr * HW, Fr * HW, HW, 1), _TD[in_dt], ext).float() * op.f[0]
+        Bsrc = op.i[6] if 0 < op.i[6] < B else B
+        x = self.view(op.p[0], (Bsrc, C, Fr, HW), (C * Fr * HW, Fr * HW, HW, 1), _TD[in_dt], ext).float() * op.f[0]
+        x = x.repeat(B // Bsrc, 1, 1, 1)
         out = self.mat(op.p[1], B * Fr * HW, ld, ld, torch.float16, ext)
         out.zero_()
         out[:, :C] = x.permute(0, 2, 3, 1).reshape(B * Fr * HW, C).half()

@@ -1,0 +1,225 @@
+"""GPU (-m gpu): the drop-in boundary rows (b) end to end.
+
+  * `tensor2vid_device` (T2V_OP_TO_UINT8) — BIT-EXACT against the reference's own `tensor2vid` (t2v_pipeline.py:447-460)
+    on identical float input, fp32 and fp16 videos (golden `infer_tiny.npz`, made by tests/golden/make_golden.py from the
+    imported reference function);
+  * `TextToVideoSynthesis.infer(prompt, ...)` and `process_modelscope(args_dict)` — frames, last latent and infotext
+    against the reference's OWN `TextToVideoSynthesis.infer` run on the CPU in fp32 (same golden file);
+  * the C entry points `t2v_unet_forward` / `t2v_vae_decode` driven directly through ctypes as INTEGRATION.md §2 shows;
+  * a communicator with one rank: the collective ops of a plan go through RCCL on the launch stream.
+"""
+import base64
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from harness import rel_l2
+from oracle import configs, synth, torch_port as tp
+from sd_webui_text2video_amd import _lib as L
+from sd_webui_text2video_amd import pipeline, unet as U, vae as V
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+DEV = "cuda:0"
+
+
+def _gold():
+    return np.load(os.path.join(GOLD, "infer_tiny.npz"))
+
+
+def test_tensor2vid_device_bit_exact_with_reference_function():
+    g = _gold()
+    vid = torch.from_numpy(g["t2v_in"])
+    for dtype, key in ((torch.float32, "t2v_u8_f32"), (torch.float16, "t2v_u8_f16")):
+        got = pipeline.tensor2vid_device(vid.to(DEV, dtype)).cpu().numpy()
+        want = g[key]
+        assert got.shape == want.shape and got.dtype == np.uint8
+        assert np.array_equal(got, want), (key, int(np.abs(got.astype(int) - want.astype(int)).max()))
+        frames = pipeline.tensor2vid(vid.to(DEV, dtype))
+        assert len(frames) == want.shape[0] and np.array_equal(np.stack(frames), want)
+    # BGR variant = channel flip; large random input against the oracle port (which test_oracle_pin pins to the reference)
+    big = torch.randn(1, 3, 5, 64, 96, generator=torch.Generator().manual_seed(3)) * 0.7
+    want = np.stack([np.asarray(f) for f in tp.tensor2vid_uint8(big)])
+    assert np.array_equal(pipeline.tensor2vid_device(big.to(DEV)).cpu().numpy(), want)
+    assert np.array_equal(pipeline.tensor2vid_device(big.to(DEV), bgr=True).cpu().numpy(), want[..., ::-1])
+
+
+class _Clip:
+    """Stand-in for the text encoder (outside the hot path): the two prompts map to fixed conditioning tensors."""
+
+    def __init__(self, c, uc):
+        self.table = {"a prompt": c, "a negative prompt": uc}
+
+    def __call__(self, texts):
+        return self.table[texts[0]]
+
+
+def _tiny_pipe(half=False):
+    net = U.UNetSD(**configs.TINY_UNET)
+    synth.load_synth(net, seed=0)
+    ae = V.AutoencoderKL(configs.TINY_VAE_DDCONFIG, 4)
+    synth.load_synth(ae, seed=3)
+    g = torch.Generator().manual_seed(17)
+    c = torch.randn(1, 7, configs.TINY_UNET["context_dim"], generator=g)
+    uc = torch.randn(1, 7, configs.TINY_UNET["context_dim"], generator=g)
+    if half:
+        net, ae = net.half(), ae.half()
+    pipe = pipeline.TextToVideoSynthesis(sd_model=net, autoencoder=ae, clip_encoder=_Clip(c, uc), device=DEV)
+    pipe.diffusion.progress = False
+    return pipe, c, uc
+
+
+def _frame_stats(got, want):
+    d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+    return float((d == 0).mean()), float((d > 1).mean()), int(d.max())
+
+
+@pytest.mark.parametrize("tag,kw", [("", dict(steps=4, frames=3, seed=1234, scale=9.0, width=128, height=128)),
+                                    ("_wide", dict(steps=3, frames=2, seed=77, scale=7.5, width=192, height=64))])
+def test_infer_matches_the_references_own_infer(tag, kw):
+    """B2: same arguments as the golden run of the reference's `TextToVideoSynthesis.infer` (CPU, fp32)."""
+    g = _gold()
+    pipe, _, _ = _tiny_pipe()
+    frames, last, info = pipe.infer("a prompt", "a negative prompt", kw["steps"], kw["frames"], kw["seed"], kw["scale"],
+                                    kw["width"], kw["height"], 0.0, "GPU (full precision)", torch.device(DEV),
+                                    sampler="DDIM_Gaussian")
+    want = g["frames_bgr" + tag]
+    assert isinstance(frames, list) and len(frames) == want.shape[0]
+    got = np.stack(frames)
+    assert got.shape == want.shape and got.dtype == np.uint8 and frames[0].flags["C_CONTIGUOUS"]
+    r = rel_l2(last.float().cpu(), torch.from_numpy(g["last_tensor" + tag]))
+    exact, off2, dmax = _frame_stats(got, want)
+    print(f"infer{tag}: last_tensor rel-L2 {r:.3e}; uint8 frames: {100 * exact:.2f}% identical, {100 * off2:.3f}% off by > 1 LSB, max |diff| {dmax}")
+    assert r < 2e-2
+    assert exact > 0.80 and off2 < 0.01 and dmax <= 6
+    # infotext: the reference's create_infotext layout (t2v_pipeline.py:462-468); only the two device-naming fields differ
+    ref_info = str(g["infotext" + tag])
+    norm = lambda s: s.replace("CPU (full precision)", "X").replace("GPU (full precision)", "X").replace("device: cpu", "device: D").replace(f"device: {DEV}", "device: D")
+    assert norm(info) == norm(ref_info)
+    assert pipe.last_tensor is last
+
+
+def test_infer_half_precision_default_path():
+    """The webui default: .half() UNet + 'GPU (half precision)' VAE (t2v_pipeline.py:103-104,337-339)."""
+    g = _gold()
+    pipe, _, _ = _tiny_pipe(half=True)
+    frames, last, _ = pipe.infer("a prompt", "a negative prompt", 4, 3, 1234, 9.0, 128, 128, sampler="DDIM_Gaussian")
+    assert next(pipe.autoencoder.parameters()).dtype == torch.float16
+    exact, off2, dmax = _frame_stats(np.stack(frames), g["frames_bgr"])
+    r = rel_l2(last.float().cpu(), torch.from_numpy(g["last_tensor"]))
+    print(f"infer fp16: last_tensor rel-L2 {r:.3e}; frames {100 * exact:.2f}% identical, {100 * off2:.3f}% off by > 1 LSB, max |diff| {dmax}")
+    assert r < 3e-2 and exact > 0.6 and off2 < 0.03
+
+
+def test_process_modelscope_entry_point():
+    """B1: args_dict in, frames out; with a `stitch` stage the reference's list of data-URLs (process_modelscope.py:248-266),
+    video b from seed + b."""
+    g = _gold()
+    pipe, c, uc = _tiny_pipe()
+    args = dict(pipe=pipe, prompt="a prompt", n_prompt="a negative prompt", steps=4, frames=3, seed=1234, cfg_scale=9.0,
+                width=128, height=128, eta=0.0, sampler="DDIM_Gaussian")
+    frames = pipeline.process_modelscope(dict(args))
+    exact, off2, _ = _frame_stats(np.stack(frames), g["frames_bgr"])
+    assert exact > 0.80 and off2 < 0.01
+    seen = []
+
+    def stitch(fr, info):
+        seen.append((np.stack(fr), info))
+        return np.stack(fr).tobytes()[:64]
+
+    urls = pipeline.process_modelscope(dict(args, batch_count=2, stitch=stitch))
+    assert len(urls) == 2 and all(u.startswith("data:video/mp4;base64,") for u in urls)
+    assert base64.b64decode(urls[0].split(",", 1)[1]) == seen[0][0].tobytes()[:64]
+    assert np.array_equal(seen[0][0], np.stack(frames)) and "seed: 1234" in seen[0][1] and "seed: 1235" in seen[1][1]
+    assert not np.array_equal(seen[0][0], seen[1][0])
+    # given conditioning tensors, batch_count videos in one batched pass: side by side, video v from seed + v
+    both = pipeline.process_modelscope(dict(args, cond=c, uncond=uc, batch_count=2))
+    wide = np.stack(both)
+    assert wide.shape == (3, 128, 256, 3)
+    e0, o0, _ = _frame_stats(wide[:, :, :128], seen[0][0])
+    e1, o1, _ = _frame_stats(wide[:, :, 128:], seen[1][0])
+    assert min(e0, e1) > 0.95 and max(o0, o1) < 0.002
+
+
+def test_c_entry_points_unet_forward_and_vae_decode_via_ctypes():
+    """a maintainer's shim holds a t2v_plan and calls t2v_unet_forward / t2v_vae_decode with raw device
+    pointers on its own stream."""
+    lib = L.load()
+    net = U.UNetSD(**configs.TINY_UNET)
+    sd = synth.load_synth(net, seed=0)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 4, 3, 16, 16, generator=g).to(DEV)
+    y = torch.randn(2, 7, 1024, generator=g).to(DEV)
+    t = torch.tensor([801.0, 401.0], device=DEV)
+    want = net(x, t, y)                                   # lowers + binds the program for this geometry
+    comp = next(iter(net._programs.values()))
+    out = torch.zeros_like(want)
+    stream = torch.cuda.Stream(device=DEV)
+    stream.wait_stream(torch.cuda.current_stream())
+    vp = ctypes.c_void_p
+    L.check(lib.t2v_unet_forward(comp.bound.handle, vp(x.data_ptr()), vp(t.data_ptr()), vp(y.data_ptr()), vp(out.data_ptr()),
+                                 vp(stream.cuda_stream)))
+    stream.synchronize()
+    assert torch.equal(out, want)
+    assert rel_l2(out.float().cpu(), tp.unet_forward(sd, configs.TINY_UNET, x.cpu(), t.long().cpu(), y.cpu())) < 5e-3
+    ae = V.AutoencoderKL(configs.TINY_VAE_DDCONFIG, 4)
+    vsd = synth.load_synth(ae, seed=3)
+    z = torch.randn(2, 4, 8, 8, generator=g).to(DEV)
+    wimg = ae.decode(z)
+    vcomp = next(iter(ae._programs.values()))
+    img = torch.zeros_like(wimg)
+    L.check(lib.t2v_vae_decode(vcomp.bound.handle, vp(z.data_ptr()), vp(img.data_ptr()), vp(stream.cuda_stream)))
+    stream.synchronize()
+    assert torch.equal(img, wimg)
+    assert rel_l2(img.float().cpu(), tp.vae_decode(vsd, configs.TINY_VAE_DDCONFIG, z.cpu())) < 5e-3
+    # a malformed record is refused at plan creation, not at launch (validation per op kind)
+    bad = L.T2VOp()
+    bad.kind = L.OP_DDIM_STEP
+    bad.i[0], bad.i[1] = 4, 0
+    h = vp()
+    assert lib.t2v_plan_create(ctypes.byref(bad), 1, ctypes.byref(h)) == -1 and b"DDIM" in lib.t2v_last_error()
+    bad.kind = L.OP_ATTENTION
+    for k, v in enumerate([4, 4, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 48]):
+        bad.i[k] = v
+    bad.f[0] = 1.0
+    for k in range(4):
+        bad.p[k] = x.data_ptr()
+    assert lib.t2v_plan_create(ctypes.byref(bad), 1, ctypes.byref(h)) == -1 and b"head_dim" in lib.t2v_last_error()
+
+
+def test_collective_ops_run_through_rccl_single_rank_communicator():
+    """One-rank RCCL communicator owned by the library: T2V_OP_ALLGATHER / T2V_OP_HALO_EXCHANGE of a plan execute on the
+    launch stream (world size 1: the gather is the identity, the clip has no neighbours)."""
+    lib = L.load()
+    ident = ctypes.create_string_buffer(128)
+    L.check(lib.t2v_comm_unique_id(ident))
+    comm = ctypes.c_void_p()
+    L.check(lib.t2v_comm_create(ident.raw, 1, 0, ctypes.byref(comm)))
+    assert lib.t2v_comm_size(comm) == 1
+    buf = torch.arange(4096, dtype=torch.uint8, device=DEV).contiguous()
+    want = buf.clone()
+    ops = (L.T2VOp * 2)()
+    ops[0].kind = L.OP_ALLGATHER
+    ops[0].i[0], ops[0].i[2], ops[0].i[3] = 1024, 1, 0
+    ops[0].p[0] = buf.data_ptr()
+    ops[1].kind = L.OP_HALO_EXCHANGE
+    ops[1].i[0], ops[1].i[2], ops[1].i[3], ops[1].i[4] = 1024, 2, -1, -1
+    ops[1].p[0] = buf.data_ptr()
+    plan = ctypes.c_void_p()
+    L.check(lib.t2v_plan_create(ops, 2, ctypes.byref(plan)))
+    L.check(lib.t2v_plan_set_comm(plan, comm))
+    L.check(lib.t2v_plan_run(plan, None, 0, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    assert torch.equal(buf, want)
+    # a 2-part gather on a 1-rank communicator is refused (parts must match the communicator)
+    ops[0].i[2] = 2
+    plan2 = ctypes.c_void_p()
+    L.check(lib.t2v_plan_create(ops, 1, ctypes.byref(plan2)))
+    L.check(lib.t2v_plan_set_comm(plan2, comm))
+    assert lib.t2v_plan_run(plan2, None, 0, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) != 0
+    lib.t2v_plan_destroy(plan)
+    lib.t2v_plan_destroy(plan2)
+    lib.t2v_comm_destroy(comm)

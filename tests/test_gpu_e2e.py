@@ -310,13 +310,8 @@ def test_unet_long_clip_and_wide_frame_geometries(tiny):
 
 
 @pytest.fixture(scope="module")
-def full():
-    """ModelScope configuration (1.41 G parameters), seeded synthetic weights."""
-    net = U.UNetSD(**configs.MODELSCOPE_UNET, init_weights=False)
-    synth.load_synth(net, seed=0)
-    betas = tp.beta_schedule_linear_sd()
-    net.register_schedule(given_betas=betas.numpy())
-    return net, betas
+def full(modelscope_full):
+    return modelscope_full
 
 
 def test_modelscope_8f_forward_and_sampling_match_reference_golden(full):
@@ -377,33 +372,34 @@ def test_tsharded_forward_two_shards_emulated_on_one_gpu(tiny):
     from harness import run_lockstep
     from sd_webui_text2video_amd import _lib as L
     from sd_webui_text2video_amd.parallel import ShardedExecutor
-    from sd_webui_text2video_amd.program import BoundProgram
+    from sd_webui_text2video_amd.program import BoundProgram, TShardSpec
     net, sd, _ = tiny
     g = torch.Generator().manual_seed(21)
-    F, R = 4, 2
-    x = torch.randn(1, 4, F, 8, 8, generator=g)
-    y = torch.randn(1, 5, 1024, generator=g)
-    t = torch.tensor([613.0])
-    ref = tp.unet_forward(sd, configs.TINY_UNET, x, t.long(), y)
-    packed = None
-    exs, exts, outs, keep = [], [], [], []
-    for r in range(R):
-        comp = net._compile(1, F // R, 8, 8, 5, "f32", "f32", "f32", shard=(R, r))
-        if packed is None:
-            packed = comp.packer.materialise(net.state_dict(), DEV)
-        arena = torch.zeros(comp.prog.arena.high + 256, dtype=torch.uint8, device=DEV)
-        wptr = {k: v.data_ptr() for k, v in packed.items()}
-        ex = ShardedExecutor(comp.prog, arena, lambda ops, c=comp, a=arena: BoundProgram(c.prog, a.data_ptr(), wptr, ops=ops))
-        xl = x[:, :, r * (F // R):(r + 1) * (F // R)].contiguous().to(DEV)
-        out = torch.empty(1, 4, F // R, 8, 8, device=DEV)
-        tt, yy = t.to(DEV), y.to(DEV)
-        keep.append((xl, tt, yy, arena, comp))
-        exs.append(ex)
-        outs.append(out)
-        exts.append({L.EXT_X: xl.data_ptr(), L.EXT_T: tt.data_ptr(), L.EXT_CTX: yy.data_ptr(), L.EXT_OUT: out.data_ptr()})
-    run_lockstep(exs, exts, torch.cuda.current_stream().cuda_stream)
-    torch.cuda.synchronize()
-    got = torch.cat([o.cpu() for o in outs], dim=2)
-    assert rel_l2(got, ref) < 5e-3
-    for f in range(F):
-        assert rel_l2(got[:, :, f], ref[:, :, f]) < 6e-3, f
+    for F, R in ((4, 2), (7, 3)):                       # 7 = 3 + 3 + 1: uneven last slice
+        x = torch.randn(1, 4, F, 8, 8, generator=g)
+        y = torch.randn(1, 5, 1024, generator=g)
+        t = torch.tensor([613.0])
+        ref = tp.unet_forward(sd, configs.TINY_UNET, x, t.long(), y)
+        packed = None
+        exs, exts, outs, keep = [], [], [], []
+        for r in range(R):
+            spec = TShardSpec.make(F, R, r)
+            comp = net._compile(1, spec.frames, 8, 8, 5, "f32", "f32", "f32", shard=spec)
+            if packed is None:
+                packed = comp.packer.materialise(net.state_dict(), DEV)
+            arena = torch.zeros(comp.prog.arena.high + 256, dtype=torch.uint8, device=DEV)
+            wptr = {k: v.data_ptr() for k, v in packed.items()}
+            ex = ShardedExecutor(comp.prog, arena, None, lambda ops, c=comp, a=arena: BoundProgram(c.prog, a.data_ptr(), wptr, ops=ops))
+            xl = x[:, :, spec.offset:spec.offset + spec.frames].contiguous().to(DEV)
+            out = torch.empty(1, 4, spec.frames, 8, 8, device=DEV)
+            tt, yy = t.to(DEV), y.to(DEV)
+            keep.append((xl, tt, yy, arena, comp))
+            exs.append(ex)
+            outs.append(out)
+            exts.append({L.EXT_X: xl.data_ptr(), L.EXT_T: tt.data_ptr(), L.EXT_CTX: yy.data_ptr(), L.EXT_OUT: out.data_ptr()})
+        run_lockstep(exs, exts, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        got = torch.cat([o.cpu() for o in outs], dim=2)
+        assert rel_l2(got, ref) < 5e-3
+        for f in range(F):
+            assert rel_l2(got[:, :, f], ref[:, :, f]) < 6e-3, (F, R, f)

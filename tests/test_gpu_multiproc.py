@@ -1,0 +1,90 @@
+"""GPU (-m gpu): the N > 1 layouts as REAL multi-process runs on one GPU.  The ranks share cuda:0 and talk over gloo
+(device buffers staged through the host by parallel.all_gather_into / exchange_pairs — RCCL refuses two ranks on one
+device), so everything except the RCCL calls themselves is the production path: `bench.py`'s runners, UNetSD.forward with
+a T group (uneven frame slices 4 + 3), the sampler with the CFG pair, eps exchange per step, VAE decode split over all
+ranks and the ordered frame gather.  The RCCL calls are covered by test_gpu_boundary (one-rank communicator) and the
+op records they receive by the gloo CPU tests."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _pipe(dev):
+    from oracle import configs, synth
+    from sd_webui_text2video_amd import pipeline, unet as U, vae as V
+    net = U.UNetSD(**configs.TINY_UNET)
+    synth.load_synth(net, seed=0)
+    ae = V.AutoencoderKL(configs.TINY_VAE_DDCONFIG, 4)
+    synth.load_synth(ae, seed=3)
+    pipe = pipeline.TextToVideoSynthesis(sd_model=net, autoencoder=ae, device=dev)
+    pipe.diffusion.progress = False
+    g = torch.Generator().manual_seed(17)
+    c = torch.randn(1, 7, 1024, generator=g)
+    uc = torch.randn(1, 7, 1024, generator=g)
+    return pipe, c, uc
+
+
+FRAMES, STEPS, SEED = 7, 3, 99
+
+
+def _worker(rank, world, port, mode, ret):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sd_webui_text2video_amd import parallel
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        pipe, c, uc = _pipe(dev)
+        runner = parallel.make_runner(pipe, world, rank, frames=FRAMES, height=64, width=64, ddim_steps=STEPS, guidance=9.0,
+                                      mode=mode)
+        out = runner(c.to(dev), uc.to(dev), SEED)
+        out2 = runner(c.to(dev), uc.to(dev), SEED)          # programs / weights / communicator state are reusable
+        assert torch.equal(out, out2)
+        if mode == "tshard":
+            # the advisor's scenario: an UNSHARDED forward after the sharded ones (and back) on the same module
+            x = torch.randn(1, 4, 2, 8, 8, device=dev)
+            pipe.sd_model(x, torch.tensor([10.0], device=dev), c.to(dev))
+            out3 = runner(c.to(dev), uc.to(dev), SEED)
+            assert torch.equal(out, out3)
+        ret[rank] = out.cpu().numpy()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,mode", [(4, "tshard"), (2, "pairs")])
+def test_runner_layouts_multi_process_on_one_gpu(world, mode):
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, mode, ret), nprocs=world, join=True)
+    dev = torch.device("cuda", 0)
+    pipe, c, uc = _pipe(dev)
+    seed = SEED + (0 if mode == "tshard" else 0)      # pair 0 / the single T-sharded video use the seed as given
+    want, _ = pipe.infer_conditioned(c, uc, STEPS, FRAMES, seed, 9.0, 64, 64, 0.0, to_host=False)
+    want = want.cpu().numpy()
+    for r in range(world):
+        got = ret[r]
+        assert got.shape == want.shape == (FRAMES, 64, 64, 3)
+        assert np.array_equal(got, ret[0])                   # every rank ends with the same gathered video
+    d = np.abs(ret[0].astype(int) - want.astype(int))
+    per_frame = [(d[f] > 1).mean() for f in range(FRAMES)]
+    print(f"{mode} x{world}: {100 * (d == 0).mean():.2f}% identical to the single-GPU video, max |diff| {d.max()}, "
+          f"worst frame {100 * max(per_frame):.3f}% off by > 1")
+    # b = 1 per-role programs (other tiles / split-K than the b = 2 single-GPU forward): rounding-level differences only;
+    # a wrong slice / halo / frame order is an O(100 %) error on the affected frames
+    assert (d == 0).mean() > 0.85 and max(per_frame) < 0.02

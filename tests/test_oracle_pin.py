@@ -131,3 +131,36 @@ def test_port_matches_live_reference_blocks():
             assert (taps[name] - r).abs().max() < 5e-5 * max(1.0, float(r.abs().max())), name
             checked += 1
     assert checked > 40
+
+
+def test_oracle_chain_reproduces_the_references_own_infer():
+    """Row a1: UNet port -> DDIM_Gaussian port -> VAE port -> tensor2vid port -> BGR == the frames the reference's
+    `TextToVideoSynthesis.infer` produced (golden infer_tiny.npz, tests/golden/make_golden.py::infer_tiny)."""
+    gold = np.load(os.path.join(GOLD, "infer_tiny.npz"))
+    cfg = configs.TINY_UNET
+    sd = synth.synth_state_dict(_spec_unet(cfg), seed=0)
+    vsd = synth.synth_state_dict(_spec_vae(configs.TINY_VAE_DDCONFIG), seed=3)
+    g = torch.Generator().manual_seed(17)
+    c = torch.randn(1, 7, cfg["context_dim"], generator=g)
+    uc = torch.randn(1, 7, cfg["context_dim"], generator=g)
+    betas = tp.beta_schedule_linear_sd()
+    for tag, (steps, frames, seed, scale, w, h) in (("", (4, 3, 1234, 9.0, 128, 128)), ("_wide", (3, 2, 77, 7.5, 192, 64))):
+        noise, _, _ = synth.synth_inputs(frames, h, w, seed=seed)
+        x0 = tp.ddim_gaussian_sample(lambda a, b, cc: tp.unet_forward(sd, cfg, a, b, cc), betas, noise, steps, c, uc, scale, 0.0)
+        assert np.abs(x0.numpy() - gold["last_tensor" + tag]).max() < 2e-4 * np.abs(gold["last_tensor" + tag]).max()
+        img = torch.cat([tp.vae_decode(vsd, configs.TINY_VAE_DDCONFIG, x0[:, :, f] / configs.SCALE_FACTOR) for f in range(frames)], 0)
+        vid = img.permute(1, 0, 2, 3).unsqueeze(0)
+        bgr = np.stack([np.asarray(f)[:, :, ::-1] for f in tp.tensor2vid_uint8(vid)])
+        d = np.abs(bgr.astype(int) - gold["frames_bgr" + tag].astype(int))
+        assert d.max() <= 1 and (d > 0).mean() < 2e-3, (tag, d.max(), (d > 0).mean())
+
+
+@pytest.mark.skipif(not rb.reference_available(), reason="/root/reference not mounted (GPU box)")
+def test_tensor2vid_port_matches_live_reference_function():
+    """fp32 and fp16 videos through the reference's own tensor2vid (t2v_pipeline.py:447-460, imported with stubs)."""
+    pl = rb.bootstrap_pipeline()
+    vid = torch.randn(2, 3, 3, 16, 24, generator=torch.Generator().manual_seed(23)) * 0.8
+    for v in (vid, vid.half()):
+        want = np.stack(pl.tensor2vid(v.clone()))
+        got = np.stack([np.asarray(f) for f in tp.tensor2vid_uint8(v.clone())])
+        assert np.array_equal(got, want)
