@@ -292,6 +292,7 @@ struct SeqAttnParams {
   const f16* q; const f16* k; const f16* v; f16* o;
   const float* ek; const float* ev;
   int T, D, heads, b_inner, R, lds_per_wave;
+  int Tq, q_off;                                           // queries = frames [q_off, q_off + Tq) of the T key frames (T-sharded clip)
   long n_items;
   long sq_seq, sq_out, sq_in;
   long sk_seq, sk_out, sk_in;
@@ -325,10 +326,11 @@ __global__ __launch_bounds__(256) void seqattn_kernel(const SeqAttnParams p) {
   const f16* kb = p.k + bo * p.sk_out + bi * p.sk_in + head * D;
   const f16* vb = p.v + bo * p.sk_out + bi * p.sk_in + head * D;
   f16* ob = p.o + bo * p.so_out + bi * p.so_in + head * D;
+  const int Tq = p.Tq;
   if (live) {
     for (int u = lane; u < T * d8; u += 64) {
       const int t = u / d8, c = u - t * d8;
-      *reinterpret_cast<f16x8*>(qs + t * DP + c * 16) = *reinterpret_cast<const f16x8*>(qb + (long)t * p.sq_seq + c * 8);
+      if (t < Tq) *reinterpret_cast<f16x8*>(qs + t * DP + c * 16) = *reinterpret_cast<const f16x8*>(qb + (long)t * p.sq_seq + c * 8);
       *reinterpret_cast<f16x8*>(ks + t * DP + c * 16) = *reinterpret_cast<const f16x8*>(kb + (long)t * p.sk_seq + c * 8);
       *reinterpret_cast<f16x8*>(vs + t * DP + c * 16) = *reinterpret_cast<const f16x8*>(vb + (long)t * p.sk_seq + c * 8);
     }
@@ -345,7 +347,7 @@ __global__ __launch_bounds__(256) void seqattn_kernel(const SeqAttnParams p) {
     if (REL) {
 #pragma unroll
       for (int e = 0; e < 2 * TB - 1; ++e) {
-        int dlt = 8 * (e - (TB - 1)) + sj - ti;
+        int dlt = 8 * (e - (TB - 1)) + sj - ti - p.q_off;
         dlt = dlt < -p.R ? -p.R : (dlt > p.R ? p.R : dlt);
         rrow[e] = (dlt + p.R) * D;
       }
@@ -355,7 +357,7 @@ __global__ __launch_bounds__(256) void seqattn_kernel(const SeqAttnParams p) {
 #pragma unroll
       for (int a = 0; a < TB; ++a) {
         const int t = ti + 8 * a;
-        if (t < T) qv[a] = *reinterpret_cast<const f16x8*>(qs + t * DP + c * 16);
+        if (t < Tq) qv[a] = *reinterpret_cast<const f16x8*>(qs + t * DP + c * 16);
         else for (int j = 0; j < 8; ++j) qv[a][j] = (f16)0.f;
       }
 #pragma unroll
@@ -399,7 +401,7 @@ __global__ __launch_bounds__(256) void seqattn_kernel(const SeqAttnParams p) {
       for (int b = 0; b < TB; ++b) { acc[a][b] = __expf(acc[a][b] - mx); sum += acc[a][b]; }
       sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4);
       const float inv = 1.0f / sum;
-      if (t < T) {
+      if (t < Tq) {
 #pragma unroll
         for (int b = 0; b < TB; ++b)
           if (sj + 8 * b < T) ps[t * (T + 1) + sj + 8 * b] = acc[a][b] * inv;
@@ -408,7 +410,7 @@ __global__ __launch_bounds__(256) void seqattn_kernel(const SeqAttnParams p) {
   }
   __syncthreads();
   if (live) {
-    for (int u = lane; u < T * d8; u += 64) {
+    for (int u = lane; u < Tq * d8; u += 64) {
       const int t = u / d8, c = u - t * d8;
       f32x8 o;
 #pragma unroll
@@ -417,7 +419,7 @@ __global__ __launch_bounds__(256) void seqattn_kernel(const SeqAttnParams p) {
         const float pv = ps[t * (T + 1) + sx];
         const f16x8 vv = *reinterpret_cast<const f16x8*>(vs + sx * DP + c * 16);
         if (REL) {
-          int dlt = sx - t;
+          int dlt = sx - t - p.q_off;
           dlt = dlt < -p.R ? -p.R : (dlt > p.R ? p.R : dlt);
           const f32x8 e = ld_f32x8(p.ev + (long)(dlt + p.R) * D + c * 8);
 #pragma unroll
@@ -444,13 +446,15 @@ hipError_t launch_seqattn(const t2v_op& op, hipStream_t s) {
   p.o = reinterpret_cast<f16*>(op.p[3]);
   p.ek = reinterpret_cast<const float*>(op.p[4]);
   p.ev = reinterpret_cast<const float*>(op.p[5]);
-  p.T = op.i[0]; p.heads = op.i[2]; p.b_inner = op.i[4]; p.D = op.i[14] > 0 ? op.i[14] : 64; p.R = op.i[15];
+  p.Tq = op.i[0]; p.T = op.i[1]; p.heads = op.i[2]; p.b_inner = op.i[4]; p.D = op.i[14] > 0 ? op.i[14] : 64; p.R = op.i[15];
+  p.q_off = op.i[16];
   p.n_items = (long)op.i[3] * op.i[4] * p.heads;
   p.sq_seq = op.i[5]; p.sq_out = op.i[6]; p.sq_in = op.i[7];
   p.sk_seq = op.i[8]; p.sk_out = op.i[9]; p.sk_in = op.i[10];
   p.so_seq = op.i[11]; p.so_out = op.i[12]; p.so_in = op.i[13];
   p.scale = op.f[0];
-  if (p.T <= 0 || p.T > 32 || op.i[1] != p.T || p.D <= 0 || p.D % 8 != 0 || p.D > 160 || p.n_items <= 0) return hipErrorInvalidValue;
+  if (p.T <= 0 || p.T > 32 || p.Tq <= 0 || p.q_off < 0 || p.q_off + p.Tq > p.T || p.D <= 0 || p.D % 8 != 0 || p.D > 160 || p.n_items <= 0)
+    return hipErrorInvalidValue;
   if (REL && (p.R < 0 || p.ek == nullptr || p.ev == nullptr)) return hipErrorInvalidValue;
   p.lds_per_wave = (3 * p.T * (p.D * 2 + 16) + p.T * (p.T + 1) * 4 + 15) / 16 * 16;
   const int lds = 4 * p.lds_per_wave;

@@ -95,7 +95,8 @@ int validate_op(const t2v_op& op, int idx) {
       return 0;
     }
     case T2V_OP_RELPOS_ATTN:
-      if (op.i[0] <= 0 || op.i[0] > 32 || op.i[1] != op.i[0]) return bad("relative-position attention needs nq == nk <= 32");
+      if (op.i[1] <= 0 || op.i[1] > 32 || op.i[0] <= 0 || op.i[16] < 0 || op.i[16] + op.i[0] > op.i[1])
+        return bad("relative-position attention needs nk <= 32 and queries [q_off, q_off + nq) inside the keys");
       if (op.i[14] <= 0 || op.i[14] % 8 != 0 || op.i[14] > 160) return bad("relative-position attention head_dim: multiple of 8, <= 160");
       if (op.i[2] <= 0 || op.i[3] <= 0 || op.i[4] <= 0 || op.i[15] < 0) return bad("empty relative-position attention");
       for (int k = 5; k <= 13; ++k)

@@ -108,6 +108,20 @@ class WeightPacker:
             self.recipes.append((name, dtype, fn))
         return name
 
+    def add_lo(self, name: str) -> str:
+        """Second-order image of an fp16 weight image: lo = fp16(W - fp16(W)), so that A.W_hi + A.W_lo carries ~22 bits of
+        the fp32 weight through two fp16 MFMA passes (packing is layout-only, hence linear: pack(W) splits like W).
+        All zeros for a model that is already `.half()`."""
+        lo = name + ":lo"
+        if lo not in self._names:
+            base = next(fn for n, d, fn in self.recipes if n == name)
+
+            def fn(sd, base=base):
+                t = base(sd).float()
+                return t - t.half().float()
+            self.add(lo, "f16", fn)
+        return lo
+
     @staticmethod
     def _cast(t: torch.Tensor, dtype: str, device) -> torch.Tensor:
         return _f16(t, device) if dtype == "f16" else _f32(t, device)

@@ -168,6 +168,8 @@ class Program:
         # larger slices on only 64 workgroups do not)
         self.gn_fused_slice_bytes = int(os.environ.get("T2V_GN_FUSED_SLICE", 64 * 1024))
         self.gn_fused_total_bytes = int(os.environ.get("T2V_GN_FUSED_TOTAL", 128 * 1024 * 1024))
+        # precision option: weight Ref -> Ref of its low-order image (packing.WeightPacker.add_lo) or None; set by a lowering
+        self.weight_lo = None
 
     # ---- memory ---------------------------------------------------------------------------
     def alloc(self, rows: int, cols: int, dtype: str, ld: Optional[int] = None) -> Buf:
@@ -265,6 +267,14 @@ class Program:
         (0,1,0,1) instead of 1 on every side."""
         conv = conv or {}
         M = out.rows if m is None else m
+        lo = self.weight_lo(w) if (self.weight_lo is not None and epi == L.EPI_NONE and not bias_along_m and w.space == "weight") else None
+        lo_tmp = None
+        if lo is not None:
+            # hi + lo weight split: t = A.W_lo (+ residual) in fp32, then the normal GEMM on W_hi with t as its residual
+            lo_tmp = self.alloc(M, n, "f32")
+            self.gemm(name + ".w_lo", a, lo, n, k, lo_tmp, ldw=ldw, gather=gather, conv=conv, residual=residual, m=m,
+                      allow_splitk=allow_splitk, halo=halo)
+            residual = lo_tmp
         n_out = n // 2 if epi == L.EPI_GEGLU else n
         assert out.cols == n_out, (name, out.cols, n_out)
         assert a.dtype == "f16" and n % 4 == 0 and k % 8 == 0
@@ -304,6 +314,8 @@ class Program:
         self._emit(op)
         if ws is not None:
             self.free(ws)     # stream order makes immediate reuse safe
+        if lo_tmp is not None:
+            self.free(lo_tmp)
         return op
 
     def groupnorm(self, name: str, x: Buf, gamma: Ref, beta: Ref, out: Buf, *, n_inst: int, eps: float,
@@ -400,7 +412,8 @@ class Program:
 
     def attention(self, name: str, q: Ref, k: Ref, v: Ref, o: Ref, *, out_buf: Optional[Buf] = None, nq: int, nk: int, heads: int,
                   b_outer: int, b_inner: int, q_strides, kv_strides, o_strides, scale: float, head_dim: int = 64,
-                  rel_k: Optional[Ref] = None, rel_v: Optional[Ref] = None, max_rel: int = 0, causal: bool = False) -> Op:
+                  rel_k: Optional[Ref] = None, rel_v: Optional[Ref] = None, max_rel: int = 0, causal: bool = False,
+                  q_offset: int = 0) -> Op:
         """softmax(q k^T scale) v over strided (sequence, outer, inner) batches.  With rel_k / rel_v (fp32
         [2*max_rel+1, head_dim] tables) the LVDM relative-position temporal attention op is emitted instead."""
         assert head_dim in (40, 64, 80, 160) or rel_k is not None
@@ -408,8 +421,8 @@ class Program:
         op.i[0:5] = [nq, nk, heads, b_outer, b_inner]
         op.i[14] = head_dim
         if rel_k is not None:
-            assert nq == nk <= 32 and head_dim % 8 == 0
-            op.i[15] = max_rel
+            assert nk <= 32 and 0 <= q_offset and q_offset + nq <= nk and head_dim % 8 == 0
+            op.i[15], op.i[16] = max_rel, q_offset
             op.p[4], op.p[5] = rel_k, rel_v
             assert not causal
         elif causal:

@@ -223,6 +223,10 @@ class UNetSD(nn.Module):
         # reference's .half() path stores everywhere), "f32" keeps them in the fp32 stream.
         self.norm_input_dtype = "f16"
         self.context_token = None     # one-shot hint consumed by the next forward (see forward_cfg_pair)
+        # Precision option (off by default): weights whose packed-image name starts with one of these prefixes are applied as
+        # hi + lo fp16 images in two MFMA passes (fp32 weights only; e.g. ("input_blocks.0", "input_blocks.1") — the blocks
+        # that produce 46 % of the weight-rounding error).  Set before the first forward.
+        self.split_weight_prefixes = ()
         self.t_shard = None           # parallel.TShard: this rank holds a contiguous slice of the clip's frames
         self.auto_refresh = True      # re-check parameter versions on every forward (~1 ms); the sampler
                                       # turns this off inside its loop after one explicit refresh
@@ -397,7 +401,7 @@ class UNetSD(nn.Module):
             if shard.frames != F:
                 raise L.T2VError(f"T-sharded forward: this rank holds {shard.frames} of {shard.total} frames, got {F}")
         key = (B, F, H, W, y.shape[1], _dt(x.dtype), _dt(y.dtype), _dt(out_dtype)) + ((shard,) if shard else ()) + \
-              ((("xb", Bx),) if Bx != B else ())
+              ((("xb", Bx),) if Bx != B else ()) + ((("split",) + tuple(self.split_weight_prefixes),) if self.split_weight_prefixes else ())
         comp = self._programs.get(key)
         if comp is None:
             comp = self._compile(B, F, H, W, y.shape[1], _dt(x.dtype), _dt(out_dtype), _dt(y.dtype), shard=shard,
@@ -477,7 +481,9 @@ class _Compiled:
         the launch stream) — or, with T2V_COLLECTIVES=host / a non-GPU group, through parallel.ShardedExecutor."""
         if self.bound is not None and self.arena is not None and self.arena.device == device:
             return
-        self.arena = torch.empty(self.prog.arena.high + 256, dtype=torch.uint8, device=device)
+        # zero-filled once at bind time: padding lanes that an op reads before any op wrote them (they only ever meet
+        # zero weights) must not hold NaN bit patterns of recycled allocator blocks
+        self.arena = torch.zeros(self.prog.arena.high + 256, dtype=torch.uint8, device=device)
         wptr = {k: v.data_ptr() for k, v in packed.items()}
         if any(op.kind in COLLECTIVE_KINDS for op in self.prog.ops):
             if t_shard is None:
@@ -512,6 +518,11 @@ class _Lowering:
         self.P = Program(f"unet b{B} f{F} {H}x{W}")
         self.P.keep_taps = keep_taps
         self.packer = pk.WeightPacker()
+        prefixes = tuple(getattr(net, "split_weight_prefixes", ()) or ())
+        if prefixes:
+            self.P.weight_lo = lambda ref: (Ref("weight", ref.off, self.packer.add_lo(ref.name))
+                                            if ref.name.startswith(prefixes) and ref.name.rsplit(":", 1)[-1] in ("lin", "c3", "t3", "qkv", "kv")
+                                            else None)
         self.emb_slices: Dict[str, Tuple[int, int]] = {}
         self.kv_slices: Dict[str, Tuple[int, int]] = {}
 

@@ -226,10 +226,11 @@ class UNetModel(UNetSD):
             raise NotImplementedError("time_emb_replace / adapter features / class labels are not on the hot path")
         return UNetSD.forward(self, x, timesteps, context)
 
-    def _compile(self, B, F, H, W, Lctx, x_dt, out_dt, ctx_dt="f32", shard=None):
-        if shard is not None:
-            raise NotImplementedError("T-sharding of the LVDM UNet")
-        low = _LvdmLowering(self, B, F, H, W, Lctx, x_dt, out_dt, ctx_dt, keep_taps=self.debug_taps)
+    def _compile(self, B, F, H, W, Lctx, x_dt, out_dt, ctx_dt="f32", shard=None, x_batch=0):
+        """shard (program.TShardSpec): the clip's frames are split over a T group.  Every GroupNorm32 of this UNet spans
+        all frames (all-gather of statistics partials) and the temporal attentions gather K/V along T; the (1,3,3)
+        convolutions, spatial / text attention and feed-forward are frame-local (no halo exchange: kernel_size_t = 1)."""
+        low = _LvdmLowering(self, B, F, H, W, Lctx, x_dt, out_dt, ctx_dt, keep_taps=self.debug_taps, shard=shard, x_batch=x_batch)
         return _Compiled(low.build(), low.packer)
 
 
@@ -306,7 +307,34 @@ class _LvdmLowering(_Lowering):
             P.free(a, res)
             return o
 
+        def temporal_attn_sharded(attn, norm, src: Buf) -> Buf:
+            """Queries = this rank's frames, keys / values = all frames of the clip (K/V projections all-gathered along T);
+            the relative position of key s to local query t is s - (t + first frame of this slice)."""
+            sh = self.shard
+            Mmax, Ftot = sh.max_frames * hw, sh.total
+            nrm = layer_norm(norm, src)
+            q = P.alloc(M, c, "f16")
+            P.gemm(f"{tb}.{attn}.to_q", nrm, self.w_linear(f"{tb}.{attn}.to_q"), c, c, q)
+            kv_all = P.alloc(sh.size * Mmax, 2 * c, "f16")
+            mine = kv_all.row_slice(sh.index * Mmax, sh.index * Mmax + M)
+            P.gemm(f"{tb}.{attn}.kv", nrm, self.w_kv(f"{tb}.{attn}"), 2 * c, c, mine)
+            P.free(nrm)
+            full = Buf(kv_all.ref, sh.size * Mmax * 2 * c * 2, 1, 1, "u8", kv_all.alloc_off)
+            P.allgather(f"{tb}.{attn}.kv.allgather", full, Mmax * 2 * c * 2, sh)
+            a = P.alloc(M, c, "f16")
+            ldk = 2 * c
+            P.attention(f"{tb}.{attn}", q.ref, kv_all.col_slice(0, c).ref, kv_all.col_slice(c, 2 * c).ref, a.ref, out_buf=a,
+                        nq=F, nk=Ftot, heads=heads, b_outer=1, b_inner=hw, q_strides=(hw * c, 0, c), kv_strides=(hw * ldk, 0, ldk),
+                        o_strides=(hw * c, 0, c), scale=scale, head_dim=d,
+                        rel_k=self.table(f"{tb}.{attn}.relative_position_k.embeddings_table"),
+                        rel_v=self.table(f"{tb}.{attn}.relative_position_v.embeddings_table"),
+                        max_rel=net.temporal_length, q_offset=sh.offset)
+            P.free(q, kv_all)
+            return out_proj(attn, a, src)
+
         def self_attn(attn, norm, src: Buf, temporal: bool) -> Buf:
+            if temporal and self.shard is not None:
+                return temporal_attn_sharded(attn, norm, src)
             nrm = layer_norm(norm, src)
             qkv = P.alloc(M, 3 * c, "f16")
             P.gemm(f"{tb}.{attn}.qkv", nrm, self.w_qkv(f"{tb}.{attn}"), 3 * c, c, qkv)
@@ -380,6 +408,7 @@ class _LvdmLowering(_Lowering):
             off += 2 * c
         n_kv = off
 
+        self.kv_all = P.alloc(B * self.Lctx, n_kv, "f16")     # first allocation, freed last: survives between runs (see unet.py)
         # ---- timestep embedding (util.py:142-162 cos|sin, base 10000) -> MLP; every ResBlock's emb projection in one GEMM
         freqs = Ref("weight", 0, self.packer.add("time_embed.freqs", "f32", lambda sd, half=mc // 2: torch.exp(
             -math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)))
@@ -399,17 +428,17 @@ class _LvdmLowering(_Lowering):
         P.free(e_silu)
 
         ctx16 = P.alloc(B * self.Lctx, net.context_dim, "f16")
-        P.copy2d("context.cast", Buf(Ref("ext", L.EXT_CTX), B * self.Lctx, net.context_dim, net.context_dim, self.ctx_dt), ctx16)
+        P.copy2d("context.cast", Buf(Ref("ext", L.EXT_CTX), B * self.Lctx, net.context_dim, net.context_dim, self.ctx_dt),
+                 ctx16).meta["step_invariant"] = True
         sts = tuple(p for p, _ in st_prefixes)
         w_kv = Ref("weight", 0, self.packer.add("kv_all:lin", "f16", lambda sd, sts=sts: torch.cat(
             [torch.cat([sd[p + ".transformer_blocks.0.attn2.to_k.weight"], sd[p + ".transformer_blocks.0.attn2.to_v.weight"]], dim=0)
              for p in sts], dim=0)))
-        self.kv_all = P.alloc(B * self.Lctx, n_kv, "f16")
-        P.gemm("attn2.kv.all", ctx16, w_kv, n_kv, net.context_dim, self.kv_all)
+        P.gemm("attn2.kv.all", ctx16, w_kv, n_kv, net.context_dim, self.kv_all).meta["step_invariant"] = True
         P.free(ctx16)
 
         xin = P.alloc(self.M(h, w), 8, "f16")
-        P.ncthw_to_cl("x.to_tokens", Ref("ext", L.EXT_X), self.x_dt, xin, B=B, C=net.in_dim, F=F, HW=h * w)
+        P.ncthw_to_cl("x.to_tokens", Ref("ext", L.EXT_X), self.x_dt, xin, B=B, C=net.in_dim, F=F, HW=h * w, src_batch=self.x_batch)
 
         def run_parts(prefix, parts, x, h, w, dest=None):
             for j, (kind, cin, cout) in enumerate(parts):

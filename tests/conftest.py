@@ -37,8 +37,11 @@ def modelscope_full():
 @pytest.fixture(scope="session")
 def modelscope_full_fp16(modelscope_full):
     """The deployed form: `.half()` weights on the device (t2v_pipeline.py:103-104)."""
-    import copy
+    from oracle import configs
+    from sd_webui_text2video_amd import unet as U
     net, betas = modelscope_full
-    net16 = copy.deepcopy(net).half().to("cuda:0")
-    net16._init_runtime()
-    return net16, betas
+    net16 = U.UNetSD(**configs.MODELSCOPE_UNET, init_weights=False)
+    names = {n for n, _ in net16.named_parameters()}
+    net16.load_state_dict({k: v for k, v in net.state_dict().items() if k in names}, strict=True)
+    net16.register_schedule(given_betas=betas.numpy())
+    return net16.half().to("cuda:0"), betas

@@ -179,7 +179,7 @@ class Interp:
             R = op.i[15]
             ek = self.view(op.p[4], (2 * R + 1, D), (D, 1), torch.float32, ext)
             ev = self.view(op.p[5], (2 * R + 1, D), (D, 1), torch.float32, ext)
-            idx = (torch.arange(nk)[None, :] - torch.arange(nq)[:, None]).clamp(-R, R) + R
+            idx = (torch.arange(nk)[None, :] - (torch.arange(nq)[:, None] + op.i[16])).clamp(-R, R) + R
             s = s + torch.einsum("abhtd,tsd->abhts", q, ek[idx])
         if not rel and op.i[15]:
             s = s.masked_fill(torch.arange(nk)[None, :] > torch.arange(nq)[:, None], float("-inf"))

@@ -169,6 +169,8 @@ def test_c_entry_points_unet_forward_and_vae_decode_via_ctypes():
     vsd = synth.load_synth(ae, seed=3)
     z = torch.randn(2, 4, 8, 8, generator=g).to(DEV)
     wimg = ae.decode(z)
+    torch.cuda.synchronize()
+    assert torch.isfinite(wimg).all()
     vcomp = next(iter(ae._programs.values()))
     img = torch.zeros_like(wimg)
     L.check(lib.t2v_vae_decode(vcomp.bound.handle, vp(z.data_ptr()), vp(img.data_ptr()), vp(stream.cuda_stream)))

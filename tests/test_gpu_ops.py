@@ -445,21 +445,27 @@ def test_gemm2_temporal_conv_and_split_k(tile):
 
 
 def test_groupnorm_split_phases_two_parts():
-    """T-sharding: statistics partials of two 'ranks' folded in the apply phase (here both parts on one GPU)."""
-    C, rows = 320, 48
+    """T-sharding: statistics partials of two 'ranks' folded in the apply phase (here both parts on one GPU); UNEVEN slices
+    (2 frames + 1 frame of 24 rows): the shorter part zero-fills its surplus partial slots, the mean is over all rows."""
+    from sd_webui_text2video_amd.program import TShardSpec
+    C, fr = 320, 24
+    rows0, rows1 = 2 * fr, fr
     P = Program()
+    P.target_cus = 1          # several statistics workgroups per part: rows per workgroup 4 -> 12 / 6 partial slots
     g = _g(31)
-    x0, x1 = P.alloc(rows, C, "f32"), P.alloc(rows, C, "f32")
-    o0, o1 = P.alloc(rows, C, "f16"), P.alloc(rows, C, "f16")
+    x0, x1 = P.alloc(rows0, C, "f32"), P.alloc(rows1, C, "f32")
+    o0, o1 = P.alloc(rows0, C, "f16"), P.alloc(rows1, C, "f16")
     w = {"g": 1 + 0.1 * torch.randn(C, generator=g), "b": 0.1 * torch.randn(C, generator=g)}
     # two programs' worth of ops sharing ONE scratch: emit by hand through the same emitter, then alias the scratch
-    opa = P.groupnorm("a", x0, Ref("weight", 0, "g"), Ref("weight", 0, "b"), o0, n_inst=1, eps=1e-5, silu=True, shard=(2, 0))
-    opb = P.groupnorm("b", x1, Ref("weight", 0, "g"), Ref("weight", 0, "b"), o1, n_inst=1, eps=1e-5, silu=True, shard=(2, 1))
+    P.groupnorm("a", x0, Ref("weight", 0, "g"), Ref("weight", 0, "b"), o0, n_inst=1, eps=1e-5, silu=True, shard=TShardSpec.make(3, 2, 0))
+    P.groupnorm("b", x1, Ref("weight", 0, "g"), Ref("weight", 0, "b"), o1, n_inst=1, eps=1e-5, silu=True, shard=TShardSpec.make(3, 2, 1))
     ops = [op for op in P.ops if op.kind == L.OP_GROUPNORM]          # a.stats, a.apply, b.stats, b.apply
     scratch = ops[0].p[4]
     for op in ops:
         op.p[4] = scratch
+    assert ops[0].i[11] == ops[2].i[11] and ops[2].i[13] == rows0 and ops[2].i[14] == rows0 + rows1
     P.ops = [ops[0], ops[2], ops[1], ops[3]]                         # both statistics first, then both applies
+    rows = None
 
     def init(it):
         fill(it, x0, g, 2.0); fill(it, x1, g, 0.5)
@@ -467,9 +473,9 @@ def test_groupnorm_split_phases_two_parts():
     _check(it, got, o0, 1e-3, "split GN part 0")
     _check(it, got, o1, 1e-3, "split GN part 1")
     # and against one GroupNorm over the concatenation
-    x = torch.cat([read(it, x0), read(it, x1)]).double().view(1, 2 * rows, 32, C // 32)
+    x = torch.cat([read(it, x0), read(it, x1)]).double().view(1, rows0 + rows1, 32, C // 32)
     m, v = x.mean(dim=(1, 3), keepdim=True), x.var(dim=(1, 3), unbiased=False, keepdim=True)
-    ref = torch.nn.functional.silu((((x - m) / torch.sqrt(v + 1e-5)).view(2 * rows, C).float() * w["g"] + w["b"]))
+    ref = torch.nn.functional.silu((((x - m) / torch.sqrt(v + 1e-5)).view(rows0 + rows1, C).float() * w["g"] + w["b"]))
     assert rel_l2(torch.cat([read(got, o0), read(got, o1)]).float(), ref) < 1e-3
 
 

@@ -92,3 +92,50 @@ def test_tsharded_unet_matches_unsharded_gloo(world, F):
     assert rel_l2(sharded, ref) < 5e-3
     for f in range(F):
         assert rel_l2(sharded[:, :, f], ref[:, :, f]) < 6e-3, f
+
+
+# ---- VideoCrafter (LVDM) UNet: every GroupNorm32 spans all frames, temporal attention has relative positions ------------
+def _lvdm_inputs(F):
+    g = torch.Generator().manual_seed(31)
+    return torch.randn(1, 4, F, 8, 8, generator=g), torch.tensor([431.0]), torch.randn(1, 9, 768, generator=g)
+
+
+def _lvdm_worker(rank, world, port, F, ret):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        from sd_webui_text2video_amd import videocrafter as VC
+        net = VC.UNetModel(**configs.TINY_LVDM_UNET, init_weights=False)
+        net.load_state_dict(synth.synth_state_dict(synth.param_spec(net), seed=0), strict=True)
+        x, t, ctx = _lvdm_inputs(F)
+        spec = TShardSpec.make(F, world, rank)
+        shard = parallel.TShard(dist.group.WORLD, list(range(world)), spec)
+        comp = net._compile(1, spec.frames, 8, 8, 9, "f32", "f32", "f32", shard=spec)
+        it = Interp(comp.prog, comp.packer.materialise(net.state_dict(), "cpu"))
+        ex = parallel.ShardedExecutor(comp.prog, it.arena, shard, lambda ops: _Seg(it, ops))
+        assert ex.n_collectives > 0 and all(op.kind == L.OP_ALLGATHER for k, op in ex.steps if k == "coll")   # no halo: kernel_size_t = 1
+        out = torch.empty(1, 4, spec.frames, 8, 8)
+        ex.run({L.EXT_X: x[:, :, spec.offset:spec.offset + spec.frames].contiguous(), L.EXT_T: t, L.EXT_CTX: ctx, L.EXT_OUT: out}, None)
+        ret[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,F", [(2, 5), (3, 7)])       # 5 = 3 + 2, 7 = 3 + 3 + 1
+def test_tsharded_lvdm_unet_matches_unsharded_gloo(world, F):
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_lvdm_worker, args=(world, port, F, ret), nprocs=world, join=True)
+    sharded = torch.cat([ret[r] for r in range(world)], dim=2)
+    from sd_webui_text2video_amd import videocrafter as VC
+    net = VC.UNetModel(**configs.TINY_LVDM_UNET, init_weights=False)
+    sd = synth.synth_state_dict(synth.param_spec(net), seed=0)
+    net.load_state_dict(sd, strict=True)
+    x, t, ctx = _lvdm_inputs(F)
+    ref = tp.lvdm_unet_forward(sd, configs.TINY_LVDM_UNET, x, t, ctx)
+    assert not torch.isnan(sharded).any()
+    assert rel_l2(sharded, ref) < 5e-3
+    for f in range(F):
+        assert rel_l2(sharded[:, :, f], ref[:, :, f]) < 7e-3, f
