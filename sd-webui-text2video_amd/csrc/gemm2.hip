@@ -414,6 +414,55 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm2_kernel(const GemmPar
     return;
   }
   const int mlane = lane & 31, nhalf = (lane >> 5) * 4;
+  if (p.epi == T2V_EPI_GEGLU && p.splitk == 1) {
+    // GEGLU through a per-wave LDS strip: a lane's (value + bias) * gelu(gate + bias) results are 4 channels of ONE row
+    // (8-byte stores scattered over 32 rows); staged as [32 rows][TN * 16 channels] they leave as whole 16-byte chunks of
+    // TN * 32-byte row segments (6 rows per store instruction at TN = 5).
+    constexpr int PITCH = TN * 32 + 16;                   // bytes per staged row (+16: rows start on different banks)
+    constexpr int CPRW = TN * 2;                          // 16-byte chunks per row
+    __builtin_amdgcn_s_barrier();                         // every wave is done reading the operand stages
+    unsigned char* strip = smem + wave * (32 * PITCH);
+    const int nw = n0 + wn * TN * 32;                     // first packed column of this wave
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+      const int mt = m0 + (wm * TM + a) * 32;
+      if (mt >= p.M) continue;                            // wave-uniform
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        const int nt = nw + b * 32;
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+          const int n_val = nt + 16 * qq + nhalf;
+          f16x4 o = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+          if (n_val < p.N) {
+            float bv[4] = {0, 0, 0, 0}, bg[4] = {0, 0, 0, 0};
+            if (p.bias) {
+              const f32x4 ba = *reinterpret_cast<const f32x4*>(p.bias + n_val);
+              const f32x4 bb = *reinterpret_cast<const f32x4*>(p.bias + n_val + 8);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) { bv[r] = ba[r]; bg[r] = bb[r]; }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (f16)((acc[a][b][8 * qq + r] + bv[r]) * t2v_gelu_erf(acc[a][b][8 * qq + 4 + r] + bg[r]));
+          }
+          *reinterpret_cast<f16x4*>(strip + mlane * PITCH + (b * 16 + 8 * qq + nhalf) * 2) = o;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      const int c_out0 = nw >> 1;                         // first output channel of the strip
+#pragma unroll
+      for (int u = lane; u < 32 * CPRW; u += 64) {
+        const int row = u / CPRW, ch = u - row * CPRW;
+        const int m = mt + row, c = c_out0 + ch * 8;
+        if (m < p.M && c < (p.N >> 1)) {
+          const f16x8 v = *reinterpret_cast<const f16x8*>(strip + row * PITCH + ch * 16);
+          *reinterpret_cast<f16x8*>(reinterpret_cast<f16*>(p.out) + (size_t)m * p.ldc + c) = v;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    }
+    return;
+  }
 #pragma unroll
   for (int a = 0; a < TM; ++a) {
     const int m = m0 + (wm * TM + a) * 32 + mlane;

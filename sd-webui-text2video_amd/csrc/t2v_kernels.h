@@ -106,14 +106,30 @@ __device__ __forceinline__ void t2v_epilogue_rows(const GemmParams& p, const f32
                                                   int m_wave, int n_wave, int split_idx) {
   const int wrow = lane & 31, wcol = (lane >> 5) * 4;
   const int rrow = lane >> 3, rcol = (lane & 7) * 4;
+  // Residual prefetch: the four row loads of a 32x32 block are issued TOGETHER and one block ahead of their use (always
+  // from a readable address: rows / columns outside the matrix park on the first element), so the epilogue keeps
+  // 8 KiB of residual reads per wave in flight instead of paying one dependent load -> add -> store chain per row.
+  const bool has_res = p.splitk == 1 && p.res != nullptr;
+  auto res_load = [&](int blk, f32x4 (&r)[4]) {
+    const int mt = m_wave + (blk / TN) * 32, n = n_wave + (blk % TN) * 32 + rcol;
 #pragma unroll
-  for (int a = 0; a < TM; ++a) {
+    for (int i = 0; i < 4; ++i) {
+      const int m = mt + rrow + 8 * i;
+      const float* src = (m < p.M && n < p.N) ? p.res + (size_t)m * p.ldr + n : p.res;
+      r[i] = *reinterpret_cast<const f32x4*>(src);
+    }
+  };
+  f32x4 rcur[4], rnxt[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { rcur[i] = f32x4{0.f, 0.f, 0.f, 0.f}; rnxt[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  if (has_res) res_load(0, rcur);
+#pragma unroll
+  for (int blk = 0; blk < TM * TN; ++blk) {
+    const int a = blk / TN, b = blk % TN;
+    if (has_res && blk + 1 < TM * TN) res_load(blk + 1, rnxt);
     const int mt = m_wave + a * 32;
-    if (mt >= p.M) continue;                               // wave-uniform
-#pragma unroll
-    for (int b = 0; b < TN; ++b) {
-      const int nt = n_wave + b * 32;
-      if (nt >= p.N) continue;
+    const int nt = n_wave + b * 32;
+    if (mt < p.M && nt < p.N) {                                // wave-uniform
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const f32x4 v = {acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
@@ -138,7 +154,7 @@ __device__ __forceinline__ void t2v_epilogue_rows(const GemmParams& p, const f32
           if (p.bias && p.bias_m) { const float bm = p.bias[m]; v[0] += bm; v[1] += bm; v[2] += bm; v[3] += bm; }
           if (p.rowbias) v += *reinterpret_cast<const f32x4*>(p.rowbias + (size_t)(m / p.rows_per_batch) * p.ldrb + n);
           if (p.act == 1) { v[0] = t2v_silu(v[0]); v[1] = t2v_silu(v[1]); v[2] = t2v_silu(v[2]); v[3] = t2v_silu(v[3]); }
-          if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.ldr + n);
+          if (has_res) v += rcur[i];
           if (p.out_f32) {
             *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n) = v;
           } else {
@@ -149,6 +165,8 @@ __device__ __forceinline__ void t2v_epilogue_rows(const GemmParams& p, const f32
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rcur[i] = rnxt[i];
   }
 }
 // exact-erf GELU (nn.GELU default, reference GEGLU t2v_model.py:817-821).  erfc(|z|) by Abramowitz-Stegun

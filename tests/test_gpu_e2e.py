@@ -88,6 +88,25 @@ def test_tiny_unet_fp16_weights_and_io(tiny):
     assert rel_l2(eps.float().cpu(), ref) < 6e-3
 
 
+def test_weight_split_precision_option(tiny):
+    """`split_weight_prefixes`: hi + lo fp16 weight images for the named blocks (two MFMA passes).  Predicted by the CPU
+    interpreter (tests/test_lowering_cpu.py): 2.07e-3 -> 1.80e-3 on this forward with input_blocks.0/1 split."""
+    net, sd, _ = tiny
+    x, t, y, *_ = _tiny_inputs()
+    gold = torch.from_numpy(np.load(os.path.join(GOLD, "tiny.npz"))["unet_eps"])
+    base = rel_l2(net(x.to(DEV), t.to(DEV), y.to(DEV)).float().cpu(), gold)
+    net2 = U.UNetSD(**configs.TINY_UNET)
+    names = {n for n, _ in net.named_parameters()}
+    net2.load_state_dict({k: v for k, v in net.state_dict().items() if k in names}, strict=True)
+    net2.split_weight_prefixes = ("input_blocks.0", "input_blocks.1")
+    split = rel_l2(net2(x.to(DEV), t.to(DEV), y.to(DEV)).float().cpu(), gold)
+    n_base = sum(1 for op in next(iter(net._programs.values())).prog.ops if op.kind == 1)
+    n_split = sum(1 for op in next(iter(net2._programs.values())).prog.ops if op.kind == 1)
+    print(f"tiny UNet forward rel-L2 vs reference fp32: {base:.3e} single-pass weights, {split:.3e} with input_blocks.0/1 split "
+          f"({n_split - n_base} extra GEMM launches)")
+    assert split < 0.95 * base and n_split > n_base
+
+
 def test_weight_mutation_is_picked_up(tiny):
     """LoRA-style in-place mutation between calls must invalidate the packed weights (SURVEY §2.1 #8)."""
     net, sd, _ = tiny

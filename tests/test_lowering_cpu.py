@@ -208,3 +208,28 @@ def test_ddim_step_op_with_several_videos_per_batch():
         o1 = torch.zeros(1, C, inner)
         Interp(P1, {}).run({L.EXT_XT: xt[s:s + 1], L.EXT_EPS: torch.stack([eps[0, s], eps[1, s]]), L.EXT_NOISE: nz[s:s + 1], L.EXT_XT_OUT: o1})
         assert torch.equal(o1[0], out[s]), s
+
+
+def test_weight_split_option_lowers_and_improves_in_interpreter():
+    """Precision option `split_weight_prefixes`: the named blocks' weights are applied as hi + lo fp16 images (two MFMA
+    passes: t = A.W_lo (+ residual) in fp32, then the usual GEMM on W_hi with t as residual).  The interpreter predicts the
+    device's quantisation error: 2.07e-3 -> 1.87e-3 (input_blocks.0) -> 1.80e-3 (+ input_blocks.1) on the tiny config."""
+    gold = torch.from_numpy(np.load(os.path.join(GOLD, "tiny.npz"))["unet_eps"])
+    errs = []
+    for prefixes in ((), ("input_blocks.0", "input_blocks.1")):
+        cfg, m, sd, x, t, y = _tiny()
+        m.split_weight_prefixes = prefixes
+        comp = m._compile(2, 3, 16, 16, 7, "f32", "f32", "f32")
+        packed = comp.packer.materialise(m.state_dict(), "cpu")
+        if prefixes:
+            lo = [k for k in packed if k.endswith(":lo")]
+            assert lo and all(k.startswith(prefixes) for k in lo)
+            # hi + lo reproduces the fp32 weight to ~2^-22 relative
+            name = "input_blocks.1.0.in_layers.2:c3"
+            w32 = next(fn for n, d, fn in comp.packer.recipes if n == name)(m.state_dict()).float()
+            assert ((packed[name].float() + packed[name + ":lo"].float()) - w32).abs().max() < 2e-6 * w32.abs().max()
+        it = Interp(comp.prog, packed)
+        out = torch.empty(2, 4, 3, 16, 16)
+        it.run({L.EXT_X: x, L.EXT_T: t, L.EXT_CTX: y, L.EXT_OUT: out})
+        errs.append(rel_l2(out, gold))
+    assert errs[1] < 0.92 * errs[0] and errs[1] < 2e-3, errs
