@@ -113,8 +113,10 @@ enum t2v_gather {
  *      7 ld_out, 8 phase (0 whole op | 1 statistics only | 2 fold gathered parts + normalise),
  *      9 nparts, 10 this rank's part, 11 rows per workgroup (0: T2V_GN_ROWS_PER_BLOCK; sizes the scratch),
  *      12 single-launch variant (phase 0 only, (C/groups) % 4 == 0): one workgroup per (instance, group);
- *      13 rows of the LARGEST part (0 = rows: equal parts) — sizes every part's slot count ceil(rows_max / rows per workgroup);
- *         a shorter part zero-fills its unused slots;  14 rows of the whole instance over all parts (0 = rows * nparts);
+ *      14 rows of the whole instance over all parts (0 = rows * nparts; T-sharded clips with uneven slices);
+ *      scratch, phase 0: block partials [n_inst][nblk][groups][2] fp64, then {mean, rstd} fp32;  phases 1 / 2: gathered parts
+ *      [nparts][n_inst][groups][2] fp64 (phase 1 folds this rank's block partials into its part; ALLGATHER of
+ *      n_inst*groups*16 bytes per part), then this rank's block partials, then {mean, rstd};
  *      f: 0 eps;  p: 0 x, 1 gamma, 2 beta, 3 out fp16, 4 scratch
  * LAYERNORM: i: 0 M, 1 C, 2 ld_in, 3 ld_out; f: 0 eps; p: 0 x fp32, 1 gamma, 2 beta, 3 out fp16
  * ATTENTION: i: 0 nq, 1 nk, 2 heads, 3 batch_outer, 4 batch_inner, 5..7 q strides (seq,

@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libt2v_hip.so")
+LIB_PATH = os.environ.get("T2V_LIB_PATH") or os.path.join(_HERE, "libt2v_hip.so")   # T2V_LIB_PATH: A/B builds of the same ABI (tools/build_variant.py)
 
 # ---- mirrors of include/t2v_hip.h (checked against the header by tests/test_abi.py) -------
 ABI_VERSION = 2

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
 // `nparts` > 1: the partials of all T-shard ranks, gathered as [part][inst][blk][group][2]; the fold
 // order (part-major, then block) is the same on every rank, so all ranks get identical statistics.
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* partials, float* finals, int n_inst, int nblk,
-                                                          int groups, double inv_n, float eps, int nparts) {
+                                                          int groups, double inv_n, float eps, int nparts, double* raw) {
   const int lane = threadIdx.x & 63;
   const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);  // (inst, group) pair
   if (idx >= n_inst * groups) return;
@@ -147,7 +147,10 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* partials
     q += st[1];
   }
   for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
-  if (lane == 0) {
+  if (lane == 0 && raw != nullptr) {        // T-shard, local fold: this rank's {sum, sum of squares} for the all-gather
+    raw[2 * idx] = s;
+    raw[2 * idx + 1] = q;
+  } else if (lane == 0) {
     const double m = s * inv_n;
     double var = q * inv_n - m * m;
     var = var < 0.0 ? 0.0 : var;
@@ -375,15 +378,15 @@ hipError_t t2v_launch_groupnorm(const t2v_op& op, hipStream_t s) {
   if (C % 8 != 0 || ld_in % 8 != 0 || ld_out % 8 != 0 || C % groups != 0 || groups > 256 || n_inst <= 0 || rows <= 0 ||
       op.p[4] == 0 || part < 0 || part >= nparts || phase < 0 || phase > 2)
     return hipErrorInvalidValue;
-  // uneven T-shards: every part has the slot count of the LARGEST part (a shorter part zero-fills its unused slots —
-  // its surplus statistics workgroups see no rows), the mean is over the rows of all parts
-  const int rows_max = op.i[13] > 0 ? op.i[13] : rows;
+  // T-sharded clips (phase 1 / 2): every rank folds ITS OWN block partials to one {sum, sum of squares} pair per
+  // (instance, group) — 512 bytes per instance — and only those are all-gathered; phase 2 sums the parts in rank order
+  // (every rank: same values, same order => bit-identical statistics) over the rows of the whole clip (i[14]).
   const long rows_total = op.i[14] > 0 ? (long)op.i[14] : (long)rows * nparts;
-  if (rows_max < rows) return hipErrorInvalidValue;
-  const int nblk = (rows_max + rpb - 1) / rpb;
-  const size_t part_len = (size_t)n_inst * nblk * groups * 2;
+  const int nblk = (rows + rpb - 1) / rpb;
+  const size_t part_len = phase == 0 ? (size_t)n_inst * nblk * groups * 2 : (size_t)n_inst * groups * 2;   // doubles per gathered part
   double* partials = reinterpret_cast<double*>(op.p[4]);
-  float* finals = reinterpret_cast<float*>(partials + part_len * nparts);
+  double* local = phase == 0 ? partials : partials + part_len * nparts;                                    // block partials of this rank
+  float* finals = reinterpret_cast<float*>(local + (size_t)n_inst * nblk * groups * 2);
   const dim3 g1(nblk, n_inst);
   const int cv = C / 8;
   const int R = cv < 256 ? 256 / cv : 1;
@@ -405,10 +408,13 @@ hipError_t t2v_launch_groupnorm(const t2v_op& op, hipStream_t s) {
       return;
     }
     if (phase != 2)
-      hipLaunchKernelGGL(gn_stats_kernel<T>, g1, dim3(256), lds, s, x, partials + part_len * part, rows, C, ld_in, groups, rpb);
+      hipLaunchKernelGGL(gn_stats_kernel<T>, g1, dim3(256), lds, s, x, local, rows, C, ld_in, groups, rpb);
+    if (phase == 1)
+      hipLaunchKernelGGL(gn_finalize_kernel, dim3(g2), dim3(256), 0, s, local, finals, n_inst, nblk, groups, 0.0, 0.f, 1,
+                         partials + part_len * part);
     if (phase != 1) {
-      hipLaunchKernelGGL(gn_finalize_kernel, dim3(g2), dim3(256), 0, s, partials, finals, n_inst, nblk, groups, inv_n,
-                         op.f[0], nparts);
+      hipLaunchKernelGGL(gn_finalize_kernel, dim3(g2), dim3(256), 0, s, partials, finals, n_inst, phase == 0 ? nblk : 1, groups,
+                         inv_n, op.f[0], nparts, static_cast<double*>(nullptr));
       const int rpa = R * GN_UNROLL;    // rows per normalise workgroup
       const dim3 g3((rows + rpa - 1) / rpa, n_inst);
       const size_t lds3 = 2 * (size_t)C * sizeof(float);

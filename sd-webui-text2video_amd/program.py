@@ -322,31 +322,35 @@ class Program:
                   silu: bool, groups: int = 32, shard: Optional[TShardSpec] = None) -> Op:
         """GroupNorm(+SiLU).  With `shard` (cross-frame statistics of a T-sharded clip; n_inst = 1) the op is split
         into: statistics (this rank's partials) -> all-gather of the fp64 partials over the T group ->
-        ordered fold of all parts + normalise; every rank ends up with bit-identical statistics.  Uneven slices: every
-        part has the slot count of the largest slice (a shorter one zero-fills the rest)."""
+        ordered fold of all parts + normalise; every rank ends up with bit-identical statistics.  Each rank folds its own
+        block partials first, so a part is one {sum, sum of squares} pair per group: 512 bytes per instance, whatever the
+        slice lengths (uneven slices need no special care)."""
         rows = x.rows // n_inst
         assert rows * n_inst == x.rows and out.dtype == "f16" and x.cols % 4 == 0
         nparts, part = (shard.size, shard.index) if shard is not None else (1, 0)
-        rows_max, rows_total = rows, rows * nparts
+        rows_total = rows * nparts
         if shard is not None:
             assert n_inst == 1 and rows % shard.frames == 0
-            per_frame = rows // shard.frames
-            rows_max, rows_total = per_frame * shard.max_frames, per_frame * shard.total
+            rows_total = rows // shard.frames * shard.total
         # rows reduced by one statistics workgroup: the smallest power of two >= 4 that keeps the grid within
-        # ~4 workgroups per CU (each thread then has several rows in flight); from the LARGEST slice, so that every
-        # rank of a T group chooses the same value
+        # ~4 workgroups per CU (each thread then has several rows in flight)
         rpb = 4
-        while n_inst * ((rows_max + rpb - 1) // rpb) > 4 * self.target_cus:
+        while n_inst * ((rows + rpb - 1) // rpb) > 4 * self.target_cus:
             rpb *= 2
-        nblk = (rows_max + rpb - 1) // rpb
-        part_bytes = n_inst * nblk * groups * 16
-        scratch = self.alloc(nparts * part_bytes + n_inst * groups * 8, 1, "u8")
+        nblk = (rows + rpb - 1) // rpb
+        if shard is None:
+            part_bytes = n_inst * nblk * groups * 16
+            scratch = self.alloc(part_bytes + n_inst * groups * 8, 1, "u8")
+        else:
+            # T-sharded: [nparts gathered {sum, sumsq} per (instance, group)] [this rank's block partials] [finals]
+            part_bytes = n_inst * groups * 16
+            scratch = self.alloc(nparts * part_bytes + n_inst * nblk * groups * 16 + n_inst * groups * 8, 1, "u8")
 
         def make(phase, suffix):
             op = Op(L.OP_GROUPNORM, name + suffix)
             op.i[0:12] = [n_inst, rows, x.cols, x.ld, groups, _DT[x.dtype], int(silu), out.ld, phase, nparts, part, rpb]
             if shard is not None:
-                op.i[13], op.i[14] = rows_max, rows_total
+                op.i[14] = rows_total
             op.f[0] = eps
             op.p[0:5] = [x.ref, gamma, beta, out.ref, scratch.ref]
             return op

@@ -127,23 +127,18 @@ class Interp:
         nparts = max(nparts, 1)
         cpg = C // groups
         x = self.mat(op.p[0], n_inst * rows, C, ld_in, _TD[in_dt], ext).double().view(n_inst, rows, groups, cpg)
-        rpb = op.i[11] if op.i[11] > 0 else L.GN_ROWS_PER_BLOCK
-        rows_max = op.i[13] if op.i[13] > 0 else rows
         rows_total = op.i[14] if op.i[14] > 0 else rows * nparts
-        nblk = (rows_max + rpb - 1) // rpb
-        part_len = n_inst * nblk * groups * 2
         if phase == 0:
             s1, s2, n = x.sum(dim=(1, 3)), (x * x).sum(dim=(1, 3)), rows * cpg
         else:
-            # scratch: fp64 partials [nparts][n_inst][nblk][groups][2] (device: one entry per 16-row block;
-            # here everything in block 0)
-            pv = self.view(op.p[4], (nparts, n_inst, nblk, groups, 2), (part_len, nblk * groups * 2, groups * 2, 2, 1), torch.float64, ext)
+            # scratch head: gathered fp64 {sum, sum of squares} [nparts][n_inst][groups][2] (each rank folds its own block
+            # partials before the all-gather)
+            pv = self.view(op.p[4], (nparts, n_inst, groups, 2), (n_inst * groups * 2, groups * 2, 2, 1), torch.float64, ext)
             if phase == 1:
-                pv[part].zero_()
-                pv[part, :, 0, :, 0] = x.sum(dim=(1, 3))
-                pv[part, :, 0, :, 1] = (x * x).sum(dim=(1, 3))
+                pv[part, :, :, 0] = x.sum(dim=(1, 3))
+                pv[part, :, :, 1] = (x * x).sum(dim=(1, 3))
                 return
-            s1, s2, n = pv[..., 0].sum(dim=(0, 2)), pv[..., 1].sum(dim=(0, 2)), rows_total * cpg
+            s1, s2, n = pv[..., 0].sum(dim=0), pv[..., 1].sum(dim=0), rows_total * cpg
         mean = (s1 / n).view(n_inst, 1, groups, 1)
         var = (s2 / n).view(n_inst, 1, groups, 1) - mean * mean
         y = ((x - mean) / torch.sqrt(var.clamp_min(0) + op.f[0])).view(n_inst * rows, C).float()

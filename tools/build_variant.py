@@ -1,0 +1,24 @@
+"""Build an A/B variant of libt2v_hip.so with extra -D flags:  python tools/build_variant.py <tag> -DFOO=0 ...
+-> sd-webui-text2video_amd/libt2v_hip_<tag>.so (select with T2V_LIB_PATH)."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+tag, flags = sys.argv[1], sys.argv[2:]
+objdir = os.path.join(ge.PKG, "build", tag)
+os.makedirs(objdir, exist_ok=True)
+procs = []
+for src in ge.SOURCES:
+    obj = os.path.join(objdir, src.replace(".hip", ".o"))
+    cmd = [ge._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c"] + ge.EXTRA_FLAGS.get(src, []) + flags + \
+          [os.path.join(ge.CSRC, src), "-o", obj]
+    procs.append((obj, subprocess.Popen(cmd, cwd=ROOT)))
+for obj, pr in procs:
+    assert pr.wait() == 0, obj
+out = os.path.join(ge.PKG, f"libt2v_hip_{tag}.so")
+subprocess.run([ge._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + [o for o, _ in procs] + ["-ldl"], check=True)
+print(out)
