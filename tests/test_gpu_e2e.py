@@ -5,9 +5,10 @@ Tolerances (rel-L2 = |y - y_ref|_2 / |y_ref|_2 vs the fp32 CPU reference):
   * the product computes with fp16 MFMA operands, fp32 accumulate, fp32 residual stream and
     fp32 norm/softmax statistics.  The reference's own GPU path (.half() + autocast) measures
     2.2e-3 on one UNet forward — that is the noise floor of fp16 operands.
-  * UNet forward      <= 5e-3   (expected ~2e-3)
-  * VAE decode        <= 4e-3   (expected ~1.2e-3)
-  * 5-step sampling   <= 2e-2   (error compounds through guidance scale 9)
+  * UNet forward      1.8e-3 (8 frames, fp32 weights) .. 2.0e-3 (24 / 125 frames, fp16 weights); gate 2.8e-3 .. 3.1e-3
+  * VAE decode        8e-4 @256x256, 1.1e-3 @1024x576; gate 1.3e-3 / 1.7e-3
+  * sampling          2.3e-3 (5 steps), 1.9e-3 (10 steps), 1.3e-3 (50 steps): the DDIM trajectory is contractive towards x0
+Gates are ~1.5x the values measured on MI355X (profiles/r02_parity_measurements.txt).
 north_star's 1e-3 is NOT met with single-pass fp16 operands; see DESIGN.md "Precision".
 """
 import os
@@ -54,7 +55,7 @@ def test_tiny_unet_forward_matches_reference_golden(tiny):
     net.debug_taps = False
     r = rel_l2(eps, gold)
     # localise a failure: per-sub-module comparison against the oracle's taps
-    if not r < 5e-3:
+    if not r < 3.1e-3:                             # measured 2.03e-3
         taps = {}
         tp.unet_forward(sd, configs.TINY_UNET, x, t, y, taps=taps)
         comp = next(iter(net._programs.values()))
@@ -341,7 +342,7 @@ def test_modelscope_8f_forward_and_sampling_match_reference_golden(full):
     eps = net(noise.to(DEV), torch.tensor([801], device=DEV), cond.to(DEV)).float().cpu()
     r = rel_l2(eps, torch.from_numpy(gold["unet_eps"]))
     print(f"ModelScope 8f UNet forward rel-L2 vs reference fp32: {r:.3e}")
-    assert r < 5e-3
+    assert r < 2.8e-3                              # measured 1.82e-3
     smp = samplers.Txt2VideoSampler(net, torch.device(DEV), betas=betas, sampler_name="DDIM_Gaussian")
     smp.progress = False
     _, nz, shape = smp.get_noise(1, 4, 8, 256, 256, seed=1234)
@@ -350,7 +351,7 @@ def test_modelscope_8f_forward_and_sampling_match_reference_golden(full):
                          batch_size=1, shape=shape, noise=nz, guidance_scale=9.0, eta=0.0, sampler_name="DDIM_Gaussian")
     r = rel_l2(x0.float().cpu(), torch.from_numpy(gold["sampler_x0"]))
     print(f"ModelScope 8f 5-step DDIM_Gaussian rel-L2 vs reference fp32: {r:.3e}")
-    assert r < 2e-2
+    assert r < 3.5e-3                              # measured 2.30e-3
 
 
 def test_modelscope_24f_batch_invariance_at_full_size(full):
@@ -380,7 +381,7 @@ def test_modelscope_vae_decode_matches_reference_golden():
     img = ae.decode((x0[:, :, 0] / configs.SCALE_FACTOR).to(DEV)).float().cpu()
     r = rel_l2(img, torch.from_numpy(gold["vae_img_frame0"]))
     print(f"ModelScope VAE decode 256x256 rel-L2 vs reference fp32: {r:.3e}")
-    assert r < 4e-3
+    assert r < 1.3e-3                              # measured 8.2e-4
 
 
 def test_tsharded_forward_two_shards_emulated_on_one_gpu(tiny):

@@ -1,6 +1,7 @@
 """GPU (-m gpu): parity at the FULL sizes BASELINE.json names, against fp32 outputs of the reference's own classes
 (tests/golden/make_golden_full.py), with the DEPLOYED precision: fp16 weights (`.half()`, t2v_pipeline.py:103-104), fp16
-conditioning, fp32 latent.  Every test prints the measured rel-L2; gates are ~1.5x the value measured on MI355X.
+conditioning, fp32 latent.  Every test prints the measured rel-L2 (committed: profiles/r02_parity_measurements.txt); gates are
+~1.5x the value measured on MI355X.
 
   configs[1]  ModelScope 24 frames @256x256: one forward, the b=2 CFG forward of the bench, 10- and 50-step DDIM_Gaussian,
               decoded uint8 frames of the 50-step video
@@ -51,7 +52,7 @@ def test_c1_24f_forward_and_cfg_batch(modelscope_full_fp16):
     pair = net(torch.cat([x, x]), torch.cat([t, t]), torch.cat([c, u]))
     r2 = rel_l2(pair[0:1].float().cpu(), torch.from_numpy(gold["unet_eps"]))
     print(f"configs[1] 24f forward, fp16 weights: rel-L2 {r:.3e} (b=1), {r2:.3e} (conditional half of the b=2 CFG forward)")
-    assert r < 4.5e-3 and r2 < 4.5e-3
+    assert r < 3.1e-3 and r2 < 3.1e-3          # measured 2.03e-3 / 2.03e-3
 
 
 def test_c1_24f_sampling_10_and_50_steps_and_frames(modelscope_full_fp16, vae16):
@@ -68,14 +69,14 @@ def test_c1_24f_sampling_10_and_50_steps_and_frames(modelscope_full_fp16, vae16)
                                     guidance_scale=9.0, eta=0.0, sampler_name="DDIM_Gaussian")
         r = rel_l2(x0[steps].float().cpu(), torch.from_numpy(gold[f"sampler_x0_{steps}"]))
         print(f"configs[1] {steps}-step DDIM_Gaussian CFG 9, fp16 weights: x0 rel-L2 {r:.3e}")
-        assert r < (3e-2 if steps == 10 else 1.5e-1)
+        assert r < (3e-3 if steps == 10 else 2e-3)      # measured 1.92e-3 (10 steps), 1.26e-3 (50 steps)
     # frames 0 / 23 of the 50-step video: VAE decode + tensor2vid as ONE program, against the reference's uint8 frames
     z = (x0[50][:, :, [0, 23]] / configs.SCALE_FACTOR).permute(0, 2, 1, 3, 4).reshape(2, 4, 32, 32)
     u8 = vae16.decode_to_uint8(z, videos=1).cpu().numpy()
     d = np.abs(u8.astype(int) - gold["frames_u8"].astype(int))
     print(f"configs[1] uint8 frames of the 50-step video: {100 * (d == 0).mean():.2f}% identical, {100 * (d > 1).mean():.3f}% off by > 1 LSB, "
           f"{100 * (d > 8).mean():.3f}% off by > 8, max |diff| {d.max()}")
-    assert (d > 8).mean() < 0.05
+    assert (d > 1).mean() < 1e-4 and d.max() <= 2      # measured: 90.4 % identical, none off by more than 1 LSB
     # decoder alone on the REFERENCE's latent: isolates the VAE + uint8 conversion from the sampling error
     zr = (torch.from_numpy(gold["sampler_x0_50"])[:, :, [0, 23]] / configs.SCALE_FACTOR).permute(0, 2, 1, 3, 4).reshape(2, 4, 32, 32)
     u8r = vae16.decode_to_uint8(zr.to(DEV), videos=1).cpu().numpy()
@@ -84,7 +85,7 @@ def test_c1_24f_sampling_10_and_50_steps_and_frames(modelscope_full_fp16, vae16)
     rv = rel_l2(img[:, :, ::2, ::2], torch.from_numpy(gold["vae_img"]))
     print(f"configs[1] VAE on the reference latent: rel-L2 {rv:.3e}; uint8 {100 * (dr == 0).mean():.2f}% identical, "
           f"{100 * (dr > 1).mean():.4f}% off by > 1 LSB, max |diff| {dr.max()}")
-    assert rv < 4e-3 and (dr > 1).mean() < 1e-3 and dr.max() <= 3
+    assert rv < 1.4e-3 and (dr > 1).mean() < 1e-4 and dr.max() <= 2      # measured 8.8e-4; 93.7 % identical, max |diff| 1
 
 
 def test_c2_125f_forward(modelscope_full_fp16):
@@ -98,7 +99,7 @@ def test_c2_125f_forward(modelscope_full_fp16):
     worst = max(rel_l2(eps[:, :, f], want[:, :, k]) for k, f in enumerate(frames))
     print(f"configs[2] 125f forward, fp16 weights: rel-L2 {r:.3e} over frames {frames}, worst single frame {worst:.3e}")
     assert abs(float(eps.std()) - float(gold["eps_std"])) < 2e-3 * float(gold["eps_std"])
-    assert r < 4.5e-3 and worst < 6e-3
+    assert r < 3e-3 and worst < 3.2e-3            # measured 1.94e-3 / 2.08e-3
 
 
 def test_c3_zeroscope_xl_forward_72x128(modelscope_full_fp16):
@@ -110,7 +111,7 @@ def test_c3_zeroscope_xl_forward_72x128(modelscope_full_fp16):
     eps = net(noise.to(DEV), torch.tensor([801], device=DEV), cond.to(DEV).half()).float().cpu()
     r = rel_l2(eps[:, :, frames], torch.from_numpy(gold["unet_eps_frames"]))
     print(f"configs[3] ZeroScope-XL geometry ({nfr}f, latent 72x128, 9216-token spatial attention), fp16 weights: rel-L2 {r:.3e}")
-    assert r < 4.5e-3
+    assert r < 3.1e-3                             # measured 2.02e-3
 
 
 def test_c3_vae_decode_1024x576(vae16):
@@ -122,7 +123,7 @@ def test_c3_vae_decode_1024x576(vae16):
     rg = rel_l2(img[:, 1::4, 2::4], torch.from_numpy(gold["vae_grid"]))
     rc = rel_l2(img[:, 128:256, 384:512], torch.from_numpy(gold["vae_crop"]))
     print(f"configs[3] VAE decode 1024x576 (mid attention over 9216 tokens), fp16 weights: rel-L2 {rg:.3e} (stride-4 grid), {rc:.3e} (crop)")
-    assert rg < 4e-3 and rc < 4e-3
+    assert rg < 1.7e-3 and rc < 1.7e-3            # measured 1.10e-3 / 1.07e-3
 
 
 def test_c4_lvdm_16f_ddim_and_decode():
@@ -146,9 +147,9 @@ def test_c4_lvdm_16f_ddim_and_decode():
                            x_T=x_T.to(DEV))
         r = rel_l2(x0.float().cpu(), torch.from_numpy(gold[f"ddim_x0_{steps}"]))
         print(f"configs[4] VideoCrafter 16f, {steps}-step lvdm DDIM CFG 7.5, fp16 weights: x0 rel-L2 {r:.3e}")
-        assert r < (5e-2 if steps == 10 else 2.5e-1)
+        assert r < (2.7e-3 if steps == 10 else 2.3e-3)  # measured 1.77e-3 (10 steps), 1.49e-3 (50 steps)
     img = ld.decode_first_stage(torch.from_numpy(gold["ddim_x0_50"])[:, :, 0:1].to(DEV).half()).float().cpu()
     img = img.reshape(-1, 3, 256, 256)[0:1]
     rv = rel_l2(img[:, :, ::2, ::2], torch.from_numpy(gold["vae_img_frame0"]))
     print(f"configs[4] decode_first_stage of the reference latent, fp16 weights: rel-L2 {rv:.3e}")
-    assert rv < 4e-3
+    assert rv < 1.8e-3                            # measured 1.15e-3
