@@ -55,7 +55,9 @@ enum t2v_op_kind {
   T2V_OP_TO_UINT8 = 15,    /* tensor2vid: float video -> uint8 frames [F,H,(i W),3], truncating (t2v_pipeline.py:447-460) */
   T2V_OP_ALLGATHER = 16,   /* in-place all-gather of equal byte parts over the plan's communicator (RCCL, launch stream) */
   T2V_OP_HALO_EXCHANGE = 17, /* +-1 frame neighbour exchange of a [F+2]-frame token buffer over the plan's communicator */
-  T2V_OP_KIND_MAX = 18
+  T2V_OP_RESHARD_ROWS = 18,  /* chunked row regrouping (pack / unpack of a frame <-> pixel resharding), optional fp32 residual */
+  T2V_OP_ALLTOALL = 19,      /* frame <-> pixel resharding of a T-sharded clip over the plan's communicator */
+  T2V_OP_KIND_MAX = 20
 };
 
 /* GEMM gather modes: how row m / reduction index k of the A operand are addressed          */
@@ -155,7 +157,16 @@ enum t2v_gather {
  * HALO_EXCHANGE: token buffer of F+2 frames (frame = `bytes`): frame 1 -> previous rank's frame F+1 slot ... i.e. this rank
  *      sends its first real frame to `prev` and its last to `next`, and receives their boundary frames into frame 0 / F+1.
  *      i: 0/1 bytes per frame (lo, hi), 2 F (local frames), 3 prev rank in the communicator (-1 none), 4 next rank (-1 none);
- *      p: 0 base.   Both collectives need t2v_plan_set_comm unless they are no-ops.
+ *      p: 0 base.   The collectives need t2v_plan_set_comm unless they are no-ops.
+ * RESHARD_ROWS: row r reads src row (r / P) * S_src + r % P and writes dst row (r / P) * S_dst + r % P (+ residual at the dst row)
+ *      i: 0 rows, 1 cols, 2 P (rows per chunk), 3 S_src, 4 S_dst (chunk strides in rows), 5 ld_src, 6 ld_dst, 7 dtype (src == dst;
+ *      fp16: cols % 8 == 0, fp32: cols % 4 == 0), 8 ld_res;  p: 0 src, 1 dst, 2 residual fp32 (optional, fp32 only)
+ * ALLTOALL: slice q of the clip holds cnt(q) frames (i[4] each, i[5] on the LAST slice); chunk = bytes of one frame's share for one
+ *      rank.  direction 0 (frames -> pixels): send cnt(me) chunks to every peer q from p0 + q*cnt(me)*chunk, receive cnt(q) chunks
+ *      from q at p1 + q*i[4]*chunk;  direction 1 (pixels -> frames): send cnt(q) chunks to q from p0 + q*i[4]*chunk, receive cnt(me)
+ *      chunks from q at p1 + q*cnt(me)*chunk.  The rank's own part is moved by RESHARD_ROWS ops.
+ *      i: 0/1 chunk bytes (lo, hi), 2 nparts, 3 this rank's part, 4 frames per slice, 5 frames of the last slice, 6 direction;
+ *      p: 0 send base, 1 receive base
  */
 typedef struct t2v_op {
   int32_t kind;

@@ -17,6 +17,7 @@ OP_LINCOMB = 12
 OP_RELPOS_ATTN = 13
 OP_EMBED_ROWS = 14
 OP_TO_UINT8, OP_ALLGATHER, OP_HALO_EXCHANGE = 15, 16, 17
+OP_RESHARD_ROWS, OP_ALLTOALL = 18, 19
 GATHER_PLAIN, GATHER_CONV3X3, GATHER_TCONV3, GATHER_CONV3X3_C8 = 0, 1, 2, 3
 EPI_NONE, EPI_GEGLU = 0, 1
 F16, F32 = 0, 1

@@ -138,3 +138,35 @@ int t2v_comm_halo(t2v_comm* c, void* base, size_t frame_bytes, int F, int prev, 
   if (rc != ncclSuccess) { err = std::string("halo exchange (ncclSend/ncclRecv): ") + r->GetErrorString(rc); return T2V_ERR_COMM; }
   return T2V_OK;
 }
+
+// Frame <-> pixel resharding of a T-sharded clip (slice q holds cnt(q) frames: base_cnt, a shorter last one).  chunk =
+// bytes of one frame's share for one rank (hw / R rows).  dir 0 (frames -> pixels): this rank sends cnt(me) chunks to every
+// peer q from send + q * cnt(me) * chunk (packed by T2V_OP_RESHARD_ROWS) and receives cnt(q) chunks from q straight into
+// recv + q * base_cnt * chunk (frames of q are consecutive in the pixel-sharded layout).  dir 1 (pixels -> frames): the
+// mirror image — sends cnt(q) chunks to q from send + q * base_cnt * chunk, receives cnt(me) chunks from q into
+// recv + q * cnt(me) * chunk (unpacked afterwards).  The rank's own part is moved by the reshard ops, not here.
+int t2v_comm_alltoall(t2v_comm* c, void* send, void* recv, size_t chunk, int nparts, int part, int base_cnt, int last_cnt, int dir,
+                      hipStream_t s, std::string& err) {
+  if (nparts <= 1 && !c) return T2V_OK;
+  const Rccl* r = rccl();
+  if (!r || !c) { err = c ? g_rccl.err : "collective op in a plan without a communicator (t2v_plan_set_comm)"; return T2V_ERR_COMM; }
+  if (c->nranks != nparts || c->rank != part) { err = "all-to-all parts do not match the communicator (nranks / rank)"; return T2V_ERR_BAD_ARG; }
+  auto cnt = [&](int q) { return (size_t)(q == nparts - 1 ? last_cnt : base_cnt); };
+  unsigned char* sb = static_cast<unsigned char*>(send);
+  unsigned char* rb = static_cast<unsigned char*>(recv);
+  ncclResult_t rc = r->GroupStart();
+  for (int q = 0; q < nparts && rc == ncclSuccess; ++q) {
+    if (q == part) continue;
+    if (dir == 0) {
+      rc = r->Send(sb + (size_t)q * cnt(part) * chunk, cnt(part) * chunk, ncclUint8, q, c->comm, s);
+      if (rc == ncclSuccess) rc = r->Recv(rb + (size_t)q * base_cnt * chunk, cnt(q) * chunk, ncclUint8, q, c->comm, s);
+    } else {
+      rc = r->Send(sb + (size_t)q * base_cnt * chunk, cnt(q) * chunk, ncclUint8, q, c->comm, s);
+      if (rc == ncclSuccess) rc = r->Recv(rb + (size_t)q * cnt(part) * chunk, cnt(part) * chunk, ncclUint8, q, c->comm, s);
+    }
+  }
+  const ncclResult_t rc2 = r->GroupEnd();
+  if (rc == ncclSuccess) rc = rc2;
+  if (rc != ncclSuccess) { err = std::string("all-to-all (ncclSend/ncclRecv): ") + r->GetErrorString(rc); return T2V_ERR_COMM; }
+  return T2V_OK;
+}

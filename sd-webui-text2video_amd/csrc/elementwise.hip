@@ -162,6 +162,31 @@ __global__ __launch_bounds__(256) void lincomb_kernel(const LinParams p) {
   }
 }
 
+// Row regrouping between the two layouts of a T-sharded clip (frame-sharded [frames][hw] rows <-> pixel-sharded
+// [frames][hw / R] rows): row r of the op reads source row (r / P) * S_src + r % P and writes destination row
+// (r / P) * S_dst + r % P (chunks of P rows, chunk strides in rows); optional fp32 residual, indexed like the
+// destination, added on the way (the TemporalTransformer's `+ x` after its output is resharded back to frames).
+template <typename T>
+__global__ __launch_bounds__(256) void reshard_rows_kernel(const T* src, T* dst, const float* res, int rows, int cols, int P,
+                                                           long s_src, long s_dst, int ld_src, int ld_dst, int ld_res) {
+  constexpr int V = 16 / sizeof(T);               // elements per 16-byte unit
+  const int cv = cols / V;
+  const long total = (long)rows * cv;
+  for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < total; u += (long)gridDim.x * 256) {
+    const long r = u / cv;
+    const int c = (int)(u - r * cv) * V;
+    const long chunk = r / P, within = r - chunk * P;
+    const long rs = chunk * s_src + within, rd = chunk * s_dst + within;
+    if constexpr (sizeof(T) == 4) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(src + rs * ld_src + c);
+      if (res) v += *reinterpret_cast<const f32x4*>(res + rd * ld_res + c);
+      *reinterpret_cast<f32x4*>(dst + rd * ld_dst + c) = v;
+    } else {
+      *reinterpret_cast<f16x8*>(dst + rd * ld_dst + c) = *reinterpret_cast<const f16x8*>(src + rs * ld_src + c);
+    }
+  }
+}
+
 // tensor2vid (t2v_pipeline.py:447-460): video[i,c,f,y,x] -> uint8 out[f, y, i*W + x, c]: v*0.5 + 0.5 (two roundings, as
 // mul_ / add_), clamp to [0,1], *255, TRUNCATED like `(image.numpy()*255).astype('uint8')`.  HALF: the reference's
 // 'GPU (half precision)' VAE hands tensor2vid an fp16 video, so every intermediate is rounded to fp16 (the input too
@@ -247,6 +272,25 @@ hipError_t t2v_launch_to_uint8(const t2v_op& op, hipStream_t s) {
     if (half) hipLaunchKernelGGL((to_uint8_kernel<f16, true>), dim3(g), dim3(256), 0, s, in, out, NI, C, F, H, W, si, sc, sf, sy, sx, bgr);
     else hipLaunchKernelGGL((to_uint8_kernel<f16, false>), dim3(g), dim3(256), 0, s, in, out, NI, C, F, H, W, si, sc, sf, sy, sx, bgr);
   }
+  return hipGetLastError();
+}
+
+hipError_t t2v_launch_reshard_rows(const t2v_op& op, hipStream_t s) {
+  const int rows = op.i[0], cols = op.i[1], P = op.i[2], ld_src = op.i[5], ld_dst = op.i[6], ld_res = op.i[8];
+  const long s_src = op.i[3], s_dst = op.i[4];
+  const bool f32 = op.i[7] == T2V_F32;
+  if (rows <= 0 || cols <= 0 || P <= 0 || cols % (f32 ? 4 : 8) != 0 || ld_src % (f32 ? 4 : 8) != 0 || ld_dst % (f32 ? 4 : 8) != 0)
+    return hipErrorInvalidValue;
+  if (op.p[2] != 0 && (!f32 || ld_res % 4 != 0)) return hipErrorInvalidValue;
+  const int g = grid_for((long)rows * (cols / (f32 ? 4 : 8)));
+  if (f32)
+    hipLaunchKernelGGL(reshard_rows_kernel<float>, dim3(g), dim3(256), 0, s, reinterpret_cast<const float*>(op.p[0]),
+                       reinterpret_cast<float*>(op.p[1]), reinterpret_cast<const float*>(op.p[2]), rows, cols, P, s_src, s_dst,
+                       ld_src, ld_dst, ld_res);
+  else
+    hipLaunchKernelGGL(reshard_rows_kernel<f16>, dim3(g), dim3(256), 0, s, reinterpret_cast<const f16*>(op.p[0]),
+                       reinterpret_cast<f16*>(op.p[1]), static_cast<const float*>(nullptr), rows, cols, P, s_src, s_dst, ld_src,
+                       ld_dst, 0);
   return hipGetLastError();
 }
 

@@ -150,6 +150,15 @@ int validate_op(const t2v_op& op, int idx) {
     case T2V_OP_HALO_EXCHANGE:
       if (op.i[2] < 1 || op.p[0] == 0 || op.i[3] < -1 || op.i[4] < -1) return bad("bad halo-exchange record");
       return 0;
+    case T2V_OP_RESHARD_ROWS:
+      if (op.i[0] <= 0 || op.i[1] <= 0 || op.i[2] <= 0 || op.i[3] < 0 || op.i[4] < 0) return bad("bad row-resharding shape");
+      if (op.i[5] < op.i[1] || op.i[6] < op.i[1] || op.p[0] == 0 || op.p[1] == 0) return bad("row resharding: leading dimension / pointer");
+      if (op.p[2] != 0 && op.i[7] != T2V_F32) return bad("row resharding: the residual form is fp32");
+      return 0;
+    case T2V_OP_ALLTOALL:
+      if (op.i[2] < 1 || op.i[3] < 0 || op.i[3] >= op.i[2] || op.i[4] < 1 || op.i[5] < 1 || op.i[5] > op.i[4]) return bad("bad all-to-all record");
+      if ((op.i[6] != 0 && op.i[6] != 1) || op.p[0] == 0 || op.p[1] == 0) return bad("bad all-to-all direction / pointer");
+      return 0;
     default:
       return bad("unknown op kind");
   }
@@ -196,6 +205,7 @@ hipError_t launch_op(const t2v_op& op, hipStream_t s) {
     case T2V_OP_RELPOS_ATTN: return t2v_launch_relpos_attention(op, s);
     case T2V_OP_EMBED_ROWS: return t2v_launch_embed_rows(op, s);
     case T2V_OP_TO_UINT8: return t2v_launch_to_uint8(op, s);
+    case T2V_OP_RESHARD_ROWS: return t2v_launch_reshard_rows(op, s);
     case T2V_OP_MEMSET: {
       const size_t bytes = (size_t)(uint32_t)op.i[0] | ((size_t)(uint32_t)op.i[1] << 32);
       return hipMemsetAsync(reinterpret_cast<void*>(op.p[0]), 0, bytes, s);
@@ -219,12 +229,15 @@ int run_resolved(const t2v_op* ops, int n, const uint64_t* ext, int n_ext, hipSt
       snprintf(buf, sizeof buf, "op %d (tag %d): unresolved external pointer slot", k, op.tag);
       return fail(T2V_ERR_BAD_ARG, buf);
     }
-    if (op.kind == T2V_OP_ALLGATHER || op.kind == T2V_OP_HALO_EXCHANGE) {
+    if (op.kind == T2V_OP_ALLGATHER || op.kind == T2V_OP_HALO_EXCHANGE || op.kind == T2V_OP_ALLTOALL) {
       const size_t bytes = (size_t)(uint32_t)op.i[0] | ((size_t)(uint32_t)op.i[1] << 32);
       std::string err;
       const int rc = op.kind == T2V_OP_ALLGATHER
                          ? t2v_comm_allgather(comm, reinterpret_cast<void*>(op.p[0]), bytes, op.i[2], op.i[3], s, err)
-                         : t2v_comm_halo(comm, reinterpret_cast<void*>(op.p[0]), bytes, op.i[2], op.i[3], op.i[4], s, err);
+                         : op.kind == T2V_OP_HALO_EXCHANGE
+                               ? t2v_comm_halo(comm, reinterpret_cast<void*>(op.p[0]), bytes, op.i[2], op.i[3], op.i[4], s, err)
+                               : t2v_comm_alltoall(comm, reinterpret_cast<void*>(op.p[0]), reinterpret_cast<void*>(op.p[1]), bytes, op.i[2],
+                                                   op.i[3], op.i[4], op.i[5], op.i[6], s, err);
       if (rc != T2V_OK) {
         char buf[300];
         snprintf(buf, sizeof buf, "op %d (kind %d, tag %d): %s", k, op.kind, op.tag, err.c_str());

@@ -80,6 +80,7 @@ hipError_t t2v_launch_softmax(const t2v_op& op, hipStream_t s);
 hipError_t t2v_launch_ncthw_to_cl(const t2v_op& op, hipStream_t s);
 hipError_t t2v_launch_cl_to_ncthw(const t2v_op& op, hipStream_t s);
 hipError_t t2v_launch_to_uint8(const t2v_op& op, hipStream_t s);
+hipError_t t2v_launch_reshard_rows(const t2v_op& op, hipStream_t s);
 hipError_t t2v_launch_time_embed(const t2v_op& op, hipStream_t s);
 hipError_t t2v_launch_copy2d(const t2v_op& op, hipStream_t s);
 hipError_t t2v_launch_ddim_step(const t2v_op& op, hipStream_t s);
@@ -196,3 +197,5 @@ void t2v_comm_impl_destroy(t2v_comm* c);
 int t2v_comm_impl_size(const t2v_comm* c);
 int t2v_comm_allgather(t2v_comm* c, void* base, size_t bytes, int nparts, int part, hipStream_t s, std::string& err);
 int t2v_comm_halo(t2v_comm* c, void* base, size_t frame_bytes, int F, int prev, int next, hipStream_t s, std::string& err);
+int t2v_comm_alltoall(t2v_comm* c, void* send, void* recv, size_t chunk, int nparts, int part, int base_cnt, int last_cnt, int dir,
+                      hipStream_t s, std::string& err);

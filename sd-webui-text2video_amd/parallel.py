@@ -7,8 +7,9 @@ all-gathered (scripts/videocrafter/lvdm/utils/dist_utils.py:13-19, sample_text2v
   * T-axis (frame) sharding x CFG pair (north_star's layout; default for N >= 4): world = 2 roles x R frame slices.
     The clip's frames are split contiguously over the R ranks of a role (slices of ceil(F / R) frames, a shorter last
     one: 125 = 32 + 32 + 32 + 29); all spatial work is frame-local, and before each temporal op the lowering inserts
-    an exchange op into the denoise program (program.py: T2V_OP_ALLGATHER of GroupNorm statistics partials / of
-    temporal-attention K/V, T2V_OP_HALO_EXCHANGE of one boundary frame for the (3,1,1) convolutions).  The library
+    an exchange op into the denoise program (program.py: T2V_OP_ALLGATHER of GroupNorm statistics, T2V_OP_HALO_EXCHANGE of
+    one boundary frame for the (3,1,1) convolutions, T2V_OP_ALLTOALL resharding frames <-> pixels around each
+    TemporalTransformer — or an all-gather of its K/V where the pixel count does not divide).  The library
     executes them with RCCL on the launch stream (csrc/comm.hip), so a sharded forward is ONE host call.  The two
     roles evaluate the conditional / unconditional forward of the same frames; one eps all-gather per DDIM step
     inside each {cond, uncond} pair, then both apply the same bitwise-deterministic update kernel.
@@ -175,6 +176,23 @@ class ShardedExecutor:
                 out = self._bytes(base, nb * shard.size)
                 mine = out[shard.index * nb: (shard.index + 1) * nb]
                 all_gather_into(out, mine, group=shard.group)
+            elif item.kind == L.OP_ALLTOALL:
+                # frame <-> pixel resharding (layouts: include/t2v_hip.h, csrc/comm.hip)
+                n, me, base_cnt, last_cnt, direction = i[2], i[3], i[4], i[5], i[6]
+                assert (n, me) == (shard.size, shard.index)
+                cnt = lambda q: last_cnt if q == n - 1 else base_cnt
+                sbase, rbase = item.p[0].off, item.p[1].off
+                sends, recvs = [], []
+                for q in range(n):
+                    if q == me:
+                        continue
+                    if direction == 0:
+                        sends.append((self._bytes(sbase + q * cnt(me) * nb, cnt(me) * nb), shard.ranks[q]))
+                        recvs.append((self._bytes(rbase + q * base_cnt * nb, cnt(q) * nb), shard.ranks[q]))
+                    else:
+                        sends.append((self._bytes(sbase + q * base_cnt * nb, cnt(q) * nb), shard.ranks[q]))
+                        recvs.append((self._bytes(rbase + q * cnt(me) * nb, cnt(me) * nb), shard.ranks[q]))
+                exchange_pairs(sends, recvs, shard.group)
             else:   # OP_HALO_EXCHANGE: frame 1 -> prev, frame F -> next; their boundary frames into frame 0 / F + 1
                 nf = i[2]
                 first, last = self._bytes(base + nb, nb), self._bytes(base + nf * nb, nb)

@@ -15,7 +15,7 @@ from typing import Dict, List, Optional, Tuple
 from . import _lib as L
 
 _ITEM = {"f16": 2, "f32": 4, "f64": 8, "u8": 1}
-COLLECTIVE_KINDS = (L.OP_ALLGATHER, L.OP_HALO_EXCHANGE)   # executed over the plan's communicator (RCCL) or by a host executor
+COLLECTIVE_KINDS = (L.OP_ALLGATHER, L.OP_HALO_EXCHANGE, L.OP_ALLTOALL)   # executed over the plan's communicator (RCCL) or by a host executor
 _DT = {"f16": L.F16, "f32": L.F32}
 
 
@@ -396,6 +396,31 @@ class Program:
         op.i[4] = shard.index + 1 if shard.index + 1 < shard.size else -1
         op.p[0] = buf.ref
         op.meta = dict(type="halo", buf=buf, frame_rows=frame_rows, frames=frames)
+        return self._emit(op)
+
+    def reshard_rows(self, name: str, src: Buf, dst: Buf, *, rows: int, chunk: int, s_src: int, s_dst: int,
+                     residual: Optional[Buf] = None) -> Op:
+        """Row r: src row (r // chunk) * s_src + r % chunk -> dst row (r // chunk) * s_dst + r % chunk (+ residual at the dst
+        row).  `src` / `dst` are views whose first row is row 0 of the mapping (pass row_slice()s for offsets)."""
+        assert src.dtype == dst.dtype and src.cols == dst.cols and src.cols % (8 if src.dtype == "f16" else 4) == 0
+        op = Op(L.OP_RESHARD_ROWS, name)
+        op.i[0:8] = [rows, src.cols, chunk, s_src, s_dst, src.ld, dst.ld, _DT[src.dtype]]
+        op.p[0], op.p[1] = src.ref, dst.ref
+        if residual is not None:
+            assert residual.dtype == "f32" and src.dtype == "f32"
+            op.i[8] = residual.ld
+            op.p[2] = residual.ref
+        op.out = dst
+        return self._emit(op)
+
+    def alltoall(self, name: str, send: Buf, recv: Buf, chunk_bytes: int, shard: TShardSpec, direction: int) -> Op:
+        """Frame <-> pixel resharding over the T group (T2V_OP_ALLTOALL; layouts in include/t2v_hip.h).  direction 0:
+        frames -> pixels, 1: pixels -> frames.  The rank's own part is moved by reshard_rows ops."""
+        op = Op(L.OP_ALLTOALL, name)
+        op.i[0], op.i[1] = chunk_bytes & 0xFFFFFFFF, chunk_bytes >> 32
+        op.i[2], op.i[3], op.i[4], op.i[5], op.i[6] = shard.size, shard.index, shard.counts[0], shard.counts[-1], direction
+        op.p[0], op.p[1] = send.ref, recv.ref
+        op.meta = dict(type="alltoall")
         return self._emit(op)
 
     def memset(self, name: str, buf: Buf) -> Op:

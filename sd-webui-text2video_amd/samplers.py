@@ -195,11 +195,14 @@ class GaussianDiffusion(object):
         pair_key = pair_ctx = pair_refs = None      # pair_refs keeps the tensors alive, so their ids stay unique
         try:
             all_t = self.get_time_steps(stride, 1).cpu()
+            # every step's timestep row, uploaded once: [steps, 2 * Bx] fp32 (the b = 2 * Bx CFG forward reads a whole row, a
+            # b = Bx forward its first half) — no per-step fill kernels inside the loop
+            tt_all = all_t[:steps].to(torch.float32).view(-1, 1).repeat(1, 2 * Bx).to(dev)
             for step in range(steps):
                 c, uc = reconstruct_conds(conditioning, unconditional_conditioning, step)
                 c0, uc0 = c, uc
                 t = int(all_t[step])
-                tt = torch.full((Bx,), t, dtype=torch.long, device=dev)
+                tt = tt_all[step, :Bx]
                 if Bx > 1:
                     c = c.expand(Bx, *c.shape[1:]) if c.shape[0] == 1 else c
                     if uc is not None:
@@ -221,7 +224,7 @@ class GaussianDiffusion(object):
                         ident = (id(c0), c0._version, id(uc0), uc0._version, Bx)
                         if pair_key != ident:
                             pair_key, pair_ctx, pair_refs = ident, torch.cat([c, uc], dim=0), (c0, uc0)
-                        eps = model.forward_cfg_pair(xt, tt, pair_ctx, context_token=pair_key)
+                        eps = model.forward_cfg_pair(xt, tt_all[step], pair_ctx, context_token=pair_key)
                     elif getattr(model, "supports_cfg_batch", False):
                         eps = model(torch.cat([xt, xt], dim=0), torch.cat([tt, tt]), torch.cat([c, uc], dim=0))
                     else:

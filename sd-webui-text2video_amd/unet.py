@@ -646,9 +646,15 @@ class _Lowering:
         P.free(h2)
         return t
 
-    def transformer_block(self, prefix, x1: Buf, inner, heads, kind, h, w) -> Buf:
-        """x1: fp32 [M, inner] residual stream (consumed).  Returns fp16 [M, inner] (feeds proj_out)."""
+    def transformer_block(self, prefix, x1: Buf, inner, heads, kind, h, w, geom=None) -> Buf:
+        """x1: fp32 [M, inner] residual stream (consumed).  Returns fp16 [M, inner] (feeds proj_out).
+        geom = (frames, pixels per frame) of x1's rows when they are NOT this rank's frame slice: the pixel-sharded
+        layout of a T-sharded TemporalTransformer — all frames of the clip, hw / R pixels — where the block is local."""
         P, Mrows, hw, F, B = self.P, x1.rows, h * w, self.F, self.B
+        local = geom is not None
+        if local:
+            F, hw = geom
+            assert B == 1 and Mrows == F * hw
         scale = 64 ** -0.5
 
         def self_attention_sharded(tag, xin: Buf) -> Buf:
@@ -682,7 +688,7 @@ class _Lowering:
             return xo
 
         def self_attention(tag, xin: Buf) -> Buf:
-            if kind == "temporal" and self.shard is not None:
+            if kind == "temporal" and self.shard is not None and not local:
                 return self_attention_sharded(tag, xin)
             n = P.alloc(Mrows, inner, "f16")
             P.layernorm(f"{prefix}.norm{tag}", xin, self.vec(f"{prefix}.norm{tag}.weight"), self.vec(f"{prefix}.norm{tag}.bias"), n)
@@ -760,6 +766,8 @@ class _Lowering:
     def temporal_transformer(self, prefix, x: Buf, c, heads, h, w, dest: Optional[Buf] = None) -> Buf:
         P = self.P
         inner = heads * 64
+        if self.shard is not None and (h * w) % self.shard.size == 0:
+            return self.temporal_transformer_resharded(prefix, x, c, heads, h, w, dest)
         n = self.gn(prefix + ".norm", x, prefix + ".norm", per_frame=False, eps=1e-6, silu=False)
         x1 = P.alloc(x.rows, inner, "f32")
         P.gemm(prefix + ".proj_in", n, self.w_linear(prefix + ".proj_in"), inner, c, x1, bias=self.vec(prefix + ".proj_in.bias"))
@@ -769,6 +777,44 @@ class _Lowering:
         P.gemm(prefix + ".proj_out", x4, self.w_linear(prefix + ".proj_out"), c, inner, out,
                bias=self.vec(prefix + ".proj_out.bias"), residual=x)
         P.free(x4)
+        return out
+
+    def temporal_transformer_resharded(self, prefix, x: Buf, c, heads, h, w, dest: Optional[Buf] = None) -> Buf:
+        """T-sharded clip: everything between the block's GroupNorm and its `+ x` is local to a PIXEL (its tokens are the
+        frames of one pixel, t2v_model.py:716-767), so instead of gathering K/V of all frames twice (6 slice-units received
+        per rank) the block is resharded once: frame split -> pixel split (all frames of hw / R pixels) of the normalised
+        fp16 tokens, the unsharded block lowering on that geometry, and the fp32 result back to the frame split where the
+        residual is added — 0.75 + 1.5 slice-units moved per rank, and the rows are balanced even for uneven frame slices.
+        Layouts: frame-sharded row = f_local * hw + pixel; pixel-sharded row = f_clip * (hw / R) + pixel_local."""
+        P, sh = self.P, self.shard
+        R, r, hw = sh.size, sh.index, h * w
+        hwr, Ft, Fl, cb = hw // R, sh.total, self.F, sh.counts[0]          # pixels per rank, clip frames, my frames, frames per slice
+        inner = heads * 64
+        n = self.gn(prefix + ".norm", x, prefix + ".norm", per_frame=False, eps=1e-6, silu=False)     # [Fl*hw, c] fp16, frame split
+        # ---- frames -> pixels: part q of `n` (pixels [q*hwr, (q+1)*hwr) of my frames) goes to rank q
+        xp = P.alloc(Ft * hwr, c, "f16")
+        stage = P.alloc(R * Fl * hwr, c, "f16")
+        for q in range(R):
+            dst = xp.row_slice(sh.offset * hwr, (sh.offset + Fl) * hwr) if q == r else stage.row_slice(q * Fl * hwr, (q + 1) * Fl * hwr)
+            P.reshard_rows(f"{prefix}.f2p.pack{q}", n.row_slice(q * hwr, n.rows), dst, rows=Fl * hwr, chunk=hwr, s_src=hw, s_dst=hwr)
+        P.alltoall(prefix + ".f2p", stage, xp, hwr * c * 2, sh, 0)
+        P.free(n, stage)
+        x1 = P.alloc(Ft * hwr, inner, "f32")
+        P.gemm(prefix + ".proj_in", xp, self.w_linear(prefix + ".proj_in"), inner, c, x1, bias=self.vec(prefix + ".proj_in.bias"))
+        P.free(xp)
+        x4 = self.transformer_block(prefix + ".transformer_blocks.0", x1, inner, heads, "temporal", h, w, geom=(Ft, hwr))
+        yp = P.alloc(Ft * hwr, c, "f32")
+        P.gemm(prefix + ".proj_out", x4, self.w_linear(prefix + ".proj_out"), c, inner, yp, bias=self.vec(prefix + ".proj_out.bias"))
+        P.free(x4)
+        # ---- pixels -> frames: frames of slice q (rows [q*cb*hwr, ...) of yp) go to rank q; then unpack + residual
+        back = P.alloc(R * Fl * hwr, c, "f32")
+        P.alltoall(prefix + ".p2f", yp, back, hwr * c * 4, sh, 1)
+        out = self._dest(dest, x.rows, c, "f32")
+        for q in range(R):
+            src = yp.row_slice(sh.offset * hwr, (sh.offset + Fl) * hwr) if q == r else back.row_slice(q * Fl * hwr, (q + 1) * Fl * hwr)
+            P.reshard_rows(f"{prefix}.p2f.unpack{q}", src, out.row_slice(q * hwr, out.rows), rows=Fl * hwr, chunk=hwr, s_src=hwr, s_dst=hw,
+                           residual=x.row_slice(q * hwr, x.rows))
+        P.free(yp, back)
         return out
 
     def resample(self, prefix, attr, x: Buf, c, h, w, *, up, dest: Optional[Buf] = None) -> Buf:

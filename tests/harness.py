@@ -72,6 +72,23 @@ def run_lockstep(executors, exts, stream):
                 off = ops[r].p[0].off
                 for q in range(n):
                     executors[r].arena[off + q * nb: off + (q + 1) * nb] = parts[q]
+        elif ops[0].kind == L.OP_ALLTOALL:
+            base_cnt, last_cnt, direction = ops[0].i[4], ops[0].i[5], ops[0].i[6]
+            cnt = lambda q: last_cnt if q == n - 1 else base_cnt
+            moves = []
+            for me in range(n):                                  # gather every (src -> dst) byte range first, then copy
+                for q in range(n):
+                    if q == me:
+                        continue
+                    if direction == 0:      # me sends cnt(me) chunks to q; q receives them at q.recv + me * base_cnt * nb
+                        src = (me, ops[me].p[0].off + q * cnt(me) * nb, cnt(me) * nb)
+                        dst = (q, ops[q].p[1].off + me * base_cnt * nb)
+                    else:                   # me sends cnt(q) chunks to q; q receives them at q.recv + me * cnt(q) * nb
+                        src = (me, ops[me].p[0].off + q * base_cnt * nb, cnt(q) * nb)
+                        dst = (q, ops[q].p[1].off + me * cnt(q) * nb)
+                    moves.append((executors[src[0]].arena[src[1]: src[1] + src[2]].clone(), dst))
+            for data, (q, off) in moves:
+                executors[q].arena[off: off + data.numel()] = data
         else:  # halo exchange: frame 1 -> prev's frame F+1 ... (byte counts / neighbours read from the op records)
             firsts, lasts = [], []
             for r in range(n):

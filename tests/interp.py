@@ -278,6 +278,19 @@ class Interp:
         raise RuntimeError("collectives are executed by parallel.ShardedExecutor, not the interpreter")
 
     _op17 = _op16
+    _op19 = _op16
+
+    # RESHARD_ROWS ---------------------------------------------------------------------------------------
+    def _op18(self, op, ext):
+        rows, cols, P, s_src, s_dst, ld_src, ld_dst, dt, ld_res = op.i[0:9]
+        r = torch.arange(rows)
+        rs, rd = (r // P) * s_src + r % P, (r // P) * s_dst + r % P
+        src = self.mat(op.p[0], int(rs.max()) + 1, cols, ld_src, _TD[dt], ext)
+        dst = self.mat(op.p[1], int(rd.max()) + 1, cols, ld_dst, _TD[dt], ext)
+        v = src[rs].clone()
+        if op.p[2].space != "null":
+            v = v + self.mat(op.p[2], int(rd.max()) + 1, cols, ld_res, torch.float32, ext)[rd]
+        dst[rd] = v
 
     # TO_UINT8 (tensor2vid) ------------------------------------------------------------------------------
     def _op15(self, op, ext):

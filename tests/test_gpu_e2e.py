@@ -395,7 +395,8 @@ def test_tsharded_forward_two_shards_emulated_on_one_gpu(tiny):
     from sd_webui_text2video_amd.program import BoundProgram, TShardSpec
     net, sd, _ = tiny
     g = torch.Generator().manual_seed(21)
-    for F, R in ((4, 2), (7, 3)):                       # 7 = 3 + 3 + 1: uneven last slice
+    # (4, 2) and (5, 2) = 3 + 2: TemporalTransformers resharded frames <-> pixels (all-to-all); (7, 3) = 3 + 3 + 1: K/V all-gather
+    for F, R in ((4, 2), (5, 2), (7, 3)):
         x = torch.randn(1, 4, F, 8, 8, generator=g)
         y = torch.randn(1, 5, 1024, generator=g)
         t = torch.tensor([613.0])

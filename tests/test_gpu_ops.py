@@ -6,7 +6,7 @@ import math
 import pytest
 import torch
 
-from harness import fill, read, rel_l2, run_both
+from harness import TD, fill, read, rel_l2, run_both
 from sd_webui_text2video_amd import _lib as L
 from sd_webui_text2video_amd import packing as pk
 from sd_webui_text2video_amd.program import Buf, Program, Ref
@@ -576,3 +576,36 @@ def test_copy2d_gelu_variants_and_embed_rows():
     assert torch.equal(read(got, emb), read(it, emb))
     assert torch.equal(read(got, emb16), read(it, emb16))
     assert torch.equal(read(got, emb)[5], w["pos"][5])
+
+
+def test_reshard_rows_pack_and_unpack_with_residual():
+    """T2V_OP_RESHARD_ROWS: chunked row regrouping between the frame-sharded and the pixel-sharded layout of a clip (fp16 pack)
+    and back (fp32 unpack + residual at the destination row), strided source / destination / residual."""
+    frames, hw, hwr, C = 3, 16, 4, 64
+    for dt, with_res in (("f16", False), ("f32", True)):
+        P = Program()
+        g = _g(41)
+        src = P.alloc(frames * hw, C, dt, ld=C + 8)
+        packed = P.alloc(frames * hwr, C, dt)
+        back = P.alloc(frames * hw, C, dt, ld=C + 16)
+        res = P.alloc(frames * hw, C, "f32", ld=C + 4) if with_res else None
+        q = 2                                                            # the pixel range of "rank" 2
+        P.reshard_rows("pack", src.row_slice(q * hwr, src.rows), packed, rows=frames * hwr, chunk=hwr, s_src=hw, s_dst=hwr)
+        P.reshard_rows("unpack", packed, back.row_slice(q * hwr, back.rows), rows=frames * hwr, chunk=hwr, s_src=hwr, s_dst=hw,
+                       residual=res.row_slice(q * hwr, res.rows) if with_res else None)
+
+        def init(it):
+            fill(it, src, g)
+            it.mat(back.ref, back.rows, back.cols, back.ld, TD[dt], {}).zero_()
+            if with_res:
+                fill(it, res, g)
+        it, got, _, _ = run_both(P, {}, {}, init)
+        a, b = read(it, back), read(got, back)
+        assert torch.equal(a, b)
+        s_, r_ = read(it, src).float(), (read(it, res) if with_res else None)
+        want = torch.zeros(frames * hw, C)
+        for f in range(frames):
+            rows = slice(f * hw + q * hwr, f * hw + (q + 1) * hwr)
+            want[rows] = s_[rows] + (r_[rows] if with_res else 0)
+        assert torch.equal(b.float(), want.to(TD[dt]).float())
+        assert torch.equal(read(got, packed).float(), torch.cat([s_[f * hw + q * hwr: f * hw + (q + 1) * hwr] for f in range(frames)]))

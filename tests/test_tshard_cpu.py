@@ -58,6 +58,13 @@ def _worker(rank, world, port, F, ret):
         it = Interp(comp.prog, comp.packer.materialise(net.state_dict(), "cpu"))
         ex = parallel.ShardedExecutor(comp.prog, it.arena, shard, lambda ops: _Seg(it, ops))
         assert ex.n_collectives == 22 * 8 + 17 * 3            # 39 temporal sites
+        kinds = [op.kind for k, op in ex.steps if k == "coll"]
+        # TemporalTransformers per level (8x8 / 4x4 / 2x2 / 1x1 pixels): 6 / 5 / 5 / 1.  Where the pixel count divides by the
+        # ranks the block is resharded frames <-> pixels (2 all-to-alls), elsewhere (1x1; everything at 3 ranks) it gathers
+        # K/V (2 all-gathers).  Statistics gathers: 88 + 17; halo exchanges: 88.
+        n_resharded = sum(n for px, n in ((64, 6), (16, 5), (4, 5), (1, 1)) if px % world == 0)
+        assert kinds.count(L.OP_ALLTOALL) == 2 * n_resharded and kinds.count(L.OP_HALO_EXCHANGE) == 88
+        assert kinds.count(L.OP_ALLGATHER) == 105 + 2 * (17 - n_resharded)
         out = torch.empty(1, 4, spec.frames, 8, 8)
         xl = x[:, :, spec.offset:spec.offset + spec.frames].contiguous()
         ex.run({L.EXT_X: xl, L.EXT_T: t, L.EXT_CTX: y, L.EXT_OUT: out}, None)
