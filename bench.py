@@ -209,8 +209,13 @@ def main():
     ctl = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl")      # "nccl" is RCCL on ROCm
+        # T2V_BENCH_ONE_DEVICE=1 (rehearsal of the N > 1 code path on a 1-GPU box): every rank on cuda:0, gloo instead of
+        # RCCL (device buffers staged through the host, parallel.all_gather_into) — never a measurement configuration
+        one_device = os.environ.get("T2V_BENCH_ONE_DEVICE") == "1"
+        dist.init_process_group(backend="gloo" if one_device else "nccl")      # "nccl" is RCCL on ROCm
         ctl = dist.new_group(backend="gloo")         # control plane (layout agreement), never on the data path
+        if one_device:
+            local_rank = 0
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -314,6 +319,8 @@ def main():
     }
     if fallback is not None:
         result["config"]["layout_fallback"] = fallback
+    if world > 1 and os.environ.get("T2V_BENCH_ONE_DEVICE") == "1":
+        result["data"] = "synthetic; REHEARSAL: all ranks on one GPU over gloo — not a measurement"
     if world > 1 and mode != "replicas":
         # the collective-free layout beside the headline: every GPU its own 24-frame video (configs[1] per GPU)
         try:

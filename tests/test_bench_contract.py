@@ -1,4 +1,4 @@
-"""CPU: the committed bench line (profiles/r01_bench_n1.json, produced by `python bench.py` on an MI355X) carries every
+"""CPU: the committed bench line (profiles/r02_bench_n1.json, produced by `python bench.py` on an MI355X) carries every
 field of the measurement contract; bench.py's command line keeps the documented flags."""
 import json
 import os
@@ -9,7 +9,7 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_n1.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_n1.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -21,6 +21,13 @@ def test_committed_bench_line_has_the_contract_fields():
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] == 2500.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and (r["traffic"] is None or r["traffic"] > 0)
+    # round 2: the line names the BASELINE configuration it ran, the layout, and the whole-job fraction of the MFMA peak
+    assert "24f@256x256" in d["metric"] and "configs[1]" in d["config"]["workload"] and d["config"]["layout"] == "single"
+    wv = r["whole_video"]
+    assert abs(wv["frac"] - wv["tflop"] / (d["ms_per_step"] * 1e-3) / d["n_gpus"] / r["peak"]) < 2e-3
+    assert r["strict_bytes_per_launch"] < r["algorithmic_bytes_per_launch"] and abs(r["traffic_over_strict"] - r["traffic"] / r["strict_bytes_per_launch"]) < 1e-2
+    big = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_n1_125f.json")))
+    assert "125f@256x256" in big["metric"] and "configs[2]" in big["config"]["workload"] and big["roofline"]["traffic"] is None
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
 
