@@ -281,6 +281,8 @@ def main():
     err = ""
     try:
         runner = build(mode, frames)
+        if os.environ.get("T2V_BENCH_INJECT_FAILURE") == str(rank):      # rehearsal hook: exercise the collective fallback
+            raise RuntimeError("injected failure (T2V_BENCH_INJECT_FAILURE)")
         runner(cond, uncond, 999)                  # first pass: lowering, weight packing, communicator set-up
         sync()
         ok = True
