@@ -609,3 +609,118 @@ def test_reshard_rows_pack_and_unpack_with_residual():
             want[rows] = s_[rows] + (r_[rows] if with_res else 0)
         assert torch.equal(b.float(), want.to(TD[dt]).float())
         assert torch.equal(read(got, packed).float(), torch.cat([s_[f * hw + q * hwr: f * hw + (q + 1) * hwr] for f in range(frames)]))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Independent op-level checks: the HIP kernels against torch.nn.functional / explicit torch formulas (NOT the interpreter
+# of tests/interp.py, which is this repository's own restatement of each op)
+# ------------------------------------------------------------------------------------------------------------------
+def _gpu_run(P, w, init):
+    it, got, _, _ = run_both(P, w, {}, init)
+    return it, got
+
+
+@pytest.mark.parametrize("kind,B,F,hw,heads,D,Lc", [("spatial", 1, 2, 1024, 5, 64, 0), ("spatial", 1, 2, 80, 8, 40, 0),
+                                                    ("cross", 2, 3, 64, 2, 64, 77), ("temporal", 2, 24, 16, 3, 64, 0),
+                                                    ("temporal", 1, 125, 4, 2, 64, 0), ("spatial", 1, 1, 144, 3, 160, 0)])
+def test_attention_against_torch_sdpa(kind, B, F, hw, heads, D, Lc):
+    inner = heads * D
+    M = B * F * hw
+    P = Program()
+    g = _g(110)
+    scale = D ** -0.5
+    if kind == "cross":
+        q, kv, o = P.alloc(M, inner, "f16"), P.alloc(B * Lc, 2 * inner, "f16"), P.alloc(M, inner, "f16")
+        k, v = kv.col_slice(0, inner), kv.col_slice(inner, 2 * inner)
+        P.attention("a", q.ref, k.ref, v.ref, o.ref, nq=hw, nk=Lc, heads=heads, b_outer=B, b_inner=F,
+                    q_strides=(inner, F * hw * inner, hw * inner), kv_strides=(kv.ld, Lc * kv.ld, 0),
+                    o_strides=(inner, F * hw * inner, hw * inner), scale=scale, head_dim=D)
+        bufs = [q, kv]
+    else:
+        qkv, o = P.alloc(M, 3 * inner, "f16"), P.alloc(M, inner, "f16")
+        ld = 3 * inner
+        q, k, v = qkv.col_slice(0, inner), qkv.col_slice(inner, 2 * inner), qkv.col_slice(2 * inner, 3 * inner)
+        if kind == "spatial":
+            P.attention("a", q.ref, k.ref, v.ref, o.ref, nq=hw, nk=hw, heads=heads, b_outer=B * F, b_inner=1,
+                        q_strides=(ld, hw * ld, 0), kv_strides=(ld, hw * ld, 0), o_strides=(inner, hw * inner, 0), scale=scale, head_dim=D)
+        else:
+            P.attention("a", q.ref, k.ref, v.ref, o.ref, nq=F, nk=F, heads=heads, b_outer=B, b_inner=hw,
+                        q_strides=(hw * ld, F * hw * ld, ld), kv_strides=(hw * ld, F * hw * ld, ld),
+                        o_strides=(hw * inner, F * hw * inner, inner), scale=scale, head_dim=D)
+        bufs = [qkv]
+    it, got = _gpu_run(P, {}, lambda it: [fill(it, b, g, 1.2) for b in bufs])
+    qf, kf, vf = read(it, q).float(), read(it, k).float(), read(it, v).float()
+    if kind == "spatial":        # '(b f) n (h d)'
+        sh = lambda t: t.view(B * F, hw, heads, D).transpose(1, 2)
+        ref = torch.nn.functional.scaled_dot_product_attention(sh(qf), sh(kf), sh(vf)).transpose(1, 2).reshape(M, inner)
+    elif kind == "temporal":     # rows (b f hw): sequences over f for every (b, pixel)
+        sh = lambda t: t.view(B, F, hw, heads, D).permute(0, 2, 3, 1, 4)
+        ref = torch.nn.functional.scaled_dot_product_attention(sh(qf), sh(kf), sh(vf)).permute(0, 3, 1, 2, 4).reshape(M, inner)
+    else:                        # text keys of sample b shared by its F frames
+        qs = qf.view(B, F, hw, heads, D).permute(0, 1, 3, 2, 4)
+        ks = kf.view(B, 1, Lc, heads, D).permute(0, 1, 3, 2, 4).expand(B, F, heads, Lc, D)
+        vs = vf.view(B, 1, Lc, heads, D).permute(0, 1, 3, 2, 4).expand(B, F, heads, Lc, D)
+        ref = torch.nn.functional.scaled_dot_product_attention(qs, ks, vs).permute(0, 1, 3, 2, 4).reshape(M, inner)
+    assert rel_l2(read(got, o).float(), ref) < 2e-3, kind
+
+
+@pytest.mark.parametrize("n_inst,rows,C,dt,silu", [(6, 1024, 320, "f32", True), (2, 3 * 256, 640, "f16", True), (4, 64, 1280, "f32", False),
+                                                  (2, 24 * 16, 1280, "f16", False), (3, 256, 128, "f32", True)])
+def test_groupnorm_against_torch_functional(n_inst, rows, C, dt, silu):
+    P = Program()
+    g = _g(120)
+    x, out = P.alloc(n_inst * rows, C, dt), P.alloc(n_inst * rows, C, "f16")
+    w = {"g": 1 + 0.1 * torch.randn(C, generator=g), "b": 0.1 * torch.randn(C, generator=g)}
+    P.groupnorm("gn", x, Ref("weight", 0, "g"), Ref("weight", 0, "b"), out, n_inst=n_inst, eps=1e-5, silu=silu)
+
+    def init(it):
+        v = fill(it, x, g, 1.7)
+        v += 0.4
+    it, got = _gpu_run(P, w, init)
+    xf = read(it, x).float().view(n_inst, rows, C).permute(0, 2, 1)                 # [N, C, L]
+    ref = torch.nn.functional.group_norm(xf, 32, w["g"], w["b"], 1e-5)
+    if silu:
+        ref = torch.nn.functional.silu(ref)
+    assert rel_l2(read(got, out).float(), ref.permute(0, 2, 1).reshape(n_inst * rows, C)) < 1e-3
+
+
+@pytest.mark.parametrize("M,C", [(1000, 320), (77, 1024), (513, 640), (64, 1280)])
+def test_layernorm_and_softmax_against_torch_functional(M, C):
+    P = Program()
+    g = _g(130)
+    x, out = P.alloc(M, C, "f32"), P.alloc(M, C, "f16")
+    s_in, s_out = P.alloc(M, C, "f32"), P.alloc(M, C, "f16")
+    w = {"g": 1 + 0.1 * torch.randn(C, generator=g), "b": 0.1 * torch.randn(C, generator=g)}
+    P.layernorm("ln", x, Ref("weight", 0, "g"), Ref("weight", 0, "b"), out)
+    P.softmax("sm", s_in, s_out, 0.37)
+    it, got = _gpu_run(P, w, lambda it: (fill(it, x, g, 3.0), fill(it, s_in, g, 4.0)))
+    ref = torch.nn.functional.layer_norm(read(it, x), (C,), w["g"], w["b"], 1e-5)
+    assert rel_l2(read(got, out).float(), ref) < 1e-3
+    ref = torch.softmax(read(it, s_in) * 0.37, dim=1)
+    assert rel_l2(read(got, s_out).float(), ref) < 1e-3
+
+
+@pytest.mark.parametrize("D,T,Tq,off,R", [(40, 16, 16, 0, 16), (80, 16, 6, 5, 16), (160, 16, 4, 12, 16), (64, 24, 24, 0, 8), (40, 7, 3, 3, 2)])
+def test_relpos_attention_against_explicit_formula(D, T, Tq, off, R):
+    """attention_temporal.py:107-144 written out with torch (the reference's RelativePosition index: clamp(s - t, -R, R) + R),
+    including the T-sharded form: Tq local queries = frames [off, off + Tq) of the T key frames."""
+    heads, hw = 2, 6
+    inner = heads * D
+    P = Program()
+    g = _g(140 + D)
+    q, kv, o = P.alloc(Tq * hw, inner, "f16"), P.alloc(T * hw, 2 * inner, "f16"), P.alloc(Tq * hw, inner, "f16")
+    w = {"ek": 0.3 * torch.randn(2 * R + 1, D, generator=g), "ev": 0.3 * torch.randn(2 * R + 1, D, generator=g)}
+    scale = D ** -0.5
+    P.attention("a", q.ref, kv.col_slice(0, inner).ref, kv.col_slice(inner, 2 * inner).ref, o.ref, nq=Tq, nk=T, heads=heads,
+                b_outer=1, b_inner=hw, q_strides=(hw * inner, 0, inner), kv_strides=(hw * kv.ld, 0, kv.ld),
+                o_strides=(hw * inner, 0, inner), scale=scale, head_dim=D, rel_k=Ref("weight", 0, "ek"), rel_v=Ref("weight", 0, "ev"),
+                max_rel=R, q_offset=off)
+    it, got = _gpu_run(P, w, lambda it: (fill(it, q, g, 1.0), fill(it, kv, g, 1.0)))
+    qf = read(it, q).float().view(Tq, hw, heads, D).permute(1, 2, 0, 3)                     # [hw, h, Tq, D]
+    kvf = read(it, kv).float().view(T, hw, 2, heads, D)
+    kf, vf = kvf[:, :, 0].permute(1, 2, 0, 3), kvf[:, :, 1].permute(1, 2, 0, 3)             # [hw, h, T, D]
+    idx = (torch.arange(T)[None, :] - (torch.arange(Tq)[:, None] + off)).clamp(-R, R) + R   # [Tq, T]
+    sim = (torch.einsum("phtd,phsd->phts", qf, kf) + torch.einsum("phtd,tsd->phts", qf, w["ek"][idx])) * scale
+    p = sim.softmax(dim=-1)
+    ref = torch.einsum("phts,phsd->phtd", p, vf) + torch.einsum("phts,tsd->phtd", p, w["ev"][idx])
+    assert rel_l2(read(got, o).float(), ref.permute(2, 0, 1, 3).reshape(Tq * hw, inner)) < 2e-3
