@@ -281,7 +281,7 @@ def main():
     err = ""
     try:
         runner = build(mode, frames)
-        if os.environ.get("T2V_BENCH_INJECT_FAILURE") == str(rank):      # rehearsal hook: exercise the collective fallback
+        if os.environ.get("T2V_BENCH_INJECT_FAILURE") in ("all", str(rank)):   # rehearsal hook: exercise the collective fallback
             raise RuntimeError("injected failure (T2V_BENCH_INJECT_FAILURE)")
         runner(cond, uncond, 999)                  # first pass: lowering, weight packing, communicator set-up
         sync()
@@ -291,6 +291,9 @@ def main():
     if not all_ok(ok):
         # An explicitly requested layout that breaks fails the run.  Under `auto` every rank switches TOGETHER to the
         # collective-free layout and the JSON line says so (requested vs. actual layout + the first error seen here).
+        # (This covers failures every rank sees at the same point — a missing library, an unsupported shape.  A failure
+        # on SOME ranks while the others already wait inside a collective cannot be agreed on: the job then ends with
+        # the process-group timeout, an explicit failure, never a silent change of what is measured.)
         if requested != "auto" or world == 1:
             raise RuntimeError(f"layout {mode!r} failed on rank {rank}: {err or 'another rank failed'}")
         fallback = {"requested_layout": mode, "reason": err or "failure on another rank"}

@@ -7,7 +7,7 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp T2V_BENCH_ONE_DEVICE=1
 run() {  # name nproc args...
   name=$1; n=$2; shift 2
-  timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $((29500 + n)) bench.py --gpus $n --steps 1 --warmup 0 --ddim-steps 2 "$@" > gpurun_out/rehearsal_$name.json 2> gpurun_out/rehearsal_$name.err
+  timeout 420 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $((29500 + n)) bench.py --gpus $n --steps 1 --warmup 0 --ddim-steps 2 "$@" > gpurun_out/rehearsal_$name.json 2> gpurun_out/rehearsal_$name.err
   echo "== $name exit $?"; python - <<PY
 import json
 try:
@@ -20,4 +20,4 @@ PY
 }
 run n4_tshard 4 --frames 9
 run n2_pairs 2 --frames 6
-T2V_BENCH_INJECT_FAILURE=2 run n4_fallback 4 --frames 9
+T2V_BENCH_INJECT_FAILURE=all run n4_fallback 4 --frames 9
