@@ -17,6 +17,7 @@ t2v_helpers/args.py:234), "DDIM" (LDM-style, ddim/sampler.py) and "UniPC" (uni_p
 from __future__ import annotations
 
 import ctypes
+import itertools
 import types
 from typing import Optional
 
@@ -199,6 +200,7 @@ class GaussianDiffusion(object):
             model.auto_refresh = False
         stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
         pair_key = pair_ctx = pair_refs = None      # pair_refs keeps the tensors alive, so their ids stay unique
+        run_nonce = next(_RUN_COUNTER)              # a new sampling run never reuses the previous run's cached context K/V
         try:
             all_t = self.get_time_steps(stride, 1).cpu()
             # every step's timestep row, uploaded once: [steps, 2 * Bx] fp32 (the b = 2 * Bx CFG forward reads a whole row, a
@@ -227,7 +229,7 @@ class GaussianDiffusion(object):
                     if hasattr(model, "forward_cfg_pair"):
                         # [cond | uncond] built once while the conditioning OBJECTS stay the same (prompt scheduling may
                         # swap them between steps, reconstruct_cond_batch); x_t is read twice by the entry op
-                        ident = (id(c0), c0._version, id(uc0), uc0._version, Bx)
+                        ident = (run_nonce, id(c0), c0._version, id(uc0), uc0._version, Bx)
                         if pair_key != ident:
                             pair_key, pair_ctx, pair_refs = ident, torch.cat([c, uc], dim=0), (c0, uc0)
                         eps = model.forward_cfg_pair(xt, tt_all[step], pair_ctx, context_token=pair_key)
@@ -303,6 +305,9 @@ def _ddim_update(out, xt, eps_pair, noise, coef, guided: int, mode: int):
     return out
 
 
+_RUN_COUNTER = itertools.count(1)
+
+
 def _require_eta0(eta):
     """Layouts that split one video over ranks (CFG pair / T shards) rely on every rank applying a bit-identical update;
     the per-step eta noise is drawn from each rank's own device RNG, so eta > 0 would let x_t diverge."""
@@ -322,7 +327,7 @@ def _eval_eps_pair(model, x, t_value, c, uc, guide, cfg_parallel=None, cache: Op
         mine = c if cfg_parallel.role == 0 else uc
         return cfg_parallel.exchange_eps(model(x, tt, mine)).contiguous(), True
     if cache is not None and hasattr(model, "forward_cfg_pair") and c.shape[0] == uc.shape[0] == x.shape[0]:
-        ident = (id(c), c._version, id(uc), uc._version)
+        ident = (cache.setdefault("nonce", next(_RUN_COUNTER)), id(c), c._version, id(uc), uc._version)
         if cache.get("key") != ident:
             cache.update(key=ident, ctx=torch.cat([c, uc], dim=0), refs=(c, uc))
         return model.forward_cfg_pair(x, tt, cache["ctx"], context_token=ident).contiguous(), True
@@ -533,6 +538,7 @@ class UniPCSampler(object):
         t_0 = 1.0 / ns.total_N
         ts = torch.linspace(t_T, t_0, steps + 1, dtype=torch.float32).to(torch.float64).tolist()   # 'time_uniform', fp32 grid
         guide = unconditional_guidance_scale
+        self._pair_cache = {}                      # per sampling run (its nonce keeps cached context K/V from leaking across runs)
         if hasattr(model, "refresh_weights"):
             model.refresh_weights(dev)
         prev_auto = getattr(model, "auto_refresh", None)

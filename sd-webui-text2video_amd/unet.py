@@ -330,6 +330,8 @@ class UNetSD(nn.Module):
             n = packer.update(self._packed, sd, device, changed, deps=self._packed_deps)
             if n >= 0:
                 self._packed_sig, self.last_repack = sig, n
+                for c in self._programs.values():
+                    c.ctx_token = None          # cached context K/V were made with the old projection weights
                 return
         elif same_dev:
             extra = sorted(set(sig) - set(self._packed_sig))
@@ -343,6 +345,7 @@ class UNetSD(nn.Module):
         self._packed_sig, self._packed_device, self.last_repack = sig, device, -1
         for c in self._programs.values():
             c.bound = None
+            c.ctx_token = None
 
     def _union_packer(self) -> pk.WeightPacker:
         if not self._programs:

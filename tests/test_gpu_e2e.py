@@ -108,6 +108,39 @@ def test_weight_split_precision_option(tiny):
     assert split < 0.95 * base and n_split > n_base
 
 
+def test_cfg_pair_entry_and_cached_context_kv(tiny):
+    """`forward_cfg_pair`: x_t read twice by the entry op == the explicit torch.cat([x, x]) batch; with an unchanged
+    context token the text K/V projections of the previous call are reused (bit-identical result); a changed context or a
+    weight refresh (LoRA merge of a to_k weight) invalidates them."""
+    net, sd, _ = tiny
+    x, t, y, *_ = _tiny_inputs()
+    x1 = x[:1].to(DEV)
+    tt = torch.tensor([801.0, 801.0], device=DEV)
+    ctx = y.to(DEV)                                     # [cond | uncond]
+    want = net(torch.cat([x1, x1]), tt, ctx)
+    a = net.forward_cfg_pair(x1, tt, ctx, context_token=("run", 1))
+    b = net.forward_cfg_pair(x1, tt, ctx, context_token=("run", 1))           # step-invariant prologue skipped
+    assert torch.equal(a, want) and torch.equal(b, want)
+    comp = next(c for k, c in net._programs.items() if ("xb", 1) in k)
+    assert comp.bound._skip_handle is not None
+    # other timestep, same token: still exact against the uncached path
+    t2 = torch.tensor([401.0, 401.0], device=DEV)
+    assert torch.equal(net.forward_cfg_pair(x1, t2, ctx, context_token=("run", 1)), net(torch.cat([x1, x1]), t2, ctx))
+    # new context content under a NEW token
+    ctx2 = (ctx * 0.5).contiguous()
+    assert torch.equal(net.forward_cfg_pair(x1, tt, ctx2, context_token=("run", 2)), net(torch.cat([x1, x1]), tt, ctx2))
+    # a weight refresh between two calls with the SAME token must not reuse the old K/V
+    mod = net.input_blocks[1][1].transformer_blocks[0].attn2.to_k
+    old = mod.weight
+    before = net.forward_cfg_pair(x1, tt, ctx, context_token=("run", 3))
+    mod.weight = torch.nn.Parameter(old.detach() * 1.5)
+    after = net.forward_cfg_pair(x1, tt, ctx, context_token=("run", 3))
+    mod.weight = old
+    assert not torch.equal(before, after)
+    assert torch.isfinite(after).all()
+    assert torch.equal(net.forward_cfg_pair(x1, tt, ctx, context_token=("run", 3)), want)
+
+
 def test_weight_mutation_is_picked_up(tiny):
     """LoRA-style in-place mutation between calls must invalidate the packed weights (SURVEY §2.1 #8)."""
     net, sd, _ = tiny
