@@ -106,7 +106,7 @@ enum t2v_gather {
  *      11 stride, 12 upsample, 13 Hout, 14 Wout, 15 rows_per_batch, 16 epilogue,
  *      17 out dtype, 18 act (0 none, 1 SiLU), 19 split_k, 20 bias_along_m, 21 ldrb,
  *      22 tile (0 = 128x128-class kernel; 1 256x256, 2 256x320, 3 128x256 (8 waves, 3-stage ring), 4 / 5 128x128 with a 4-deep
- *         ring on 4 / 8 waves, 6 / 7 = 1 / 2 with the two-group ping-pong schedule),
+ *         ring on 4 / 8 waves, 6 / 7 = 1 / 2 with the two-group ping-pong schedule, 8 / 9 192x320 / 192x256 on 12 waves),
  *      23 tconv halo (input rows are [clip][F+2][HW]: one halo frame either side, T-sharding);
  *         for CONV3X3: 1 = zero padding (0,1,0,1) instead of (1,1,1,1) (LDM encoder Downsample, taps at +0..+2)
  *   p: 0 A fp16, 1 W fp16 [N,K], 2 bias fp32 [N] (or [M] if bias_along_m), 3 rowbias fp32

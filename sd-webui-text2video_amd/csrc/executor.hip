@@ -65,7 +65,7 @@ int validate_op(const t2v_op& op, int idx) {
       if (op.i[16] == T2V_EPI_GEGLU && (N % 32 != 0 || op.i[17] != T2V_F16)) return bad("GEGLU needs N % 32 == 0, fp16 out");
       if (op.i[19] > 1 && op.p[6] == 0) return bad("split-K without workspace");
       if (op.p[3] != 0 && op.i[15] <= 0) return bad("rowbias without rows_per_batch");
-      if (op.i[22] < 0 || op.i[22] > 7) return bad("unknown tile id");
+      if (op.i[22] < 0 || op.i[22] > 9) return bad("unknown tile id");
       return 0;
     }
     case T2V_OP_GROUPNORM: {
@@ -189,7 +189,7 @@ hipError_t launch_op(const t2v_op& op, hipStream_t s) {
       p.halo = op.i[23];
       const int tile = op.i[22];
       // the large-tile kernel advances its source pointers by whole k-tiles: needs K % BK == 0
-      if (tile >= 1 && tile <= 7 && p.gather != T2V_GATHER_CONV3X3_C8 && p.K % 64 == 0) return t2v_launch_gemm2(p, tile, s);
+      if (tile >= 1 && tile <= 9 && p.gather != T2V_GATHER_CONV3X3_C8 && p.K % 64 == 0) return t2v_launch_gemm2(p, tile, s);
       return t2v_launch_gemm(p, s);
     }
     case T2V_OP_GROUPNORM: return t2v_launch_groupnorm(op, s);

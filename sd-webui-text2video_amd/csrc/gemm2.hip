@@ -549,7 +549,7 @@ hipError_t launch_cfg(const GemmParams& pin, hipStream_t s) {
 
 }  // namespace
 
-// tile ids (t2v_op.i[22]):  1 = 256x256, 2 = 256x320, 3 = 128x256 (8 waves), 4 / 5 = 128x128 with a 4-deep ring
+// tile ids (t2v_op.i[22]):  1 = 256x256, 2 = 256x320, 8 = 192x320 / 9 = 192x256 (12 waves), 3 = 128x256 (8 waves), 4 / 5 = 128x128 with a 4-deep ring
 // (few-row levels: latency-bound, keep 96 KiB per CU in flight) — 64-wide k-tiles
 // (full 128-byte lines per row = one conv reduction chunk), 2-3 stage ring, one workgroup per CU.
 hipError_t t2v_launch_gemm2(const GemmParams& p, int tile, hipStream_t s) {
@@ -559,6 +559,8 @@ hipError_t t2v_launch_gemm2(const GemmParams& p, int tile, hipStream_t s) {
     case 3: return launch_cfg<2, 4, 2, 2, 64, 3, 2>(p, s);   // 3 x 48 KiB
     case 4: return launch_cfg<2, 2, 2, 2, 64, 4, 1>(p, s);   // 128x128, 4 waves, 4 x 32 KiB: 3 k-tiles in flight
     case 5: return launch_cfg<2, 4, 2, 1, 64, 4, 2>(p, s);   // 128x128, 8 waves, 4 x 32 KiB
+    case 8: return launch_cfg<6, 2, 1, 5, 64, 2, 3>(p, s);   // 192x320, 12 waves (3 per SIMD), 2 x 64 KiB: M = 49152 -> exactly 256 workgroups
+    case 9: return launch_cfg<6, 2, 1, 4, 64, 2, 3>(p, s);   // 192x256, 12 waves, 2 x 56 KiB (N = 256 * j where 256-row grids fill badly)
     case 6: return launch_cfg<2, 4, 4, 2, 64, 2, 2, true>(p, s);   // 256x256 ping-pong (two staggered wave groups)
     case 7:                                                         // 256x320 ping-pong
       if (p.gather == T2V_GATHER_CONV3X3 && p.up) return launch_cfg<4, 2, 2, 5, 64, 2, 2>(p, s);   // (upsample gather: register budget)

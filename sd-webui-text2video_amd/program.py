@@ -209,9 +209,15 @@ class Program:
             tile = 0
         elif M >= 32768:                               # 32x32 level: big tiles, 320-wide when it divides
             tile = 2 if n % 320 == 0 and n != 960 else 1
+            # 192x320 on 12 waves: M = 49152 gives exactly 256 / 768 workgroups for N = 320 / 960 instead of 192 / 768 tiles of
+            # 256 rows on 256 CUs; measured (tools/gemm_sweep.py L0) +13 % / +6 % on the C -> C and QKV linears, +3-6 % on the
+            # K = 960 .. 2880 convolutions, -7 % on the 8-wave-deep GEGLU GEMM (LDS traffic per MFMA is higher) -> only where
+            # the 256-row grid is a few, badly filled waves
+            if n % 320 == 0 and math.ceil(M / 256) * (n // 320) <= 640 and os.environ.get("T2V_TILE8", "1") != "0":
+                tile = 8
         elif M >= 8192:                                # 16x16 level (b=2) / 32x32 level of a single CFG role (b=1)
             if gather == L.GATHER_CONV3X3 and k >= 2560 and n % 320 == 0:
-                tile = 2
+                tile = self._fill_choice(M, n, k) if allow_splitk else 2
             elif n >= 2560:
                 tile = 2 if n % 320 == 0 else 1
             elif n >= 1536:
@@ -225,6 +231,12 @@ class Program:
                 tile = 1 if M >= 1024 else (0 if M >= 512 else 5)
             elif n >= 2560:
                 tile = 1 if M >= 2048 else (3 if M >= 1024 else 5)
+                # 256-row tiles of M = 3072 x N = 3840 are 180 workgroups for 256 CUs; 192-row tiles give 240
+                if tile == 1 and n % 256 == 0 and os.environ.get("T2V_TILE8", "1") != "0":
+                    w1, w9 = math.ceil(M / 256) * (n // 256), math.ceil(M / 192) * (n // 256)
+                    fill = lambda wgs: wgs / (math.ceil(wgs / cus) * cus)
+                    if fill(w9) > fill(w1) + 0.05:
+                        tile = 9
             elif gather == L.GATHER_CONV3X3 and k >= 8192:
                 tile = 2 if (M >= 4096 and n % 320 == 0) else 3
             else:
@@ -233,7 +245,7 @@ class Program:
             bm, bn, bk = 128, (64 if (n % 128 != 0 and n % 128 <= 64) else 128), 64
         else:
             bm, bn, bk = {1: (256, 256, 64), 2: (256, 320, 64), 3: (128, 256, 64), 4: (128, 128, 64), 5: (128, 128, 64),
-                          6: (256, 256, 64), 7: (256, 320, 64)}[tile]
+                          6: (256, 256, 64), 7: (256, 320, 64), 8: (192, 320, 64), 9: (192, 256, 64)}[tile]
         tiles = math.ceil(M / bm) * math.ceil(n / bn)
         kt = math.ceil(k / bk)
         split = 1
@@ -250,6 +262,23 @@ class Program:
                 # one workgroup per CU: keep tiles*split within ONE wave of workgroups
                 split = max(1, min(cus // tiles, kt // 8, 32))
         return tile, split
+
+    def _fill_choice(self, M: int, n: int, k: int) -> int:
+        """256x320 (tile 2) or 192x320 on 12 waves (tile 8) for a long-K convolution with N = 320 * j: whichever grid,
+        after its split-K, fills the last wave of workgroups better (M = 12288, N = 640: 96 x 2 splits = 192 of 256 CUs
+        against 128 x 2 = 256)."""
+        if os.environ.get("T2V_TILE8", "1") == "0":
+            return 2
+        cus, kt = self.target_cus, math.ceil(k / 64)
+        best, best_fill = 2, -1.0
+        for tile, bm in ((2, 256), (8, 192)):
+            tiles = math.ceil(M / bm) * (n // 320)
+            split = max(1, min(cus // tiles, kt // 8, 32)) if (kt >= 16 and tiles < 0.6 * cus) else 1
+            wgs = tiles * split
+            fill = wgs / (math.ceil(wgs / cus) * cus)
+            if fill > best_fill + 0.05:
+                best, best_fill = tile, fill
+        return best
 
     # ---- ops ------------------------------------------------------------------------------
     def begin(self):

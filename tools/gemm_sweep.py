@@ -33,8 +33,8 @@ for label, gather, M, N, K, conv, epi in SHAPES:
     if only and only not in label:
         continue
     res = []
-    for tile in (0, 1, 2, 3, 4, 5, 6, 7):
-        if tile in (2, 7) and N % 320 != 0:
+    for tile in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9):
+        if tile in (2, 7, 8) and N % 320 != 0:
             continue
         splits = [1]
         P0 = Program(); P0.force_tile = tile
