@@ -215,17 +215,21 @@ class Program:
             # the 256-row grid is a few, badly filled waves
             if n % 320 == 0 and math.ceil(M / 256) * (n // 320) <= 640 and os.environ.get("T2V_TILE8", "1") != "0":
                 tile = 8
+            elif tile == 1 and n % 256 == 0 and os.environ.get("T2V_TILE8", "1") != "0":
+                # the stem TemporalTransformer (inner = 512): 192 x 2 tiles of 256x256 = 384 workgroups, 192x256 gives 512
+                w1, w9 = math.ceil(M / 256) * (n // 256), math.ceil(M / 192) * (n // 256)
+                fill = lambda wgs: wgs / (math.ceil(wgs / cus) * cus)
+                if w1 <= 1280 and fill(w9) > fill(w1) + 0.05:
+                    tile = 9
         elif M >= 8192:                                # 16x16 level (b=2) / 32x32 level of a single CFG role (b=1)
             if gather == L.GATHER_CONV3X3 and k >= 2560 and n % 320 == 0:
                 tile = self._fill_choice(M, n, k) if allow_splitk else 2
             elif n >= 2560:
                 tile = 2 if n % 320 == 0 else 1
             elif n >= 1536:
-                tile = 3
-            elif gather == L.GATHER_PLAIN and k >= 2048:
-                tile = 5
+                tile = 9 if os.environ.get("T2V_TILE8", "1") != "0" else 3      # 16x16-level QKV (12288, 1920, 640): 492 vs 452 TF/s
             else:
-                tile = 0
+                tile = 0               # (the 4-deep-ring 128x128 tile measured 640 vs 668 TF/s on the K = 2560 feed-forward GEMM)
         else:                                          # 8x8 / 4x4 levels: few rows, latency-bound
             if n >= 8192:
                 tile = 1 if M >= 1024 else (0 if M >= 512 else 5)
