@@ -222,7 +222,11 @@ class Program:
                 if w1 <= 1280 and fill(w9) > fill(w1) + 0.05:
                     tile = 9
         elif M >= 8192:                                # 16x16 level (b=2) / 32x32 level of a single CFG role (b=1)
-            if gather == L.GATHER_CONV3X3 and k >= 2560 and n % 320 == 0:
+            if M >= 16384 and n <= 1024 and os.environ.get("T2V_TILE8", "1") != "0":
+                # one CFG role per GPU (pairs / T-shard layouts: M = 24576): 192x256 on 12 waves gives 128 x ceil(N / 256)
+                # workgroups; measured (SWEEP_BATCH=1 tools/gemm_sweep.py L0) +7 % QKV, +9 % feed-forward, +13 % temporal conv
+                tile = 9
+            elif gather == L.GATHER_CONV3X3 and k >= 2560 and n % 320 == 0:
                 tile = self._fill_choice(M, n, k) if allow_splitk else 2
             elif n >= 2560:
                 tile = 2 if n % 320 == 0 else 1
