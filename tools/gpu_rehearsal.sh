@@ -20,4 +20,4 @@ PY
 }
 run n4_tshard 4 --frames 9
 run n2_pairs 2 --frames 6
-T2V_BENCH_INJECT_FAILURE=all run n4_fallback 4 --frames 9
+T2V_BENCH_INJECT_FAILURE=all run n4_fallback 4 --frames 9      # every rank fails at the same point -> collective switch to replicas
