@@ -329,6 +329,11 @@ class UNetSD(nn.Module):
             changed = [n for n, v in sig.items() if self._packed_sig[n] != v]
             n = packer.update(self._packed, sd, device, changed, deps=self._packed_deps)
             if n >= 0:
+                # images that only an EVICTED program declared are not refreshed by `update`: drop them, a re-compiled
+                # geometry packs them again (`_pack_missing`) instead of finding a stale copy
+                for k in [k for k in self._packed if k not in packer._names]:
+                    del self._packed[k]
+                    self._packed_deps.pop(k, None)
                 self._packed_sig, self.last_repack = sig, n
                 for c in self._programs.values():
                     c.ctx_token = None          # cached context K/V were made with the old projection weights

@@ -233,3 +233,25 @@ def test_weight_split_option_lowers_and_improves_in_interpreter():
         it.run({L.EXT_X: x, L.EXT_T: t, L.EXT_CTX: y, L.EXT_OUT: out})
         errs.append(rel_l2(out, gold))
     assert errs[1] < 0.92 * errs[0] and errs[1] < 2e-3, errs
+
+
+def test_program_cache_eviction_and_stale_images():
+    """At most `max_programs` compiled geometries are kept; packed images that only an evicted program declared are dropped
+    at the next partial weight refresh, so a later re-compile cannot pick up a stale copy (host bookkeeping only)."""
+    cfg, m, sd, x, t, y = _tiny()
+    m.max_programs = 2
+    keys = []
+    for F in (1, 2, 3):
+        key = (1, F, 8, 8, 7, "f32", "f32", "f32")
+        m._programs[key] = m._compile(1, F, 8, 8, 7, "f32", "f32")
+        m._evict_programs(keep=key)
+        keys.append(key)
+    assert list(m._programs) == keys[1:]
+    m.refresh_weights("cpu")
+    assert m.last_repack == -1 and "kv_all:lin" in m._packed
+    m._packed["only_an_evicted_program:lin"] = torch.zeros(4)            # stands for an image of the evicted geometry
+    m._packed_deps["only_an_evicted_program:lin"] = frozenset({"out.2.weight"})
+    with torch.no_grad():
+        m.out[2].weight.mul_(1.5)
+    m.refresh_weights("cpu")
+    assert m.last_repack >= 1 and "only_an_evicted_program:lin" not in m._packed
