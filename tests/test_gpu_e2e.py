@@ -338,7 +338,8 @@ def test_unet_frame_count_edge_cases(tiny):
     """F=1 (single frame: temporal convs see only padding) and odd spatial sizes."""
     net, sd, _ = tiny
     g = torch.Generator().manual_seed(9)
-    for (B, F, H, W, Lc) in [(1, 1, 8, 8, 3), (1, 5, 8, 24, 77), (2, 2, 16, 8, 1)]:
+    # + a 154-token context (a prompt of two 77-token chunks, clip_hardcode.py) and a batch of three
+    for (B, F, H, W, Lc) in [(1, 1, 8, 8, 3), (1, 5, 8, 24, 77), (2, 2, 16, 8, 1), (1, 3, 8, 8, 154), (3, 2, 8, 8, 77)]:
         x = torch.randn(B, 4, F, H, W, generator=g)
         y = torch.randn(B, Lc, 1024, generator=g)
         t = torch.randint(0, 1000, (B,), generator=g)
