@@ -172,6 +172,18 @@ def gemm_strict_bytes(op) -> int:
     return a + N * K * 2 + M * (N // 2 if epi == 1 else N) * 2
 
 
+def choose_layout(world: int, requested: str, frames_arg: int = 0):
+    """-> (layout, frames per video).  auto: one GPU = configs[1] (24 frames, cond + uncond batched); 2 GPUs = one 24-frame
+    video per CFG pair; an even world >= 4 = configs[2], ONE 125-frame video, frames sharded along T over world / 2 GPUs x the
+    CFG pair (north_star's layout); an odd world > 1 = one video per GPU.  `--frames` overrides the frame count only."""
+    mode = requested
+    if mode == "auto":
+        mode = "single" if world == 1 else ("pairs" if world == 2 else ("tshard" if world % 2 == 0 else "replicas"))
+    if world == 1:
+        mode = "single"
+    return mode, (frames_arg or (125 if mode == "tshard" else 24))
+
+
 BASELINE_CONFIGS = {(24, 256, 256): "BASELINE.json configs[1]", (125, 256, 256): "BASELINE.json configs[2]",
                     (24, 576, 1024): "BASELINE.json configs[3]", (8, 256, 256): "BASELINE.json configs[0] geometry"}
 
@@ -235,10 +247,7 @@ def main():
     uncond = torch.randn(1, 77, 1024, generator=g).half().to(dev)
 
     requested = args.parallel
-    mode = requested
-    if mode == "auto":
-        mode = "single" if world == 1 else ("pairs" if world == 2 else ("tshard" if world % 2 == 0 else "replicas"))
-    frames = args.frames or (125 if mode == "tshard" else 24)
+    mode, frames = choose_layout(world, requested, args.frames)
 
     def build(mode_, frames_, videos=args.videos):
         return parallel.make_runner(pipe, world, rank, frames=frames_, height=args.height, width=args.width,

@@ -111,12 +111,6 @@ class TShard:
         self.index, self.size = spec.index, spec.size
         self._comm: Optional[Communicator] = None
 
-    def with_frames(self, total_frames: int) -> "TShard":
-        """Same group, another clip length."""
-        t = TShard(self.group, self.ranks, TShardSpec.make(total_frames, self.size, self.index))
-        t._comm = self._comm
-        return t
-
     @property
     def prev(self) -> Optional[int]:
         return self.ranks[self.index - 1] if self.index > 0 else None

@@ -1,0 +1,83 @@
+"""CPU: host logic of the outer entry points (boundary B1 / bench layout choice) with stand-in pipelines — no GPU, no
+arithmetic: the `batch_count` loop of process_modelscope (process_modelscope.py:152-266: video b from seed + b, -1 stays
+random, one data-URL per video), its frame-returning form, and bench.py's layout selection."""
+import base64
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+from sd_webui_text2video_amd import pipeline
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+class _FakePipe:
+    def __init__(self):
+        self.calls = []
+
+    def infer(self, prompt, n_prompt, steps, frames, seed, scale, width=256, height=256, eta=0.0, sampler="DDIM_Gaussian", **kw):
+        self.calls.append(("infer", prompt, n_prompt, steps, frames, seed, scale, width, height, eta, sampler))
+        fr = [np.full((height, width, 3), (seed + f) % 256, dtype=np.uint8) for f in range(frames)]
+        return fr, None, f"{prompt}\nseed: {seed}"
+
+    def infer_conditioned(self, c, uc, steps, frames, seed, scale, width=256, height=256, eta=0.0, sampler="DDIM_Gaussian",
+                          videos=1, **kw):
+        self.calls.append(("cond", steps, frames, seed, scale, videos))
+        return [np.full((height, videos * width, 3), seed % 256, dtype=np.uint8) for _ in range(frames)], None
+
+
+def _args(pipe, **kw):
+    d = dict(pipe=pipe, prompt="p", n_prompt="n", steps=7, frames=3, seed=40, cfg_scale=9.0, width=16, height=8, eta=0.0,
+             sampler="DDIM_Gaussian")
+    d.update(kw)
+    return d
+
+
+def test_process_modelscope_batch_loop_and_data_urls():
+    pipe = _FakePipe()
+    frames = pipeline.process_modelscope(_args(pipe))
+    assert len(frames) == 3 and frames[0].shape == (8, 16, 3) and pipe.calls == [("infer", "p", "n", 7, 3, 40, 9.0, 16, 8, 0.0, "DDIM_Gaussian")]
+    assert pipeline.pipe is pipe                               # module-global model cache, process_modelscope.py:29
+    pipe.calls.clear()
+    seen = []
+    urls = pipeline.process_modelscope(_args(pipe, batch_count=3, stitch=lambda fr, info: seen.append(info) or bytes([fr[0][0, 0, 0]])))
+    assert [c[5] for c in pipe.calls] == [40, 41, 42]          # seed + batch
+    assert all(u.startswith("data:video/mp4;base64,") for u in urls) and len(urls) == 3
+    assert [base64.b64decode(u.split(",", 1)[1])[0] for u in urls] == [40, 41, 42] and "seed: 41" in seen[1]
+    pipe.calls.clear()
+    pipeline.process_modelscope(_args(pipe, batch_count=2, stitch=lambda fr, info: b"x", seed=-1))
+    assert [c[5] for c in pipe.calls] == [-1, -1]              # -1 stays random for every video (process_modelscope.py:218)
+    pipe.calls.clear()
+    side = pipeline.process_modelscope(_args(pipe, cond="C", uncond="U", batch_count=4))
+    assert pipe.calls == [("cond", 7, 3, 40, 9.0, 4)] and side[0].shape == (8, 64, 3)      # one batched pass, side by side
+
+
+def test_infer_without_text_encoder_is_an_error_not_a_fallback():
+    p = pipeline.TextToVideoSynthesis.__new__(pipeline.TextToVideoSynthesis)
+    p.clip_encoder = None
+    with pytest.raises(RuntimeError, match="text encoder"):
+        p.preprocess("a", "b", 5)
+    assert pipeline.create_infotext(dict(prompt="a cat", n_prompt="blurry", steps=5, seed=1, mask=None)) == \
+        "a cat\nNegative prompt: blurry\nsteps: 5, seed: 1"
+
+
+def test_bench_layout_choice_and_byte_counts():
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.choose_layout(1, "auto") == ("single", 24)                  # N = 1 stays configs[1]
+    assert bench.choose_layout(2, "auto") == ("pairs", 24)
+    assert bench.choose_layout(4, "auto") == ("tshard", 125) and bench.choose_layout(8, "auto") == ("tshard", 125)   # configs[2]
+    assert bench.choose_layout(3, "auto") == ("replicas", 24)
+    assert bench.choose_layout(8, "replicas") == ("replicas", 24) and bench.choose_layout(8, "auto", 48) == ("tshard", 48)
+    assert bench.choose_layout(1, "tshard") == ("single", 24)
+    assert bench.BASELINE_CONFIGS[(125, 256, 256)].endswith("configs[2]")
+    # strict bytes = fp16 activations once + weights once + fp16 result; the design's count adds fp32 stream traffic
+    from sd_webui_text2video_amd.program import Program, Ref
+    P = Program()
+    a, out, res = P.alloc(512, 320, "f16"), P.alloc(512, 320, "f32"), P.alloc(512, 320, "f32")
+    op = P.gemm("g", a, Ref("weight", 0, "w"), 320, 320, out, residual=res)
+    assert bench.gemm_strict_bytes(op) == 512 * 320 * 2 + 320 * 320 * 2 + 512 * 320 * 2
+    assert bench.gemm_algorithmic_bytes(op) == 512 * 320 * 2 + 320 * 320 * 2 + 512 * 320 * 4 + 512 * 320 * 4
