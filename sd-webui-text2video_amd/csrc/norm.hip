@@ -317,7 +317,69 @@ __global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(const T* __restri
   }
 }
 
-// LayerNorm: one wave per row, row held in registers (C <= 64*4*MAXV)
+// LayerNorm: one wave per row, row held in registers (C <= 64*4*MAXV).  A wave walks several rows (grid-stride): gamma / beta
+// stay in registers and the NEXT row's loads are issued before the current row's two reductions, so the wave always has a
+// row in flight (12 k single-row workgroups per launch were latency-bound: 3.8 TB/s at the 32x32 level).
+template <int MAXV>
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* x, const float* gamma, const float* beta,
+                                                             f16* out, int M, int C, int ld_in, int ld_out, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int nwaves = gridDim.x * 4;
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int cv = C >> 2;
+  f32x4 g[MAXV], b[MAXV], v[MAXV], nx[MAXV];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int u = lane + i * 64;
+    if (u < cv) {
+      g[i] = *reinterpret_cast<const f32x4*>(gamma + u * 4);
+      b[i] = *reinterpret_cast<const f32x4*>(beta + u * 4);
+      nx[i] = *reinterpret_cast<const f32x4*>(x + (size_t)row * ld_in + u * 4);
+    }
+  }
+  const float inv_c = 1.0f / (float)C;
+  for (; row < M; row += nwaves) {
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) v[i] = nx[i];
+    const int nrow = row + nwaves;
+    if (nrow < M) {                                   // wave-uniform
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i) {
+        const int u = lane + i * 64;
+        if (u < cv) nx[i] = *reinterpret_cast<const f32x4*>(x + (size_t)nrow * ld_in + u * 4);
+      }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+      if (lane + i * 64 < cv) s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s * inv_c;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+      if (lane + i * 64 < cv) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+      }
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = rsqrtf(q * inv_c + eps);
+    f16* yr = out + (size_t)row * ld_out;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int u = lane + i * 64;
+      if (u < cv) {
+        f16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (f16)((v[i][e] - mean) * rstd * g[i][e] + b[i][e]);
+        *reinterpret_cast<f16x4*>(yr + u * 4) = o;
+      }
+    }
+  }
+}
+
+// Wide rows (C > 768: the 8x8 / 4x4 levels, few rows): one row per wave, no register double-buffering.
 template <int MAXV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const float* gamma, const float* beta,
                                                         f16* out, int M, int C, int ld_in, int ld_out, float eps) {
@@ -434,9 +496,15 @@ hipError_t t2v_launch_layernorm(const t2v_op& op, hipStream_t s) {
   const float* gamma = reinterpret_cast<const float*>(op.p[1]);
   const float* beta = reinterpret_cast<const float*>(op.p[2]);
   f16* out = reinterpret_cast<f16*>(op.p[3]);
-  const dim3 grid((M + 3) / 4);
+  // C <= 768 (the 32x32 / 16x16 levels: many rows): at most 8 workgroups per CU, longer tensors are walked grid-stride
+  // (~6 rows per wave at the 32x32 level); wider rows: one row per wave
+  const int wgs = (M + 3) / 4;
+  const int cap = op.i[4] > 0 ? op.i[4] : 8 * 256;
+  const dim3 grid_rows(wgs < cap ? wgs : cap), grid(wgs);
   if (C <= 64 * 4 * 2)
-    hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, s, x, gamma, beta, out, M, C, ld_in, ld_out, op.f[0]);
+    hipLaunchKernelGGL(layernorm_rows_kernel<2>, grid_rows, dim3(256), 0, s, x, gamma, beta, out, M, C, ld_in, ld_out, op.f[0]);
+  else if (C <= 64 * 4 * 3)
+    hipLaunchKernelGGL(layernorm_rows_kernel<3>, grid_rows, dim3(256), 0, s, x, gamma, beta, out, M, C, ld_in, ld_out, op.f[0]);
   else if (C <= 64 * 4 * 5)
     hipLaunchKernelGGL(layernorm_kernel<5>, grid, dim3(256), 0, s, x, gamma, beta, out, M, C, ld_in, ld_out, op.f[0]);
   else

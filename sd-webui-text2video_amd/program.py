@@ -471,6 +471,7 @@ class Program:
         assert x.dtype == "f32" and out.dtype == "f16"
         op = Op(L.OP_LAYERNORM, name)
         op.i[0:4] = [x.rows, x.cols, x.ld, out.ld]
+        op.i[4] = int(os.environ.get("T2V_LN_CAP", 0))      # workgroup cap of the grid-stride kernel (0 = library default; A/B knob)
         op.f[0] = eps
         op.p[0:4] = [x.ref, gamma, beta, out.ref]
         op.out = out
