@@ -109,6 +109,8 @@ enum t2v_gather {
  *         ring on 4 / 8 waves, 6 / 7 = 1 / 2 with the two-group ping-pong schedule, 8 / 9 192x320 / 192x256 on 12 waves),
  *      23 tconv halo (input rows are [clip][F+2][HW]: one halo frame either side, T-sharding);
  *         for CONV3X3: 1 = zero padding (0,1,0,1) instead of (1,1,1,1) (LDM encoder Downsample, taps at +0..+2)
+ *      PLAIN gather only: 8 = 1 -> fused LayerNorm second output (tile 8, N == 320, fp32 out, no split-K): p[7] fp16 [M, i[9]] =
+ *         LayerNorm(out row, eps f[0]) * gamma + beta with p[3] = fp32 [2N] gamma | beta (instead of a row bias)
  *   p: 0 A fp16, 1 W fp16 [N,K], 2 bias fp32 [N] (or [M] if bias_along_m), 3 rowbias fp32
  *      [M/rows_per_batch, ldrb], 4 residual fp32 [M,ldr], 5 out, 6 split-K workspace fp32
  * GROUPNORM: i: 0 n_inst, 1 rows_per_inst, 2 C, 3 ld_in, 4 groups, 5 in dtype, 6 silu,

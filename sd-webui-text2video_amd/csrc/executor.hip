@@ -64,8 +64,14 @@ int validate_op(const t2v_op& op, int idx) {
         return bad("M not a multiple of F*HW");
       if (op.i[16] == T2V_EPI_GEGLU && (N % 32 != 0 || op.i[17] != T2V_F16)) return bad("GEGLU needs N % 32 == 0, fp16 out");
       if (op.i[19] > 1 && op.p[6] == 0) return bad("split-K without workspace");
-      if (op.p[3] != 0 && op.i[15] <= 0) return bad("rowbias without rows_per_batch");
+      if (op.p[3] != 0 && op.i[15] <= 0 && !(g == T2V_GATHER_PLAIN && op.i[8] == 1)) return bad("rowbias without rows_per_batch");
       if (op.i[22] < 0 || op.i[22] > 9) return bad("unknown tile id");
+      if (g == T2V_GATHER_PLAIN && op.i[8] == 1) {
+        if (op.i[22] != 8 || N != 320 || op.i[19] > 1 || op.i[16] != T2V_EPI_NONE || op.i[17] != T2V_F32 || op.i[18] != 0 || op.i[20] != 0 ||
+            K % 64 != 0)
+          return bad("fused LayerNorm output needs the 192x320 tile, N == 320, fp32 out, no split-K / activation");
+        if (op.p[3] == 0 || op.p[7] == 0 || op.i[9] < N || op.i[9] % 4 != 0) return bad("fused LayerNorm output: gamma|beta, output pointer or leading dimension");
+      }
       return 0;
     }
     case T2V_OP_GROUPNORM: {
@@ -188,6 +194,13 @@ hipError_t launch_op(const t2v_op& op, hipStream_t s) {
       p.ws = reinterpret_cast<float*>(op.p[6]);
       p.halo = op.i[23];
       const int tile = op.i[22];
+      if (p.gather == T2V_GATHER_PLAIN && op.i[8] == 1) {       // fused LayerNorm second output (validated: tile 8, N == 320)
+        p.ln_gb = reinterpret_cast<const float*>(op.p[3]);
+        p.rowbias = nullptr;
+        p.ln_out = reinterpret_cast<f16*>(op.p[7]);
+        p.ld_ln = op.i[9];
+        p.ln_eps = op.f[0];
+      }
       // the large-tile kernel advances its source pointers by whole k-tiles: needs K % BK == 0
       if (tile >= 1 && tile <= 9 && p.gather != T2V_GATHER_CONV3X3_C8 && p.K % 64 == 0) return t2v_launch_gemm2(p, tile, s);
       return t2v_launch_gemm(p, s);

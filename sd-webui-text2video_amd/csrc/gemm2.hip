@@ -87,7 +87,7 @@ __device__ __forceinline__ void epi_store_geglu(const GemmParams& p, int m, int 
 }
 
 // WM x WN waves; each wave owns TM x TN MFMA tiles (32 tokens x 32 channels each).
-template <int WM, int WN, int TM, int TN, int BK, int STAGES, int MINW, int GATHER, bool PP>
+template <int WM, int WN, int TM, int TN, int BK, int STAGES, int MINW, int GATHER, bool PP, bool LN = false>
 __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm2_kernel(const GemmParams p) {
   constexpr int NW = WM * WN;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -409,6 +409,12 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm2_kernel(const GemmPar
   // ---- epilogue ---------------------------------------------------------------------------------
   if (p.epi == T2V_EPI_NONE) {      // row-coalesced through a per-wave LDS buffer (t2v_kernels.h); also the split-K slabs
     __builtin_amdgcn_s_barrier();   // every wave is done reading the operand stages
+    if constexpr (LN) {             // whole rows in this tile (192x320, N == 320, validated by the executor): fused LayerNorm output
+      float* fs = reinterpret_cast<float*>(smem);
+      t2v_epilogue_rows_ln<TN>(p, acc, fs + wave * (32 * T2V_EPI_SP), fs + NW * (32 * T2V_EPI_SP), lane, wave, m0 + wm * 32,
+                               n0 + wn * TN * 32);
+      return;
+    }
     t2v_epilogue_rows<TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wave * (32 * T2V_EPI_SP), lane, m0 + wm * TM * 32,
                               n0 + wn * TN * 32, blockIdx.y);
     return;
@@ -504,12 +510,12 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm2_kernel(const GemmPar
   }
 }
 
-template <int WM, int WN, int TM, int TN, int BK, int STAGES, int MINW, int GATHER, bool PP>
+template <int WM, int WN, int TM, int TN, int BK, int STAGES, int MINW, int GATHER, bool PP, bool LN = false>
 hipError_t launch_cfg_gather(const GemmParams& p, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int lds = STAGES * (BM + BN) * BK * 2 + 1024;
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  auto k = gemm2_kernel<WM, WN, TM, TN, BK, STAGES, MINW, GATHER, PP>;
+  auto k = gemm2_kernel<WM, WN, TM, TN, BK, STAGES, MINW, GATHER, PP, LN>;
   static bool attr_set = false;     // once per instantiation (the call costs microseconds on the host)
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -534,7 +540,15 @@ hipError_t launch_cfg(const GemmParams& pin, hipStream_t s) {
   }
   hipError_t e;
   switch (p.gather) {
-    case T2V_GATHER_PLAIN: e = launch_cfg_gather<WM, WN, TM, TN, BK, STAGES, MINW, T2V_GATHER_PLAIN, PP>(p, s); break;
+    case T2V_GATHER_PLAIN:
+      if constexpr (WM == 6 && WN == 2 && TM == 1 && TN == 5 && !PP) {
+        if (p.ln_out != nullptr) {
+          e = launch_cfg_gather<WM, WN, TM, TN, BK, STAGES, MINW, T2V_GATHER_PLAIN, PP, true>(p, s);
+          break;
+        }
+      }
+      e = launch_cfg_gather<WM, WN, TM, TN, BK, STAGES, MINW, T2V_GATHER_PLAIN, PP>(p, s);
+      break;
     case T2V_GATHER_CONV3X3:
       if (p.up) e = launch_cfg_gather<WM, WN, TM, TN, BK, STAGES, MINW, G_CONV_UP, PP>(p, s);
       else e = launch_cfg_gather<WM, WN, TM, TN, BK, STAGES, MINW, T2V_GATHER_CONV3X3, PP>(p, s);

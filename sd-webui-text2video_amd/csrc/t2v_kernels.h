@@ -33,6 +33,11 @@ struct GemmParams {
                                                // ([B][F+2][HW] rows, T-sharded forward); all 3 taps are in range.
                                                // conv3x3: 1 = asymmetric (0,1,0,1) zero padding (taps at +0..+2)
   int panel;                                   // tile columns per panel of the XCD-aware tile order (set by the launcher)
+  // fused LayerNorm second output (192x320 tile, N == 320 == one tile row, no split-K): ln_out = LN(out row) * gamma + beta
+  const float* ln_gb;                          // fp32 [2 N]: gamma | beta
+  f16* ln_out;
+  int ld_ln;
+  float ln_eps;
 };
 
 // ---- XCD-aware tile order -----------------------------------------------------------------------------
@@ -171,6 +176,106 @@ __device__ __forceinline__ void t2v_epilogue_rows(const GemmParams& p, const f32
     for (int i = 0; i < 4; ++i) rcur[i] = rnxt[i];
   }
 }
+// Epilogue of the 192x320 tile (12 waves: 6 row strips x 2 column halves, TM = 1, TN = 5) with a fused LayerNorm: the tile
+// holds WHOLE rows (N == 320), so after bias / residual the fp32 result goes to `out` as usual and, from the values kept
+// in the accumulator registers, LayerNorm(row) * gamma + beta goes to `ln_out` (fp16) — the separate LayerNorm launch
+// (read fp32, write fp16: 94 MB at the 32x32 level) and its launch boundary disappear.  Two-pass statistics (mean, then
+// centred squares) like the stand-alone kernel; the two waves of a row strip exchange their half-row sums through LDS.
+template <int TN>
+__device__ __forceinline__ void t2v_epilogue_rows_ln(const GemmParams& p, f32x16 (&acc)[1][TN], float* stg, float* xch, int lane,
+                                                     int wave, int m_wave, int n_wave) {
+  const int wrow = lane & 31, wcol = (lane >> 5) * 4;
+  const int rrow = lane >> 3, rcol = (lane & 7) * 4;
+  const bool has_res = p.res != nullptr;
+  auto res_load = [&](int blk, f32x4 (&r)[4]) {
+    const int n = n_wave + blk * 32 + rcol;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m_wave + rrow + 8 * i;
+      const float* src = (m < p.M && n < p.N) ? p.res + (size_t)m * p.ldr + n : p.res;
+      r[i] = *reinterpret_cast<const f32x4*>(src);
+    }
+  };
+  f32x4 rcur[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) rcur[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float rs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int b = 0; b < TN; ++b) {
+    if (has_res) res_load(b, rcur);                    // four row loads in flight while the block turns through LDS
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = {acc[0][b][4 * q], acc[0][b][4 * q + 1], acc[0][b][4 * q + 2], acc[0][b][4 * q + 3]};
+      *reinterpret_cast<f32x4*>(stg + wrow * T2V_EPI_SP + 8 * q + wcol) = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    const int n = n_wave + b * 32 + rcol;
+    f32x4 cb = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) cb = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = rrow + 8 * i;
+      f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * T2V_EPI_SP + rcol);
+      const int m = m_wave + row;
+      v += cb;
+      if (has_res) v += rcur[i];
+      if (m < p.M) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n) = v;
+      acc[0][b][4 * i] = v[0]; acc[0][b][4 * i + 1] = v[1]; acc[0][b][4 * i + 2] = v[2]; acc[0][b][4 * i + 3] = v[3];   // row-major now
+      rs[i] += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  }
+  // half-row sums -> whole-row mean: 8 lanes share a row (xor 1, 2, 4), the partner wave (other column half) through LDS
+  float* mine = xch + wave * 32;
+  float* other = xch + (wave ^ 1) * 32;
+  float mean[4], rstd[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float s = rs[i];
+    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+    rs[i] = s;
+    if ((lane & 7) == 0) mine[rrow + 8 * i] = s;
+  }
+  __syncthreads();
+  const float inv_n = 1.0f / (float)p.N;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) mean[i] = (rs[i] + other[rrow + 8 * i]) * inv_n;
+  float rq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int b = 0; b < TN; ++b)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float d = acc[0][b][4 * i + e] - mean[i]; rq[i] += d * d; }
+  __syncthreads();                                   // every wave has read its partner's sums: the slots are reused
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float q = rq[i];
+    q += __shfl_xor(q, 1); q += __shfl_xor(q, 2); q += __shfl_xor(q, 4);
+    rq[i] = q;
+    if ((lane & 7) == 0) mine[rrow + 8 * i] = q;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) rstd[i] = rsqrtf((rq[i] + other[rrow + 8 * i]) * inv_n + p.ln_eps);
+#pragma unroll
+  for (int b = 0; b < TN; ++b) {
+    const int n = n_wave + b * 32 + rcol;
+    const f32x4 g = *reinterpret_cast<const f32x4*>(p.ln_gb + n);
+    const f32x4 be = *reinterpret_cast<const f32x4*>(p.ln_gb + p.N + n);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m_wave + rrow + 8 * i;
+      if (m < p.M) {
+        f16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (f16)((acc[0][b][4 * i + e] - mean[i]) * rstd[i] * g[e] + be[e]);
+        *reinterpret_cast<f16x4*>(p.ln_out + (size_t)m * p.ld_ln + n) = o;
+      }
+    }
+  }
+}
+
 // exact-erf GELU (nn.GELU default, reference GEGLU t2v_model.py:817-821).  erfc(|z|) by Abramowitz-Stegun
 // 7.1.26 (|abs err| < 1.5e-7, far below the fp16 output rounding); the negative side uses erfc directly, so
 // the tail keeps its relative accuracy.  ~14 instructions, branch-free (the epilogue of the GEGLU GEMMs

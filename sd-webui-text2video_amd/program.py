@@ -299,9 +299,12 @@ class Program:
              ldw: Optional[int] = None, gather: int = L.GATHER_PLAIN, conv: Optional[dict] = None,
              rowbias: Optional[Buf] = None, rows_per_batch: int = 0, residual: Optional[Buf] = None,
              epi: int = L.EPI_NONE, act: int = 0, bias_along_m: bool = False, m: Optional[int] = None,
-             allow_splitk: bool = True, halo: bool = False) -> Op:
+             allow_splitk: bool = True, halo: bool = False, ln: Optional[tuple] = None) -> Op:
         """out[M, n_out] = epi(gather(a)[M, k] @ w[n, k]^T).  conv['pad_after_only'] (3x3, stride 2): zero padding
-        (0,1,0,1) instead of 1 on every side."""
+        (0,1,0,1) instead of 1 on every side.
+        ln = (gamma|beta Ref (fp32 [2n]), gamma Ref, beta Ref, ln_out Buf fp16, eps): LayerNorm of the fp32 result rows as a second
+        output.  Fused into the GEMM epilogue when the op runs on the 192x320 tile with whole rows (n == 320, no split-K:
+        the 32x32-level C -> C linears); otherwise a separate LayerNorm op follows."""
         conv = conv or {}
         M = out.rows if m is None else m
         lo = self.weight_lo(w) if (self.weight_lo is not None and epi == L.EPI_NONE and not bias_along_m and w.space == "weight") else None
@@ -341,14 +344,27 @@ class Program:
             assert residual.dtype == "f32" and residual.rows >= M and residual.cols == n_out
         tile, split = self.choose_tile(M, n, k, gather, allow_splitk)
         I[19], I[22] = split, tile
+        ln_fused = False
+        if ln is not None:
+            gb, gamma, beta, ln_out, ln_eps = ln
+            assert out.dtype == "f32" and ln_out.dtype == "f16" and ln_out.cols == n and ln_out.rows >= M
+            ln_fused = (tile == 8 and split == 1 and n == 320 and gather == L.GATHER_PLAIN and epi == L.EPI_NONE and act == 0
+                        and rowbias is None and not bias_along_m and k % 64 == 0 and os.environ.get("T2V_LN_FUSE", "1") != "0")
+            if ln_fused:
+                I[8], I[9] = 1, ln_out.ld
+                op.f[0] = ln_eps
+                op.p[3], op.p[7] = gb, ln_out.ref
         ws = None
         if split > 1:
             ws = self.alloc(split * M, n, "f32")
             op.p[6] = ws.ref
         op.flops = 2.0 * M * n * k
         op.out = out
-        op.meta = dict(M=M, N=n, K=k, gather=gather, conv=dict(conv), epi=epi, split=split, tile=tile, halo=halo)
+        op.meta = dict(M=M, N=n, K=k, gather=gather, conv=dict(conv), epi=epi, split=split, tile=tile, halo=halo, ln=int(ln_fused))
         self._emit(op)
+        if ln is not None and not ln_fused:
+            self.layernorm(name + ".ln", out if m is None else out.row_slice(0, M), gamma, beta,
+                           ln_out if m is None else ln_out.row_slice(0, M), ln_eps)
         if ws is not None:
             self.free(ws)     # stream order makes immediate reuse safe
         if lo_tmp is not None:

@@ -564,6 +564,12 @@ class _Lowering:
         return (Ref("weight", 0, self.packer.add(key + ":geglu", "f16", wfn)),
                 Ref("weight", 0, self.packer.add(key + ":geglu_b", "f32", bfn)))
 
+    def ln_arg(self, key, out: Buf, eps: float = 1e-5) -> tuple:
+        """`ln=` argument of Program.gemm for the LayerNorm `key` applied to a GEMM's fp32 result: fused into the epilogue of the
+        192x320 tile (one fp32 [2C] vector gamma | beta), a separate LayerNorm op otherwise."""
+        gb = Ref("weight", 0, self.packer.add(key + ":ln_gb", "f32", lambda sd, k=key: torch.cat([sd[k + ".weight"], sd[k + ".bias"]])))
+        return (gb, self.vec(key + ".weight"), self.vec(key + ".bias"), out, eps)
+
     def vec(self, key) -> Ref:
         """fp32 vector (bias / norm affine), zero-padded to a multiple of 4."""
         return Ref("weight", 0, self.packer.add(key + ":v", "f32", lambda sd, k=key: pk.pad_rows(sd[k])))
@@ -654,8 +660,9 @@ class _Lowering:
         P.free(h2)
         return t
 
-    def transformer_block(self, prefix, x1: Buf, inner, heads, kind, h, w, geom=None) -> Buf:
-        """x1: fp32 [M, inner] residual stream (consumed).  Returns fp16 [M, inner] (feeds proj_out).
+    def transformer_block(self, prefix, x1: Buf, n1: Optional[Buf], inner, heads, kind, h, w, geom=None) -> Buf:
+        """x1: fp32 [M, inner] residual stream (consumed); n1 = LayerNorm1(x1) fp16, written by the proj_in GEMM (None in the
+        K/V-gather lowering of a T-sharded temporal block, which normalises on its own).  Returns fp16 [M, inner] (feeds proj_out).
         geom = (frames, pixels per frame) of x1's rows when they are NOT this rank's frame slice: the pixel-sharded
         layout of a T-sharded TemporalTransformer — all frames of the clip, hw / R pixels — where the block is local."""
         P, Mrows, hw, F, B = self.P, x1.rows, h * w, self.F, self.B
@@ -695,11 +702,10 @@ class _Lowering:
             P.free(a, xin)
             return xo
 
-        def self_attention(tag, xin: Buf) -> Buf:
-            if kind == "temporal" and self.shard is not None and not local:
-                return self_attention_sharded(tag, xin)
-            n = P.alloc(Mrows, inner, "f16")
-            P.layernorm(f"{prefix}.norm{tag}", xin, self.vec(f"{prefix}.norm{tag}.weight"), self.vec(f"{prefix}.norm{tag}.bias"), n)
+        def self_attention(tag, xin: Buf, n: Buf, next_norm: str) -> Tuple[Buf, Buf]:
+            """n = LayerNorm{tag}(xin) (made by the op that produced xin).  Returns (x + attention, LayerNorm{next_norm} of it):
+            the to_out GEMM writes the fp32 stream AND — fused into its epilogue where the tile holds whole rows — the next
+            LayerNorm's fp16 output."""
             qkv = P.alloc(Mrows, 3 * inner, "f16")
             P.gemm(f"{prefix}.attn{tag}.qkv", n, self.w_qkv(f"{prefix}.attn{tag}"), 3 * inner, inner, qkv)
             P.free(n)
@@ -717,36 +723,43 @@ class _Lowering:
                             o_strides=(hw * inner, F * hw * inner, inner), scale=scale)
             P.free(qkv)
             xo = P.alloc(Mrows, inner, "f32")
+            nn_ = P.alloc(Mrows, inner, "f16")
             P.gemm(f"{prefix}.attn{tag}.to_out", a, self.w_linear(f"{prefix}.attn{tag}.to_out.0"), inner, inner, xo,
-                   bias=self.vec(f"{prefix}.attn{tag}.to_out.0.bias"), residual=xin)
+                   bias=self.vec(f"{prefix}.attn{tag}.to_out.0.bias"), residual=xin, ln=self.ln_arg(f"{prefix}.{next_norm}", nn_))
             P.free(a, xin)
-            return xo
+            return xo, nn_
 
-        x2 = self_attention(1, x1)
-        if kind == "spatial":
-            n = P.alloc(Mrows, inner, "f16")
-            P.layernorm(f"{prefix}.norm2", x2, self.vec(f"{prefix}.norm2.weight"), self.vec(f"{prefix}.norm2.bias"), n)
-            q = P.alloc(Mrows, inner, "f16")
-            P.gemm(f"{prefix}.attn2.to_q", n, self.w_linear(f"{prefix}.attn2.to_q"), inner, inner, q)
-            P.free(n)
-            k0, k1 = self.kv_slices[prefix + ".attn2"]
-            kv = self.kv_all
-            kbuf, vbuf = kv.col_slice(k0, k0 + inner), kv.col_slice(k0 + inner, k1)
-            a = P.alloc(Mrows, inner, "f16")
-            Lc = self.Lctx
-            P.attention(f"{prefix}.attn2", q.ref, kbuf.ref, vbuf.ref, a.ref, out_buf=a, nq=hw, nk=Lc, heads=heads,
-                        b_outer=B, b_inner=F, q_strides=(inner, F * hw * inner, hw * inner),
-                        kv_strides=(kv.ld, Lc * kv.ld, 0), o_strides=(inner, F * hw * inner, hw * inner), scale=scale)
-            P.free(q)
-            x3 = P.alloc(Mrows, inner, "f32")
-            P.gemm(f"{prefix}.attn2.to_out", a, self.w_linear(f"{prefix}.attn2.to_out.0"), inner, inner, x3,
-                   bias=self.vec(f"{prefix}.attn2.to_out.0.bias"), residual=x2)
-            P.free(a, x2)
+        sharded_temporal = kind == "temporal" and self.shard is not None and not local
+        if sharded_temporal:
+            # K/V-gather lowering (pixel count not divisible by the T group): LayerNorms as separate ops
+            x2 = self_attention_sharded(1, x1)
+            x3 = self_attention_sharded(2, x2)
+            n3 = P.alloc(Mrows, inner, "f16")
+            P.layernorm(f"{prefix}.norm3", x3, self.vec(f"{prefix}.norm3.weight"), self.vec(f"{prefix}.norm3.bias"), n3)
         else:
-            x3 = self_attention(2, x2)
+            x2, n2 = self_attention(1, x1, n1, "norm2")
+            if kind == "spatial":
+                q = P.alloc(Mrows, inner, "f16")
+                P.gemm(f"{prefix}.attn2.to_q", n2, self.w_linear(f"{prefix}.attn2.to_q"), inner, inner, q)
+                P.free(n2)
+                k0, k1 = self.kv_slices[prefix + ".attn2"]
+                kv = self.kv_all
+                kbuf, vbuf = kv.col_slice(k0, k0 + inner), kv.col_slice(k0 + inner, k1)
+                a = P.alloc(Mrows, inner, "f16")
+                Lc = self.Lctx
+                P.attention(f"{prefix}.attn2", q.ref, kbuf.ref, vbuf.ref, a.ref, out_buf=a, nq=hw, nk=Lc, heads=heads,
+                            b_outer=B, b_inner=F, q_strides=(inner, F * hw * inner, hw * inner),
+                            kv_strides=(kv.ld, Lc * kv.ld, 0), o_strides=(inner, F * hw * inner, hw * inner), scale=scale)
+                P.free(q)
+                x3 = P.alloc(Mrows, inner, "f32")
+                n3 = P.alloc(Mrows, inner, "f16")
+                P.gemm(f"{prefix}.attn2.to_out", a, self.w_linear(f"{prefix}.attn2.to_out.0"), inner, inner, x3,
+                       bias=self.vec(f"{prefix}.attn2.to_out.0.bias"), residual=x2, ln=self.ln_arg(f"{prefix}.norm3", n3))
+                P.free(a, x2)
+            else:
+                x3, n3 = self_attention(2, x2, n2, "norm3")
         # feed-forward: GEGLU fused in the first GEMM's epilogue
-        n = P.alloc(Mrows, inner, "f16")
-        P.layernorm(f"{prefix}.norm3", x3, self.vec(f"{prefix}.norm3.weight"), self.vec(f"{prefix}.norm3.bias"), n)
+        n = n3
         wg, bg = self.w_geglu(f"{prefix}.ff.net.0.proj")
         g = P.alloc(Mrows, 4 * inner, "f16")
         P.gemm(f"{prefix}.ff.geglu", n, wg, 8 * inner, inner, g, bias=bg, epi=L.EPI_GEGLU)
@@ -762,9 +775,12 @@ class _Lowering:
         heads = c // 64
         n = self.gn(prefix + ".norm", x, prefix + ".norm", per_frame=True, eps=1e-6, silu=False)
         x1 = P.alloc(x.rows, c, "f32")
-        P.gemm(prefix + ".proj_in", n, self.w_linear(prefix + ".proj_in"), c, c, x1, bias=self.vec(prefix + ".proj_in.bias"))
+        n1 = P.alloc(x.rows, c, "f16")
+        tb = prefix + ".transformer_blocks.0"
+        P.gemm(prefix + ".proj_in", n, self.w_linear(prefix + ".proj_in"), c, c, x1, bias=self.vec(prefix + ".proj_in.bias"),
+               ln=self.ln_arg(tb + ".norm1", n1))
         P.free(n)
-        x4 = self.transformer_block(prefix + ".transformer_blocks.0", x1, c, heads, "spatial", h, w)
+        x4 = self.transformer_block(tb, x1, n1, c, heads, "spatial", h, w)
         out = self._dest(dest, x.rows, c, "f32")
         P.gemm(prefix + ".proj_out", x4, self.w_linear(prefix + ".proj_out"), c, c, out,
                bias=self.vec(prefix + ".proj_out.bias"), residual=x)
@@ -778,9 +794,12 @@ class _Lowering:
             return self.temporal_transformer_resharded(prefix, x, c, heads, h, w, dest)
         n = self.gn(prefix + ".norm", x, prefix + ".norm", per_frame=False, eps=1e-6, silu=False)
         x1 = P.alloc(x.rows, inner, "f32")
-        P.gemm(prefix + ".proj_in", n, self.w_linear(prefix + ".proj_in"), inner, c, x1, bias=self.vec(prefix + ".proj_in.bias"))
+        tb = prefix + ".transformer_blocks.0"
+        n1 = None if self.shard is not None else P.alloc(x.rows, inner, "f16")
+        P.gemm(prefix + ".proj_in", n, self.w_linear(prefix + ".proj_in"), inner, c, x1, bias=self.vec(prefix + ".proj_in.bias"),
+               ln=None if n1 is None else self.ln_arg(tb + ".norm1", n1))
         P.free(n)
-        x4 = self.transformer_block(prefix + ".transformer_blocks.0", x1, inner, heads, "temporal", h, w)
+        x4 = self.transformer_block(tb, x1, n1, inner, heads, "temporal", h, w)
         out = self._dest(dest, x.rows, c, "f32")
         P.gemm(prefix + ".proj_out", x4, self.w_linear(prefix + ".proj_out"), c, inner, out,
                bias=self.vec(prefix + ".proj_out.bias"), residual=x)
@@ -808,9 +827,12 @@ class _Lowering:
         P.alltoall(prefix + ".f2p", stage, xp, hwr * c * 2, sh, 0)
         P.free(n, stage)
         x1 = P.alloc(Ft * hwr, inner, "f32")
-        P.gemm(prefix + ".proj_in", xp, self.w_linear(prefix + ".proj_in"), inner, c, x1, bias=self.vec(prefix + ".proj_in.bias"))
+        n1 = P.alloc(Ft * hwr, inner, "f16")
+        tb = prefix + ".transformer_blocks.0"
+        P.gemm(prefix + ".proj_in", xp, self.w_linear(prefix + ".proj_in"), inner, c, x1, bias=self.vec(prefix + ".proj_in.bias"),
+               ln=self.ln_arg(tb + ".norm1", n1))
         P.free(xp)
-        x4 = self.transformer_block(prefix + ".transformer_blocks.0", x1, inner, heads, "temporal", h, w, geom=(Ft, hwr))
+        x4 = self.transformer_block(tb, x1, n1, inner, heads, "temporal", h, w, geom=(Ft, hwr))
         yp = P.alloc(Ft * hwr, c, "f32")
         P.gemm(prefix + ".proj_out", x4, self.w_linear(prefix + ".proj_out"), c, inner, yp, bias=self.vec(prefix + ".proj_out.bias"))
         P.free(x4)

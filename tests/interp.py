@@ -110,7 +110,8 @@ class Interp:
             n_out = N // 2
         else:
             res, n_out = acc, N
-            if op.p[3].space != "null":
+            ln_fused = gather == L.GATHER_PLAIN and I[8] == 1     # fused LayerNorm second output: p[3] = gamma | beta, p[7] = fp16 out
+            if op.p[3].space != "null" and not ln_fused:
                 rpb, ldrb = I[15], I[21]
                 rb = self.mat(op.p[3], M // rpb, N, ldrb, torch.float32, ext)
                 res = res + rb.repeat_interleave(rpb, dim=0)
@@ -120,6 +121,10 @@ class Interp:
                 res = res + self.mat(op.p[4], M, N, ldr, torch.float32, ext)
         out = self.mat(op.p[5], M, n_out, ldc, _TD[I[17]], ext)
         out.copy_(res.to(out.dtype))
+        if epi != L.EPI_GEGLU and gather == L.GATHER_PLAIN and I[8] == 1:
+            gb = self.view(op.p[3], (2 * N,), (1,), torch.float32, ext)
+            y = F.layer_norm(res.float(), (N,), gb[:N], gb[N:], op.f[0])
+            self.mat(op.p[7], M, N, I[9], torch.float16, ext).copy_(y.half())
 
     # GROUPNORM ----------------------------------------------------------------------------------------
     def _op2(self, op, ext):

@@ -724,3 +724,31 @@ def test_relpos_attention_against_explicit_formula(D, T, Tq, off, R):
     p = sim.softmax(dim=-1)
     ref = torch.einsum("phts,phsd->phtd", p, vf) + torch.einsum("phts,tsd->phtd", p, w["ev"][idx])
     assert rel_l2(read(got, o).float(), ref.permute(2, 0, 1, 3).reshape(Tq * hw, inner)) < 2e-3
+
+
+@pytest.mark.parametrize("M,K,with_res", [(400, 320, True), (192 * 3 + 5, 1280, True), (77, 64, False), (4096, 320, True)])
+def test_gemm_with_fused_layernorm_output(M, K, with_res):
+    """192x320 tile with whole rows (N == 320): the epilogue writes the fp32 stream AND LayerNorm(row) * gamma + beta (fp16) —
+    checked against the interpreter and against torch.nn.functional.layer_norm of the device's own fp32 output."""
+    N = 320
+    P = Program()
+    P.force_tile = 8
+    g = _g(150 + M)
+    a, out, n_out = P.alloc(M, K, "f16"), P.alloc(M, N, "f32"), P.alloc(M, N, "f16", ld=N + 8)
+    res = P.alloc(M, N, "f32") if with_res else None
+    gamma, beta = 1 + 0.2 * torch.randn(N, generator=g), 0.2 * torch.randn(N, generator=g)
+    w = {"w": (torch.randn(N, K, generator=g) / math.sqrt(K)).half(), "b": torch.randn(N, generator=g), "g": gamma, "be": beta,
+         "gb": torch.cat([gamma, beta])}
+    op = P.gemm("g", a, Ref("weight", 0, "w"), N, K, out, bias=Ref("weight", 0, "b"), residual=res, allow_splitk=False,
+                ln=(Ref("weight", 0, "gb"), Ref("weight", 0, "g"), Ref("weight", 0, "be"), n_out, 1e-5))
+    assert op.i[22] == 8 and op.i[8] == 1 and len(P.ops) == 1          # fused: no separate LayerNorm op
+
+    def init(it):
+        fill(it, a, g)
+        if with_res:
+            fill(it, res, g, 2.0)
+    it, got, _, _ = run_both(P, w, {}, init)
+    _check(it, got, out, 2e-5, "gemm + fused LN: fp32 stream")
+    _check(it, got, n_out, 1e-3, "gemm + fused LN: fp16 LayerNorm output")
+    ref = torch.nn.functional.layer_norm(read(got, out), (N,), gamma, beta, 1e-5)
+    assert rel_l2(read(got, n_out).float(), ref) < 1e-3

@@ -13,6 +13,7 @@ from sd_webui_text2video_amd import _lib as L
 from sd_webui_text2video_amd import packing as pk
 from sd_webui_text2video_amd import unet as U
 from sd_webui_text2video_amd import vae as V
+from sd_webui_text2video_amd.program import Program, Ref
 from sd_webui_text2video_amd.program import Arena
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -255,3 +256,31 @@ def test_program_cache_eviction_and_stale_images():
         m.out[2].weight.mul_(1.5)
     m.refresh_weights("cpu")
     assert m.last_repack >= 1 and "only_an_evicted_program:lin" not in m._packed
+
+
+def test_gemm_ln_option_fuses_on_the_192x320_tile_and_falls_back_elsewhere():
+    """Program.gemm(ln=...): one op with a fused LayerNorm second output when the tile holds whole rows (tile 8, N == 320), a
+    separate LayerNorm op otherwise; both forms against torch in the interpreter."""
+    import math
+    g = torch.Generator().manual_seed(3)
+    for tile, N, fused in ((8, 320, True), (0, 320, False), (8, 640, False)):
+        M, K = 200, 128
+        P = Program()
+        P.force_tile = tile
+        a, out, n_out = P.alloc(M, K, "f16"), P.alloc(M, N, "f32"), P.alloc(M, N, "f16")
+        res = P.alloc(M, N, "f32")
+        gamma, beta = 1 + 0.2 * torch.randn(N, generator=g), 0.2 * torch.randn(N, generator=g)
+        w = {"w": (torch.randn(N, K, generator=g) / math.sqrt(K)).half(), "b": torch.randn(N, generator=g), "g": gamma, "be": beta,
+             "gb": torch.cat([gamma, beta])}
+        P.gemm("g", a, Ref("weight", 0, "w"), N, K, out, bias=Ref("weight", 0, "b"), residual=res, allow_splitk=False,
+               ln=(Ref("weight", 0, "gb"), Ref("weight", 0, "g"), Ref("weight", 0, "be"), n_out, 1e-5))
+        assert [op.kind for op in P.ops] == ([L.OP_GEMM] if fused else [L.OP_GEMM, L.OP_LAYERNORM])
+        it = Interp(P, w, poison=False)
+        A = it.mat(a.ref, M, K, K, torch.float16, {}); A.copy_(torch.randn(M, K, generator=g).half())
+        R = it.mat(res.ref, M, N, N, torch.float32, {}); R.copy_(torch.randn(M, N, generator=g))
+        it.run({})
+        want = A.float() @ w["w"].float().t() + w["b"] + R
+        got_out = it.mat(out.ref, M, N, N, torch.float32, {})
+        assert rel_l2(got_out, want) < 1e-5
+        ln = torch.nn.functional.layer_norm(got_out, (N,), gamma, beta, 1e-5)
+        assert rel_l2(it.mat(n_out.ref, M, N, N, torch.float16, {}).float(), ln) < 1e-3
