@@ -26,6 +26,8 @@ def test_header_constants_match_binding():
         "T2V_EXT_OUT": L.EXT_OUT, "T2V_EXT_XT": L.EXT_XT, "T2V_EXT_XT_OUT": L.EXT_XT_OUT,
         "T2V_EXT_NOISE": L.EXT_NOISE, "T2V_EXT_EPS": L.EXT_EPS, "T2V_OP_NI": L.OP_NI, "T2V_OP_NF": L.OP_NF,
         "T2V_OP_NP": L.OP_NP, "T2V_GN_ROWS_PER_BLOCK": L.GN_ROWS_PER_BLOCK,
+        "T2V_OP_EMBED_ROWS": L.OP_EMBED_ROWS, "T2V_OP_TO_UINT8": L.OP_TO_UINT8, "T2V_OP_ALLGATHER": L.OP_ALLGATHER,
+        "T2V_OP_HALO_EXCHANGE": L.OP_HALO_EXCHANGE, "T2V_OP_RESHARD_ROWS": L.OP_RESHARD_ROWS, "T2V_OP_ALLTOALL": L.OP_ALLTOALL,
     }
     for k, v in expect.items():
         assert allc[k] == v, (k, allc[k], v)
@@ -52,6 +54,55 @@ def test_validation_rejects_bad_programs_without_gpu(built_lib):
     op[0].i[0], op[0].i[1], op[0].i[2] = 128, 6, 64          # N not a multiple of 4
     assert built_lib.t2v_plan_create(op, 1, ctypes.byref(h)) == -1
     assert b"multiple of 4" in built_lib.t2v_last_error()
+
+
+def test_validation_covers_every_op_kind_without_gpu(built_lib):
+    """ADVICE r01: `t2v_plan_create` / `t2v_run_ops` validate the records of EVERY op kind (not only GEMM) before any HIP call;
+    each malformed record below is refused with T2V_ERR_BAD_ARG and a message naming the problem."""
+    h = ctypes.c_void_p()
+    ptr = 0x1000                                                      # any non-null, non-slot value: nothing is dereferenced
+
+    def refused(kind, i=(), f=(), p=(), needle=b""):
+        op = (L.T2VOp * 1)()
+        op[0].kind = kind
+        for k, v in enumerate(i):
+            op[0].i[k] = v
+        for k, v in enumerate(f):
+            op[0].f[k] = v
+        for k, v in enumerate(p):
+            op[0].p[k] = v
+        rc = built_lib.t2v_plan_create(op, 1, ctypes.byref(h))
+        msg = built_lib.t2v_last_error()
+        assert rc == -1 and needle in msg, (kind, rc, msg)
+
+    refused(L.OP_GROUPNORM, i=(1, 16, 330, 336, 32, 1, 1, 336), p=(ptr,) * 5, needle=b"GroupNorm")          # C % groups != 0
+    refused(L.OP_LAYERNORM, i=(8, 4096, 4096, 4096), p=(ptr,) * 4, needle=b"LayerNorm")                      # C > 2048
+    refused(L.OP_ATTENTION, i=(4, 4, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 48), f=(1.0,), p=(ptr,) * 4, needle=b"head_dim")
+    refused(L.OP_ATTENTION, i=(4, 5, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 64, 1), f=(1.0,), p=(ptr,) * 4, needle=b"causal")
+    refused(L.OP_RELPOS_ATTN, i=(40, 40, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 64, 4), p=(ptr,) * 6, needle=b"relative-position")
+    refused(L.OP_RELPOS_ATTN, i=(4, 16, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 64, 4, 14), p=(ptr,) * 6, needle=b"inside the keys")
+    refused(L.OP_SOFTMAX, i=(4, 64, 32, 64), p=(ptr, ptr), needle=b"softmax")                                # ld < cols
+    refused(L.OP_COPY2D, i=(4, 6, 8, 8), p=(ptr, ptr), needle=b"cols % 4")
+    refused(L.OP_DDIM_STEP, i=(4, 0), p=(ptr, ptr, 0, ptr), needle=b"DDIM")                                  # inner == 0 (division by zero on the device)
+    refused(L.OP_DDIM_STEP, i=(6, 64, 0, 0, 0, 0, 4), p=(ptr, ptr, 0, ptr), needle=b"DDIM")                  # C % channels-per-sample
+    refused(L.OP_LINCOMB, i=(16, 7), p=(ptr,) * 7, needle=b"lincomb")
+    refused(L.OP_TIME_EMBED, i=(2, 321), p=(ptr,) * 3, needle=b"time-embedding")
+    refused(L.OP_TO_UINT8, i=(1, 3, 0, 8, 8), p=(ptr, ptr), needle=b"uint8")
+    refused(L.OP_ALLGATHER, i=(512, 0, 2, 2), p=(ptr,), needle=b"all-gather")                                # part >= nparts
+    refused(L.OP_HALO_EXCHANGE, i=(512, 0, 0, -1, -1), p=(ptr,), needle=b"halo")
+    refused(L.OP_RESHARD_ROWS, i=(8, 64, 0, 4, 4, 64, 64, 0), p=(ptr, ptr), needle=b"resharding")            # chunk of 0 rows
+    refused(L.OP_ALLTOALL, i=(512, 0, 4, 1, 3, 4, 0), p=(ptr, ptr), needle=b"all-to-all")                    # last slice longer than the others
+    refused(L.OP_GEMM, i=(256, 640, 64, 64, 64, 640, 0, 0, 1, 640, 0, 0, 0, 0, 0, 0, 0, 1, 0, 1, 0, 0, 8), p=(ptr, ptr, 0, ptr, 0, ptr, 0, ptr),
+            needle=b"fused LayerNorm")                                                                        # N != 320 on the LN-fused form
+    # and a well-formed record of each collective kind is accepted (nothing runs at plan creation)
+    ok = (L.T2VOp * 2)()
+    ok[0].kind, ok[1].kind = L.OP_ALLGATHER, L.OP_ALLTOALL
+    ok[0].i[0], ok[0].i[2], ok[0].i[3], ok[0].p[0] = 512, 4, 1, ptr
+    for k, v in enumerate((1024, 0, 4, 1, 32, 29, 1)):
+        ok[1].i[k] = v
+    ok[1].p[0], ok[1].p[1] = ptr, ptr
+    assert built_lib.t2v_plan_create(ok, 2, ctypes.byref(h)) == 0 and built_lib.t2v_plan_num_ops(h) == 2
+    built_lib.t2v_plan_destroy(h)
 
 
 def test_product_path_has_no_cpu_fallback():
