@@ -9,17 +9,26 @@ A "step" is ONE whole video through the hot path behind the reference's entry po
 classifier-free guidance 9, eta 0; cond+uncond batched => 50 b=2 UNet forwards + 50 fused
 update kernels) + batched VAE decode of all frames + uint8 conversion, all on device
 (inputs — noise, conditioning, weights — are resident in HBM before the timed region).
-Workload at N=1 (and N=2, one video per CFG pair): BASELINE.json configs[1] — ModelScope t2v fp16, 24 frames @256x256.
-N>=4 (even): configs[2] — ONE 125-frame video, frames sharded along T over N/2 GPUs x the CFG pair (exchanges inside the
-library over RCCL); the replicas layout (every GPU its own 24-frame video) is timed beside it and reported as `replicas`.
+Workload, every N: BASELINE.json configs[1] — ModelScope t2v fp16, 24 frames @256x256, one video per GPU in flight
+(`replicas`: videos are independent objects, no data-path collective; weak scaling, so the per-N values are comparable).
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment launches its own N ranks (re-exec under
+torch.distributed.run on 127.0.0.1, the reference's launcher does the same: scripts/videocrafter/ddp_wrapper.py:9-13).
+Beside the headline, rank 0 then times the COLLECTIVE layout of that N as a separate N-rank job under a timeout and reports
+it as `collective_layout`: N = 2 — one video per CFG pair (eps all-gather per step); even N >= 4 — configs[2], ONE 125-frame
+video, frames sharded along T over N/2 GPUs x the CFG pair, exchanges executed by the library over its own RCCL communicators
+(north_star's layout; `--parallel tshard` makes it the headline).  It runs in its own job so that a failure or hang of the
+RCCL path can never take the headline measurement down with it.
 Weights are random-init of the exact ModelScope architecture (no checkpoints offline).
 
 Prints ONE JSON line (rank 0) with the driver's fields plus
   roofline     — dominant kernel = the MFMA implicit-GEMM family (conv3x3 / temporal conv /
                  linear): algorithmic FLOPs of its launches in one UNet step / their summed
                  durations, measured live with HIP events on the launch stream
+                 + `calibration`: an 8192^3 fp16 GEMM of the same kernel family on random data before and after the timed
+                 region (TF/s) and the clocks / power amd-smi reports — boxes differ by +-5-10 %, this makes lines comparable
   cpu_baseline — the oracle port (oracle/torch_port.py, fp32, torch CPU) timed on the host
-                 cores on a bounded sample of the same workload, extrapolated to frames/s
+                 cores on a bounded sample of the same workload, extrapolated to frames/s; beside it the REAL reference's
+                 own CPU timings recorded when the goldens were generated (tests/golden/*.npz `timing`)
 """
 import argparse
 import json
@@ -110,7 +119,32 @@ def cpu_baseline_worker(frames, ddim_steps):
                                 f"{t_w:.0f}s, untimed); extrapolated to {frames}f x {ddim_steps} steps x 2 (CFG) + decode"}))
 
 
+def reference_cpu_timing():
+    """The REAL reference's CPU timings, recorded by tests/golden/make_golden_full.py when it ran the reference's own classes
+    (fp32, torch CPU) in the build container: [seconds of one 24-frame forward, seconds of the 50-step DDIM_Gaussian CFG loop
+    (100 forwards), torch threads].  /root/reference cannot travel to the GPU box, so this is a recorded figure of another
+    host, reported beside the live port timing — not a measurement of this run."""
+    try:
+        import numpy as np
+        path = os.path.join(ROOT, "tests", "golden", "modelscope_24f_w16.npz")
+        if not os.path.exists(path):
+            path = os.path.join(ROOT, "tests", "golden", "modelscope_24f.npz")
+        t_fwd, t50, threads = [float(v) for v in np.load(path)["timing"]]
+        return {"value": round(24.0 / t50, 5), "unit": "frames/s", "cores": int(threads), "kind": "reference",
+                "sample": f"kabachuha/sd-webui-text2video's own UNetSD + Txt2VideoSampler.sample_loop, fp32, {int(threads)} torch threads in "
+                          f"the build container (recorded in {os.path.basename(path)}): 50 DDIM_Gaussian steps x 2 forwards of 24f@256x256 = "
+                          f"{t50:.0f}s (one forward {t_fwd:.1f}s); VAE decode not included (< 1 %)"}
+    except Exception as exc:                           # noqa: BLE001
+        return {"value": None, "kind": "reference", "sample": f"no recorded timing: {exc}"}
+
+
 def cpu_baseline(frames, ddim_steps, timeout_s=240):
+    out = _cpu_baseline_port(frames, ddim_steps, timeout_s)
+    out["reference_recorded"] = reference_cpu_timing()
+    return out
+
+
+def _cpu_baseline_port(frames, ddim_steps, timeout_s=240):
     import subprocess
     try:
         out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--frames", str(frames),
@@ -130,9 +164,7 @@ def pmc_traffic():
     """HBM bytes per launch of the GEMM family from the committed PMC passes (collected with
     tools/gpu_profile.sh -> tools/pmc_post.py; counters cannot be read from inside this process)."""
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    path = os.path.join(here, "r02_pmc_traffic.json")
-    if not os.path.exists(path):
-        path = os.path.join(here, "r01_pmc_traffic.json")
+    path = next((q for q in (os.path.join(here, f"r0{r}_pmc_traffic.json") for r in (3, 2, 1)) if os.path.exists(q)), "")
     try:
         with open(path) as fh:
             return round(json.load(fh)["hbm_bytes_per_launch"])
@@ -172,13 +204,125 @@ def gemm_strict_bytes(op) -> int:
     return a + N * K * 2 + M * (N // 2 if epi == 1 else N) * 2
 
 
+def smi_snapshot():
+    """Clocks / power of GPU 0 as amd-smi (or rocm-smi) reports them right now; None when neither tool answers."""
+    import subprocess
+    for cmd in (["amd-smi", "metric", "-g", "0", "--clock", "--power", "--json"], ["rocm-smi", "-d", "0", "--showclocks", "--showpower", "--json"]):
+        try:
+            out = subprocess.run(cmd, capture_output=True, text=True, timeout=20)
+            if out.returncode != 0 or "{" not in out.stdout:
+                continue
+            txt = out.stdout[out.stdout.index("{") if out.stdout.lstrip().startswith("{") else out.stdout.index("["):]
+            doc = json.loads(txt)
+            flat = {}
+
+            def walk(prefix, node):
+                if isinstance(node, dict):
+                    if set(node) >= {"value", "unit"}:
+                        flat[prefix] = f"{node['value']} {node['unit']}"
+                        return
+                    for k, v in node.items():
+                        walk(f"{prefix}.{k}" if prefix else str(k), v)
+                elif isinstance(node, list):
+                    for k, v in enumerate(node):
+                        walk(f"{prefix}[{k}]", v)
+                elif node not in (None, "N/A", ""):
+                    flat[prefix] = node
+            walk("", doc)
+            keep = {k: v for k, v in flat.items() if any(t in k.lower() for t in ("gfx_0.clk", "gfx_0.min", "gfx_0.max", "mem_0.clk", "socket_power",
+                                                                                   "sclk", "mclk", "power"))}
+            return {"tool": cmd[0], **dict(list(keep.items())[:12])}
+        except Exception:                              # noqa: BLE001
+            continue
+    return None
+
+
+def calibration_gemm(dev, n=8192, reps=8):
+    """TF/s of an n^3 fp16 GEMM (256x256 tile of the product's own gemm2 kernel, N(0,1) operands): the box's sustained matrix
+    rate under this chip's power limit, the quantity that differs between boxes of the pool."""
+    from sd_webui_text2video_amd.program import BoundProgram, Program, Ref
+    P = Program("calibration")
+    P.force_tile = 1
+    a, out = P.alloc(n, n, "f16"), P.alloc(n, n, "f16")
+    P.gemm("calibration", a, Ref("weight", 0, "w"), n, n, out, allow_splitk=False)
+    P.ops = P.ops * reps
+    arena = torch.zeros(P.arena.high + 256, dtype=torch.uint8, device=dev)
+    arena.view(torch.float16).normal_(0, 1)
+    w = torch.empty(n, n, device=dev, dtype=torch.float16).normal_(0, 1)
+    bp = BoundProgram(P, arena.data_ptr(), {"w": w.data_ptr()})
+    st = torch.cuda.current_stream(dev).cuda_stream
+    bp.run({}, st)
+    ms = sorted(bp.run_timed({}, st))[reps // 2]
+    torch.cuda.synchronize(dev)
+    return round(2.0 * n ** 3 / ms / 1e9, 1)
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _launch_env():
+    """Environment of a self-launched job: no inherited rank variables, the dmabuf IPC setting RCCL needs on this pool."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK",
+                                                            "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return env
+
+
+def self_launch(n: int, argv, timeout_s=None, capture=False):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, one process per GPU, under
+    torch.distributed.run on 127.0.0.1 (ddp_wrapper.py:9-13 does the same for the reference's VideoCrafter sampling).
+    -> (exit code, stdout or None)."""
+    import subprocess
+    if os.environ.get("T2V_BENCH_ONE_DEVICE") != "1" and "--launch-check" not in argv:
+        have = torch.cuda.device_count()
+        if have < n:
+            print(f"[bench] --gpus {n} but this node exposes {have} GPU(s)", file=sys.stderr, flush=True)
+            return 2, None
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    try:
+        out = subprocess.run(cmd, env=_launch_env(), timeout=timeout_s, stdout=subprocess.PIPE if capture else None, text=True,
+                             start_new_session=capture)
+        return out.returncode, out.stdout
+    except subprocess.TimeoutExpired as exc:
+        return 124, (exc.stdout if isinstance(exc.stdout, str) else None)
+
+
+def collective_layout_job(n: int, args, timeout_s: int):
+    """The collective layout of N GPUs (pairs at N = 2, T-shard x CFG pair for even N >= 4) as its OWN N-rank job, bounded by a
+    timeout: a failure or hang of the RCCL path is reported, it cannot take the headline down.  Called by rank 0 after the
+    headline job's process group is gone (the other ranks have released their GPUs' queues; memory is not a constraint)."""
+    mode = "pairs" if n == 2 else "tshard"
+    argv = ["--gpus", str(n), "--parallel", mode, "--steps", "1", "--warmup", "1", "--ddim-steps", str(args.ddim_steps),
+            "--height", str(args.height), "--width", str(args.width), "--no-cpu-baseline", "--also-batched", "0", "--no-collective-job"]
+    t0 = time.time()
+    rc, out = self_launch(n, argv, timeout_s=timeout_s, capture=True)
+    line = next((ln for ln in reversed((out or "").splitlines()) if ln.startswith("{")), None)
+    if rc == 0 and line:
+        d = json.loads(line)
+        return {"layout": mode, "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "scaling": d["scaling"],
+                "metric": d["metric"], "frames_per_video": d["config"]["frames_per_video"], "parallelism": d["config"]["parallelism"],
+                "rccl_communicators": d["config"].get("rccl_communicators"), "whole_video": d.get("roofline", {}).get("whole_video"),
+                "job_s": round(time.time() - t0, 1), "note": "separate N-rank job after the headline; not the headline"}
+    return {"layout": mode, "value": None, "exit_code": rc, "job_s": round(time.time() - t0, 1),
+            "note": ("timed out" if rc == 124 else "failed") + f" (limit {timeout_s}s); the headline is unaffected"}
+
+
 def choose_layout(world: int, requested: str, frames_arg: int = 0):
-    """-> (layout, frames per video).  auto: one GPU = configs[1] (24 frames, cond + uncond batched); 2 GPUs = one 24-frame
-    video per CFG pair; an even world >= 4 = configs[2], ONE 125-frame video, frames sharded along T over world / 2 GPUs x the
-    CFG pair (north_star's layout); an odd world > 1 = one video per GPU.  `--frames` overrides the frame count only."""
+    """-> (layout, frames per video).  auto: configs[1] at every N — one 24-frame video per GPU (cond + uncond batched as b=2):
+    `single` on one GPU, `replicas` on N (weak scaling, the per-N values are comparable).  `--parallel pairs | tshard` select the
+    collective layouts explicitly (tshard = configs[2], ONE 125-frame video, frames sharded along T over world / 2 GPUs x the CFG
+    pair — north_star's layout); under auto they are timed beside the headline as a separate job (`collective_layout`).
+    `--frames` overrides the frame count only."""
     mode = requested
     if mode == "auto":
-        mode = "single" if world == 1 else ("pairs" if world == 2 else ("tshard" if world % 2 == 0 else "replicas"))
+        mode = "single" if world == 1 else "replicas"
     if world == 1:
         mode = "single"
     return mode, (frames_arg or (125 if mode == "tshard" else 24))
@@ -207,17 +351,42 @@ def main():
                          "`batched` beside the headline (0 / 1 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--parallel", default="auto", choices=["auto", "replicas", "pairs", "tshard"],
-                    help="N>1 layout; auto = one video per CFG pair at N=2, ONE T-sharded video (frames over N/2 GPUs x CFG pair) "
-                         "for even N>=4, one video per GPU otherwise")
+                    help="N>1 layout; auto = one 24-frame video per GPU (replicas; configs[1] at every N) as the headline, with the "
+                         "collective layout of that N (pairs at N=2, ONE T-sharded 125-frame video for even N>=4) timed beside it as a "
+                         "separate job; pairs / tshard make the collective layout the headline")
+    ap.add_argument("--no-collective-job", action="store_true",
+                    help="N>1, --parallel auto: skip the separate job that times the collective layout beside the headline")
+    ap.add_argument("--collective-timeout", type=int, default=int(os.environ.get("T2V_BENCH_COLLECTIVE_TIMEOUT", 420)),
+                    help="seconds the separate collective-layout job may take before it is abandoned (reported, headline unaffected)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only check the launch path: ranks rendezvous over gloo, all-reduce their ranks, rank 0 prints one JSON line (no GPU)")
     args = ap.parse_args()
     if args.cpu_baseline_worker:
         cpu_baseline_worker(args.frames, args.ddim_steps)
         return
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: start the ranks ourselves (one process per GPU); their rank 0 prints the JSON line
+        rc, _ = self_launch(args.gpus, sys.argv[1:])
+        sys.exit(rc)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.launch_check:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world > 1:
+            dist.init_process_group(backend="gloo")
+        v = torch.tensor([rank + 1], dtype=torch.int64)
+        if world > 1:
+            dist.all_reduce(v)
+        assert world == args.gpus and int(v.item()) == world * (world + 1) // 2
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "rank_sum": int(v.item())}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     ctl = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -310,6 +479,12 @@ def main():
         net.t_shard = None
         mode, frames = "replicas", args.frames or 24
         runner = build(mode, frames)
+    cal_before = None
+    if rank == 0:
+        try:
+            cal_before = calibration_gemm(dev)
+        except Exception:                          # noqa: BLE001
+            cal_before = None
     elapsed = timed(runner, args.warmup, args.steps)
 
     total_frames = runner.frames_per_video_all_ranks * args.steps
@@ -335,6 +510,7 @@ def main():
         result["config"]["layout_fallback"] = fallback
     if world > 1 and os.environ.get("T2V_BENCH_ONE_DEVICE") == "1":
         result["data"] = "synthetic; REHEARSAL: all ranks on one GPU over gloo — not a measurement"
+    result["config"]["rccl_communicators"] = runner.communicators() if hasattr(runner, "communicators") else []
     if world > 1 and mode != "replicas":
         # the collective-free layout beside the headline: every GPU its own 24-frame video (configs[1] per GPU)
         try:
@@ -345,8 +521,13 @@ def main():
         except Exception as exc:                   # noqa: BLE001
             result["replicas"] = {"value": None, "note": f"failed: {type(exc).__name__}: {exc}"}
 
+    cal0 = None
     if rank == 0:
         # ---- live roofline of the dominant kernel (HIP events on the launch stream) -------------
+        try:
+            cal0 = {"gemm_8192_tflops_after": calibration_gemm(dev), "smi_after": smi_snapshot()}
+        except Exception as exc:                   # noqa: BLE001
+            cal0 = {"error": f"{type(exc).__name__}: {exc}"}
         F_loc = runner.unet_frames
         net.t_shard = None
         x = torch.randn(runner.unet_batch, 4, F_loc, args.height // 8, args.width // 8, device=dev)
@@ -376,6 +557,10 @@ def main():
             "unet_step_tflops_all_kernels": round(prog.total_flops() / (step_ms * 1e-3) / 1e12, 1),
             "unet_step_frac_of_peak": round(prog.total_flops() / (step_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
             "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 --pmc, profiles/r0N_pmc_traffic.json)",
+            # box calibration either side of the timed region: the same kernel family on an 8192^3 fp16 GEMM (random data)
+            "calibration": {"gemm_8192_tflops_before": cal_before, **(cal0 or {}),
+                            "note": "8192^3 fp16 GEMM, 256x256 tile of gemm2_kernel, N(0,1) operands, median of 8 launches (HIP events); "
+                                    "boxes of the pool differ by +-5-10 % on it (power-limited clocks) — divide to compare lines"},
             "algorithmic_bytes_per_launch": round(alg_bytes / n_gemm),
             "strict_bytes_per_launch": round(strict_bytes / n_gemm),
             "traffic_over_strict": round(traffic / (strict_bytes / n_gemm), 3) if traffic else None,
@@ -401,10 +586,18 @@ def main():
                                  "ms_per_step": round(tb * 1e3, 2), "note": "same workload, several videos per batch; not the headline"}
         if not args.no_cpu_baseline and world == 1:       # the CPU leg is reported at N=1 only
             result["cpu_baseline"] = cpu_baseline(frames, args.ddim_steps)
-        print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        want_job = (world > 1 and requested == "auto" and not args.no_collective_job and (world == 2 or world % 2 == 0)
+                    and os.environ.get("T2V_BENCH_COLLECTIVE_JOB", "1") != "0")
+        if want_job:
+            # the other ranks are leaving; this rank's own buffers can go too before the N-rank job starts
+            del runner
+            torch.cuda.empty_cache()
+            result["collective_layout"] = collective_layout_job(world, args, args.collective_timeout)
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":

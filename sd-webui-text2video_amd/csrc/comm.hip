@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -47,13 +48,20 @@ bool sym(void* h, const char* name, F& fn) {
 }
 
 void load_rccl() {
+  // T2V_RCCL_SONAME: use exactly this library (deployments with a private RCCL build; tests force the failure path with it)
+  const char* forced = getenv("T2V_RCCL_SONAME");
   const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  std::string last;
   for (const char* n : names) {
+    if (forced && *forced) n = forced;
     g_rccl.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
     if (g_rccl.handle) break;
+    const char* e = dlerror();      // dlerror() clears the message: read it exactly once per failure
+    last = std::string(n) + ": " + (e ? e : "?");
+    if (forced && *forced) break;
   }
   if (!g_rccl.handle) {
-    g_rccl.err = std::string("cannot dlopen librccl: ") + (dlerror() ? dlerror() : "?");
+    g_rccl.err = "cannot dlopen librccl (" + last + ")";
     return;
   }
   void* h = g_rccl.handle;

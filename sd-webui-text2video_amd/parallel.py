@@ -269,6 +269,13 @@ class _Runner:
                          f"{n_videos} video(s) in parallel, each on a CFG pair (cond | uncond UNet forwards on 2 GPUs, "
                          f"eps all-gather per step over RCCL), VAE frames split over the pair")
 
+    def communicators(self) -> List[dict]:
+        """What this layout created for its data path (bench.py reports it: `config.rccl_communicators`)."""
+        if self.pair.size == 1:
+            return []
+        return [{"kind": f"torch.distributed {dist.get_backend(self.pair.group)} group (eps all-gather per step, uint8 frame gather)",
+                 "size": self.pair.size}]
+
     @torch.no_grad()
     def __call__(self, cond, uncond, seed):
         pipe, pair = self.pipe, self.pair
@@ -356,6 +363,17 @@ class _TShardRunner:
                          f"({counts} frames per slice; statistics / halo / K-V exchanges as program ops over RCCL on the launch "
                          f"stream) x CFG pair (eps all-gather per step); VAE frames split over all ranks")
 
+    def communicators(self) -> List[dict]:
+        """The communicators this rank's data path runs over (bench.py: `config.rccl_communicators`): the library's own RCCL
+        communicator of the T group (created lazily by the first sharded forward; None = the exchanges went through the host
+        executor), the CFG pair group and the world group of the frame gather."""
+        ts = self.topo.tshard
+        lib_comm = ts._comm.size if ts._comm is not None else None
+        return [{"kind": "libt2v_hip t2v_comm: RCCL communicator owned by the library (statistics all-gather, halo send/recv, "
+                         "frame<->pixel all-to-all as program ops on the launch stream)", "size": lib_comm, "t_group_ranks": ts.size},
+                {"kind": f"torch.distributed {dist.get_backend(self.topo.pair_group)} group (eps all-gather per step)", "size": 2},
+                {"kind": f"torch.distributed {dist.get_backend()} world group (uint8 frame gather)", "size": self.topo.world}]
+
     @torch.no_grad()
     def __call__(self, cond, uncond, seed):
         pipe, topo = self.pipe, self.topo
@@ -377,7 +395,7 @@ class _TShardRunner:
         a, b = topo.decode_share()
         order = topo.frame_order()
         nmax = max(n for _, _, n in order)
-        H, W = self.height, self.width
+        H, W = 8 * (self.height // 8), 8 * (self.width // 8)        # what the decoder produces for a latent of H//8 x W//8
         send = torch.zeros((nmax, H, W, 3), dtype=torch.uint8, device=dev)
         if b > a:
             send[: b - a] = pipe.decode_frames(x0[:, :, a:b])
@@ -403,12 +421,13 @@ class _ReplicaRunner(_Runner):
 
 def make_runner(pipe, world: int, rank: int, *, frames, height, width, ddim_steps, guidance, mode: str = "auto",
                 videos: int = 1):
-    """'tshard' (default for an even world >= 4): ONE `frames`-frame video on 2 x R GPUs, T-sharded inside the UNet
-    (statistics / halo / K-V exchanges before the temporal ops, executed by the library over RCCL) x the CFG pair.
-    'pairs' (default for world == 2): one video per CFG pair — cond | uncond UNet forwards on 2 GPUs, one eps all-gather
-    per step.  'replicas': one video per GPU (throughput; no data-path collective; default for an odd world > 1)."""
+    """'replicas' (auto for world > 1): one video per GPU (throughput; no data-path collective — the reference's own
+    data-parallel mode).  'tshard' (even world >= 4): ONE `frames`-frame video on 2 x R GPUs, T-sharded inside the UNet
+    (statistics / halo / frame<->pixel exchanges before the temporal ops, executed by the library over RCCL) x the CFG pair.
+    'pairs': one video per CFG pair — cond | uncond UNet forwards on 2 GPUs, one eps all-gather per step (world == 1: the
+    single-GPU runner)."""
     if mode == "auto":
-        mode = "pairs" if world <= 2 else ("tshard" if world % 2 == 0 else "replicas")
+        mode = "pairs" if world == 1 else "replicas"
     if mode == "replicas":
         return _ReplicaRunner(pipe, world, rank, frames, height, width, ddim_steps, guidance, videos=videos)
     if mode == "tshard":

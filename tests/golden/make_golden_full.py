@@ -1,6 +1,14 @@
 """Full-size golden fixtures FROM THE REAL REFERENCE for BASELINE.json configs[1]..[4] (run in the build container).
 
     python tests/golden/make_golden_full.py [c1] [c2] [c3] [c4]      # default: all (~45 min on 8 cores)
+    python tests/golden/make_golden_full.py w16 [c1] [c2] [c3] [c4]  # "deployed-weights" goldens  -> *_w16.npz
+    python tests/golden/make_golden_full.py w16 c3x12                # 12-frame ZeroScope-XL forward -> zeroscope_xl_12f_w16.npz
+
+"w16" (round 3): the SAME reference classes, the SAME fp32 CPU arithmetic, but every parameter and the
+text conditioning are first rounded to fp16 and back (`w.half().float()`).  The reference pipeline always deploys `.half()`
+weights (t2v_pipeline.py:103-104), so these are the "identical inputs" north_star words: the product receives exactly these
+fp16 values, and what the golden then measures is the product's ARITHMETIC, not the fp32 -> fp16 rounding of the inputs
+that both the product and the reference's own GPU path perform before any kernel runs.
 
 Same recipe as make_golden.py (reference classes imported read-only through oracle/ref_bootstrap.py, seeded
 synthetic weights/inputs of oracle/synth.py, fp32 CPU arithmetic); only OUTPUTS are stored.  The large outputs
@@ -37,12 +45,33 @@ FRAMES_XL = [0, 1, 3]
 N_FRAMES_XL = 4
 XL_GRID = (slice(1, None, 4), slice(2, None, 4))            # [3, 144, 256] of the 576 x 1024 image
 XL_CROP = (slice(128, 256), slice(384, 512))
+N_FRAMES_XL12 = 12
+FRAMES_XL12 = [0, 5, 11]
+W16 = False                 # set by "w16" on the command line
+SUFFIX = ""
+
+
+def _deploy(module):
+    """fp16-representable parameters held in fp32 (the deployed values, fp32 arithmetic)."""
+    if W16:
+        with torch.no_grad():
+            for p in module.parameters():
+                p.copy_(p.half().float())
+    return module
+
+
+def _inputs(frames, h, w):
+    noise, cond, uncond = synth.synth_inputs(frames, h, w)
+    if W16:
+        cond, uncond = cond.half().float(), uncond.half().float()
+    return noise, cond, uncond
 
 
 def _unet():
     t0 = time.time()
     unet, betas = rb.build_reference_unet(configs.MODELSCOPE_UNET)
     synth.load_synth(unet, seed=0)
+    _deploy(unet)
     print(f"reference UNetSD + synthetic weights {time.time() - t0:.1f}s", flush=True)
     return unet, betas
 
@@ -65,7 +94,7 @@ def tensor2vid_ref(video):
 def c1():
     ref = rb.bootstrap()
     unet, betas = _unet()
-    noise, cond, uncond = synth.synth_inputs(24, 256, 256)
+    noise, cond, uncond = _inputs(24, 256, 256)
     with torch.no_grad():
         t0 = time.time()
         eps = unet(noise, torch.tensor([801]), cond)
@@ -81,11 +110,12 @@ def c1():
     del unet
     vae = rb.build_reference_vae(configs.VAE_DDCONFIG)
     synth.load_synth(vae, seed=3)
+    _deploy(vae)
     with torch.no_grad():
         imgs = torch.cat([vae.decode(x50[:, :, f] / configs.SCALE_FACTOR) for f in (0, 23)], dim=0)   # [2,3,256,256]
     vid = imgs.permute(1, 0, 2, 3).unsqueeze(0)                # [1,3,F,H,W] as t2v_pipeline.py:355-357
     frames_u8 = np.stack(tensor2vid_ref(vid))                  # [2,256,256,3]
-    np.savez_compressed(os.path.join(OUT, "modelscope_24f.npz"), unet_eps=eps.numpy(), sampler_x0_10=x10.numpy(),
+    np.savez_compressed(os.path.join(OUT, f"modelscope_24f{SUFFIX}.npz"), unet_eps=eps.numpy(), sampler_x0_10=x10.numpy(),
                         sampler_x0_50=x50.numpy(), frames_u8=frames_u8, vae_img=imgs.numpy().astype(np.float32)[:, :, ::2, ::2],
                         timing=np.array([t_fwd, t50, torch.get_num_threads()], dtype=np.float64))
     print("c1 done", flush=True)
@@ -93,12 +123,12 @@ def c1():
 
 def c2():
     unet, _ = _unet()
-    noise, cond, _ = synth.synth_inputs(125, 256, 256)
+    noise, cond, _ = _inputs(125, 256, 256)
     with torch.no_grad():
         t0 = time.time()
         eps = unet(noise, torch.tensor([801]), cond)
         t_fwd = time.time() - t0
-    np.savez_compressed(os.path.join(OUT, "modelscope_125f.npz"), unet_eps_frames=eps[:, :, FRAMES_125].numpy(),
+    np.savez_compressed(os.path.join(OUT, f"modelscope_125f{SUFFIX}.npz"), unet_eps_frames=eps[:, :, FRAMES_125].numpy(),
                         frames=np.array(FRAMES_125), eps_std=np.float64(eps.std()),
                         timing=np.array([t_fwd, torch.get_num_threads()], dtype=np.float64))
     print(f"c2 done forward {t_fwd:.1f}s std {eps.std():.4f}", flush=True)
@@ -106,7 +136,7 @@ def c2():
 
 def c3():
     unet, _ = _unet()
-    noise, cond, _ = synth.synth_inputs(N_FRAMES_XL, 576, 1024)
+    noise, cond, _ = _inputs(N_FRAMES_XL, 576, 1024)
     with torch.no_grad():
         t0 = time.time()
         eps = unet(noise, torch.tensor([801]), cond)
@@ -115,12 +145,13 @@ def c3():
     del unet
     vae = rb.build_reference_vae(configs.VAE_DDCONFIG)
     synth.load_synth(vae, seed=3)
+    _deploy(vae)
     z = noise[:, :, 0] / configs.SCALE_FACTOR
     with torch.no_grad():
         t0 = time.time()
         img = vae.decode(z)[0]                                 # [3,576,1024]
         t_vae = time.time() - t0
-    np.savez_compressed(os.path.join(OUT, "zeroscope_xl.npz"), unet_eps_frames=eps[:, :, FRAMES_XL].numpy(),
+    np.savez_compressed(os.path.join(OUT, f"zeroscope_xl{SUFFIX}.npz"), unet_eps_frames=eps[:, :, FRAMES_XL].numpy(),
                         frames=np.array(FRAMES_XL), vae_grid=img[:, XL_GRID[0], XL_GRID[1]].numpy(),
                         vae_crop=img[:, XL_CROP[0], XL_CROP[1]].numpy(), vae_std=np.float64(img.std()),
                         timing=np.array([t_fwd, t_vae, torch.get_num_threads()], dtype=np.float64))
@@ -137,9 +168,12 @@ def c4():
     dd.DDIMSampler.register_buffer = lambda self, name, attr: setattr(self, name, attr)
     net = om.UNetModel(**configs.LVDM_UNET).eval()
     synth.load_synth(net, seed=0)
+    _deploy(net)
     g = torch.Generator().manual_seed(1234)
     x_T = torch.randn(1, 4, 16, 32, 32, generator=g)
     ctx = torch.randn(2, 77, 768, generator=g)
+    if W16:
+        ctx = ctx.half().float()
     betas = vu.make_beta_schedule("linear", 1000, linear_start=0.00085, linear_end=0.012)
     ac = np.cumprod(1.0 - betas, axis=0)
     f32 = lambda a: torch.tensor(a, dtype=torch.float32)
@@ -159,14 +193,32 @@ def c4():
     del net
     vae = rb.build_reference_vae(configs.VAE_DDCONFIG)
     synth.load_synth(vae, seed=3)
+    _deploy(vae)
     with torch.no_grad():       # decode_first_stage_2DAE: z = 1/scale_factor * z, per frame (ddpm3d.py:776-793)
         img = vae.decode(torch.from_numpy(out["ddim_x0_50"])[:, :, 0] / configs.SCALE_FACTOR)
-    np.savez_compressed(os.path.join(OUT, "lvdm_16f_ddim.npz"), vae_img_frame0=img.numpy()[:, :, ::2, ::2], **out)
+    np.savez_compressed(os.path.join(OUT, f"lvdm_16f_ddim{SUFFIX}.npz"), vae_img_frame0=img.numpy()[:, :, ::2, ::2], **out)
     print("c4 done", flush=True)
+
+
+def c3x12():
+    """configs[3] at 12 frames (VERDICT r02 missing #3): batch 12 x 5 heads of the 9216-token attention = 60 score matrices
+    of 0.34 GB (+ softmax copies) fit this container; 24 frames do not."""
+    unet, _ = _unet()
+    noise, cond, _ = _inputs(N_FRAMES_XL12, 576, 1024)
+    with torch.no_grad():
+        t0 = time.time()
+        eps = unet(noise, torch.tensor([801]), cond)
+        t_fwd = time.time() - t0
+    np.savez_compressed(os.path.join(OUT, f"zeroscope_xl_12f{SUFFIX}.npz"), unet_eps_frames=eps[:, :, FRAMES_XL12].numpy(),
+                        frames=np.array(FRAMES_XL12), eps_std=np.float64(eps.std()),
+                        timing=np.array([t_fwd, torch.get_num_threads()], dtype=np.float64))
+    print(f"c3x12 done forward {t_fwd:.1f}s std {eps.std():.4f}", flush=True)
 
 
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = [a for a in sys.argv[1:] if a in ("c1", "c2", "c3", "c4")] or ["c2", "c3", "c4", "c1"]
+    if "w16" in sys.argv[1:]:
+        W16, SUFFIX = True, "_w16"
+    which = [a for a in sys.argv[1:] if a in ("c1", "c2", "c3", "c4", "c3x12")] or ["c2", "c3", "c4", "c1"]
     for name in which:
         globals()[name]()

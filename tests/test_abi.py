@@ -113,3 +113,27 @@ def test_product_path_has_no_cpu_fallback():
     net = unet.UNetSD(**configs.TINY_UNET, init_weights=False)
     with pytest.raises(L.T2VError):
         net(torch.zeros(1, 4, 2, 8, 8), torch.tensor([1]), torch.zeros(1, 7, 1024))
+
+
+def test_missing_rccl_is_an_error_code_not_a_crash(built_lib):
+    """with an unloadable librccl the communicator entry points return T2V_ERR_COMM and a message (the loader
+    used to call dlerror() twice and build a std::string from the NULL the second call returns -> SIGSEGV in rank 0 while the
+    other ranks hung in the id broadcast).  Forced here with T2V_RCCL_SONAME; runs in a child process because the library
+    resolves RCCL once per process."""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes, sys\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from sd_webui_text2video_amd import _lib as L\n"
+        "lib = L.load()\n"
+        "buf = ctypes.create_string_buffer(128)\n"
+        "rc = lib.t2v_comm_unique_id(buf)\n"
+        "h = ctypes.c_void_p()\n"
+        "rc2 = lib.t2v_comm_create(buf, 2, 0, ctypes.byref(h))\n"
+        "print('RC', rc, rc2, lib.t2v_last_error().decode())\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                         env={**os.environ, "T2V_RCCL_SONAME": "/nonexistent/librccl.so.1"})
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = next(ln for ln in out.stdout.splitlines() if ln.startswith("RC "))
+    assert line.startswith("RC -5 -5 ") and "cannot dlopen librccl" in line and "/nonexistent/librccl.so.1" in line

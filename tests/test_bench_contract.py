@@ -37,3 +37,34 @@ def test_bench_cli_flags():
     assert out.returncode == 0
     for flag in ("--gpus", "--steps", "--warmup", "--parallel", "--videos"):
         assert flag in out.stdout
+
+
+def test_bench_self_launches_its_ranks_without_an_external_launcher():
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment starts its own N ranks (the bare form
+    used to die on `assert world == args.gpus`).  --launch-check stops after the rendezvous, so this runs without a GPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--launch-check"], capture_output=True,
+                         text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line == {"launch_check": True, "n_gpus": 3, "rank_sum": 6}
+
+
+def test_bench_refuses_more_gpus_than_the_node_has():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "T2V_BENCH_ONE_DEVICE")}
+    env["HIP_VISIBLE_DEVICES"] = ""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1"], capture_output=True,
+                         text=True, timeout=300, env=env)
+    assert out.returncode == 2 and "--gpus 64 but this node exposes" in out.stderr
+
+
+def test_layout_choice_is_comparable_across_n():
+    """the headline workload is configs[1] at every N (one 24-frame video per GPU); the collective layouts are
+    explicit choices (and timed beside the headline as their own job)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.choose_layout(1, "auto") == ("single", 24)
+    for n in (2, 3, 4, 8):
+        assert bench.choose_layout(n, "auto") == ("replicas", 24)
+    assert bench.choose_layout(8, "tshard") == ("tshard", 125) and bench.choose_layout(2, "pairs") == ("pairs", 24)
+    assert bench.choose_layout(8, "tshard", 64) == ("tshard", 64)
