@@ -71,6 +71,8 @@ int validate_op(const t2v_op& op, int idx) {
             K % 64 != 0)
           return bad("fused LayerNorm output needs the 192x320 tile, N == 320, fp32 out, no split-K / activation");
         if (op.p[3] == 0 || op.p[7] == 0 || op.i[9] < N || op.i[9] % 4 != 0) return bad("fused LayerNorm output: gamma|beta, output pointer or leading dimension");
+        // the epilogue moves whole f32x4 / f16x4 groups without tail guards
+        if (op.i[5] < N || (op.p[4] != 0 && (op.i[6] < N || op.i[6] % 4 != 0))) return bad("fused LayerNorm output: ldc / ldr must be >= N and multiples of 4");
       }
       return 0;
     }

@@ -109,9 +109,14 @@ class WeightPacker:
         return name
 
     def add_lo(self, name: str) -> str:
-        """Second-order image of an fp16 weight image: lo = fp16(W - fp16(W)), so that A.W_hi + A.W_lo carries ~22 bits of
+        """Second-order image of an fp16 weight image: lo = fp16(W - fp16(W)), so that A.W_hi + A.W_lo carries more of
         the fp32 weight through two fp16 MFMA passes (packing is layout-only, hence linear: pack(W) splits like W).
-        All zeros for a model that is already `.half()`."""
+        All zeros for a model that is already `.half()` (the deployed form, t2v_pipeline.py:103-104).
+        Precision actually carried: the residual is ~2^-12 |W|; for |W| below 2^-3 it lies in the fp16 SUBNORMAL
+        range, whose spacing is 2^-24 absolute — torch's conversion and the gfx950 MFMA keep subnormals, so nothing is flushed,
+        but the pair then resolves W to ~2^-25 absolute = 19-21 significant bits for the 1e-2..1e-1 weights of these networks
+        (the full 22 only for |W| >= 2^-3).  A 2^11 pre-scale of `lo` with the factor folded into the second pass would restore
+        the rest; not done — with fp16 deployment the option only matters for fp32-weight experiments."""
         lo = name + ":lo"
         if lo not in self._names:
             base = next(fn for n, d, fn in self.recipes if n == name)

@@ -230,40 +230,112 @@ class TextToVideoSynthesis(object):
 pipe: Optional[TextToVideoSynthesis] = None     # module-global model cache, as process_modelscope.py:29
 
 
+def frames_to_video_tensor(frames) -> torch.Tensor:
+    """[F, H, W, 3] uint8 RGB frames -> [1, 3, F, H, W] float32 in [-1, 1]: the array arithmetic of process_modelscope.py:117-131
+    (`/ 255`, `2 * x - 1`, one sample).  Reading / resizing the frames (ffmpeg, PIL) is host plumbing left to the caller."""
+    arr = np.asarray(frames)
+    if arr.ndim != 4 or arr.shape[-1] != 3:
+        raise ValueError(f"expected frames [F, H, W, 3], got {arr.shape}")
+    bcfhw = arr[np.newaxis].transpose(0, 4, 1, 2, 3).astype(np.float32) / 255
+    return 2 * torch.from_numpy(np.ascontiguousarray(bcfhw)) - 1
+
+
 def process_modelscope(args_dict: dict, extra_args=None):
     """Entry point B1 (process_modelscope.py:34-266).  The reference body is webui file / ffmpeg / Gradio plumbing around
     the `batch_count` loop of `pipe.infer(...)` calls (:152-221) and returns `list[str]`: one `data:video/mp4;base64,`
     URL per video, made from the mp4 that ffmpeg stitched (:248-266).  Here:
       args_dict = {model_dir | pipe, prompt, n_prompt, steps, frames, seed, cfg_scale, width, height, eta, sampler,
-                   batch_count, clip_encoder | (cond, uncond), stitch}
+                   batch_count, clip_encoder | (cond, uncond), stitch,
+                   do_vid2vid, vid2vid_frames, strength,                      # :80-147
+                   inpainting_frames, inpainting_image, inpainting_weights}   # :170-217
     * `stitch(frames_bgr, infotext) -> bytes` (the ffmpeg stage, out of scope — e.g. the reference's own
       `ffmpeg_stitch_video` behind a temp directory) given: returns the reference's list of data-URLs, video b from
       seed + b (seed -1 stays random), exactly the reference loop;
     * no `stitch`: returns the BGR uint8 frames of the (last) video — what the reference writes as PNGs (:225-229);
       with (cond, uncond) tensors and batch_count > 1 the videos of seeds seed .. seed + batch_count - 1 are made in ONE
-      batched pass, frames side by side."""
+      batched pass, frames side by side.
+    * vid2vid (`do_vid2vid`, :80-142): `vid2vid_frames` = the input clip as [F, H, W, 3] uint8 RGB frames already at
+      (height, width) — what the reference has after vid2frames + PIL resize — or a [1, 3, F, H, W] float video in [-1, 1], or
+      ready latents [1, 4, F, h, w]; encoded by ONE batched VAE-encoder program (`compute_latents`), then
+      `skip_steps = floor(steps * clamp(1 - strength, 0, 1))` and `infer(..., latents, strength, skip_steps, is_vid2vid=True)`.
+    * img2vid inpainting (`inpainting_frames` > 0 with an `inpainting_image` [H, W, 3] uint8 RGB, :170-217): the image is encoded
+      for every frame, `inpainting_weights` = the per-frame mask weights (a sequence of `frames` floats — the reference reads
+      them from its deforum-style key string through T2VAnimKeys, host plumbing), latents = image * (1 - mask) + N(0,1) * mask
+      with the noise from numpy's GLOBAL generator exactly like the reference (:205), `strength = 1`, and `mask` goes to the
+      sampler (where, for DDIM_Gaussian, the reference's hook is inert: SURVEY App. C #5)."""
+    import math
     global pipe
     a = SimpleNamespace(**args_dict)
     if getattr(a, "pipe", None) is not None:
         pipe = a.pipe
     elif pipe is None:
         pipe = TextToVideoSynthesis(a.model_dir, clip_encoder=getattr(a, "clip_encoder", None))
-    common = dict(steps=a.steps, frames=a.frames, scale=a.cfg_scale, width=getattr(a, "width", 256),
-                  height=getattr(a, "height", 256), eta=getattr(a, "eta", 0.0),
+    width, height = getattr(a, "width", 256), getattr(a, "height", 256)
+    common = dict(frames=a.frames, scale=a.cfg_scale, width=width, height=height, eta=getattr(a, "eta", 0.0),
                   sampler=getattr(a, "sampler", available_samplers[0].name))
     batch_count = int(getattr(a, "batch_count", 1))
     stitch = getattr(a, "stitch", None)
-    if getattr(a, "cond", None) is not None and stitch is None:
-        frames, _ = pipe.infer_conditioned(a.cond, a.uncond, seed=a.seed, videos=batch_count, **common)
+    cpu_vae = getattr(a, "cpu_vae", "GPU (half precision)")
+    device = pipe.device
+    do_vid2vid = bool(getattr(a, "do_vid2vid", False))
+    inpainting = int(getattr(a, "inpainting_frames", 0) or 0) > 0 and getattr(a, "inpainting_image", None) is not None
+    have_cond = getattr(a, "cond", None) is not None
+
+    def to_latents(video):
+        """frames / float video / latents -> [1, 4, F, h, w] on the host (compute_latents, t2v_pipeline.py:148-194)."""
+        if isinstance(video, torch.Tensor) and video.ndim == 5 and video.shape[1] == 4:
+            return video.float().cpu()
+        vd = video if (isinstance(video, torch.Tensor) and video.ndim == 5) else frames_to_video_tensor(video)
+        if vd.shape[-2:] != (height, width):
+            raise ValueError(f"input frames are {tuple(vd.shape[-2:])}, expected (height, width) = {(height, width)}: resize on the host")
+        return pipe.compute_latents(vd, cpu_vae, device)
+
+    mask = None
+    if do_vid2vid:
+        src = getattr(a, "vid2vid_frames", None)
+        if src is None:
+            raise FileNotFoundError("Please upload a video :()")          # process_modelscope.py:82
+        latents = to_latents(src).to(device)
+        strength = float(a.strength)
+        skip_steps = int(math.floor(a.steps * max(0, min(1 - strength, 1))))
+    else:
+        latents, strength, skip_steps = None, 1, 0            # `args.strength = 1` (:145): UniPC starts at t_start = 1.0, like ns.T
+
+    if have_cond and stitch is None and not do_vid2vid and not inpainting:
+        frames, _ = pipe.infer_conditioned(a.cond, a.uncond, steps=a.steps, seed=a.seed, videos=batch_count, **common)
         return frames
     urls, frames = [], None
     for batch in range(batch_count):
         seed = a.seed + batch if a.seed != -1 else -1
-        if getattr(a, "cond", None) is not None:
-            frames, _ = pipe.infer_conditioned(a.cond, a.uncond, seed=seed, **common)
+        if inpainting:
+            img = np.asarray(a.inpainting_image)
+            if img.shape != (height, width, 3):
+                raise ValueError(f"inpainting image is {img.shape}, expected {(height, width, 3)}: resize on the host")
+            image_latents = to_latents(np.repeat(img[np.newaxis], a.frames, axis=0)).numpy()
+            lh, lw = height // 8, width // 8
+            latent_noise = np.random.normal(size=(1, 4, a.frames, lh, lw))            # the reference's unseeded draw (:205)
+            weights = getattr(a, "inpainting_weights", None)
+            if weights is None or isinstance(weights, str):
+                raise ValueError("inpainting_weights: pass the per-frame mask weights as a sequence of floats (the key-string "
+                                 "parser T2VAnimKeys is webui plumbing)")
+            wts = [float(weights(i)) if callable(weights) else float(weights[i]) for i in range(a.frames)]
+            m = np.ones(shape=(1, 4, a.frames, lh, lw))
+            for i in range(a.frames):
+                m[:, :, i, :, :] = wts[i]
+            latents = torch.tensor(image_latents * (1 - m) + latent_noise * m).to(device)    # float64, like the reference
+            mask = torch.tensor(m).to(device)
+            strength = 1
+        if have_cond:
+            st = None if (strength == 0.0 and not do_vid2vid) else strength
+            if "half precision" in str(cpu_vae) and getattr(pipe, "autoencoder", None) is not None:
+                pipe.autoencoder.half()                      # what `infer` does before decoding (t2v_pipeline.py:337-339)
+            frames, _ = pipe.infer_conditioned(a.cond, a.uncond, a.steps - skip_steps, seed=seed if seed != -1 else random.randint(0, 2 ** 32 - 1),
+                                               latents=latents, strength=st, mask=mask, is_vid2vid=do_vid2vid, device=device, **common)
             info = ""
         else:
-            frames, _, info = pipe.infer(a.prompt, getattr(a, "n_prompt", ""), seed=seed, **common)
+            frames, _, info = pipe.infer(a.prompt, getattr(a, "n_prompt", ""), a.steps, seed=seed, cpu_vae=cpu_vae, device=device,
+                                         latents=latents, skip_steps=skip_steps, strength=strength, mask=mask, is_vid2vid=do_vid2vid,
+                                         **common)
         if stitch is not None:
             import base64
             urls.append("data:video/mp4;base64," + base64.b64encode(stitch(frames, info)).decode())

@@ -299,7 +299,7 @@ class Program:
              ldw: Optional[int] = None, gather: int = L.GATHER_PLAIN, conv: Optional[dict] = None,
              rowbias: Optional[Buf] = None, rows_per_batch: int = 0, residual: Optional[Buf] = None,
              epi: int = L.EPI_NONE, act: int = 0, bias_along_m: bool = False, m: Optional[int] = None,
-             allow_splitk: bool = True, halo: bool = False, ln: Optional[tuple] = None) -> Op:
+             allow_splitk: bool = True, halo: bool = False, ln: Optional[tuple] = None, step_invariant: bool = False) -> Op:
         """out[M, n_out] = epi(gather(a)[M, k] @ w[n, k]^T).  conv['pad_after_only'] (3x3, stride 2): zero padding
         (0,1,0,1) instead of 1 on every side.
         ln = (gamma|beta Ref (fp32 [2n]), gamma Ref, beta Ref, ln_out Buf fp16, eps): LayerNorm of the fp32 result rows as a second
@@ -313,7 +313,7 @@ class Program:
             # hi + lo weight split: t = A.W_lo (+ residual) in fp32, then the normal GEMM on W_hi with t as its residual
             lo_tmp = self.alloc(M, n, "f32")
             self.gemm(name + ".w_lo", a, lo, n, k, lo_tmp, ldw=ldw, gather=gather, conv=conv, residual=residual, m=m,
-                      allow_splitk=allow_splitk, halo=halo)
+                      allow_splitk=allow_splitk, halo=halo, step_invariant=step_invariant)
             residual = lo_tmp
         n_out = n // 2 if epi == L.EPI_GEGLU else n
         assert out.cols == n_out, (name, out.cols, n_out)
@@ -363,6 +363,8 @@ class Program:
         op.flops = 2.0 * M * n * k
         op.out = out
         op.meta = dict(M=M, N=n, K=k, gather=gather, conv=dict(conv), epi=epi, split=split, tile=tile, halo=halo, ln=int(ln_fused))
+        if step_invariant:
+            op.meta["step_invariant"] = True      # (also set on the .w_lo pass above: both halves of a split weight are skipped together)
         self._emit(op)
         if ln is not None and not ln_fused:
             self.layernorm(name + ".ln", out if m is None else out.row_slice(0, M), gamma, beta,

@@ -408,8 +408,7 @@ class UNetSD(nn.Module):
             shard = self.t_shard.spec                             # x holds only this rank's frames
             if shard.frames != F:
                 raise L.T2VError(f"T-sharded forward: this rank holds {shard.frames} of {shard.total} frames, got {F}")
-        key = (B, F, H, W, y.shape[1], _dt(x.dtype), _dt(y.dtype), _dt(out_dtype)) + ((shard,) if shard else ()) + \
-              ((("xb", Bx),) if Bx != B else ()) + ((("split",) + tuple(self.split_weight_prefixes),) if self.split_weight_prefixes else ())
+        key = self._program_key(B, F, H, W, y.shape[1], x.dtype, y.dtype, out_dtype, shard, Bx)
         comp = self._programs.get(key)
         if comp is None:
             comp = self._compile(B, F, H, W, y.shape[1], _dt(x.dtype), _dt(out_dtype), _dt(y.dtype), shard=shard,
@@ -431,6 +430,16 @@ class UNetSD(nn.Module):
             comp.bound.run(ext, torch.cuda.current_stream(x.device).cuda_stream)
         comp.ctx_token, comp.ctx_bound = token, comp.bound
         return out
+
+    def _program_key(self, B, F, H, W, Lctx, x_dtype, y_dtype, out_dtype, shard=None, Bx=None):
+        """Cache key of a compiled geometry (one helper for forward and forward_timed)."""
+        return (B, F, H, W, Lctx, _dt(x_dtype), _dt(y_dtype), _dt(out_dtype)) + ((shard,) if shard else ()) + \
+            ((("xb", Bx),) if (Bx is not None and Bx != B) else ()) + \
+            ((("split",) + tuple(self.split_weight_prefixes),) if self.split_weight_prefixes else ()) + self._lowering_options()
+
+    def _lowering_options(self) -> tuple:
+        """Lowering switches that change the program (part of the cache key)."""
+        return ()
 
     def forward_cfg_pair(self, x, t, ctx_pair, context_token=None):
         """One guided step's two evaluations (gaussian_sampler.py:161-162) as ONE forward: x [V,4,F,h,w] is read twice by
@@ -455,8 +464,8 @@ class UNetSD(nn.Module):
         """Like forward, but returns (eps, per-op milliseconds) using HIP events around every op
         on the launch stream (bench.py roofline measurement)."""
         out = UNetSD.forward(self, x, t, y)
-        comp = self._programs[(x.shape[0], x.shape[2], x.shape[3], x.shape[4], y.shape[1], _dt(x.dtype),
-                               _dt(y.dtype), _dt(out.dtype))]
+        comp = self._programs[self._program_key(y.shape[0], x.shape[2], x.shape[3], x.shape[4], y.shape[1], x.dtype, y.dtype, out.dtype,
+                                                Bx=x.shape[0])]
         xs, ys = x.contiguous(), y.contiguous()
         tf = t.to(device=x.device, dtype=torch.float32).contiguous()
         ext = {L.EXT_X: xs.data_ptr(), L.EXT_T: tf.data_ptr(), L.EXT_CTX: ys.data_ptr(), L.EXT_OUT: out.data_ptr()}
@@ -914,7 +923,7 @@ class _Lowering:
             w_kv = Ref("weight", 0, self.packer.add("kv_all:lin", "f16", lambda sd, ps=tuple(p for p, _ in st_prefixes): torch.cat(
                 [torch.cat([sd[p + ".transformer_blocks.0.attn2.to_k.weight"], sd[p + ".transformer_blocks.0.attn2.to_v.weight"]], dim=0)
                  for p in ps], dim=0)))
-            P.gemm("attn2.kv.all", ctx16, w_kv, n_kv, net.context_dim, self.kv_all).meta["step_invariant"] = True
+            P.gemm("attn2.kv.all", ctx16, w_kv, n_kv, net.context_dim, self.kv_all, step_invariant=True)
         P.free(ctx16)
 
         # ---- entry layout conversion: b c f h w -> tokens x 8 channels (4 real + 4 zero)

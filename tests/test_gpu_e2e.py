@@ -306,6 +306,48 @@ def test_vae_encode_and_vid2vid_match_reference_golden(tiny):
     assert r < 2e-2, r
 
 
+def test_vid2vid_through_process_modelscope_matches_reference_golden(tiny):
+    """the vid2vid argument path of B1 (process_modelscope.py:80-147): do_vid2vid + vid2vid_frames (here: the
+    clip's latents) + strength -> skip_steps = floor(steps * (1 - strength)) -> infer(..., latents, strength, skip_steps,
+    is_vid2vid=True), against the reference sampler's own vid2vid output (golden `vid2vid_x0`: sample_loop(steps=4,
+    strength=0.5) = B1 with steps=8, strength=0.5).  Also from uint8 frames: they reach the sampler through the VAE encoder."""
+    from sd_webui_text2video_amd import pipeline
+    net, sd, betas = tiny
+    *_, c, uc = _tiny_inputs()
+    gold = np.load(os.path.join(GOLD, "tiny.npz"))
+    ae = V.AutoencoderKL(configs.TINY_VAE_DDCONFIG, 4, init_weights=False)
+    ae.load_state_dict(synth.synth_state_dict(synth.param_spec(ae), seed=3), strict=True)
+    pipe = pipeline.TextToVideoSynthesis(sd_model=net, autoencoder=ae, betas=betas, device=DEV)
+    pipe.diffusion.progress = False
+    z0 = torch.randn((1, 4, 3, 16, 16), generator=torch.Generator().manual_seed(11))
+    args = dict(pipe=pipe, cond=c, uncond=uc, steps=8, frames=3, seed=1234, cfg_scale=9.0, width=128, height=128, eta=0.0,
+                sampler="DDIM_Gaussian", cpu_vae="GPU", do_vid2vid=True, strength=0.5)
+    frames = pipeline.process_modelscope(dict(args, vid2vid_frames=z0))
+    r = rel_l2(pipe.last_tensor.float().cpu(), torch.from_numpy(gold["vid2vid_x0"]))
+    print(f"B1 vid2vid (latents in): x0 rel-L2 vs the reference sampler {r:.3e}")
+    assert r < 2e-2, r
+    assert len(frames) == 3 and frames[0].shape == (128, 128, 3) and frames[0].dtype == np.uint8
+    # uint8 frames in: encode on the GPU, same path; deterministic and different from the latent-input clip
+    clip = (torch.rand(3, 128, 128, 3, generator=torch.Generator().manual_seed(4)) * 255).to(torch.uint8).numpy()
+    f1 = np.stack(pipeline.process_modelscope(dict(args, vid2vid_frames=clip)))
+    x_a = pipe.last_tensor.clone()
+    f2 = np.stack(pipeline.process_modelscope(dict(args, vid2vid_frames=clip)))
+    assert np.array_equal(f1, f2) and torch.equal(x_a, pipe.last_tensor) and torch.isfinite(x_a).all()
+    lat = pipe.compute_latents(pipeline.frames_to_video_tensor(clip), "GPU", torch.device(DEV))
+    smp = samplers.Txt2VideoSampler(net, torch.device(DEV), betas=betas, sampler_name="DDIM_Gaussian")
+    smp.progress = False
+    _, noise, shape = smp.get_noise(1, 4, 3, 128, 128, seed=1234)
+    want = smp.sample_loop(steps=4, strength=0.5, conditioning=c.to(DEV), unconditional_conditioning=uc.to(DEV), batch_size=1,
+                           latents=lat.to(DEV), shape=shape, noise=noise, is_vid2vid=True, guidance_scale=9.0, eta=0.0,
+                           sampler_name="DDIM_Gaussian")
+    assert torch.equal(want, x_a)
+    # img2vid inpainting keys: weights 0 keep the image latent as the start of that frame, mask reaches the sampler
+    np.random.seed(3)
+    fi = pipeline.process_modelscope(dict(args, do_vid2vid=False, steps=4, inpainting_frames=2, inpainting_image=clip[0],
+                                          inpainting_weights=[0.0, 0.5, 1.0]))
+    assert len(fi) == 3 and torch.isfinite(pipe.last_tensor).all()
+
+
 def test_sampler_interrupt_raises(tiny):
     net, sd, betas = tiny
     *_, c, uc = _tiny_inputs()

@@ -17,14 +17,18 @@ class _FakePipe:
     def __init__(self):
         self.calls = []
 
+    device = "cpu"
+
     def infer(self, prompt, n_prompt, steps, frames, seed, scale, width=256, height=256, eta=0.0, sampler="DDIM_Gaussian", **kw):
         self.calls.append(("infer", prompt, n_prompt, steps, frames, seed, scale, width, height, eta, sampler))
+        self.kw = kw
         fr = [np.full((height, width, 3), (seed + f) % 256, dtype=np.uint8) for f in range(frames)]
         return fr, None, f"{prompt}\nseed: {seed}"
 
     def infer_conditioned(self, c, uc, steps, frames, seed, scale, width=256, height=256, eta=0.0, sampler="DDIM_Gaussian",
                           videos=1, **kw):
         self.calls.append(("cond", steps, frames, seed, scale, videos))
+        self.kw = kw
         return [np.full((height, videos * width, 3), seed % 256, dtype=np.uint8) for _ in range(frames)], None
 
 
@@ -54,6 +58,52 @@ def test_process_modelscope_batch_loop_and_data_urls():
     assert pipe.calls == [("cond", 7, 3, 40, 9.0, 4)] and side[0].shape == (8, 64, 3)      # one batched pass, side by side
 
 
+def test_process_modelscope_vid2vid_and_inpainting_keys():
+    """B1's vid2vid (process_modelscope.py:80-147) and img2vid-inpainting (:170-217) argument paths: host arithmetic only —
+    frame tensor conversion, skip_steps from strength, mask / masked latents from the per-frame weights — with a stand-in
+    pipeline whose compute_latents returns a known tensor."""
+    import torch
+
+    class P(_FakePipe):
+        def compute_latents(self, vd, cpu_vae="GPU (half precision)", device=None):
+            self.vd = vd
+            b, _, F, h, w = vd.shape
+            return torch.full((b, 4, F, h // 8, w // 8), 0.5)
+
+    pipe = P()
+    clip = np.random.default_rng(0).integers(0, 256, size=(3, 8, 16, 3), dtype=np.uint8)
+    pipeline.process_modelscope(_args(pipe, do_vid2vid=True, vid2vid_frames=clip, strength=0.7))
+    assert pipe.vd.shape == (1, 3, 3, 8, 16) and pipe.vd.dtype == torch.float32
+    assert torch.allclose(pipe.vd[0, :, 1, 2, 5], torch.from_numpy(clip[1, 2, 5].astype(np.float32)) / 255 * 2 - 1)
+    kw = pipe.kw
+    assert kw["is_vid2vid"] is True and kw["strength"] == 0.7 and kw["skip_steps"] == int(np.floor(7 * (1 - 0.7))) == 2
+    assert kw["latents"].shape == (1, 4, 3, 1, 2) and kw["mask"] is None
+    with pytest.raises(FileNotFoundError):
+        pipeline.process_modelscope(_args(pipe, do_vid2vid=True, vid2vid_frames=None, strength=0.5))
+    with pytest.raises(ValueError, match="resize"):
+        pipeline.process_modelscope(_args(pipe, do_vid2vid=True, vid2vid_frames=clip[:, :4], strength=0.5))
+    # ready latents are passed through; with (cond, uncond) the sampler is called with steps - skip_steps like infer does
+    lat = torch.randn(1, 4, 3, 1, 2)
+    pipeline.process_modelscope(_args(pipe, do_vid2vid=True, vid2vid_frames=lat, strength=0.5, cond="C", uncond="U"))
+    assert pipe.calls[-1][:2] == ("cond", 7 - 3) and torch.equal(pipe.kw["latents"], lat) and pipe.kw["strength"] == 0.5
+    # inpainting: weights 1 -> pure noise frame, 0 -> the image latent; numpy's global generator like the reference (:205)
+    img = np.zeros((8, 16, 3), dtype=np.uint8)
+    np.random.seed(5)
+    pipeline.process_modelscope(_args(pipe, inpainting_frames=2, inpainting_image=img, inpainting_weights=[0.0, 0.25, 1.0]))
+    np.random.seed(5)
+    noise = np.random.normal(size=(1, 4, 3, 1, 2))
+    kw = pipe.kw
+    assert kw["strength"] == 1 and kw["is_vid2vid"] is False and kw["mask"].dtype == torch.float64
+    assert torch.equal(kw["mask"][0, :, :, 0, 0], torch.tensor([[0.0, 0.25, 1.0]] * 4, dtype=torch.float64))
+    want = 0.5 * (1 - kw["mask"].numpy()) + noise * kw["mask"].numpy()
+    assert np.allclose(kw["latents"].numpy(), want) and pipe.vd.shape == (1, 3, 3, 8, 16)
+    with pytest.raises(ValueError, match="per-frame"):
+        pipeline.process_modelscope(_args(pipe, inpainting_frames=2, inpainting_image=img, inpainting_weights="0:(1)"))
+    # plain text-to-video hands the reference's strength = 1 through (process_modelscope.py:145)
+    pipeline.process_modelscope(_args(pipe))
+    assert pipe.kw["strength"] == 1 and pipe.kw["skip_steps"] == 0 and pipe.kw["latents"] is None
+
+
 def test_infer_without_text_encoder_is_an_error_not_a_fallback():
     p = pipeline.TextToVideoSynthesis.__new__(pipeline.TextToVideoSynthesis)
     p.clip_encoder = None
@@ -68,10 +118,11 @@ def test_bench_layout_choice_and_byte_counts():
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     assert bench.choose_layout(1, "auto") == ("single", 24)                  # N = 1 stays configs[1]
-    assert bench.choose_layout(2, "auto") == ("pairs", 24)
-    assert bench.choose_layout(4, "auto") == ("tshard", 125) and bench.choose_layout(8, "auto") == ("tshard", 125)   # configs[2]
+    # round 3: the headline workload is configs[1] on every GPU at every N; collective layouts are explicit
+    assert bench.choose_layout(2, "auto") == ("replicas", 24) and bench.choose_layout(2, "pairs") == ("pairs", 24)
+    assert bench.choose_layout(4, "auto") == ("replicas", 24) and bench.choose_layout(8, "tshard") == ("tshard", 125)   # configs[2]
     assert bench.choose_layout(3, "auto") == ("replicas", 24)
-    assert bench.choose_layout(8, "replicas") == ("replicas", 24) and bench.choose_layout(8, "auto", 48) == ("tshard", 48)
+    assert bench.choose_layout(8, "replicas") == ("replicas", 24) and bench.choose_layout(8, "tshard", 48) == ("tshard", 48)
     assert bench.choose_layout(1, "tshard") == ("single", 24)
     assert bench.BASELINE_CONFIGS[(125, 256, 256)].endswith("configs[2]")
     # strict bytes = fp16 activations once + weights once + fp16 result; the design's count adds fp32 stream traffic
