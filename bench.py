@@ -126,9 +126,7 @@ def reference_cpu_timing():
     host, reported beside the live port timing — not a measurement of this run."""
     try:
         import numpy as np
-        path = os.path.join(ROOT, "tests", "golden", "modelscope_24f_w16.npz")
-        if not os.path.exists(path):
-            path = os.path.join(ROOT, "tests", "golden", "modelscope_24f.npz")
+        path = os.path.join(ROOT, "tests", "golden", "modelscope_24f.npz")      # (the _w16 run shared the cores with other jobs)
         t_fwd, t50, threads = [float(v) for v in np.load(path)["timing"]]
         return {"value": round(24.0 / t50, 5), "unit": "frames/s", "cores": int(threads), "kind": "reference",
                 "sample": f"kabachuha/sd-webui-text2video's own UNetSD + Txt2VideoSampler.sample_loop, fp32, {int(threads)} torch threads in "
@@ -393,6 +391,10 @@ def main():
         # T2V_BENCH_ONE_DEVICE=1 (rehearsal of the N > 1 code path on a 1-GPU box): every rank on cuda:0, gloo instead of
         # RCCL (device buffers staged through the host, parallel.all_gather_into) — never a measurement configuration
         one_device = os.environ.get("T2V_BENCH_ONE_DEVICE") == "1"
+        if one_device:
+            # several processes share the GPU: the single-pass GroupNorm's grid barrier needs all its workgroups resident,
+            # which more than two concurrent processes cannot guarantee -> three-launch path in the rehearsal
+            os.environ.setdefault("T2V_GN_COOP", "0")
         dist.init_process_group(backend="gloo" if one_device else "nccl")      # "nccl" is RCCL on ROCm
         ctl = dist.new_group(backend="gloo")         # control plane (layout agreement), never on the data path
         if one_device:

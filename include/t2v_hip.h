@@ -95,6 +95,11 @@ enum t2v_gather {
  * caller sizes the scratch as nparts*n_inst*ceil(rows/16)*groups*16 + n_inst*groups*8 bytes. */
 #define T2V_GN_ROWS_PER_BLOCK 64
 
+/* Device-side synchronisation words a program may hand to its ops: T2V_SYNC_INTS int32 arrival counters for the split-K fold
+ * (GEMM p[7]) followed by 64 more for the grid barrier of the single-pass GroupNorm (GROUPNORM p[5] points at the first of
+ * them).  All zero before the first launch; the kernels leave them zero (counters) or monotonic (barrier generation). */
+#define T2V_SYNC_INTS 4096
+
 #define T2V_OP_NI 24
 #define T2V_OP_NF 8
 #define T2V_OP_NP 8
@@ -112,16 +117,21 @@ enum t2v_gather {
  *      PLAIN gather only: 8 = 1 -> fused LayerNorm second output (tile 8, N == 320, fp32 out, no split-K): p[7] fp16 [M, i[9]] =
  *         LayerNorm(out row, eps f[0]) * gamma + beta with p[3] = fp32 [2N] gamma | beta (instead of a row bias)
  *   p: 0 A fp16, 1 W fp16 [N,K], 2 bias fp32 [N] (or [M] if bias_along_m), 3 rowbias fp32
- *      [M/rows_per_batch, ldrb], 4 residual fp32 [M,ldr], 5 out, 6 split-K workspace fp32
+ *      [M/rows_per_batch, ldrb], 4 residual fp32 [M,ldr], 5 out, 6 split-K workspace fp32 [split_k, M, N],
+ *      7 split-K (epilogue NONE): T2V_SYNC_INTS zeroed int32 tile tickets -> the last workgroup of a tile to arrive folds the
+ *        slabs in split order and applies the epilogue (no reduction launch); 0 -> a reduction kernel follows
  * GROUPNORM: i: 0 n_inst, 1 rows_per_inst, 2 C, 3 ld_in, 4 groups, 5 in dtype, 6 silu,
  *      7 ld_out, 8 phase (0 whole op | 1 statistics only | 2 fold gathered parts + normalise),
  *      9 nparts, 10 this rank's part, 11 rows per workgroup (0: T2V_GN_ROWS_PER_BLOCK; sizes the scratch),
  *      12 single-launch variant (phase 0 only, (C/groups) % 4 == 0): one workgroup per (instance, group);
  *      14 rows of the whole instance over all parts (0 = rows * nparts; T-sharded clips with uneven slices);
+ *      15 single-PASS cooperative variant allowed (phase 0, groups <= 32, p[5] given): grid <= one workgroup per CU, the tensor
+ *         is read once into registers, statistics meet at a grid barrier (p[5] = 2 zero-initialised uint32 words); the library
+ *         uses it when the instance chunks fit (else the launches above on the same scratch);
  *      scratch, phase 0: block partials [n_inst][nblk][groups][2] fp64, then {mean, rstd} fp32;  phases 1 / 2: gathered parts
  *      [nparts][n_inst][groups][2] fp64 (phase 1 folds this rank's block partials into its part; ALLGATHER of
  *      n_inst*groups*16 bytes per part), then this rank's block partials, then {mean, rstd};
- *      f: 0 eps;  p: 0 x, 1 gamma, 2 beta, 3 out fp16, 4 scratch
+ *      f: 0 eps;  p: 0 x, 1 gamma, 2 beta, 3 out fp16, 4 scratch, 5 grid-barrier words (i[15])
  * LAYERNORM: i: 0 M, 1 C, 2 ld_in, 3 ld_out, 4 workgroup cap (0 = 2048; rows beyond 4 x cap are walked grid-stride); f: 0 eps;
  *      p: 0 x fp32, 1 gamma, 2 beta, 3 out fp16
  * ATTENTION: i: 0 nq, 1 nk, 2 heads, 3 batch_outer, 4 batch_inner, 5..7 q strides (seq,
@@ -134,11 +144,12 @@ enum t2v_gather {
  *      out[t] = sum_s softmax_s(sim)[t,s] * (v[s] + Ev[clip(s-t)])   (attention_temporal.py:107-144)
  * SOFTMAX: i: 0 rows, 1 cols, 2 ld_in, 3 ld_out; f: 0 scale; p: 0 in fp32, 1 out fp16
  * NCTHW_TO_CL: i: 0 B, 1 C, 2 F, 3 HW, 4 ld_out, 5 in dtype, 6 samples in the source (0 = B; fewer: output sample b reads
- *      source sample b % i[6] — the cond | uncond pair of a guided step shares x_t); f: 0 scale; p: 0 in, 1 out fp16
+ *      source sample b % i[6] — the cond | uncond pair of a guided step shares x_t); f: 0 scale; p: 0 in, 1 out fp16,
+ *      2 (optional) low-order fp16 image, same layout: out_lo = fp16(v - float(fp16(v))) — hi + lo operand split of a consumer GEMM
  * CL_TO_NCTHW: i: 0 B, 1 C, 2 F, 3 HW, 4 ld_in, 5 out dtype; p: 0 in fp32, 1 out
  * TIME_EMBED: i: 0 B, 1 dim; p: 0 t fp32 [B], 1 freqs fp32 [dim/2], 2 out fp16 [B,dim]
  * COPY2D: i: 0 rows, 1 cols, 2 ld_src, 3 ld_dst, 4 src dtype, 5 dst dtype, 6 act (0 none, 1 SiLU, 2 GELU(erf),
- *      3 quick-GELU x*sigmoid(1.702x)); p: 0 src, 1 dst
+ *      3 quick-GELU x*sigmoid(1.702x)); p: 0 src, 1 dst, 2 (optional, fp32 -> fp16 only) low-order fp16 image of the cast, ld_dst
  * DDIM_STEP: i: 0 C (= samples * channels), 1 inner (F*h*w), 2 guided channels (per sample), 3 eps dtype, 4 x dtype, 5 mode,
  *      6 channels per sample (0 = C: one video per batch); x [samples, channels, inner], eps [2, samples, channels, inner];
  *      mode 0 (DDIM_Gaussian, gaussian_sampler.py:103-108,199-211,269-283):

@@ -14,7 +14,7 @@ namespace {
 
 template <typename TIN>
 __global__ __launch_bounds__(256) void ncthw_to_cl_kernel(const TIN* in, f16* out, int B, int C, int F, int HW,
-                                                          int ld, float scale, int Bsrc) {
+                                                          int ld, float scale, int Bsrc, f16* out_lo) {
   // one thread per output token; writes ld (>= C, multiple of 4) channels, zero padded.  Bsrc < B: the source holds
   // Bsrc samples and output sample b reads source sample b % Bsrc (the cond | uncond pair of a guided step shares x_t,
   // gaussian_sampler.py:161-162 — no torch.cat([x, x]) on the host)
@@ -28,7 +28,9 @@ __global__ __launch_bounds__(256) void ncthw_to_cl_kernel(const TIN* in, f16* ou
     for (int c = 0; c < ld; ++c) {
       float v = 0.f;
       if (c < C) v = (float)in[(((size_t)bs * C + c) * F + f) * HW + pix] * scale;
-      o[c] = (f16)v;
+      const f16 hi = (f16)v;
+      o[c] = hi;
+      if (out_lo) out_lo[tkn * ld + c] = (f16)(v - (float)hi);      // low-order image: hi + lo carries the fp32 value (p[2])
     }
   }
 }
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(256) void time_embed_kernel(const float* t, const f
 
 template <typename TS, typename TD>
 __global__ __launch_bounds__(256) void copy2d_kernel(const TS* src, TD* dst, int rows, int cols, int lds_,
-                                                     int ldd, int act) {
+                                                     int ldd, int act, f16* dst_lo) {
   const int cv = cols >> 2;
   const long total = (long)rows * cv;
   for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < total; u += (long)gridDim.x * 256) {
@@ -84,6 +86,10 @@ __global__ __launch_bounds__(256) void copy2d_kernel(const TS* src, TD* dst, int
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) d[e] = (TD)v[e];
+    if (dst_lo) {                     // low-order fp16 image of an fp32 -> fp16 cast (same leading dimension): hi + lo = v to ~2^-22
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dst_lo[r * ldd + c + e] = (f16)(v[e] - (float)(f16)v[e]);
+    }
   }
 }
 
@@ -235,10 +241,10 @@ hipError_t t2v_launch_ncthw_to_cl(const t2v_op& op, hipStream_t s) {
   f16* out = reinterpret_cast<f16*>(op.p[1]);
   if (op.i[5] == T2V_F32)
     hipLaunchKernelGGL(ncthw_to_cl_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s,
-                       reinterpret_cast<const float*>(op.p[0]), out, B, C, F, HW, ld, op.f[0], Bsrc);
+                       reinterpret_cast<const float*>(op.p[0]), out, B, C, F, HW, ld, op.f[0], Bsrc, reinterpret_cast<f16*>(op.p[2]));
   else
     hipLaunchKernelGGL(ncthw_to_cl_kernel<f16>, dim3(grid_for(n)), dim3(256), 0, s,
-                       reinterpret_cast<const f16*>(op.p[0]), out, B, C, F, HW, ld, op.f[0], Bsrc);
+                       reinterpret_cast<const f16*>(op.p[0]), out, B, C, F, HW, ld, op.f[0], Bsrc, reinterpret_cast<f16*>(op.p[2]));
   return hipGetLastError();
 }
 
@@ -309,16 +315,16 @@ hipError_t t2v_launch_copy2d(const t2v_op& op, hipStream_t s) {
   const int g = grid_for((long)rows * (cols / 4));
   if (sdt == T2V_F32 && ddt == T2V_F32)
     hipLaunchKernelGGL((copy2d_kernel<float, float>), dim3(g), dim3(256), 0, s, reinterpret_cast<const float*>(op.p[0]),
-                       reinterpret_cast<float*>(op.p[1]), rows, cols, lds_, ldd, act);
+                       reinterpret_cast<float*>(op.p[1]), rows, cols, lds_, ldd, act, static_cast<f16*>(nullptr));
   else if (sdt == T2V_F32 && ddt == T2V_F16)
     hipLaunchKernelGGL((copy2d_kernel<float, f16>), dim3(g), dim3(256), 0, s, reinterpret_cast<const float*>(op.p[0]),
-                       reinterpret_cast<f16*>(op.p[1]), rows, cols, lds_, ldd, act);
+                       reinterpret_cast<f16*>(op.p[1]), rows, cols, lds_, ldd, act, reinterpret_cast<f16*>(op.p[2]));
   else if (sdt == T2V_F16 && ddt == T2V_F16)
     hipLaunchKernelGGL((copy2d_kernel<f16, f16>), dim3(g), dim3(256), 0, s, reinterpret_cast<const f16*>(op.p[0]),
-                       reinterpret_cast<f16*>(op.p[1]), rows, cols, lds_, ldd, act);
+                       reinterpret_cast<f16*>(op.p[1]), rows, cols, lds_, ldd, act, static_cast<f16*>(nullptr));
   else
     hipLaunchKernelGGL((copy2d_kernel<f16, float>), dim3(g), dim3(256), 0, s, reinterpret_cast<const f16*>(op.p[0]),
-                       reinterpret_cast<float*>(op.p[1]), rows, cols, lds_, ldd, act);
+                       reinterpret_cast<float*>(op.p[1]), rows, cols, lds_, ldd, act, static_cast<f16*>(nullptr));
   return hipGetLastError();
 }
 

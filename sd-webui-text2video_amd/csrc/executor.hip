@@ -127,6 +127,7 @@ int validate_op(const t2v_op& op, int idx) {
       if (op.i[0] <= 0 || op.i[1] <= 0 || op.i[1] % 4 != 0) return bad("copy2d needs cols % 4 == 0");
       if (op.i[2] < op.i[1] || op.i[3] < op.i[1] || op.i[6] < 0 || op.i[6] > 3) return bad("copy2d leading dimension / activation");
       if (op.p[0] == 0 || op.p[1] == 0) return bad("null copy2d pointer");
+      if (op.p[2] != 0 && !(op.i[4] == T2V_F32 && op.i[5] == T2V_F16)) return bad("copy2d: the low-order output exists for fp32 -> fp16 casts only");
       return 0;
     case T2V_OP_DDIM_STEP: {
       const int C = op.i[0], cps = op.i[6] > 0 ? op.i[6] : C;
@@ -196,6 +197,8 @@ hipError_t launch_op(const t2v_op& op, hipStream_t s) {
       p.ws = reinterpret_cast<float*>(op.p[6]);
       p.halo = op.i[23];
       const int tile = op.i[22];
+      // split-K: p[7] = T2V_SYNC_INTS zeroed ints -> the fold runs in the GEMM's last-arriving workgroups; 0 -> reduction kernel
+      if (p.splitk > 1 && !(p.gather == T2V_GATHER_PLAIN && op.i[8] == 1)) p.tickets = reinterpret_cast<int*>(op.p[7]);
       if (p.gather == T2V_GATHER_PLAIN && op.i[8] == 1) {       // fused LayerNorm second output (validated: tile 8, N == 320)
         p.ln_gb = reinterpret_cast<const float*>(op.p[3]);
         p.rowbias = nullptr;

@@ -259,7 +259,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmParams p) 
   if (p.epi == T2V_EPI_NONE) {      // row-coalesced through a per-wave LDS buffer (t2v_kernels.h); also the split-K slabs
     __syncthreads();                // every wave is done reading the operand stages
     t2v_epilogue_rows<TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wave * (32 * T2V_EPI_SP), lane, m0 + wm * TM * 32,
-                              n0 + wn * TN * 32, blockIdx.y);
+                              n0 + wn * TN * 32, blockIdx.y, tile_m * tiles_n + tile_n);
     return;
   }
   const int mlane = lane & 31, nhalf = (lane >> 5) * 4;
@@ -397,11 +397,17 @@ hipError_t t2v_launch_gemm(const GemmParams& pin, hipStream_t s) {
   // Tile choice: 128x128 by default; 128x64 when the last 128-wide column tile would be at
   // most half full (N = 320, 960, 4, 8 ...), to avoid 25-97 % padded columns.
   const bool narrow = (p.N % 128 != 0) && (p.N % 128 <= 64);
+  {
+    const int bn = narrow ? 64 : 128;
+    const long tiles = (long)((p.M + 127) / 128) * ((p.N + bn - 1) / bn);
+    // in-kernel fold by the last-arriving workgroup of a tile (t2v_epilogue_rows) where a ticket buffer is given; else the reduction kernel
+    if (p.splitk <= 1 || p.epi != T2V_EPI_NONE || tiles > T2V_SYNC_INTS) p.tickets = nullptr;
+  }
   if (narrow)
     e = launch_tile<128, 64, 4, 1>(p, s);
   else
     e = launch_tile<128, 128, 2, 2>(p, s);
   if (e != hipSuccess) return e;
-  if (p.splitk > 1) e = t2v_launch_splitk_reduce(p, s);
+  if (p.splitk > 1 && p.tickets == nullptr) e = t2v_launch_splitk_reduce(p, s);
   return e;
 }

@@ -416,7 +416,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm2_kernel(const GemmPar
       return;
     }
     t2v_epilogue_rows<TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wave * (32 * T2V_EPI_SP), lane, m0 + wm * TM * 32,
-                              n0 + wn * TN * 32, blockIdx.y);
+                              n0 + wn * TN * 32, blockIdx.y, tile_m * tiles_n + tile_n);
     return;
   }
   const int mlane = lane & 31, nhalf = (lane >> 5) * 4;
@@ -537,6 +537,9 @@ hipError_t launch_cfg(const GemmParams& pin, hipStream_t s) {
   {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     p.panel = t2v_choose_panel(p, (p.M + BM - 1) / BM, (p.N + BN - 1) / BN);
+    const long tiles = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    // in-kernel fold by the last-arriving workgroup of a tile (t2v_epilogue_rows) where a ticket buffer is given; else the reduction kernel
+    if (p.splitk <= 1 || p.epi != T2V_EPI_NONE || tiles > T2V_SYNC_INTS) p.tickets = nullptr;
   }
   hipError_t e;
   switch (p.gather) {
@@ -557,7 +560,7 @@ hipError_t launch_cfg(const GemmParams& pin, hipStream_t s) {
     default: return hipErrorInvalidValue;
   }
   if (e != hipSuccess) return e;
-  if (p.splitk > 1) e = t2v_launch_splitk_reduce(p, s);
+  if (p.splitk > 1 && p.tickets == nullptr) e = t2v_launch_splitk_reduce(p, s);
   return e;
 }
 

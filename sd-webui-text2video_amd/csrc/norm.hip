@@ -317,6 +317,167 @@ __global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(const T* __restri
   }
 }
 
+
+// ---- single-pass cooperative GroupNorm (op.i[15] = 1) ---------------------------------------------------------------------
+// The three launches above read the tensor twice (4 + 4 B read, 2 B written per element at 2.6 TB/s aggregate) and pay two
+// launch boundaries per site.  Here the grid is at most ONE workgroup per CU, every workgroup loads its rows x C chunk ONCE into
+// registers (KR rows x 8 channels per thread: the chip's register files hold the whole tensor, 63 MB at the 32x32 level against
+// 128 MB of VGPRs), publishes its {sum, sum of squares} partial per group, meets the others at a grid-wide barrier, folds the
+// partials of its instance (every workgroup the same values in the same order: bit-identical statistics everywhere, no atomics
+// on data), and normalises from registers: 4 B read + 2 B written per element, one launch.
+// Co-residency: grid <= number of CUs and <= half a CU's threads / registers per workgroup, so all workgroups of the launch
+// are resident once earlier kernels on the GPU drain (a spinning workgroup never waits for one that cannot be scheduled).
+// With MORE than two processes sharing one GPU that guarantee is gone — such set-ups (the one-GPU multi-process rehearsals)
+// select the three-launch path with T2V_GN_COOP=0.
+constexpr int GNC_THREADS = 512;
+
+// sense-reversing grid barrier on two words {arrivals, generation} of the program's zero-initialised sync buffer: arrivals
+// returns to 0, the generation only ever grows, so the words need no reset between launches.
+__device__ __forceinline__ void gn_grid_barrier(unsigned* bar, unsigned nwg) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    t2v_release_agent();                                                            // this workgroup's partials are visible
+    const unsigned gen = __hip_atomic_load(bar + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);   // read BEFORE arriving
+    const unsigned prev = __hip_atomic_fetch_add(bar, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev == nwg - 1) {
+      __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(bar + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      while (__hip_atomic_load(bar + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == gen) __builtin_amdgcn_s_sleep(4);
+    }
+    t2v_acquire_agent();
+  }
+  __syncthreads();
+}
+
+template <typename T, bool SILU, int KR>
+__global__ __launch_bounds__(GNC_THREADS) void gn_coop_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, f16* __restrict__ out, double* partials,
+                                                              unsigned* bar, int rows, int C, int ld_in, int ld_out, int groups,
+                                                              int nchunk, int rc, double inv_n, float eps) {
+  extern __shared__ float sh[];            // phase 1: parked sums [2][R][C]; phase 2: scale[C] | shift[C]
+  __shared__ float stat[2 * 32];           // {mean, rstd} per group (groups <= 32)
+  const int tid = threadIdx.x;
+  const int inst = blockIdx.x / nchunk, chunk = blockIdx.x - inst * nchunk;
+  const int cv = C >> 3;
+  const int R = GNC_THREADS / cv;
+  const int cs = tid % cv, rr = tid / cv;
+  const bool live = rr < R;
+  const int r0 = chunk * rc, r1 = min(rows, r0 + rc);
+  const int c8 = cs * 8;
+  const T* xb = x + (size_t)inst * rows * ld_in + c8;
+  f32x8 v[KR];
+  f32x8 s, q;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+  if (live) {
+#pragma unroll
+    for (int k = 0; k < KR; ++k) {
+      const int r = r0 + rr + k * R;
+      if (r < r1) v[k] = Load8<T>::ld(xb + (size_t)r * ld_in);
+      else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[k][e] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < KR; ++k) { s += v[k]; q += v[k] * v[k]; }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sh[rr * C + c8 + e] = s[e]; sh[(R + rr) * C + c8 + e] = q[e]; }
+  }
+  __syncthreads();
+  const int cpg = C / groups;
+  const int g = tid >> 4, sub = tid & 15;          // 16 lanes per group (groups <= 32)
+  {
+    double ds = 0.0, dq = 0.0;
+    if (g < groups) {
+      const int n = R * cpg;
+      for (int i = sub; i < n; i += 16) {
+        const int k = i / cpg, c = g * cpg + (i - k * cpg);
+        ds += (double)sh[k * C + c];
+        dq += (double)sh[(R + k) * C + c];
+      }
+    }
+    for (int o = 1; o < 16; o <<= 1) { ds += __shfl_xor(ds, o); dq += __shfl_xor(dq, o); }
+    if (g < groups && sub == 0) {
+      double* st = partials + (((size_t)inst * nchunk + chunk) * groups + g) * 2;
+      st[0] = ds;
+      st[1] = dq;
+    }
+  }
+  gn_grid_barrier(bar, gridDim.x);
+  {
+    double ds = 0.0, dq = 0.0;
+    if (g < groups) {
+      for (int c = sub; c < nchunk; c += 16) {                // fixed order: the same on every workgroup of the instance
+        const double* st = partials + (((size_t)inst * nchunk + c) * groups + g) * 2;
+        ds += __hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        dq += __hip_atomic_load(st + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    for (int o = 1; o < 16; o <<= 1) { ds += __shfl_xor(ds, o); dq += __shfl_xor(dq, o); }
+    if (g < groups && sub == 0) {
+      const double m = ds * inv_n;
+      double var = dq * inv_n - m * m;
+      var = var < 0.0 ? 0.0 : var;
+      stat[2 * g] = (float)m;
+      stat[2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+  }
+  __syncthreads();                                            // (also: everyone is done with the parked sums)
+  for (int c = tid; c < C; c += GNC_THREADS) {
+    const int grp = c / cpg;
+    const float a = stat[2 * grp + 1] * gamma[c];
+    sh[c] = a;
+    sh[C + c] = beta[c] - stat[2 * grp] * a;
+  }
+  __syncthreads();
+  if (!live) return;
+  const f32x8 a = Load8<float>::ld(sh + c8), b = Load8<float>::ld(sh + C + c8);
+  f16* ob = out + (size_t)inst * rows * ld_out + c8;
+#pragma unroll
+  for (int k = 0; k < KR; ++k) {
+    const int r = r0 + rr + k * R;
+    if (r < r1) {
+      f16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float y = v[k][e] * a[e] + b[e];
+        if (SILU) y = t2v_silu(y);
+        o[e] = (f16)y;
+      }
+      *reinterpret_cast<f16x8*>(ob + (size_t)r * ld_out) = o;
+    }
+  }
+}
+
+template <typename T, bool SILU>
+void gn_coop_launch(int kr, dim3 grid, size_t lds, hipStream_t s, const T* x, const float* gamma, const float* beta, f16* out,
+                    double* partials, unsigned* bar, int rows, int C, int ld_in, int ld_out, int groups, int nchunk, int rc, double inv_n,
+                    float eps) {
+#define GNC_CASE(K)                                                                                                              \
+  case K:                                                                                                                        \
+    hipLaunchKernelGGL((gn_coop_kernel<T, SILU, K>), grid, dim3(GNC_THREADS), lds, s, x, gamma, beta, out, partials, bar, rows, C, \
+                       ld_in, ld_out, groups, nchunk, rc, inv_n, eps);                                                           \
+    break;
+  switch (kr) {
+    GNC_CASE(4) GNC_CASE(8) GNC_CASE(12) GNC_CASE(16) GNC_CASE(20)
+    default: break;
+  }
+#undef GNC_CASE
+}
+
+int gn_num_cus() {
+  static int ncu = 0;
+  if (ncu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+    if (ncu <= 0) ncu = 1;
+  }
+  return ncu;
+}
+
 // LayerNorm: one wave per row, row held in registers (C <= 64*4*MAXV).  A wave walks several rows (grid-stride): gamma / beta
 // stay in registers and the NEXT row's loads are issued before the current row's two reductions, so the wave always has a
 // row in flight (12 k single-row workgroups per launch were latency-bound: 3.8 TB/s at the 32x32 level).
@@ -460,8 +621,27 @@ hipError_t t2v_launch_groupnorm(const t2v_op& op, hipStream_t s) {
   f16* out = reinterpret_cast<f16*>(op.p[3]);
   const bool fused = op.i[12] != 0;
   if (fused && (phase != 0 || (C / groups) % 4 != 0 || (C / groups) / 4 > GNF_THREADS)) return hipErrorInvalidValue;
+  // single-pass cooperative variant: the smallest rows-per-thread count whose grid still fits one workgroup per CU
+  int coop_kr = 0, coop_rc = 0, coop_nchunk = 0;
+  if (op.i[15] != 0 && op.p[5] != 0 && phase == 0 && !fused && groups <= 32 && cv <= GNC_THREADS) {
+    const int Rc = GNC_THREADS / cv, ncu = gn_num_cus();
+    for (int kr : {4, 8, 12, 16, 20}) {
+      const int rc = Rc * kr, nchunk = (rows + rc - 1) / rc;
+      if ((long)n_inst * nchunk <= ncu && nchunk <= nblk) { coop_kr = kr; coop_rc = rc; coop_nchunk = nchunk; break; }
+    }
+  }
   auto run = [&](auto* x) {
     using T = typename std::remove_cv<typename std::remove_pointer<decltype(x)>::type>::type;
+    if (coop_kr) {
+      const size_t ldsc = (size_t)2 * (GNC_THREADS / cv) * C * sizeof(float);
+      unsigned* bar = reinterpret_cast<unsigned*>(op.p[5]);
+      const dim3 grid(n_inst * coop_nchunk);
+      if (silu) gn_coop_launch<T, true>(coop_kr, grid, ldsc, s, x, gamma, beta, out, partials, bar, rows, C, ld_in, ld_out, groups, coop_nchunk,
+                                        coop_rc, inv_n, op.f[0]);
+      else gn_coop_launch<T, false>(coop_kr, grid, ldsc, s, x, gamma, beta, out, partials, bar, rows, C, ld_in, ld_out, groups, coop_nchunk,
+                                    coop_rc, inv_n, op.f[0]);
+      return;
+    }
     if (fused) {
       if (silu) hipLaunchKernelGGL((gn_fused_kernel<T, true>), dim3(groups * n_inst), dim3(GNF_THREADS), 0, s, x, gamma, beta, out, rows,
                                    C, ld_in, ld_out, groups, op.f[0]);

@@ -38,7 +38,16 @@ struct GemmParams {
   f16* ln_out;
   int ld_ln;
   float ln_eps;
+  // split-K without a reduction launch (EPI_NONE): one arrival counter per output tile (T2V_SYNC_INTS ints, all zero between
+  // launches); the LAST workgroup of a tile to arrive folds the slabs in split order and runs the fused epilogue
+  int* tickets;
 };
+
+
+// Device-scope ordering helpers.  The 8 XCDs have private L2s: a release writes this XCD's dirty lines back, an acquire drops
+// its non-coherent lines (the compiler emits buffer_wbl2 sc1 / buffer_inv sc1 for agent-scope fences on gfx950).
+__device__ __forceinline__ void t2v_release_agent() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }
+__device__ __forceinline__ void t2v_acquire_agent() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
 
 // ---- XCD-aware tile order -----------------------------------------------------------------------------
 // Workgroup b of a launch runs on XCD b % 8 (round-robin dispatch) and each of the 8 XCDs has a private L2:
@@ -109,7 +118,7 @@ constexpr int T2V_EPI_SP = 36;     // floats per staged row: 16-lane phases of t
 
 template <int TM, int TN>
 __device__ __forceinline__ void t2v_epilogue_rows(const GemmParams& p, const f32x16 (&acc)[TM][TN], float* stg, int lane,
-                                                  int m_wave, int n_wave, int split_idx) {
+                                                  int m_wave, int n_wave, int split_idx, int tile_id = 0) {
   const int wrow = lane & 31, wcol = (lane >> 5) * 4;
   const int rrow = lane >> 3, rcol = (lane & 7) * 4;
   // Residual prefetch: the four row loads of a 32x32 block are issued TOGETHER and one block ahead of their use (always
@@ -174,6 +183,50 @@ __device__ __forceinline__ void t2v_epilogue_rows(const GemmParams& p, const f32
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) rcur[i] = rnxt[i];
+  }
+  if (p.splitk > 1 && p.tickets != nullptr) {
+    // ---- split-K fold by the last-arriving workgroup of this output tile (no splitk_reduce launch) -------------------------
+    // Every workgroup has stored its slab above.  release -> ticket -> the last arrival (ticket == splitk - 1) re-arms the
+    // counter, acquires, and sums ALL slabs in split order 0 .. splitk-1 from memory (its own included): the same values in the
+    // same order as the reduction kernel this replaces, whichever workgroup happens to be last — bitwise reproducible.
+    __shared__ int s_last;
+    t2v_release_agent();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int t = __hip_atomic_fetch_add(p.tickets + tile_id, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = t == p.splitk - 1;
+      if (s_last) __hip_atomic_store(p.tickets + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    t2v_acquire_agent();
+#pragma unroll
+    for (int blk = 0; blk < TM * TN; ++blk) {
+      const int mt = m_wave + (blk / TN) * 32, nt = n_wave + (blk % TN) * 32;
+      if (mt >= p.M || nt >= p.N) continue;                    // wave-uniform
+      const int n = nt + rcol;
+      if (n >= p.N) continue;
+      f32x4 cb = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias && !p.bias_m) cb = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = mt + rrow + 8 * i;
+        if (m >= p.M) continue;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < p.splitk; ++z) v += *reinterpret_cast<const f32x4*>(p.ws + ((size_t)z * p.M + m) * p.N + n);
+        v += cb;
+        if (p.bias && p.bias_m) { const float bm = p.bias[m]; v[0] += bm; v[1] += bm; v[2] += bm; v[3] += bm; }
+        if (p.rowbias) v += *reinterpret_cast<const f32x4*>(p.rowbias + (size_t)(m / p.rows_per_batch) * p.ldrb + n);
+        if (p.act == 1) { v[0] = t2v_silu(v[0]); v[1] = t2v_silu(v[1]); v[2] = t2v_silu(v[2]); v[3] = t2v_silu(v[3]); }
+        if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.ldr + n);
+        if (p.out_f32) {
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n) = v;
+        } else {
+          f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+          *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(p.out) + (size_t)m * p.ldc + n) = o;
+        }
+      }
+    }
   }
 }
 // Epilogue of the 192x320 tile (12 waves: 6 row strips x 2 column halves, TM = 1, TN = 5) with a fused LayerNorm: the tile

@@ -170,6 +170,11 @@ class Program:
         self.gn_fused_total_bytes = int(os.environ.get("T2V_GN_FUSED_TOTAL", 128 * 1024 * 1024))
         # precision option: weight Ref -> Ref of its low-order image (packing.WeightPacker.add_lo) or None; set by a lowering
         self.weight_lo = None
+        # Device-side synchronisation words (never freed, zero from the bind-time fill, self-resetting): L.SYNC_INTS tickets of
+        # the split-K fold (one per output tile) followed by the {arrivals, generation} pair of the cooperative GroupNorm's grid barrier
+        self._sync: Optional[Buf] = None
+        self.splitk_tickets = os.environ.get("T2V_SPLITK_TICKETS", "1") != "0"
+        self.gn_coop = os.environ.get("T2V_GN_COOP", "1") != "0"
 
     # ---- memory ---------------------------------------------------------------------------
     def alloc(self, rows: int, cols: int, dtype: str, ld: Optional[int] = None) -> Buf:
@@ -184,6 +189,11 @@ class Program:
             if self.keep_taps and any(t.alloc_off == b.alloc_off for t in self.taps.values()):
                 continue
             self.arena.free(b.alloc_off)
+
+    def sync_ref(self, which: str) -> Ref:
+        if self._sync is None:
+            self._sync = self.alloc(L.SYNC_INTS + 64, 1, "f32")
+        return self._sync.ref if which == "tickets" else self._sync.ref.shifted(4 * L.SYNC_INTS)
 
     def tap(self, name: str, buf: Buf):
         if self.keep_taps:
@@ -299,7 +309,8 @@ class Program:
              ldw: Optional[int] = None, gather: int = L.GATHER_PLAIN, conv: Optional[dict] = None,
              rowbias: Optional[Buf] = None, rows_per_batch: int = 0, residual: Optional[Buf] = None,
              epi: int = L.EPI_NONE, act: int = 0, bias_along_m: bool = False, m: Optional[int] = None,
-             allow_splitk: bool = True, halo: bool = False, ln: Optional[tuple] = None, step_invariant: bool = False) -> Op:
+             allow_splitk: bool = True, halo: bool = False, ln: Optional[tuple] = None, step_invariant: bool = False,
+             a_lo: Optional[Buf] = None) -> Op:
         """out[M, n_out] = epi(gather(a)[M, k] @ w[n, k]^T).  conv['pad_after_only'] (3x3, stride 2): zero padding
         (0,1,0,1) instead of 1 on every side.
         ln = (gamma|beta Ref (fp32 [2n]), gamma Ref, beta Ref, ln_out Buf fp16, eps): LayerNorm of the fp32 result rows as a second
@@ -307,6 +318,19 @@ class Program:
         the 32x32-level C -> C linears); otherwise a separate LayerNorm op follows."""
         conv = conv or {}
         M = out.rows if m is None else m
+        if a_lo is not None:
+            # hi + lo ACTIVATION split (the weights are exact fp16): t = A_lo.W (+ residual) in fp32, then the normal GEMM on
+            # A_hi with t as its residual — the operand reaches the MFMA with ~22 bits instead of 11 (precise_operands, unet.py)
+            assert a_lo.dtype == "f16" and (a_lo.rows, a_lo.cols, a_lo.ld) == (a.rows, a.cols, a.ld) and epi == L.EPI_NONE and ln is None
+            t_lo = self.alloc(M, n, "f32")
+            self.gemm(name + ".a_lo", a_lo, w, n, k, t_lo, ldw=ldw, gather=gather, conv=conv, residual=residual, m=m,
+                      allow_splitk=allow_splitk, halo=halo, step_invariant=step_invariant)
+            op = self.gemm(name, a, w, n, k, out, bias=bias, ldw=ldw, gather=gather, conv=conv, rowbias=rowbias, rows_per_batch=rows_per_batch,
+                           residual=t_lo, act=0, bias_along_m=bias_along_m, m=m, allow_splitk=allow_splitk, halo=halo,
+                           step_invariant=step_invariant)
+            assert act == 0
+            self.free(t_lo)
+            return op
         lo = self.weight_lo(w) if (self.weight_lo is not None and epi == L.EPI_NONE and not bias_along_m and w.space == "weight") else None
         lo_tmp = None
         if lo is not None:
@@ -360,6 +384,8 @@ class Program:
         if split > 1:
             ws = self.alloc(split * M, n, "f32")
             op.p[6] = ws.ref
+            if self.splitk_tickets and epi == L.EPI_NONE and not ln_fused:
+                op.p[7] = self.sync_ref("tickets")     # the last-arriving workgroup of a tile folds the slabs: no reduction launch
         op.flops = 2.0 * M * n * k
         op.out = out
         op.meta = dict(M=M, N=n, K=k, gather=gather, conv=dict(conv), epi=epi, split=split, tile=tile, halo=halo, ln=int(ln_fused))
@@ -420,7 +446,12 @@ class Program:
             if self.gn_fused_slice_bytes and x.cols % groups == 0 and cpg % 4 == 0 and rows * cpg * item <= self.gn_fused_slice_bytes \
                     and x.rows * x.cols * item <= self.gn_fused_total_bytes:
                 op.i[12] = 1
-            op.meta = dict(n_inst=n_inst, rows=rows, C=x.cols, dt=x.dtype, fused=int(op.i[12]))
+            if self.gn_coop and not op.i[12] and groups <= 32:
+                # single-pass cooperative kernel where the tensor fits the chip's registers at one workgroup per CU (decided
+                # by the library from the device's CU count; otherwise it runs the three launches on the same scratch)
+                op.i[15] = 1
+                op.p[5] = self.sync_ref("barrier")
+            op.meta = dict(n_inst=n_inst, rows=rows, C=x.cols, dt=x.dtype, fused=int(op.i[12]), coop=int(op.i[15]))
             op.out = out
             self._emit(op)
         else:
@@ -534,13 +565,18 @@ class Program:
         op.out = out
         return self._emit(op)
 
-    def ncthw_to_cl(self, name: str, src: Ref, src_dtype: str, out: Buf, *, B, C, F, HW, scale=1.0, src_batch: int = 0) -> Op:
-        """src_batch (< B): the source holds that many samples, output sample b reads sample b % src_batch."""
+    def ncthw_to_cl(self, name: str, src: Ref, src_dtype: str, out: Buf, *, B, C, F, HW, scale=1.0, src_batch: int = 0,
+                    lo: Optional[Buf] = None) -> Op:
+        """src_batch (< B): the source holds that many samples, output sample b reads sample b % src_batch.
+        lo: second fp16 output of the same layout holding fp16(v - fp16(v)) (hi + lo operand split of the consumer)."""
         assert src_batch == 0 or B % src_batch == 0
         op = Op(L.OP_NCTHW_TO_CL, name)
         op.i[0:7] = [B, C, F, HW, out.ld, _DT[src_dtype], src_batch]
         op.f[0] = scale
         op.p[0:2] = [src, out.ref]
+        if lo is not None:
+            assert (lo.rows, lo.cols, lo.ld, lo.dtype) == (out.rows, out.cols, out.ld, "f16")
+            op.p[2] = lo.ref
         op.out = out
         return self._emit(op)
 
@@ -570,11 +606,15 @@ class Program:
         op.out = out
         return self._emit(op)
 
-    def copy2d(self, name: str, src: Buf, dst: Buf, act: int = 0) -> Op:
+    def copy2d(self, name: str, src: Buf, dst: Buf, act: int = 0, lo: Optional[Buf] = None) -> Op:
+        """lo (fp32 -> fp16 casts): second fp16 output, same shape / leading dimension, = fp16(v - fp16(v))."""
         assert src.rows == dst.rows and src.cols == dst.cols and src.cols % 4 == 0
         op = Op(L.OP_COPY2D, name)
         op.i[0:7] = [src.rows, src.cols, src.ld, dst.ld, _DT[src.dtype], _DT[dst.dtype], act]
         op.p[0:2] = [src.ref, dst.ref]
+        if lo is not None:
+            assert src.dtype == "f32" and dst.dtype == "f16" and (lo.rows, lo.cols, lo.ld, lo.dtype) == (dst.rows, dst.cols, dst.ld, "f16")
+            op.p[2] = lo.ref
         op.out = dst
         return self._emit(op)
 

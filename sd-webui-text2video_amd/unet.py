@@ -227,6 +227,11 @@ class UNetSD(nn.Module):
         # hi + lo fp16 images in two MFMA passes (fp32 weights only; e.g. ("input_blocks.0", "input_blocks.1") — the blocks
         # that produce 46 % of the weight-rounding error).  Set before the first forward.
         self.split_weight_prefixes = ()
+        # Precision (on by default): the fp32 -> fp16 operand casts whose rounding error reaches the output un-normalised — the
+        # latent at the entry and the residual stream in front of the 1x1 skip convolutions — are emitted as hi + lo fp16
+        # images and their (small) GEMMs run twice: 23 % of the activation-rounding error variance of a forward for ~15 extra
+        # launches and +1.5 % FLOPs (tools/precision_probe.py; DESIGN.md "Precision").  Part of the program cache key.
+        self.precise_operands = True
         self.t_shard = None           # parallel.TShard: this rank holds a contiguous slice of the clip's frames
         self.auto_refresh = True      # re-check parameter versions on every forward (~1 ms); the sampler
                                       # turns this off inside its loop after one explicit refresh
@@ -439,7 +444,7 @@ class UNetSD(nn.Module):
 
     def _lowering_options(self) -> tuple:
         """Lowering switches that change the program (part of the cache key)."""
-        return ()
+        return (("precise",),) if getattr(self, "precise_operands", False) else ()
 
     def forward_cfg_pair(self, x, t, ctx_pair, context_token=None):
         """One guided step's two evaluations (gaussian_sampler.py:161-162) as ONE forward: x [V,4,F,h,w] is read twice by
@@ -532,6 +537,8 @@ class _Lowering:
         self.net, self.B, self.F, self.H, self.W, self.Lctx = net, B, F, H, W, Lctx
         self.x_dt, self.out_dt, self.ctx_dt = x_dt, out_dt, ctx_dt
         self.x_batch = x_batch if 0 < x_batch < B else 0      # x holds fewer samples than the batch: sample b reads x[b % x_batch]
+        self.precise = bool(getattr(net, "precise_operands", False))
+        self.xin_lo = None
         self.P = Program(f"unet b{B} f{F} {H}x{W}")
         self.P.keep_taps = keep_taps
         self.packer = pk.WeightPacker()
@@ -596,7 +603,7 @@ class _Lowering:
         return out
 
     def conv3(self, name, a: Buf, key, cout, h, w, *, stride=1, up=0, out_dtype="f32", rowbias=None,
-              residual=None, cin=None, dest: Optional[Buf] = None) -> Buf:
+              residual=None, cin=None, dest: Optional[Buf] = None, a_lo: Optional[Buf] = None) -> Buf:
         """`dest`: write the result into this (sub-)buffer instead of a fresh allocation — the producers of the two
         halves of a skip-connection concat write straight into the concat buffer (no copy ops)."""
         cin = a.cols if cin is None else cin
@@ -608,7 +615,7 @@ class _Lowering:
         self.P.gemm(name, a, self.w_conv3(key, 8 if cin == 8 else 0), n, 9 * cin, out, bias=self.vec(key + ".bias"),
                     gather=gather, conv=dict(Hin=h, Win=w, Cin=cin, stride=stride, up=up, Hout=ho, Wout=wo),
                     rowbias=rowbias, rows_per_batch=self.F * ho * wo if rowbias is not None else 0,
-                    residual=residual)
+                    residual=residual, a_lo=a_lo)
         return out
 
     def _dest(self, dest: Optional[Buf], rows, cols, dtype) -> Buf:
@@ -628,11 +635,12 @@ class _Lowering:
         P.free(h1)
         if cin != cout:
             x16 = P.alloc(x.rows, cin, "f16")
-            P.copy2d(prefix + ".skip.cast", x, x16)
+            x16lo = P.alloc(x.rows, cin, "f16") if self.precise else None
+            P.copy2d(prefix + ".skip.cast", x, x16, lo=x16lo)
             skip = P.alloc(x.rows, cout, "f32")
             P.gemm(prefix + ".skip_connection", x16, self.w_linear(prefix + ".skip_connection"), cout, cin, skip,
-                   bias=self.vec(prefix + ".skip_connection.bias"))
-            P.free(x16)
+                   bias=self.vec(prefix + ".skip_connection.bias"), a_lo=x16lo)
+            P.free(x16, x16lo)
         else:
             skip = x
         h2 = self.conv3(prefix + ".out_layers.3", b, prefix + ".out_layers.3", cout, h, w, residual=skip)
@@ -928,14 +936,17 @@ class _Lowering:
 
         # ---- entry layout conversion: b c f h w -> tokens x 8 channels (4 real + 4 zero)
         xin = P.alloc(self.M(h, w), 8, "f16")
-        P.ncthw_to_cl("x.to_tokens", Ref("ext", L.EXT_X), self.x_dt, xin, B=B, C=net.in_dim, F=F, HW=h * w, src_batch=self.x_batch)
+        self.xin_lo = P.alloc(self.M(h, w), 8, "f16") if (self.precise and self.x_dt == "f32") else None
+        P.ncthw_to_cl("x.to_tokens", Ref("ext", L.EXT_X), self.x_dt, xin, B=B, C=net.in_dim, F=F, HW=h * w, src_batch=self.x_batch,
+                      lo=self.xin_lo)
 
         def run_parts(prefix, parts, bare, x, h, w, dest=None):
             for i, (kind, cin, cout) in enumerate(parts):
                 p = prefix if bare else f"{prefix}.{i}"
                 d = dest if i == len(parts) - 1 else None         # the block's result goes straight into a concat buffer
                 if kind == "stem":
-                    y = self.conv3(p, x, p, cout, h, w, cin=8, dest=d)
+                    y = self.conv3(p, x, p, cout, h, w, cin=8, dest=d, a_lo=self.xin_lo)
+                    P.free(self.xin_lo)
                 elif kind == "res":
                     y = self.res_block(p, x, cin, cout, h, w, dest=d)
                 elif kind == "st":

@@ -55,6 +55,11 @@ class Interp:
     def mat(self, ref: Ref, rows, cols, ld, dtype, ext):
         return self.view(ref, (rows, cols), (ld, 1), dtype, ext)
 
+    def _st(self, view, value, dtype):
+        """Store `value` into an output view of logical type `dtype` (fp16 buffers hold fp16-rounded values).  One hook for
+        every fp16 write, so that tools/precision_probe.py can switch the rounding of chosen tensors off."""
+        view.copy_(value.to(dtype))
+
     # ---- execution -----------------------------------------------------------------------------
     def run(self, ext: Dict[int, torch.Tensor], ops=None):
         for op in (self.prog.ops if ops is None else ops):
@@ -120,11 +125,11 @@ class Interp:
             if op.p[4].space != "null":
                 res = res + self.mat(op.p[4], M, N, ldr, torch.float32, ext)
         out = self.mat(op.p[5], M, n_out, ldc, _TD[I[17]], ext)
-        out.copy_(res.to(out.dtype))
+        self._st(out, res, _TD[I[17]])
         if epi != L.EPI_GEGLU and gather == L.GATHER_PLAIN and I[8] == 1:
             gb = self.view(op.p[3], (2 * N,), (1,), torch.float32, ext)
             y = F.layer_norm(res.float(), (N,), gb[:N], gb[N:], op.f[0])
-            self.mat(op.p[7], M, N, I[9], torch.float16, ext).copy_(y.half())
+            self._st(self.mat(op.p[7], M, N, I[9], torch.float16, ext), y, torch.float16)
 
     # GROUPNORM ----------------------------------------------------------------------------------------
     def _op2(self, op, ext):
@@ -152,7 +157,7 @@ class Interp:
         y = y * g + b
         if silu:
             y = F.silu(y)
-        self.mat(op.p[3], n_inst * rows, C, ld_out, torch.float16, ext).copy_(y.half())
+        self._st(self.mat(op.p[3], n_inst * rows, C, ld_out, torch.float16, ext), y, torch.float16)
 
     # LAYERNORM ----------------------------------------------------------------------------------------
     def _op3(self, op, ext):
@@ -161,7 +166,7 @@ class Interp:
         g = self.view(op.p[1], (C,), (1,), torch.float32, ext)
         b = self.view(op.p[2], (C,), (1,), torch.float32, ext)
         y = F.layer_norm(x, (C,), g, b, op.f[0])
-        self.mat(op.p[3], M, C, ld_out, torch.float16, ext).copy_(y.half())
+        self._st(self.mat(op.p[3], M, C, ld_out, torch.float16, ext), y, torch.float16)
 
     # ATTENTION ----------------------------------------------------------------------------------------
     def _op4(self, op, ext, rel=False):
@@ -187,7 +192,7 @@ class Interp:
         o = torch.einsum("abhij,abhjd->abhid", p, vv)
         if rel:
             o = o + torch.einsum("abhts,tsd->abhtd", p, ev[idx])
-        v(op.p[3], nq, so).copy_(o.half())
+        self._st(v(op.p[3], nq, so), o, torch.float16)
 
     def _op13(self, op, ext):
         self._op4(op, ext, rel=True)
@@ -196,7 +201,7 @@ class Interp:
     def _op5(self, op, ext):
         rows, cols, ld_in, ld_out = op.i[0:4]
         x = self.mat(op.p[0], rows, cols, ld_in, torch.float32, ext)
-        self.mat(op.p[1], rows, cols, ld_out, torch.float16, ext).copy_(torch.softmax(x * op.f[0], dim=1).half())
+        self._st(self.mat(op.p[1], rows, cols, ld_out, torch.float16, ext), torch.softmax(x * op.f[0], dim=1), torch.float16)
 
     # NCTHW_TO_CL --------------------------------------------------------------------------------------
     def _op6(self, op, ext):
@@ -206,7 +211,12 @@ class Interp:
         x = x.repeat(B // Bsrc, 1, 1, 1)
         out = self.mat(op.p[1], B * Fr * HW, ld, ld, torch.float16, ext)
         out.zero_()
-        out[:, :C] = x.permute(0, 2, 3, 1).reshape(B * Fr * HW, C).half()
+        v = x.permute(0, 2, 3, 1).reshape(B * Fr * HW, C)
+        self._st(out[:, :C], v, torch.float16)
+        if op.p[2].space != "null":                      # low-order image of the cast
+            lo = self.mat(op.p[2], B * Fr * HW, ld, ld, torch.float16, ext)
+            lo.zero_()
+            self._st(lo[:, :C], v - v.half().float(), torch.float16)
 
     # CL_TO_NCTHW --------------------------------------------------------------------------------------
     def _op7(self, op, ext):
@@ -221,7 +231,7 @@ class Interp:
         t = self.view(op.p[0], (B,), (1,), torch.float32, ext)
         fr = self.view(op.p[1], (dim // 2,), (1,), torch.float32, ext)
         a = torch.outer(t, fr)
-        self.mat(op.p[2], B, dim, dim, torch.float16, ext).copy_(torch.cat([torch.cos(a), torch.sin(a)], dim=1).half())
+        self._st(self.mat(op.p[2], B, dim, dim, torch.float16, ext), torch.cat([torch.cos(a), torch.sin(a)], dim=1), torch.float16)
 
     # COPY2D -------------------------------------------------------------------------------------------
     def _op9(self, op, ext):
@@ -234,7 +244,9 @@ class Interp:
         elif act == 3:
             x = x * torch.sigmoid(1.702 * x)
         out = self.mat(op.p[1], rows, cols, ldd, _TD[ddt], ext)
-        out.copy_(x.to(out.dtype))
+        self._st(out, x, _TD[ddt])
+        if op.p[2].space != "null":                      # low-order image of an fp32 -> fp16 cast
+            self._st(self.mat(op.p[2], rows, cols, ldd, torch.float16, ext), x - x.half().float(), torch.float16)
 
     # EMBED_ROWS ---------------------------------------------------------------------------------------
     def _op14(self, op, ext):

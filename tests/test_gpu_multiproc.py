@@ -44,6 +44,7 @@ FRAMES, STEPS, SEED = 7, 3, 99
 
 def _worker(rank, world, port, mode, ret):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["T2V_GN_COOP"] = "0"      # 2-4 processes share ONE GPU here: no co-residency guarantee for a grid barrier (csrc/norm.hip)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from sd_webui_text2video_amd import parallel

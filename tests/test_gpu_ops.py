@@ -180,12 +180,13 @@ def test_temporal_conv_gather(B, F, HW, C):
 @pytest.mark.parametrize("n_inst,rows,C,dt,silu", [(6, 256, 320, "f32", True), (2, 24 * 64, 640, "f32", True),
                                                    (4, 16, 1280, "f32", False), (3, 64, 64, "f16", True),
                                                    (2, 100, 2560, "f32", True), (2, 4096, 128, "f32", True)])
-@pytest.mark.parametrize("variant", ["three_launch", "single_launch"])
+@pytest.mark.parametrize("variant", ["three_launch", "cooperative", "single_launch"])
 def test_groupnorm(n_inst, rows, C, dt, silu, variant):
     if variant == "single_launch" and (C // 32) % 4 != 0:
         pytest.skip("single-launch GroupNorm needs (C/groups) % 4 == 0")
     P = Program()
-    P.gn_fused_slice_bytes = 0 if variant == "three_launch" else 1 << 30
+    P.gn_coop = variant == "cooperative"          # single-pass kernel with a grid barrier (csrc/norm.hip) vs statistics / fold / apply
+    P.gn_fused_slice_bytes = 1 << 30 if variant == "single_launch" else 0
     P.gn_fused_total_bytes = 1 << 30
     P.begin()
     g = _g(8)
@@ -195,7 +196,7 @@ def test_groupnorm(n_inst, rows, C, dt, silu, variant):
     P.groupnorm("gn", x, Ref("weight", 0, "g"), Ref("weight", 0, "b"), out, n_inst=n_inst, eps=1e-5, silu=silu)
     P.groupnorm("gn2", x, Ref("weight", 0, "g"), Ref("weight", 0, "b"), out2, n_inst=n_inst, eps=1e-6, silu=silu)   # ping-pong buffer
     P.finish()
-    assert all(op.i[12] == (variant == "single_launch") for op in P.ops if op.kind == L.OP_GROUPNORM)
+    assert all(op.i[12] == (variant == "single_launch") and op.i[15] == (variant == "cooperative") for op in P.ops if op.kind == L.OP_GROUPNORM)
 
     def init(it):
         v = fill(it, x, g, scale=2.0)
@@ -609,6 +610,104 @@ def test_reshard_rows_pack_and_unpack_with_residual():
             want[rows] = s_[rows] + (r_[rows] if with_res else 0)
         assert torch.equal(b.float(), want.to(TD[dt]).float())
         assert torch.equal(read(got, packed).float(), torch.cat([s_[f * hw + q * hwr: f * hw + (q + 1) * hwr] for f in range(frames)]))
+
+
+@pytest.mark.parametrize("n_inst,rows,C,dt,silu", [(2, 24 * 1024, 320, "f32", True),      # 32x32 level, cross-frame: 256 workgroups, 16 rows / thread
+                                                   (48, 1024, 320, "f16", True),        # 32x32 level, per frame: 5 chunks per instance, 20 rows / thread
+                                                   (2, 24 * 256, 640, "f16", False),    # 16x16 level, cross-frame
+                                                   (2, 24 * 64, 1280, "f32", True),     # 8x8 level
+                                                   (1, 24 * 1024, 320, "f32", True),    # one CFG role (b = 1)
+                                                   (5, 77, 64, "f32", False)])          # ragged chunks, tiny C
+def test_groupnorm_cooperative_full_size(n_inst, rows, C, dt, silu):
+    """The single-pass GroupNorm at the sizes of the UNet's 32x32 .. 8x8 levels (grids up to one workgroup per CU): against
+    torch.nn.functional.group_norm, against the three-launch kernels (same statistics to ~1e-7), and run back to back on the same
+    barrier words (the generation counter keeps growing, the arrival counter returns to zero) with bit-identical results."""
+    import torch.nn.functional as F
+    g = _g(31)
+    w = {"g": 1 + 0.1 * torch.randn(C, generator=g), "b": 0.1 * torch.randn(C, generator=g)}
+    xs = torch.randn(n_inst * rows, C, generator=g) * 1.7 + 0.4
+    outs = {}
+    for coop in (True, False):
+        P = Program()
+        P.gn_coop = coop
+        P.gn_fused_slice_bytes = 0
+        x = P.alloc(n_inst * rows, C, dt)
+        o = [P.alloc(n_inst * rows, C, "f16") for _ in range(3)]
+        for k in range(3):
+            P.groupnorm(f"gn{k}", x, Ref("weight", 0, "g"), Ref("weight", 0, "b"), o[k], n_inst=n_inst, eps=1e-5, silu=silu)
+        dev = torch.device("cuda:0")
+        arena = torch.zeros(P.arena.high + 256, dtype=torch.uint8, device=dev)
+        td = torch.float16 if dt == "f16" else torch.float32
+        arena[x.ref.off: x.ref.off + xs.numel() * (2 if dt == "f16" else 4)].view(td).copy_(xs.to(td).reshape(-1))
+        wg = {k: v.to(dev) for k, v in w.items()}
+        from sd_webui_text2video_amd.program import BoundProgram
+        bp = BoundProgram(P, arena.data_ptr(), {k: v.data_ptr() for k, v in wg.items()})
+        st = torch.cuda.current_stream(dev).cuda_stream
+        for _ in range(2):
+            bp.run({}, st)
+        torch.cuda.synchronize()
+        got = [arena[b.ref.off: b.ref.off + b.rows * C * 2].view(torch.float16).view(b.rows, C).float().cpu() for b in o]
+        assert torch.equal(got[0], got[1]) and torch.equal(got[0], got[2])
+        outs[coop] = got[0]
+    xin = xs.to(torch.float16 if dt == "f16" else torch.float32).float().view(n_inst, rows, C).permute(0, 2, 1)
+    want = F.group_norm(xin, 32, w["g"], w["b"], 1e-5)
+    want = (F.silu(want) if silu else want).permute(0, 2, 1).reshape(n_inst * rows, C)
+    assert rel_l2(outs[True], want) < 6e-4 and rel_l2(outs[False], want) < 6e-4
+    assert rel_l2(outs[True], outs[False]) < 2e-4        # both round the same fp32 values to fp16: differences are 1-ulp flips
+
+
+def test_split_k_ticket_fold_is_bitwise_the_reduction_kernel():
+    """Split-K with the fold in the last-arriving workgroup of each tile (default) against the stand-alone reduction kernel
+    (T2V_SPLITK_TICKETS=0 / Program.splitk_tickets = False): same slabs summed in the same order -> identical bits, for every
+    kernel family and epilogue variant; repeated runs re-arm the tickets."""
+    from sd_webui_text2video_amd.program import BoundProgram
+    dev = torch.device("cuda:0")
+    g = _g(77)
+    cases = [dict(M=768, N=1280, K=3840, gather=L.GATHER_TCONV3, tile=5, cus=256, out="f16", res=False),
+             dict(M=768, N=1280, K=11520, gather=L.GATHER_CONV3X3, tile=3, cus=256, out="f32", res=True),
+             dict(M=768, N=1280, K=1280, gather=L.GATHER_PLAIN, tile=0, cus=256, out="f32", res=True),
+             dict(M=3072, N=1280, K=11520, gather=L.GATHER_CONV3X3, tile=2, cus=256, out="f16", res=False),
+             dict(M=200, N=324, K=2560, gather=L.GATHER_PLAIN, tile=0, cus=64, out="f16", res=True)]      # ragged M / N tails
+    for c in cases:
+        M, N, K = c["M"], c["N"], c["K"]
+        results = []
+        for tickets in (True, False):
+            P = Program()
+            P.force_tile, P.target_cus, P.splitk_tickets = c["tile"], c["cus"], tickets
+            cin = K // (9 if c["gather"] == L.GATHER_CONV3X3 else 3 if c["gather"] == L.GATHER_TCONV3 else 1)
+            a = P.alloc(M, cin, "f16")
+            out = P.alloc(M, N, c["out"])
+            res = P.alloc(M, N, "f32") if c["res"] else None
+            conv = {}
+            if c["gather"] == L.GATHER_CONV3X3:
+                hh = 16 if M % 256 == 0 else 8
+                conv = dict(Hin=hh, Win=hh, Cin=cin, stride=1, up=0, Hout=hh, Wout=hh)
+                assert M % (hh * hh) == 0
+            elif c["gather"] == L.GATHER_TCONV3:
+                conv = dict(F=6, HW=M // 12, Cin=cin)
+            op = P.gemm("g", a, Ref("weight", 0, "w"), N, K, out, bias=Ref("weight", 0, "b"), gather=c["gather"], conv=conv, residual=res)
+            assert op.i[19] > 1 and (op.p[7].space != "null") == tickets
+            arena = torch.zeros(P.arena.high + 256, dtype=torch.uint8, device=dev)
+            gg = torch.Generator().manual_seed(5)
+            arena[a.ref.off: a.ref.off + M * cin * 2].view(torch.float16).copy_(torch.randn(M * cin, generator=gg).half())
+            if res is not None:
+                arena[res.ref.off: res.ref.off + M * N * 4].view(torch.float32).copy_(torch.randn(M * N, generator=gg))
+            w = {"w": (torch.randn(N, K, generator=gg) / math.sqrt(K)).half().to(dev), "b": torch.randn(N, generator=gg).to(dev)}
+            bp = BoundProgram(P, arena.data_ptr(), {k: v.data_ptr() for k, v in w.items()})
+            st = torch.cuda.current_stream(dev).cuda_stream
+            runs = []
+            for _ in range(3):
+                bp.run({}, st)
+                torch.cuda.synchronize()
+                nb = M * N * (2 if c["out"] == "f16" else 4)
+                runs.append(arena[out.ref.off: out.ref.off + nb].clone())
+            assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2]), c
+            if tickets:
+                sync = P._sync
+                assert int(arena[sync.ref.off: sync.ref.off + 4 * L.SYNC_INTS].view(torch.int32).abs().sum()) == 0      # all tickets re-armed
+            results.append(runs[0])
+        assert torch.equal(results[0], results[1]), c
+        assert not torch.isnan(results[0].view(torch.float16 if c["out"] == "f16" else torch.float32)).any()
 
 
 # ------------------------------------------------------------------------------------------------------------------

@@ -1,0 +1,150 @@
+"""Which fp16-stored ACTIVATION tensors cost how much parity?  (VERDICT r02 "what's weak" #1: weights were ranked in round 2,
+activation operands never were.)
+
+Runs the SAME denoise program the GPU executes through the CPU interpreter (tests/interp.py: same op records, arena, packed
+weights; it predicted the device's error to 2 % in round 2) with a float32 SHADOW of every fp16 arena buffer: for a chosen
+class of tensors the fp16 rounding at the store is switched off (the consumer then sees fp32 values = what an exact hi + lo
+operand split delivers), everything else stays fp16.  Error is rel-L2 against the fp32 oracle port on the DEPLOYED weights
+(`w.half().float()`, t2v_pipeline.py:103-104), i.e. the comparison of the `*_w16.npz` goldens.
+
+    python tools/precision_probe.py [tiny|small] [frames]
+
+Output: baseline, every class switched off alone (gain), everything but one class (what that class alone costs), cumulative
+greedy order.  CPU only; test infrastructure (imports oracle/ and tests/interp.py)."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from interp import Interp  # noqa: E402
+from oracle import configs, synth, torch_port as tp  # noqa: E402
+from sd_webui_text2video_amd import _lib as L  # noqa: E402
+from sd_webui_text2video_amd import unet as U  # noqa: E402
+
+
+def classify(op) -> str:
+    """Class of the fp16 tensor an op writes (by op kind / name)."""
+    n = op.name
+    if op.kind == L.OP_GROUPNORM:
+        if ".temopral_conv." in n:
+            return "gn.tconv"                 # GN+SiLU -> temporal conv operand
+        if n.endswith(".norm") or ".norm." in n:
+            return "gn.transformer"           # GN -> proj_in operand
+        return "gn.resblock"                  # GN+SiLU -> 3x3 conv operand (incl. the head)
+    if op.kind == L.OP_LAYERNORM:
+        return "ln"
+    if op.kind == L.OP_ATTENTION:
+        return "attn.out"
+    if op.kind == L.OP_NCTHW_TO_CL:
+        return "x.latent"
+    if op.kind == L.OP_TIME_EMBED:
+        return "time"
+    if op.kind == L.OP_COPY2D:                # fp32 stream -> fp16 operand casts
+        return "cast.ctx" if n.startswith("context") else ("cast.skip" if n.endswith(".skip.cast") else "cast.resample")
+    if op.kind == L.OP_GEMM:
+        if op.i[16] == L.EPI_GEGLU:
+            return "geglu.out"
+        if n.endswith(".qkv") or n.endswith(".to_q") or n.endswith(".kv") or n == "attn2.kv.all":
+            return "qkv"
+        if n.startswith("time_embed") or n == "emb_layers.all":
+            return "time"
+        if ".temopral_conv." in n or n.endswith(".in_layers.2"):
+            return "norm_input"               # conv outputs consumed only by a GroupNorm (norm_input_dtype = f16)
+        if n.endswith(".ff.net.2"):
+            return "ff.out"                   # x4: fp16 operand of proj_out
+        return "gemm.other"
+    return "other"
+
+
+class Probe(Interp):
+    def __init__(self, prog, weights, exact=()):
+        super().__init__(prog, weights, poison=False)
+        self.shadow = torch.zeros(self.arena.numel() // 2, dtype=torch.float32)
+        self.exact = set(exact)
+        self.cur = None
+        self.seen = {}
+
+    def view(self, ref, shape, strides, dtype, ext):
+        if dtype == torch.float16 and ref.space == "arena":
+            assert ref.off % 2 == 0
+            return torch.as_strided(self.shadow, tuple(shape), tuple(strides), ref.off // 2)
+        return super().view(ref, shape, strides, dtype, ext)
+
+    def _st(self, view, value, dtype):
+        if dtype == torch.float16 and view.dtype == torch.float32:          # a shadowed fp16 buffer
+            cls = classify(self.cur)
+            self.nst += 1
+            if self.nst == 2 and self.cur.kind in (L.OP_COPY2D, L.OP_NCTHW_TO_CL):
+                # the low-order image of a hi + lo cast (precise_operands): carries nothing when the hi store is already exact
+                view.copy_(value.float() * 0 if cls in self.exact else value.half().float())
+                return
+            self.seen[cls] = self.seen.get(cls, 0) + 1
+            view.copy_(value.float() if cls in self.exact else value.half().float())
+        else:
+            view.copy_(value.to(dtype))
+
+    def run(self, ext, ops=None):
+        for op in (self.prog.ops if ops is None else ops):
+            self.cur, self.nst = op, 0
+            getattr(self, f"_op{op.kind}")(op, ext)
+
+
+def main():
+    which = sys.argv[1] if len(sys.argv) > 1 else "tiny"
+    F = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+    cfg = dict(configs.TINY_UNET)
+    hw = 16
+    if which == "small":           # same topology, wider: closer to the full model's K (error averages down with K)
+        cfg.update(dim=128)
+    torch.manual_seed(0)
+    net = U.UNetSD(**cfg, init_weights=False)
+    synth.load_synth(net, seed=0)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.copy_(p.half().float())
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 4, F, hw, hw, generator=g)
+    y = torch.randn(1, 7, cfg["context_dim"], generator=g).half().float()
+    t = torch.tensor([801.0])
+    ref = tp.unet_forward(sd, cfg, x, t.long(), y)
+    net16 = net.half()
+    comp = net16._compile(1, F, hw, hw, 7, "f32", "f16", "f16")
+    weights = comp.packer.materialise(net16.state_dict(), "cpu")
+
+    def run(exact=()):
+        it = Probe(comp.prog, weights, exact)
+        out = torch.empty(1, 4, F, hw, hw, dtype=torch.float16)
+        it.run({L.EXT_X: x, L.EXT_T: t, L.EXT_CTX: y.half(), L.EXT_OUT: out})
+        e = out.float() - ref
+        return float(e.norm() / ref.norm()), it.seen
+
+    base, seen = run()
+    classes = sorted(seen)
+    if len(sys.argv) > 3:
+        classes = [c for c in classes if c.startswith(sys.argv[3])]
+    print(f"{which} UNet, {F} frames @{hw}x{hw}, deployed (fp16-representable) weights and context; rel-L2 vs the fp32 oracle")
+    print(f"baseline (all fp16 operands, as on the device): {base:.3e}; fp16 output rounding alone ~2.8e-4", flush=True)
+    print(f"{'class':16s} {'stores':>6s} {'exact alone':>12s} {'gain':>8s} {'all-but-this exact':>20s}")
+    alone = {}
+    for c in classes:
+        r1, _ = run({c})
+        r2, _ = run(set(sorted(seen)) - {c})
+        alone[c] = r1
+        print(f"{c:16s} {seen[c]:6d} {r1:12.3e} {100 * (1 - r1 / base):7.1f}% {r2:20.3e}", flush=True)
+    rall, _ = run(set(sorted(seen)))
+    print(f"every class exact: {rall:.3e} (floor: fp16 eps output + fp32 accumulation order)")
+    print(f"every class exact: {rall:.3e}", flush=True)
+    # cumulative, in the order of the single-class gains (one run per class)
+    order, chosen = [], set()
+    for c in sorted(classes, key=lambda c: alone[c]):
+        chosen.add(c)
+        order.append((c, run(chosen)[0]))
+    print("cumulative, best single gains first: " + " -> ".join(f"{c} {r:.2e}" for c, r in order), flush=True)
+
+
+if __name__ == "__main__":
+    main()
