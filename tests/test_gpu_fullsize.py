@@ -23,6 +23,9 @@ from sd_webui_text2video_amd import samplers, vae as V
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 DEV = "cuda:0"
+# gates against the deployed-weights goldens (north_star: 1e-3 rel-L2 on identical inputs; VERDICT r02 #1: forward <= 1.5e-3)
+GATE_FWD_W16 = 1.5e-3
+GATE_VIDEO_W16 = 1.0e-3
 
 
 def _gold(name):
@@ -30,6 +33,13 @@ def _gold(name):
     if not os.path.exists(path):
         pytest.skip(f"{name} not generated (tests/golden/make_golden_full.py)")
     return np.load(path)
+
+
+def _gold16(name):
+    """The "deployed-weights" golden (make_golden_full.py w16): the reference's classes in fp32 on the fp16-representable weights
+    and conditioning the product actually receives — `north_star`'s identical inputs.  None when not generated."""
+    path = os.path.join(GOLD, name.replace(".npz", "_w16.npz"))
+    return np.load(path) if os.path.exists(path) else None
 
 
 @pytest.fixture(scope="module")
@@ -53,6 +63,12 @@ def test_c1_24f_forward_and_cfg_batch(modelscope_full_fp16):
     r2 = rel_l2(pair[0:1].float().cpu(), torch.from_numpy(gold["unet_eps"]))
     print(f"configs[1] 24f forward, fp16 weights: rel-L2 {r:.3e} (b=1), {r2:.3e} (conditional half of the b=2 CFG forward)")
     assert r < 3.1e-3 and r2 < 3.1e-3          # measured 2.03e-3 / 2.03e-3
+    g16 = _gold16("modelscope_24f.npz")
+    if g16 is not None:
+        ra = rel_l2(eps.float().cpu(), torch.from_numpy(g16["unet_eps"]))
+        rb = rel_l2(pair[0:1].float().cpu(), torch.from_numpy(g16["unet_eps"]))
+        print(f"configs[1] 24f forward vs the reference on the DEPLOYED (fp16-representable) weights: rel-L2 {ra:.3e} (b=1), {rb:.3e} (b=2 CFG half)")
+        assert ra < GATE_FWD_W16 and rb < GATE_FWD_W16
 
 
 def test_c1_24f_sampling_10_and_50_steps_and_frames(modelscope_full_fp16, vae16):
@@ -70,6 +86,10 @@ def test_c1_24f_sampling_10_and_50_steps_and_frames(modelscope_full_fp16, vae16)
         r = rel_l2(x0[steps].float().cpu(), torch.from_numpy(gold[f"sampler_x0_{steps}"]))
         print(f"configs[1] {steps}-step DDIM_Gaussian CFG 9, fp16 weights: x0 rel-L2 {r:.3e}")
         assert r < (3e-3 if steps == 10 else 2e-3)      # measured 1.92e-3 (10 steps), 1.26e-3 (50 steps)
+        if _gold16("modelscope_24f.npz") is not None:
+            ra = rel_l2(x0[steps].float().cpu(), torch.from_numpy(_gold16("modelscope_24f.npz")[f"sampler_x0_{steps}"]))
+            print(f"configs[1] {steps}-step DDIM_Gaussian CFG 9 vs the reference on the DEPLOYED weights: x0 rel-L2 {ra:.3e}")
+            assert ra < (GATE_FWD_W16 if steps == 10 else GATE_VIDEO_W16)
     # frames 0 / 23 of the 50-step video: VAE decode + tensor2vid as ONE program, against the reference's uint8 frames
     z = (x0[50][:, :, [0, 23]] / configs.SCALE_FACTOR).permute(0, 2, 1, 3, 4).reshape(2, 4, 32, 32)
     u8 = vae16.decode_to_uint8(z, videos=1).cpu().numpy()
@@ -100,6 +120,13 @@ def test_c2_125f_forward(modelscope_full_fp16):
     print(f"configs[2] 125f forward, fp16 weights: rel-L2 {r:.3e} over frames {frames}, worst single frame {worst:.3e}")
     assert abs(float(eps.std()) - float(gold["eps_std"])) < 2e-3 * float(gold["eps_std"])
     assert r < 3e-3 and worst < 3.2e-3            # measured 1.94e-3 / 2.08e-3
+    g16 = _gold16("modelscope_125f.npz")
+    if g16 is not None:
+        w16 = torch.from_numpy(g16["unet_eps_frames"])
+        ra = rel_l2(eps[:, :, frames], w16)
+        wa = max(rel_l2(eps[:, :, f], w16[:, :, k]) for k, f in enumerate(frames))
+        print(f"configs[2] 125f forward vs the reference on the DEPLOYED weights: rel-L2 {ra:.3e}, worst single frame {wa:.3e}")
+        assert ra < GATE_FWD_W16 and wa < 1.1 * GATE_FWD_W16
 
 
 def test_c3_zeroscope_xl_forward_72x128(modelscope_full_fp16):
@@ -112,6 +139,29 @@ def test_c3_zeroscope_xl_forward_72x128(modelscope_full_fp16):
     r = rel_l2(eps[:, :, frames], torch.from_numpy(gold["unet_eps_frames"]))
     print(f"configs[3] ZeroScope-XL geometry ({nfr}f, latent 72x128, 9216-token spatial attention), fp16 weights: rel-L2 {r:.3e}")
     assert r < 3.1e-3                             # measured 2.02e-3
+    g16 = _gold16("zeroscope_xl.npz")
+    if g16 is not None:
+        ra = rel_l2(eps[:, :, frames], torch.from_numpy(g16["unet_eps_frames"]))
+        print(f"configs[3] ZeroScope-XL geometry ({nfr}f) vs the reference on the DEPLOYED weights: rel-L2 {ra:.3e}")
+        assert ra < GATE_FWD_W16
+
+
+def test_c3_zeroscope_xl_forward_12_frames(modelscope_full_fp16):
+    """VERDICT r02 missing #3: the 9216-token spatial attention at batch 12 x 5 heads (the 4-frame golden covers the geometry,
+    this one the batch that 24 frames put on the attention kernel's grid: 60 instead of 20 (frame, head) problems), against the
+    reference on the deployed weights — the largest clip whose fp32 CPU attention fits the build container."""
+    net, _ = modelscope_full_fp16
+    path = os.path.join(GOLD, "zeroscope_xl_12f_w16.npz")
+    if not os.path.exists(path):
+        pytest.skip("zeroscope_xl_12f_w16.npz not generated (make_golden_full.py w16 c3x12)")
+    gold = np.load(path)
+    frames = [int(f) for f in gold["frames"]]
+    noise, cond, _ = synth.synth_inputs(12, 576, 1024)
+    eps = net(noise.to(DEV), torch.tensor([801], device=DEV), cond.to(DEV).half()).float().cpu()
+    r = rel_l2(eps[:, :, frames], torch.from_numpy(gold["unet_eps_frames"]))
+    print(f"configs[3] ZeroScope-XL geometry, 12 frames @1024x576 vs the reference on the DEPLOYED weights: rel-L2 {r:.3e} over frames {frames}")
+    assert abs(float(eps.std()) - float(gold["eps_std"])) < 2e-3 * float(gold["eps_std"])
+    assert r < GATE_FWD_W16
 
 
 def test_c3_vae_decode_1024x576(vae16):
@@ -124,6 +174,11 @@ def test_c3_vae_decode_1024x576(vae16):
     rc = rel_l2(img[:, 128:256, 384:512], torch.from_numpy(gold["vae_crop"]))
     print(f"configs[3] VAE decode 1024x576 (mid attention over 9216 tokens), fp16 weights: rel-L2 {rg:.3e} (stride-4 grid), {rc:.3e} (crop)")
     assert rg < 1.7e-3 and rc < 1.7e-3            # measured 1.10e-3 / 1.07e-3
+    g16 = _gold16("zeroscope_xl.npz")
+    if g16 is not None:
+        ra = rel_l2(img[:, 1::4, 2::4], torch.from_numpy(g16["vae_grid"]))
+        print(f"configs[3] VAE decode 1024x576 vs the reference on the DEPLOYED weights: rel-L2 {ra:.3e} (stride-4 grid)")
+        assert ra < 1.5e-3
 
 
 def test_c4_lvdm_16f_ddim_and_decode():
@@ -148,6 +203,11 @@ def test_c4_lvdm_16f_ddim_and_decode():
         r = rel_l2(x0.float().cpu(), torch.from_numpy(gold[f"ddim_x0_{steps}"]))
         print(f"configs[4] VideoCrafter 16f, {steps}-step lvdm DDIM CFG 7.5, fp16 weights: x0 rel-L2 {r:.3e}")
         assert r < (2.7e-3 if steps == 10 else 2.3e-3)  # measured 1.77e-3 (10 steps), 1.49e-3 (50 steps)
+        g16 = _gold16("lvdm_16f_ddim.npz")
+        if g16 is not None:
+            ra = rel_l2(x0.float().cpu(), torch.from_numpy(g16[f"ddim_x0_{steps}"]))
+            print(f"configs[4] VideoCrafter 16f, {steps}-step lvdm DDIM vs the reference on the DEPLOYED weights: x0 rel-L2 {ra:.3e}")
+            assert ra < GATE_FWD_W16
     img = ld.decode_first_stage(torch.from_numpy(gold["ddim_x0_50"])[:, :, 0:1].to(DEV).half()).float().cpu()
     img = img.reshape(-1, 3, 256, 256)[0:1]
     rv = rel_l2(img[:, :, ::2, ::2], torch.from_numpy(gold["vae_img_frame0"]))
