@@ -312,6 +312,86 @@ def collective_layout_job(n: int, args, timeout_s: int):
             "note": ("timed out" if rc == 124 else "failed") + f" (limit {timeout_s}s); the headline is unaffected"}
 
 
+LVDM_UNET_TFLOP_16F = 3.302     # UNetModel.forward, 16 frames @256x256 (2*MAC, conv + matmul)
+
+
+def main_lvdm(args):
+    """`bench.py --model lvdm`: BASELINE.json configs[4] — VideoCrafter LVDM fp16, 16 frames @256x256 — through the reference's
+    own entry point for that model, `sample_text2video` (videocrafter/sample_text2video.py:92-152 as process_videocrafter.py:71-78
+    calls it: n_samples = batch_size = 1, DDIM, CFG 7.5): 50 lvdm-DDIM steps (one b=2 UNetModel forward + one fused update kernel
+    each) + decode_first_stage of the 16 frames + uint8 conversion.  One step = one whole video; 1 GPU."""
+    assert args.gpus == 1, "the VideoCrafter line is a single-GPU configuration (configs[4])"
+    from sd_webui_text2video_amd import configs, videocrafter as VC
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    frames = args.frames or 16
+    ld = VC.LatentDiffusion(configs.LVDM_UNET, dict(ddconfig=configs.VAE_DDCONFIG, embed_dim=4), image_size=[args.height // 8, args.width // 8],
+                            video_length=frames, init_weights=False, **configs.LVDM_SCHEDULE)
+    ld = ld.half().to(dev).eval()
+    net = ld.model.diffusion_model
+    random_weights_(net, 0)
+    random_weights_(ld.first_stage_model, 3)
+    g = torch.Generator().manual_seed(1)
+    table = {"a prompt": torch.randn(1, 77, 768, generator=g).half().to(dev), "": torch.randn(1, 77, 768, generator=g).half().to(dev)}
+
+    class Clip:                      # the text tower is outside the timed path (text_encoder.py: 1.9 ms for cond + uncond)
+        def encode(self, prompts):
+            return torch.cat([table[p] for p in prompts], 0)
+    ld.cond_stage_model = Clip()
+    smp = VC.DDIMSampler(ld)
+
+    def one(seed):
+        smp.noise_gen.manual_seed(seed)
+        return VC.sample_text2video(ld, "a prompt", "", 1, 1, sample_type="ddim", sampler=smp, ddim_steps=args.ddim_steps, eta=0.0,
+                                    cfg_scale=7.5, decode_frame_bs=None, show_denoising_progress=False, num_frames=frames)
+    one(0)
+    for i in range(args.warmup):
+        one(1 + i)
+    torch.cuda.synchronize(dev)
+    cal_before = calibration_gemm(dev)
+    t0 = time.perf_counter()
+    out = None
+    for i in range(args.steps):
+        out = one(100 + i)
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    assert out.shape == (1, frames, args.height, args.width, 3) and out.dtype.name == "uint8"
+    cal_after = calibration_gemm(dev)
+    ms_per_step = elapsed / args.steps * 1e3
+    px = (args.height // 8) * (args.width // 8) / 1024.0
+    video_tflop = (2 * args.ddim_steps * LVDM_UNET_TFLOP_16F / 16 + VAE_TFLOP_PER_FRAME) * px * frames
+    x = torch.randn(2, 4, frames, args.height // 8, args.width // 8, device=dev)
+    y = torch.cat([table["a prompt"], table[""]], 0)
+    t = torch.full((2,), 500, device=dev)
+    net.forward_timed(x, t, y)
+    _, ms, prog = net.forward_timed(x, t, y)
+    gemm_ms = sum(m for op, m in zip(prog.ops, ms) if op.kind == 1)
+    gemm_fl = sum(op.flops for op in prog.ops if op.kind == 1)
+    n_gemm = sum(1 for op in prog.ops if op.kind == 1)
+    step_ms = sum(ms)
+    achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12
+    named = "BASELINE.json configs[4]" if (frames, args.height, args.width, args.ddim_steps) == (16, 256, 256, 50) else "custom geometry"
+    result = {
+        "metric": f"denoised frames/sec (UNet+VAE), VideoCrafter LVDM {frames}f@{args.width}x{args.height}",
+        "value": round(frames * args.steps / elapsed, 4), "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
+        "data": "synthetic",
+        "config": {"workload": f"VideoCrafter LVDM fp16 (random-init 0.96B UNetModel + VAE decoder), {frames} frames @ {args.width}x{args.height}, "
+                               f"{args.ddim_steps} lvdm DDIM steps, CFG 7.5, eta 0 ({named}); one step = one whole video through sample_text2video",
+                   "frames_per_video": frames, "videos_per_batch": 1, "layout": "single", "layout_requested": args.parallel,
+                   "parallelism": "1 GPU: cond+uncond batched as b=2", "rccl_communicators": []},
+        "roofline": {"bound": "mfma", "kernel": "gemm2_kernel / gemm_kernel family (conv (1,3,3) / linear)", "achieved": round(achieved, 1),
+                     "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                     "launches_per_unet_step": n_gemm, "avg_launch_us": round(gemm_ms / n_gemm * 1e3, 2),
+                     "unet_step_ms_events": round(step_ms, 3),
+                     "unet_step_frac_of_peak": round(prog.total_flops() / (step_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                     "calibration": {"gemm_8192_tflops_before": cal_before, "gemm_8192_tflops_after": cal_after, "smi_after": smi_snapshot()},
+                     "whole_video": {"tflop": round(video_tflop, 1), "tflops_per_gpu": round(video_tflop / (ms_per_step * 1e-3), 1),
+                                     "frac": round(video_tflop / (ms_per_step * 1e-3) / MFMA_PEAK_TFLOPS, 4)}},
+    }
+    print(json.dumps(result), flush=True)
+
+
 def choose_layout(world: int, requested: str, frames_arg: int = 0):
     """-> (layout, frames per video).  auto: configs[1] at every N — one 24-frame video per GPU (cond + uncond batched as b=2):
     `single` on one GPU, `replicas` on N (weak scaling, the per-N values are comparable).  `--parallel pairs | tshard` select the
@@ -356,12 +436,19 @@ def main():
                     help="N>1, --parallel auto: skip the separate job that times the collective layout beside the headline")
     ap.add_argument("--collective-timeout", type=int, default=int(os.environ.get("T2V_BENCH_COLLECTIVE_TIMEOUT", 420)),
                     help="seconds the separate collective-layout job may take before it is abandoned (reported, headline unaffected)")
+    ap.add_argument("--model", default="modelscope", choices=["modelscope", "lvdm"],
+                    help="modelscope (default; configs[1]-[3]) or lvdm = VideoCrafter, BASELINE.json configs[4]: 16 frames @256x256 through "
+                         "sample_text2video (1 GPU; reported beside the headline, never the driver's default line)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--launch-check", action="store_true",
                     help="only check the launch path: ranks rendezvous over gloo, all-reduce their ranks, rank 0 prints one JSON line (no GPU)")
     args = ap.parse_args()
     if args.cpu_baseline_worker:
         cpu_baseline_worker(args.frames, args.ddim_steps)
+        return
+
+    if args.model == "lvdm":
+        main_lvdm(args)
         return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

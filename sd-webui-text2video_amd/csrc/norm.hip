@@ -336,16 +336,18 @@ constexpr int GNC_THREADS = 512;
 __device__ __forceinline__ void gn_grid_barrier(unsigned* bar, unsigned nwg) {
   __syncthreads();
   if (threadIdx.x == 0) {
-    t2v_release_agent();                                                            // this workgroup's partials are visible
-    const unsigned gen = __hip_atomic_load(bar + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);   // read BEFORE arriving
-    const unsigned prev = __hip_atomic_fetch_add(bar, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    // (the partials were written with device-scope stores and waited for by their writers before the __syncthreads above;
+    //  all flag accesses are relaxed device-scope atomics: no cache-wide write-back / invalidate, see t2v_kernels.h)
+    const unsigned gen = __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // read BEFORE arriving
+    t2v_wait_vm0();
+    const unsigned prev = __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (prev == nwg - 1) {
       __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_fetch_add(bar + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      t2v_wait_vm0();                                                                // re-armed before anyone is released
+      __hip_atomic_fetch_add(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
-      while (__hip_atomic_load(bar + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == gen) __builtin_amdgcn_s_sleep(4);
+      while (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) __builtin_amdgcn_s_sleep(2);
     }
-    t2v_acquire_agent();
   }
   __syncthreads();
 }
@@ -401,8 +403,9 @@ __global__ __launch_bounds__(GNC_THREADS) void gn_coop_kernel(const T* __restric
     for (int o = 1; o < 16; o <<= 1) { ds += __shfl_xor(ds, o); dq += __shfl_xor(dq, o); }
     if (g < groups && sub == 0) {
       double* st = partials + (((size_t)inst * nchunk + chunk) * groups + g) * 2;
-      st[0] = ds;
-      st[1] = dq;
+      __hip_atomic_store(st, ds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // device-scope (write-through) stores,
+      __hip_atomic_store(st + 1, dq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      t2v_wait_vm0();                                                                // complete before this workgroup arrives
     }
   }
   gn_grid_barrier(bar, gridDim.x);

@@ -44,10 +44,23 @@ struct GemmParams {
 };
 
 
-// Device-scope ordering helpers.  The 8 XCDs have private L2s: a release writes this XCD's dirty lines back, an acquire drops
-// its non-coherent lines (the compiler emits buffer_wbl2 sc1 / buffer_inv sc1 for agent-scope fences on gfx950).
-__device__ __forceinline__ void t2v_release_agent() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }
-__device__ __forceinline__ void t2v_acquire_agent() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+// Device-scope data exchange between workgroups of ONE launch.  The 8 XCDs have private, mutually non-coherent L2s; an
+// agent-scope fence makes that safe by writing back / invalidating the WHOLE L2 of the XCD (buffer_wbl2 sc1 / buffer_inv sc1)
+// — measured here: every workgroup doing that turned 26 us split-K GEMMs into 72 us ones and gave every cooperative GroupNorm
+// a 35 us floor, because the co-running workgroups lost their cached operands.  So the exchanged data itself moves with
+// device-scope accesses (sc1: stores write through to the device's coherence point, loads do not hit non-coherent lines),
+// ordered by s_waitcnt vmcnt(0) and RELAXED device-scope atomics on the flag words: no cache-wide operation anywhere.
+__device__ __forceinline__ void t2v_st_dev(float* p, f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ f32x4 t2v_ld_dev(const float* p) {
+  f32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(v) : "v"(p) : "memory");      // completion: t2v_wait_dev below
+  return v;
+}
+// the loads issued by t2v_ld_dev have landed; the operands tie the consumers of the four values to this point
+__device__ __forceinline__ void t2v_wait_dev(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
+}
+__device__ __forceinline__ void t2v_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // ---- XCD-aware tile order -----------------------------------------------------------------------------
 // Workgroup b of a launch runs on XCD b % 8 (round-robin dispatch) and each of the 8 XCDs has a private L2:
@@ -163,7 +176,9 @@ __device__ __forceinline__ void t2v_epilogue_rows(const GemmParams& p, const f32
         const int m = mt + row;
         if (m < p.M && ncol) {
           if (p.splitk > 1) {
-            *reinterpret_cast<f32x4*>(p.ws + ((size_t)split_idx * p.M + m) * p.N + n) = v;
+            float* slab = p.ws + ((size_t)split_idx * p.M + m) * p.N + n;
+            if (p.tickets) t2v_st_dev(slab, v);                  // read by another workgroup of this launch: write through
+            else *reinterpret_cast<f32x4*>(slab) = v;            // read by the reduction kernel that follows
             continue;
           }
           v += cb;
@@ -186,20 +201,20 @@ __device__ __forceinline__ void t2v_epilogue_rows(const GemmParams& p, const f32
   }
   if (p.splitk > 1 && p.tickets != nullptr) {
     // ---- split-K fold by the last-arriving workgroup of this output tile (no splitk_reduce launch) -------------------------
-    // Every workgroup has stored its slab above.  release -> ticket -> the last arrival (ticket == splitk - 1) re-arms the
-    // counter, acquires, and sums ALL slabs in split order 0 .. splitk-1 from memory (its own included): the same values in the
-    // same order as the reduction kernel this replaces, whichever workgroup happens to be last — bitwise reproducible.
+    // Every workgroup has stored its slab above (device-scope write-through stores).  stores complete -> ticket -> the last
+    // arrival (ticket == splitk - 1) re-arms the counter and sums ALL slabs in split order 0 .. splitk-1 with device-scope
+    // loads (its own included): the same values in the same order as the reduction kernel this replaces, whichever workgroup
+    // happens to be last — bitwise reproducible.
     __shared__ int s_last;
-    t2v_release_agent();
+    t2v_wait_vm0();
     __syncthreads();
     if (threadIdx.x == 0) {
-      const int t = __hip_atomic_fetch_add(p.tickets + tile_id, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      const int t = __hip_atomic_fetch_add(p.tickets + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       s_last = t == p.splitk - 1;
       if (s_last) __hip_atomic_store(p.tickets + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     if (!s_last) return;
-    t2v_acquire_agent();
 #pragma unroll
     for (int blk = 0; blk < TM * TN; ++blk) {
       const int mt = m_wave + (blk / TN) * 32, nt = n_wave + (blk % TN) * 32;
@@ -213,7 +228,19 @@ __device__ __forceinline__ void t2v_epilogue_rows(const GemmParams& p, const f32
         const int m = mt + rrow + 8 * i;
         if (m >= p.M) continue;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        for (int z = 0; z < p.splitk; ++z) v += *reinterpret_cast<const f32x4*>(p.ws + ((size_t)z * p.M + m) * p.N + n);
+        const float* col = p.ws + (size_t)m * p.N + n;
+        const size_t zs = (size_t)p.M * p.N;
+        for (int z = 0; z < p.splitk; z += 4) {                  // four slabs in flight; missing ones re-read slab 0 and are dropped
+          f32x4 t0 = t2v_ld_dev(col + (size_t)z * zs);
+          f32x4 t1 = t2v_ld_dev(col + (size_t)(z + 1 < p.splitk ? z + 1 : 0) * zs);
+          f32x4 t2 = t2v_ld_dev(col + (size_t)(z + 2 < p.splitk ? z + 2 : 0) * zs);
+          f32x4 t3 = t2v_ld_dev(col + (size_t)(z + 3 < p.splitk ? z + 3 : 0) * zs);
+          t2v_wait_dev(t0, t1, t2, t3);
+          v += t0;
+          if (z + 1 < p.splitk) v += t1;
+          if (z + 2 < p.splitk) v += t2;
+          if (z + 3 < p.splitk) v += t3;
+        }
         v += cb;
         if (p.bias && p.bias_m) { const float bm = p.bias[m]; v[0] += bm; v[1] += bm; v[2] += bm; v[3] += bm; }
         if (p.rowbias) v += *reinterpret_cast<const f32x4*>(p.rowbias + (size_t)(m / p.rows_per_batch) * p.ldrb + n);

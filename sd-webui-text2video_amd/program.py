@@ -172,7 +172,10 @@ class Program:
         self.weight_lo = None
         # Device-side synchronisation words (never freed, zero from the bind-time fill, self-resetting): L.SYNC_INTS tickets of
         # the split-K fold (one per output tile) followed by the {arrivals, generation} pair of the cooperative GroupNorm's grid barrier
-        self._sync: Optional[Buf] = None
+        # Allocated HERE, before any other buffer: an allocation made later could land on memory that an EARLIER op of the
+        # program (whose buffer was already freed at lowering time) rewrites on every run — the words must only ever be
+        # touched by the kernels that own them.
+        self._sync: Buf = self.alloc(L.SYNC_INTS + 64, 1, "f32")
         self.splitk_tickets = os.environ.get("T2V_SPLITK_TICKETS", "1") != "0"
         self.gn_coop = os.environ.get("T2V_GN_COOP", "1") != "0"
 
@@ -191,8 +194,6 @@ class Program:
             self.arena.free(b.alloc_off)
 
     def sync_ref(self, which: str) -> Ref:
-        if self._sync is None:
-            self._sync = self.alloc(L.SYNC_INTS + 64, 1, "f32")
         return self._sync.ref if which == "tickets" else self._sync.ref.shifted(4 * L.SYNC_INTS)
 
     def tap(self, name: str, buf: Buf):
