@@ -96,9 +96,11 @@ enum t2v_gather {
 #define T2V_GN_ROWS_PER_BLOCK 64
 
 /* Device-side synchronisation words a program may hand to its ops: T2V_SYNC_INTS int32 arrival counters for the split-K fold
- * (GEMM p[7]) followed by 64 more for the grid barrier of the single-pass GroupNorm (GROUPNORM p[5] points at the first of
- * them).  All zero before the first launch; the kernels leave them zero (counters) or monotonic (barrier generation). */
+ * (GEMM p[7]) followed by T2V_SYNC_BARRIER_INTS more for the two-level grid barrier of the single-pass GroupNorm (GROUPNORM
+ * p[5] points at the first of them).  All zero before the first launch; the kernels leave them zero (counters) or monotonic
+ * (barrier generation).  They must not alias any buffer an op of the program writes. */
 #define T2V_SYNC_INTS 4096
+#define T2V_SYNC_BARRIER_INTS 512
 
 #define T2V_OP_NI 24
 #define T2V_OP_NF 8
@@ -126,7 +128,7 @@ enum t2v_gather {
  *      12 single-launch variant (phase 0 only, (C/groups) % 4 == 0): one workgroup per (instance, group);
  *      14 rows of the whole instance over all parts (0 = rows * nparts; T-sharded clips with uneven slices);
  *      15 single-PASS cooperative variant allowed (phase 0, groups <= 32, p[5] given): grid <= one workgroup per CU, the tensor
- *         is read once into registers, statistics meet at a grid barrier (p[5] = 2 zero-initialised uint32 words); the library
+ *         is read once into registers, statistics meet at a grid barrier (p[5] = T2V_SYNC_BARRIER_INTS zero-initialised uint32 words); the library
  *         uses it when the instance chunks fit (else the launches above on the same scratch);
  *      scratch, phase 0: block partials [n_inst][nblk][groups][2] fp64, then {mean, rstd} fp32;  phases 1 / 2: gathered parts
  *      [nparts][n_inst][groups][2] fp64 (phase 1 folds this rank's block partials into its part; ALLGATHER of

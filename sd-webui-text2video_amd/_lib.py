@@ -26,6 +26,7 @@ EXT_X, EXT_T, EXT_CTX, EXT_OUT, EXT_XT, EXT_XT_OUT, EXT_NOISE, EXT_EPS = 1, 2, 3
 OP_NI, OP_NF, OP_NP = 24, 8, 8
 GN_ROWS_PER_BLOCK = 64           # T2V_GN_ROWS_PER_BLOCK
 SYNC_INTS = 4096                 # T2V_SYNC_INTS
+SYNC_BARRIER_INTS = 512          # T2V_SYNC_BARRIER_INTS
 
 EXPORTS = [
     "t2v_abi_version", "t2v_last_error", "t2v_device_info", "t2v_run_ops", "t2v_plan_create",

@@ -331,22 +331,35 @@ __global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(const T* __restri
 // select the three-launch path with T2V_GN_COOP=0.
 constexpr int GNC_THREADS = 512;
 
-// sense-reversing grid barrier on two words {arrivals, generation} of the program's zero-initialised sync buffer: arrivals
-// returns to 0, the generation only ever grows, so the words need no reset between launches.
+// Sense-reversing grid barrier on words of the program's zero-initialised sync buffer.  Two levels, because atomics on ONE
+// address serialise at ~25 ns each (256 arrivals = 6 us): workgroup b arrives at counter b % 8 (its own 128-byte line), the last
+// arrival of each counter re-arms it and arrives at the top counter, the last of those re-arms that and bumps the generation
+// word every waiter polls.  Counters return to 0 and the generation only grows, so nothing needs a reset between launches.
+// All flag accesses are relaxed device-scope atomics (no cache-wide write-back / invalidate: t2v_kernels.h); the partials were
+// written with device-scope stores that their writers waited for before the __syncthreads below.
+constexpr int GNB_STRIDE = 32;                       // ints between level-1 counters (one 128-byte line each)
+constexpr int GNB_TOP = 8 * GNB_STRIDE, GNB_GEN = 9 * GNB_STRIDE;
 __device__ __forceinline__ void gn_grid_barrier(unsigned* bar, unsigned nwg) {
   __syncthreads();
   if (threadIdx.x == 0) {
-    // (the partials were written with device-scope stores and waited for by their writers before the __syncthreads above;
-    //  all flag accesses are relaxed device-scope atomics: no cache-wide write-back / invalidate, see t2v_kernels.h)
-    const unsigned gen = __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // read BEFORE arriving
+    const unsigned grp = blockIdx.x & 7u;
+    const unsigned ngrp = nwg < 8u ? nwg : 8u;
+    const unsigned in_grp = (nwg - grp + 7u) >> 3;                                   // workgroups b with b % 8 == grp
+    const unsigned gen = __hip_atomic_load(bar + GNB_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // read BEFORE arriving
     t2v_wait_vm0();
-    const unsigned prev = __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (prev == nwg - 1) {
-      __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      t2v_wait_vm0();                                                                // re-armed before anyone is released
-      __hip_atomic_fetch_add(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool release = false;
+    if (__hip_atomic_fetch_add(bar + grp * GNB_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_grp - 1) {
+      __hip_atomic_store(bar + grp * GNB_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__hip_atomic_fetch_add(bar + GNB_TOP, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngrp - 1) {
+        __hip_atomic_store(bar + GNB_TOP, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        release = true;
+      }
+    }
+    if (release) {
+      t2v_wait_vm0();                                                                // every counter re-armed before anyone leaves
+      __hip_atomic_fetch_add(bar + GNB_GEN, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
-      while (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) __builtin_amdgcn_s_sleep(2);
+      while (__hip_atomic_load(bar + GNB_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) __builtin_amdgcn_s_sleep(8);
     }
   }
   __syncthreads();
@@ -403,8 +416,10 @@ __global__ __launch_bounds__(GNC_THREADS) void gn_coop_kernel(const T* __restric
     for (int o = 1; o < 16; o <<= 1) { ds += __shfl_xor(ds, o); dq += __shfl_xor(dq, o); }
     if (g < groups && sub == 0) {
       double* st = partials + (((size_t)inst * nchunk + chunk) * groups + g) * 2;
-      __hip_atomic_store(st, ds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // device-scope (write-through) stores,
-      __hip_atomic_store(st + 1, dq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      union { double d[2]; f32x4 v; } pk;
+      pk.d[0] = ds;
+      pk.d[1] = dq;
+      t2v_st_dev(reinterpret_cast<float*>(st), pk.v);                                // one 16-byte device-scope (write-through) store,
       t2v_wait_vm0();                                                                // complete before this workgroup arrives
     }
   }
@@ -412,10 +427,22 @@ __global__ __launch_bounds__(GNC_THREADS) void gn_coop_kernel(const T* __restric
   {
     double ds = 0.0, dq = 0.0;
     if (g < groups) {
-      for (int c = sub; c < nchunk; c += 16) {                // fixed order: the same on every workgroup of the instance
-        const double* st = partials + (((size_t)inst * nchunk + c) * groups + g) * 2;
-        ds += __hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        dq += __hip_atomic_load(st + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // fixed order (the same on every workgroup of the instance); four 16-byte device-scope loads in flight per round —
+      // one load-use round trip at a time made this fold the longest phase of the kernel (8 dependent ~2 us latencies)
+      const double* base = partials + ((size_t)inst * nchunk * groups + g) * 2;
+      for (int c = sub; c < nchunk; c += 64) {
+        const int c1 = c + 16, c2 = c + 32, c3 = c + 48;
+        f32x4 t0 = t2v_ld_dev(reinterpret_cast<const float*>(base + (size_t)c * groups * 2));
+        f32x4 t1 = t2v_ld_dev(reinterpret_cast<const float*>(base + (size_t)(c1 < nchunk ? c1 : c) * groups * 2));
+        f32x4 t2 = t2v_ld_dev(reinterpret_cast<const float*>(base + (size_t)(c2 < nchunk ? c2 : c) * groups * 2));
+        f32x4 t3 = t2v_ld_dev(reinterpret_cast<const float*>(base + (size_t)(c3 < nchunk ? c3 : c) * groups * 2));
+        t2v_wait_dev(t0, t1, t2, t3);
+        union { f32x4 v; double d[2]; } u0, u1, u2, u3;
+        u0.v = t0; u1.v = t1; u2.v = t2; u3.v = t3;
+        ds += u0.d[0]; dq += u0.d[1];
+        if (c1 < nchunk) { ds += u1.d[0]; dq += u1.d[1]; }
+        if (c2 < nchunk) { ds += u2.d[0]; dq += u2.d[1]; }
+        if (c3 < nchunk) { ds += u3.d[0]; dq += u3.d[1]; }
       }
     }
     for (int o = 1; o < 16; o <<= 1) { ds += __shfl_xor(ds, o); dq += __shfl_xor(dq, o); }

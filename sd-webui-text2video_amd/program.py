@@ -175,8 +175,11 @@ class Program:
         # Allocated HERE, before any other buffer: an allocation made later could land on memory that an EARLIER op of the
         # program (whose buffer was already freed at lowering time) rewrites on every run — the words must only ever be
         # touched by the kernels that own them.
-        self._sync: Buf = self.alloc(L.SYNC_INTS + 64, 1, "f32")
-        self.splitk_tickets = os.environ.get("T2V_SPLITK_TICKETS", "1") != "0"
+        self._sync: Buf = self.alloc(L.SYNC_INTS + L.SYNC_BARRIER_INTS, 1, "f32")
+        # split-K fold in the last-arriving workgroup of a tile instead of a reduction launch: implemented and bit-identical, but
+        # MEASURED SLOWER (same box, 83 split-K ops of a step: 5.24 vs 4.73 ms): only `tiles` workgroups fold, each behind a chain
+        # of device-scope load latencies, where the reduction kernel uses the whole chip -> off by default
+        self.splitk_tickets = os.environ.get("T2V_SPLITK_TICKETS", "0") != "0"
         self.gn_coop = os.environ.get("T2V_GN_COOP", "1") != "0"
 
     # ---- memory ---------------------------------------------------------------------------

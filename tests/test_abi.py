@@ -25,7 +25,7 @@ def test_header_constants_match_binding():
         "T2V_EXT_SLOTS": L.EXT_SLOTS, "T2V_EXT_X": L.EXT_X, "T2V_EXT_T": L.EXT_T, "T2V_EXT_CTX": L.EXT_CTX,
         "T2V_EXT_OUT": L.EXT_OUT, "T2V_EXT_XT": L.EXT_XT, "T2V_EXT_XT_OUT": L.EXT_XT_OUT,
         "T2V_EXT_NOISE": L.EXT_NOISE, "T2V_EXT_EPS": L.EXT_EPS, "T2V_OP_NI": L.OP_NI, "T2V_OP_NF": L.OP_NF,
-        "T2V_OP_NP": L.OP_NP, "T2V_GN_ROWS_PER_BLOCK": L.GN_ROWS_PER_BLOCK, "T2V_SYNC_INTS": L.SYNC_INTS,
+        "T2V_OP_NP": L.OP_NP, "T2V_GN_ROWS_PER_BLOCK": L.GN_ROWS_PER_BLOCK, "T2V_SYNC_INTS": L.SYNC_INTS, "T2V_SYNC_BARRIER_INTS": L.SYNC_BARRIER_INTS,
         "T2V_OP_EMBED_ROWS": L.OP_EMBED_ROWS, "T2V_OP_TO_UINT8": L.OP_TO_UINT8, "T2V_OP_ALLGATHER": L.OP_ALLGATHER,
         "T2V_OP_HALO_EXCHANGE": L.OP_HALO_EXCHANGE, "T2V_OP_RESHARD_ROWS": L.OP_RESHARD_ROWS, "T2V_OP_ALLTOALL": L.OP_ALLTOALL,
     }

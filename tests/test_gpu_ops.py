@@ -657,8 +657,9 @@ def test_groupnorm_cooperative_full_size(n_inst, rows, C, dt, silu):
 
 
 def test_split_k_ticket_fold_is_bitwise_the_reduction_kernel():
-    """Split-K with the fold in the last-arriving workgroup of each tile (default) against the stand-alone reduction kernel
-    (T2V_SPLITK_TICKETS=0 / Program.splitk_tickets = False): same slabs summed in the same order -> identical bits, for every
+    """Split-K with the fold in the last-arriving workgroup of each tile (T2V_SPLITK_TICKETS=1 / Program.splitk_tickets; off by
+    default: measured slower than the reduction launch) against the stand-alone reduction kernel: same slabs summed in the same
+    order -> identical bits, for every
     kernel family and epilogue variant; repeated runs re-arm the tickets."""
     from sd_webui_text2video_amd.program import BoundProgram
     dev = torch.device("cuda:0")
