@@ -74,6 +74,11 @@ enum t2v_gather {
 #define T2V_EPI_NONE 0
 #define T2V_EPI_GEGLU 1   /* out[m, j] = (a_j + b_j) * gelu(g_j + c_j); weight rows interleaved
                              in blocks of 16 = 8 value rows | 8 gate rows                    */
+#define T2V_EPI_TATTN 2   /* fused QKV projection + temporal self-attention (tile 10): W = [heads][q 64 | k 64 | v 64][K]
+                             (head-major), N = 192 * heads; the tile's rows are i[10] pixels x F (= i[8] <= 32) frames of
+                             one sample (input / output row of (sample s, frame f, pixel x) = (s*F + f)*HW + x, HW = i[9]);
+                             M = samples * ceil(HW / i[10]) * 192 (tile rows, not tokens); out fp16 [samples*F*HW, ldc]:
+                             softmax(q k^T f[1]) v of every pixel's frame sequence, head h at columns 64 h .. 64 h + 63 */
 
 /* dtype tags */
 #define T2V_F16 0
@@ -113,7 +118,8 @@ enum t2v_gather {
  *      11 stride, 12 upsample, 13 Hout, 14 Wout, 15 rows_per_batch, 16 epilogue,
  *      17 out dtype, 18 act (0 none, 1 SiLU), 19 split_k, 20 bias_along_m, 21 ldrb,
  *      22 tile (0 = 128x128-class kernel; 1 256x256, 2 256x320, 3 128x256 (8 waves, 3-stage ring), 4 / 5 128x128 with a 4-deep
- *         ring on 4 / 8 waves, 6 / 7 = 1 / 2 with the two-group ping-pong schedule, 8 / 9 192x320 / 192x256 on 12 waves),
+ *         ring on 4 / 8 waves, 6 / 7 = 1 / 2 with the two-group ping-pong schedule, 8 / 9 192x320 / 192x256 on 12 waves,
+ *         10 = 192x192 on 12 waves, T2V_EPI_TATTN only),
  *      23 tconv halo (input rows are [clip][F+2][HW]: one halo frame either side, T-sharding);
  *         for CONV3X3: 1 = zero padding (0,1,0,1) instead of (1,1,1,1) (LDM encoder Downsample, taps at +0..+2)
  *      PLAIN gather only: 8 = 1 -> fused LayerNorm second output (tile 8, N == 320, fp32 out, no split-K): p[7] fp16 [M, i[9]] =

@@ -65,7 +65,20 @@ int validate_op(const t2v_op& op, int idx) {
       if (op.i[16] == T2V_EPI_GEGLU && (N % 32 != 0 || op.i[17] != T2V_F16)) return bad("GEGLU needs N % 32 == 0, fp16 out");
       if (op.i[19] > 1 && op.p[6] == 0) return bad("split-K without workspace");
       if (op.p[3] != 0 && op.i[15] <= 0 && !(g == T2V_GATHER_PLAIN && op.i[8] == 1)) return bad("rowbias without rows_per_batch");
-      if (op.i[22] < 0 || op.i[22] > 9) return bad("unknown tile id");
+      if (op.i[22] < 0 || op.i[22] > 10) return bad("unknown tile id");
+      if ((op.i[16] == T2V_EPI_TATTN) != (op.i[22] == 10)) return bad("tile 10 is the fused QKV + temporal attention tile (T2V_EPI_TATTN), and only that");
+      if (op.i[16] == T2V_EPI_TATTN) {
+        const int F = op.i[8], HW = op.i[9], tpix = op.i[10];
+        if (g != T2V_GATHER_PLAIN || N % 192 != 0 || K % 64 != 0 || op.i[17] != T2V_F16 || op.i[19] > 1 || op.i[18] != 0)
+          return bad("fused temporal attention: plain gather, N = 192 * heads, K % 64 == 0, fp16 out, no split-K / activation");
+        if (F < 2 || F > 32 || HW < 1 || tpix < 1 || tpix > 12 || tpix * F > 192) return bad("fused temporal attention: 2 <= F <= 32, 1 <= pixels per tile <= 12, pixels * F <= 192");
+        const int tiles_ps = (HW + tpix - 1) / tpix;
+        if (M % 192 != 0 || (M / 192) % tiles_ps != 0) return bad("fused temporal attention: M must be samples * ceil(HW / pixels per tile) * 192");
+        if (op.p[2] != 0 || op.p[3] != 0 || op.p[4] != 0 || op.p[0] == 0 || op.p[1] == 0 || op.p[5] == 0 || !(op.f[1] > 0.f))
+          return bad("fused temporal attention: no bias / row bias / residual; A, W, out and a positive scale are required");
+        if (op.i[5] < (N / 192) * 64 || op.i[5] % 4 != 0) return bad("fused temporal attention: ldc < heads * 64");
+        return 0;
+      }
       if (g == T2V_GATHER_PLAIN && op.i[8] == 1) {
         if (op.i[22] != 8 || N != 320 || op.i[19] > 1 || op.i[16] != T2V_EPI_NONE || op.i[17] != T2V_F32 || op.i[18] != 0 || op.i[20] != 0 ||
             K % 64 != 0)
@@ -197,9 +210,16 @@ hipError_t launch_op(const t2v_op& op, hipStream_t s) {
       p.ws = reinterpret_cast<float*>(op.p[6]);
       p.halo = op.i[23];
       const int tile = op.i[22];
+      if (p.epi == T2V_EPI_TATTN) {                              // fused QKV projection + temporal attention (tile 10)
+        p.F = op.i[8]; p.HW = op.i[9]; p.tpix = op.i[10];
+        p.tiles_ps = (p.HW + p.tpix - 1) / p.tpix;
+        p.attn_scale_log2 = op.f[1] * 1.44269504088896340736f;
+        p.Hin = p.Win = 0; p.Cin = 0;
+        return t2v_launch_gemm2(p, tile, s);
+      }
       // split-K: p[7] = T2V_SYNC_INTS zeroed ints -> the fold runs in the GEMM's last-arriving workgroups; 0 -> reduction kernel
       if (p.splitk > 1 && !(p.gather == T2V_GATHER_PLAIN && op.i[8] == 1)) p.tickets = reinterpret_cast<int*>(op.p[7]);
-      if (p.gather == T2V_GATHER_PLAIN && op.i[8] == 1) {       // fused LayerNorm second output (validated: tile 8, N == 320)
+      if (p.gather == T2V_GATHER_PLAIN && op.i[8] == 1) {       // fused LayerNorm second output (validated: tile 8, N == 320; TATTN returned above)
         p.ln_gb = reinterpret_cast<const float*>(op.p[3]);
         p.rowbias = nullptr;
         p.ln_out = reinterpret_cast<f16*>(op.p[7]);

@@ -31,6 +31,7 @@ __device__ __attribute__((aligned(256))) unsigned char g2_zero_page[256];
 
 // internal gather id: 3x3 conv with the nearest-2x upsample folded in (no affine tap offset)
 constexpr int G_CONV_UP = 100;
+constexpr int BM_OF(int wm, int tm) { return wm * tm * 32; }
 
 
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
@@ -87,7 +88,7 @@ __device__ __forceinline__ void epi_store_geglu(const GemmParams& p, int m, int 
 }
 
 // WM x WN waves; each wave owns TM x TN MFMA tiles (32 tokens x 32 channels each).
-template <int WM, int WN, int TM, int TN, int BK, int STAGES, int MINW, int GATHER, bool PP, bool LN = false>
+template <int WM, int WN, int TM, int TN, int BK, int STAGES, int MINW, int GATHER, bool PP, bool LN = false, bool TAT = false>
 __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm2_kernel(const GemmParams p) {
   constexpr int NW = WM * WN;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -150,7 +151,17 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm2_kernel(const GemmPar
     xmask[j] = 0; xstep[j] = 0;
     xptr[j] = zero;
     if (GATHER == T2V_GATHER_PLAIN) {
-      if (valid) {
+      if constexpr (TAT) {
+        // fused QKV + temporal attention: the tile's rows are p.tpix pixels x p.F frames of ONE sample (row r = pixel r / F,
+        // frame r % F), so that every sequence (the frames of a pixel) is complete inside the workgroup
+        const int pl = r / p.F, f = r - pl * p.F;
+        const int smp = tile_m / p.tiles_ps, pix = (tile_m - smp * p.tiles_ps) * p.tpix + pl;
+        if (pl < p.tpix && pix < p.HW) {
+          const long mm = ((long)smp * p.F + f) * p.HW + pix;
+          xptr[j] = reinterpret_cast<const unsigned char*>(p.A + mm * p.lda + (long)kt_begin * BK + lc * 8);
+          xstep[j] = STEP;
+        }
+      } else if (valid) {
         xptr[j] = reinterpret_cast<const unsigned char*>(p.A + (long)m * p.lda + (long)kt_begin * BK + lc * 8);
         xstep[j] = STEP;
       }
@@ -407,6 +418,105 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm2_kernel(const GemmPar
   wait_vmcnt<0>();   // drain the zero-page loads of the dead stages before the LDS goes away
 
   // ---- epilogue ---------------------------------------------------------------------------------
+  if constexpr (TAT) {
+    // Fused temporal self-attention (t2v_model.py:716-767 with CrossAttention :540-584): this tile holds q | k | v (64 channels
+    // each: ONE head, the weight rows are packed head-major) of all F frames of p.tpix pixels.  The accumulators go to LDS as
+    // fp16 (q | k row-major, V transposed: [pixel][d][frame slot]), then one wave per pixel runs the 32-key attention tile of
+    // attention.hip (S^T = K Q^T with the key on the MFMA row axis, in-lane softmax, P from the accumulator registers) and
+    // writes O for its F frames.  Q, K, V never reach HBM: 3 x the tensor written + read per attention before.
+    static_assert(TM == 1 && TN == 3 && WM == 6 && WN == 2, "the fused attention epilogue is written for the 192x192 tile");
+    constexpr int QK_PITCH = 272;                          // bytes per row: q (128 B) | k (128 B) + 16
+    constexpr int VT_PITCH = 72;                           // bytes per V^T row: 32 frame slots x 2 B + 8
+    __syncthreads();                                       // every wave is done reading the operand stages
+    unsigned char* qk = smem;
+    unsigned char* vt = smem + BM * QK_PITCH;
+    const int F = p.F;
+    {
+      const int wrow = wm * 32 + (lane & 31);              // tile row of this lane's accumulator column
+      const int pl = wrow / F, f = wrow - pl * F;
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int col = wn * (TN * 32) + b * 32 + 8 * q + 4 * (lane >> 5);
+          const f16x4 v = {(f16)acc[0][b][4 * q], (f16)acc[0][b][4 * q + 1], (f16)acc[0][b][4 * q + 2], (f16)acc[0][b][4 * q + 3]};
+          if (col < 128) {
+            *reinterpret_cast<f16x4*>(qk + wrow * QK_PITCH + col * 2) = v;
+          } else if (pl < p.tpix) {
+            const int d = col - 128;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) *reinterpret_cast<f16*>(vt + (pl * 64 + d + e) * VT_PITCH + f * 2) = v[e];
+          }
+        }
+      // frame slots F .. 31 of V^T: zero (they meet probabilities that are exactly 0, but must not hold NaN patterns)
+      for (int u = tid; u < p.tpix * 64; u += NW * 64)
+        for (int k = F; k < 32; ++k) *reinterpret_cast<f16*>(vt + u * VT_PITCH + k * 2) = (f16)0.f;
+    }
+    __syncthreads();
+    const int frow = lane & 31, fhalf = lane >> 5;
+    const int smp = tile_m / p.tiles_ps;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int pl = wave; pl < p.tpix; pl += NW) {
+      const int pix = (tile_m - smp * p.tiles_ps) * p.tpix + pl;
+      if (pix >= p.HW) continue;                           // wave-uniform
+      const unsigned char* rowp = qk + (pl * F + frow) * QK_PITCH;    // rows >= F of the pixel: next pixel / V^T bytes, finite, masked below
+      f32x16 sc = zero16;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const f16x8 qf = *reinterpret_cast<const f16x8*>(rowp + ((kk * 2 + fhalf) << 4));
+        const f16x8 kf = *reinterpret_cast<const f16x8*>(rowp + 128 + ((kk * 2 + fhalf) << 4));
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf, sc, 0, 0, 0);
+      }
+      float mx = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+        if (key >= F) sc[r] = -INFINITY;
+        mx = fmaxf(mx, sc[r]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      if (frow >= F) mx = 0.f;                             // padded queries: any finite reference, the result is dropped
+      const float neg_m = -mx * p.attn_scale_log2;
+      float psum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], p.attn_scale_log2, neg_m));
+        sc[r] = pv;
+        psum += pv;
+      }
+      psum += __shfl_xor(psum, 32);
+      f32x16 oacc[2] = {zero16, zero16};
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        f16x8 pf;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pf[e] = (f16)sc[8 * t + e];
+        const int kofs = (t * 16 + 4 * fhalf) * 2;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          const unsigned char* vrow = vt + (pl * 64 + d * 32 + frow) * VT_PITCH + kofs;
+          const f16x4 lo = *reinterpret_cast<const f16x4*>(vrow);
+          const f16x4 hi = *reinterpret_cast<const f16x4*>(vrow + 16);
+          const f16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, oacc[d], 0, 0, 0);
+        }
+      }
+      if (frow < F) {
+        const float inv = 1.0f / psum;
+        f16* orow = reinterpret_cast<f16*>(p.out) + (((long)smp * F + frow) * p.HW + pix) * p.ldc + tile_n * 64;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+          for (int qd = 0; qd < 4; ++qd) {
+            f16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (f16)(oacc[d][4 * qd + r] * inv);
+            *reinterpret_cast<f16x4*>(orow + d * 32 + 8 * qd + 4 * fhalf) = o;
+          }
+      }
+    }
+    return;
+  }
   if (p.epi == T2V_EPI_NONE) {      // row-coalesced through a per-wave LDS buffer (t2v_kernels.h); also the split-K slabs
     __builtin_amdgcn_s_barrier();   // every wave is done reading the operand stages
     if constexpr (LN) {             // whole rows in this tile (192x320, N == 320, validated by the executor): fused LayerNorm output
@@ -510,12 +620,14 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm2_kernel(const GemmPar
   }
 }
 
-template <int WM, int WN, int TM, int TN, int BK, int STAGES, int MINW, int GATHER, bool PP, bool LN = false>
+template <int WM, int WN, int TM, int TN, int BK, int STAGES, int MINW, int GATHER, bool PP, bool LN = false, bool TAT = false>
 hipError_t launch_cfg_gather(const GemmParams& p, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  constexpr int lds = STAGES * (BM + BN) * BK * 2 + 1024;
+  // TAT: the attention epilogue re-uses the operand ring for q | k (BM x 272 B) and V^T (<= 12 pixels x 64 x 72 B)
+  constexpr int lds = TAT ? (BM * 272 + 12 * 64 * 72 > STAGES * (BM + BN) * BK * 2 + 1024 ? BM * 272 + 12 * 64 * 72 : STAGES * (BM + BN) * BK * 2 + 1024)
+                          : STAGES * (BM + BN) * BK * 2 + 1024;
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  auto k = gemm2_kernel<WM, WN, TM, TN, BK, STAGES, MINW, GATHER, PP, LN>;
+  auto k = gemm2_kernel<WM, WN, TM, TN, BK, STAGES, MINW, GATHER, PP, LN, TAT>;
   static bool attr_set = false;     // once per instantiation (the call costs microseconds on the host)
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -544,6 +656,12 @@ hipError_t launch_cfg(const GemmParams& pin, hipStream_t s) {
   hipError_t e;
   switch (p.gather) {
     case T2V_GATHER_PLAIN:
+      if constexpr (WM == 6 && WN == 2 && TM == 1 && TN == 3 && !PP) {
+        if (p.epi != T2V_EPI_TATTN || p.splitk != 1 || p.tpix < 1 || p.tpix > 12 || p.tpix * p.F > BM_OF(WM, TM) || p.F > 32) return hipErrorInvalidValue;
+        e = launch_cfg_gather<WM, WN, TM, TN, BK, STAGES, MINW, T2V_GATHER_PLAIN, PP, false, true>(p, s);
+        break;
+      }
+      if (p.epi == T2V_EPI_TATTN) return hipErrorInvalidValue;
       if constexpr (WM == 6 && WN == 2 && TM == 1 && TN == 5 && !PP) {
         if (p.ln_out != nullptr) {
           e = launch_cfg_gather<WM, WN, TM, TN, BK, STAGES, MINW, T2V_GATHER_PLAIN, PP, true>(p, s);
@@ -578,6 +696,7 @@ hipError_t t2v_launch_gemm2(const GemmParams& p, int tile, hipStream_t s) {
     case 5: return launch_cfg<2, 4, 2, 1, 64, 4, 2>(p, s);   // 128x128, 8 waves, 4 x 32 KiB
     case 8: return launch_cfg<6, 2, 1, 5, 64, 2, 3>(p, s);   // 192x320, 12 waves (3 per SIMD), 2 x 64 KiB: M = 49152 -> exactly 256 workgroups
     case 9: return launch_cfg<6, 2, 1, 4, 64, 2, 3>(p, s);   // 192x256, 12 waves, 2 x 56 KiB (N = 256 * j where 256-row grids fill badly)
+    case 10: return launch_cfg<6, 2, 1, 3, 64, 2, 3>(p, s);  // 192x192, 12 waves: fused QKV projection + temporal attention (T2V_EPI_TATTN only)
     case 6: return launch_cfg<2, 4, 4, 2, 64, 2, 2, true>(p, s);   // 256x256 ping-pong (two staggered wave groups)
     case 7:                                                         // 256x320 ping-pong
       if (p.gather == T2V_GATHER_CONV3X3 && p.up) return launch_cfg<4, 2, 2, 5, 64, 2, 2>(p, s);   // (upsample gather: register budget)

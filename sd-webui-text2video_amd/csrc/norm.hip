@@ -427,22 +427,24 @@ __global__ __launch_bounds__(GNC_THREADS) void gn_coop_kernel(const T* __restric
   {
     double ds = 0.0, dq = 0.0;
     if (g < groups) {
-      // fixed order (the same on every workgroup of the instance); four 16-byte device-scope loads in flight per round —
+      // fixed order (the same on every workgroup of the instance); EIGHT 16-byte device-scope loads in flight per round —
       // one load-use round trip at a time made this fold the longest phase of the kernel (8 dependent ~2 us latencies)
       const double* base = partials + ((size_t)inst * nchunk * groups + g) * 2;
-      for (int c = sub; c < nchunk; c += 64) {
-        const int c1 = c + 16, c2 = c + 32, c3 = c + 48;
-        f32x4 t0 = t2v_ld_dev(reinterpret_cast<const float*>(base + (size_t)c * groups * 2));
-        f32x4 t1 = t2v_ld_dev(reinterpret_cast<const float*>(base + (size_t)(c1 < nchunk ? c1 : c) * groups * 2));
-        f32x4 t2 = t2v_ld_dev(reinterpret_cast<const float*>(base + (size_t)(c2 < nchunk ? c2 : c) * groups * 2));
-        f32x4 t3 = t2v_ld_dev(reinterpret_cast<const float*>(base + (size_t)(c3 < nchunk ? c3 : c) * groups * 2));
-        t2v_wait_dev(t0, t1, t2, t3);
-        union { f32x4 v; double d[2]; } u0, u1, u2, u3;
-        u0.v = t0; u1.v = t1; u2.v = t2; u3.v = t3;
-        ds += u0.d[0]; dq += u0.d[1];
-        if (c1 < nchunk) { ds += u1.d[0]; dq += u1.d[1]; }
-        if (c2 < nchunk) { ds += u2.d[0]; dq += u2.d[1]; }
-        if (c3 < nchunk) { ds += u3.d[0]; dq += u3.d[1]; }
+      for (int c = sub; c < nchunk; c += 128) {
+        f32x4 t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int cj = c + 16 * j;
+          t[j] = t2v_ld_dev(reinterpret_cast<const float*>(base + (size_t)(cj < nchunk ? cj : c) * groups * 2));
+        }
+        t2v_wait_dev(t[0], t[1], t[2], t[3]);      // vmcnt(0): all eight have landed; the second call only ties the operands
+        t2v_wait_dev(t[4], t[5], t[6], t[7]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          union { f32x4 v; double d[2]; } u;
+          u.v = t[j];
+          if (c + 16 * j < nchunk) { ds += u.d[0]; dq += u.d[1]; }
+        }
       }
     }
     for (int o = 1; o < 16; o <<= 1) { ds += __shfl_xor(ds, o); dq += __shfl_xor(dq, o); }

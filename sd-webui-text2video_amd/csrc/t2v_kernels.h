@@ -38,6 +38,9 @@ struct GemmParams {
   f16* ln_out;
   int ld_ln;
   float ln_eps;
+  // fused QKV + temporal attention (T2V_EPI_TATTN, 192x192 tile): tile rows = tpix pixels x F frames of one sample
+  int tpix, tiles_ps;                          // pixels per tile, row tiles per sample (ceil(HW / tpix))
+  float attn_scale_log2;                       // softmax scale * log2(e)
   // split-K without a reduction launch (EPI_NONE): one arrival counter per output tile (T2V_SYNC_INTS ints, all zero between
   // launches); the LAST workgroup of a tile to arrive folds the slabs in split order and runs the fused epilogue
   int* tickets;

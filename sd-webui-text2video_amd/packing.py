@@ -60,6 +60,14 @@ def tconv3(w: torch.Tensor) -> torch.Tensor:
     return w.reshape(co, 3, ci // KCHUNK, KCHUNK).permute(0, 2, 1, 3).reshape(co, 3 * ci)
 
 
+def qkv_head_major(wq: torch.Tensor, wk: torch.Tensor, wv: torch.Tensor, head_dim: int = 64) -> torch.Tensor:
+    """to_q / to_k / to_v weights [heads * d, K] -> [heads][q (d) | k (d) | v (d)][K]: one head's three projections are 3 * d
+    consecutive output columns = one tile of the fused QKV + temporal attention GEMM (T2V_EPI_TATTN)."""
+    heads = wq.shape[0] // head_dim
+    parts = [w.reshape(heads, head_dim, -1) for w in (wq, wk, wv)]
+    return torch.stack(parts, dim=1).reshape(3 * heads * head_dim, -1)
+
+
 def geglu_perm(n_half: int, device=None) -> torch.Tensor:
     """Row permutation for the fused GEGLU epilogue: packed row 16u + 8g + j  <-  source row
     (g ? n_half : 0) + 8u + j   (value rows first, gate rows second in nn.Linear(dim, 2*inner),

@@ -405,6 +405,35 @@ class Program:
             self.free(lo_tmp)
         return op
 
+    @staticmethod
+    def tattn_pixels_per_tile(frames: int) -> int:
+        """Pixels whose `frames`-long sequences share one 192-row tile of the fused QKV + temporal attention GEMM."""
+        return min(12, 192 // frames) if 2 <= frames <= 32 else 0
+
+    def qkv_temporal_attention(self, name: str, a: Buf, w: Ref, out: Buf, *, samples: int, frames: int, hw: int, heads: int,
+                               k: int, scale: float) -> Op:
+        """out[tokens, heads*64] = temporal self-attention of the QKV projection of `a` — ONE launch (T2V_EPI_TATTN, tile 10):
+        every 192-row tile is `pixels` pixels x `frames` frames of one sample, its 192 columns q | k | v of one head (`w` =
+        [heads][q | k | v][k] head-major, packing.qkv_head_major), and the attention of those sequences runs in the epilogue.
+        Token row of (sample s, frame f, pixel x) = (s * frames + f) * hw + x in `a` and `out`."""
+        pix = self.tattn_pixels_per_tile(frames)
+        assert pix >= 1 and a.dtype == "f16" and out.dtype == "f16" and out.cols == heads * 64 and k % 64 == 0 and a.cols == k
+        assert a.rows == samples * frames * hw == out.rows
+        tiles_ps = -(-hw // pix)
+        op = Op(L.OP_GEMM, name)
+        I = op.i
+        I[0], I[1], I[2] = samples * tiles_ps * 192, 192 * heads, k
+        I[3], I[4], I[5] = a.ld, k, out.ld
+        I[7], I[8], I[9], I[10] = L.GATHER_PLAIN, frames, hw, pix
+        I[16], I[17], I[19], I[22] = L.EPI_TATTN, L.F16, 1, 10
+        op.f[1] = scale
+        op.p[0], op.p[1], op.p[5] = a.ref, w, out.ref
+        op.flops = 2.0 * a.rows * (192 * heads) * k + 4.0 * frames * frames * 64 * heads * samples * hw
+        op.out = out
+        op.meta = dict(M=a.rows, N=192 * heads, K=k, gather=L.GATHER_PLAIN, conv={}, epi=L.EPI_TATTN, split=1, tile=10, halo=False, ln=0,
+                       frames=frames, hw=hw, heads=heads)
+        return self._emit(op)
+
     def groupnorm(self, name: str, x: Buf, gamma: Ref, beta: Ref, out: Buf, *, n_inst: int, eps: float,
                   silu: bool, groups: int = 32, shard: Optional[TShardSpec] = None) -> Op:
         """GroupNorm(+SiLU).  With `shard` (cross-frame statistics of a T-sharded clip; n_inst = 1) the op is split

@@ -22,6 +22,7 @@ Every `rearrange(...).contiguous()` of the reference (t2v_model.py:429,458,648,6
 from __future__ import annotations
 
 import math
+import os
 from functools import partial
 from typing import Dict, List, Optional, Tuple
 
@@ -232,6 +233,10 @@ class UNetSD(nn.Module):
         # images and their (small) GEMMs run twice: 23 % of the activation-rounding error variance of a forward for ~15 extra
         # launches and +1.5 % FLOPs (tools/precision_probe.py; DESIGN.md "Precision").  Part of the program cache key.
         self.precise_operands = True
+        # TemporalTransformer self-attention as ONE launch per attention (QKV projection + attention of every pixel's frame
+        # sequence in the GEMM epilogue, T2V_EPI_TATTN): Q / K / V never reach HBM.  Clips of 2..32 frames; longer clips (and the
+        # K/V-gather form of a T-sharded clip) keep the projection GEMM + attention kernel pair.  Part of the program cache key.
+        self.fused_temporal_attention = os.environ.get("T2V_FUSED_TATTN", "1") != "0"
         self.t_shard = None           # parallel.TShard: this rank holds a contiguous slice of the clip's frames
         self.auto_refresh = True      # re-check parameter versions on every forward (~1 ms); the sampler
                                       # turns this off inside its loop after one explicit refresh
@@ -444,7 +449,8 @@ class UNetSD(nn.Module):
 
     def _lowering_options(self) -> tuple:
         """Lowering switches that change the program (part of the cache key)."""
-        return (("precise",),) if getattr(self, "precise_operands", False) else ()
+        return ((("precise",),) if getattr(self, "precise_operands", False) else ()) + \
+            ((("tattn",),) if getattr(self, "fused_temporal_attention", False) else ())
 
     def forward_cfg_pair(self, x, t, ctx_pair, context_token=None):
         """One guided step's two evaluations (gaussian_sampler.py:161-162) as ONE forward: x [V,4,F,h,w] is read twice by
@@ -538,6 +544,7 @@ class _Lowering:
         self.x_dt, self.out_dt, self.ctx_dt = x_dt, out_dt, ctx_dt
         self.x_batch = x_batch if 0 < x_batch < B else 0      # x holds fewer samples than the batch: sample b reads x[b % x_batch]
         self.precise = bool(getattr(net, "precise_operands", False))
+        self.fused_tattn = bool(getattr(net, "fused_temporal_attention", False))
         self.xin_lo = None
         self.P = Program(f"unet b{B} f{F} {H}x{W}")
         self.P.keep_taps = keep_taps
@@ -564,6 +571,11 @@ class _Lowering:
         def fn(sd, p=prefix):
             return torch.cat([sd[p + ".to_q.weight"], sd[p + ".to_k.weight"], sd[p + ".to_v.weight"]], dim=0)
         return Ref("weight", 0, self.packer.add(prefix + ":qkv", "f16", fn))
+
+    def w_qkv_heads(self, prefix) -> Ref:
+        def fn(sd, p=prefix):
+            return pk.qkv_head_major(sd[p + ".to_q.weight"], sd[p + ".to_k.weight"], sd[p + ".to_v.weight"])
+        return Ref("weight", 0, self.packer.add(prefix + ":qkvh", "f16", fn))
 
     def w_kv(self, prefix) -> Ref:
         def fn(sd, p=prefix):
@@ -723,6 +735,18 @@ class _Lowering:
             """n = LayerNorm{tag}(xin) (made by the op that produced xin).  Returns (x + attention, LayerNorm{next_norm} of it):
             the to_out GEMM writes the fp32 stream AND — fused into its epilogue where the tile holds whole rows — the next
             LayerNorm's fp16 output."""
+            if kind != "spatial" and self.fused_tattn and P.tattn_pixels_per_tile(F) >= 1 and inner % 64 == 0:
+                # temporal self-attention: QKV projection + attention in ONE launch (q / k / v never reach HBM)
+                a = P.alloc(Mrows, inner, "f16")
+                P.qkv_temporal_attention(f"{prefix}.attn{tag}.qkv_attn", n, self.w_qkv_heads(f"{prefix}.attn{tag}"), a, samples=B, frames=F,
+                                         hw=hw, heads=heads, k=inner, scale=scale)
+                P.free(n)
+                xo = P.alloc(Mrows, inner, "f32")
+                nn_ = P.alloc(Mrows, inner, "f16")
+                P.gemm(f"{prefix}.attn{tag}.to_out", a, self.w_linear(f"{prefix}.attn{tag}.to_out.0"), inner, inner, xo,
+                       bias=self.vec(f"{prefix}.attn{tag}.to_out.0.bias"), residual=xin, ln=self.ln_arg(f"{prefix}.{next_norm}", nn_))
+                P.free(a, xin)
+                return xo, nn_
             qkv = P.alloc(Mrows, 3 * inner, "f16")
             P.gemm(f"{prefix}.attn{tag}.qkv", n, self.w_qkv(f"{prefix}.attn{tag}"), 3 * inner, inner, qkv)
             P.free(n)

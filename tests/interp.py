@@ -66,8 +66,25 @@ class Interp:
             getattr(self, f"_op{op.kind}")(op, ext)
 
     # GEMM ------------------------------------------------------------------------------------------
+    def _op1_tattn(self, op, ext):
+        """T2V_EPI_TATTN: QKV projection (fp32 accumulate, fp16 q / k / v) + softmax(q k^T scale) v per (sample, pixel, head)."""
+        I = op.i
+        N, K, lda, ldc, Fr, HW, pix = I[1], I[2], I[3], I[5], I[8], I[9], I[10]
+        heads = N // 192
+        samples = I[0] // 192 // -(-HW // pix)
+        T = samples * Fr * HW
+        A = self.mat(op.p[0], T, K, lda, torch.float16, ext).float()
+        W = self.mat(op.p[1], N, K, K, torch.float16, ext).float()
+        qkv = (A @ W.t()).half().float().view(samples, Fr, HW, heads, 3, 64)
+        q, k, v = qkv[..., 0, :], qkv[..., 1, :], qkv[..., 2, :]
+        s = torch.einsum("bfxhd,bgxhd->bxhfg", q, k) * op.f[1]
+        o = torch.einsum("bxhfg,bgxhd->bfxhd", torch.softmax(s, dim=-1), v).reshape(T, heads * 64)
+        self._st(self.mat(op.p[5], T, heads * 64, ldc, torch.float16, ext), o, torch.float16)
+
     def _op1(self, op, ext):
         I = op.i
+        if I[16] == L.EPI_TATTN:
+            return self._op1_tattn(op, ext)
         M, N, K, lda, ldw, ldc, ldr, gather = I[0:8]
         A16 = None
         if gather == L.GATHER_PLAIN:

@@ -21,7 +21,7 @@ def test_header_constants_match_binding():
         "T2V_OP_TIME_EMBED": L.OP_TIME_EMBED, "T2V_OP_COPY2D": L.OP_COPY2D, "T2V_OP_DDIM_STEP": L.OP_DDIM_STEP,
         "T2V_OP_MEMSET": L.OP_MEMSET, "T2V_OP_LINCOMB": L.OP_LINCOMB, "T2V_OP_RELPOS_ATTN": L.OP_RELPOS_ATTN, "T2V_GATHER_PLAIN": L.GATHER_PLAIN, "T2V_GATHER_CONV3X3": L.GATHER_CONV3X3,
         "T2V_GATHER_TCONV3": L.GATHER_TCONV3, "T2V_GATHER_CONV3X3_C8": L.GATHER_CONV3X3_C8,
-        "T2V_EPI_NONE": L.EPI_NONE, "T2V_EPI_GEGLU": L.EPI_GEGLU, "T2V_F16": L.F16, "T2V_F32": L.F32,
+        "T2V_EPI_NONE": L.EPI_NONE, "T2V_EPI_GEGLU": L.EPI_GEGLU, "T2V_EPI_TATTN": L.EPI_TATTN, "T2V_F16": L.F16, "T2V_F32": L.F32,
         "T2V_EXT_SLOTS": L.EXT_SLOTS, "T2V_EXT_X": L.EXT_X, "T2V_EXT_T": L.EXT_T, "T2V_EXT_CTX": L.EXT_CTX,
         "T2V_EXT_OUT": L.EXT_OUT, "T2V_EXT_XT": L.EXT_XT, "T2V_EXT_XT_OUT": L.EXT_XT_OUT,
         "T2V_EXT_NOISE": L.EXT_NOISE, "T2V_EXT_EPS": L.EXT_EPS, "T2V_OP_NI": L.OP_NI, "T2V_OP_NF": L.OP_NF,

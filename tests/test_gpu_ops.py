@@ -656,6 +656,35 @@ def test_groupnorm_cooperative_full_size(n_inst, rows, C, dt, silu):
     assert rel_l2(outs[True], outs[False]) < 2e-4        # both round the same fp32 values to fp16: differences are 1-ulp flips
 
 
+@pytest.mark.parametrize("samples,F,hw,heads,K", [(2, 24, 64, 5, 320), (1, 16, 20, 2, 128), (1, 32, 9, 1, 64), (2, 5, 7, 3, 192),
+                                                  (1, 24, 1024, 5, 320), (2, 2, 16, 2, 128)])
+def test_fused_qkv_temporal_attention(samples, F, hw, heads, K):
+    """T2V_EPI_TATTN (tile 10): QKV projection + temporal self-attention of every pixel's frame sequence in one launch, against
+    the interpreter (fp32-accumulated projection rounded to fp16, then softmax(q k^T scale) v) and against the unfused pair of
+    ops (QKV GEMM + attention kernel) this replaces.  Ragged pixel counts (hw % pixels-per-tile != 0), F = 2 .. 32."""
+    g = _g(41)
+    C = heads * 64
+    T = samples * F * hw
+    wq, wk, wv = [(torch.randn(C, K, generator=g) / math.sqrt(K)) for _ in range(3)]
+    w = {"wh": pk.qkv_head_major(wq, wk, wv).half(), "wf": torch.cat([wq, wk, wv], 0).half()}
+    P = Program()
+    a = P.alloc(T, K, "f16")
+    o_fused, o_ref = P.alloc(T, C, "f16"), P.alloc(T, C, "f16")
+    qkv = P.alloc(T, 3 * C, "f16")
+    scale = 64 ** -0.5
+    op = P.qkv_temporal_attention("tattn", a, Ref("weight", 0, "wh"), o_fused, samples=samples, frames=F, hw=hw, heads=heads, k=K, scale=scale)
+    assert op.i[22] == 10 and op.i[16] == L.EPI_TATTN and op.i[10] == min(12, 192 // F)
+    P.gemm("qkv", a, Ref("weight", 0, "wf"), 3 * C, K, qkv)
+    q, k, v = qkv.col_slice(0, C), qkv.col_slice(C, 2 * C), qkv.col_slice(2 * C, 3 * C)
+    ld = 3 * C
+    P.attention("attn", q.ref, k.ref, v.ref, o_ref.ref, out_buf=o_ref, nq=F, nk=F, heads=heads, b_outer=samples, b_inner=hw,
+                q_strides=(hw * ld, F * hw * ld, ld), kv_strides=(hw * ld, F * hw * ld, ld), o_strides=(hw * C, F * hw * C, C), scale=scale)
+    it, got, _, _ = run_both(P, w, {}, lambda it: fill(it, a, g, scale=1.5))
+    _check(it, got, o_fused, 1.5e-3, "fused QKV + temporal attention vs interpreter")
+    r = rel_l2(read(got, o_fused).float(), read(got, o_ref).float())
+    assert r < 1.5e-3, f"fused vs the GEMM + attention kernel pair: {r:.3e}"
+
+
 def test_split_k_ticket_fold_is_bitwise_the_reduction_kernel():
     """Split-K with the fold in the last-arriving workgroup of each tile (T2V_SPLITK_TICKETS=1 / Program.splitk_tickets; off by
     default: measured slower than the reduction launch) against the stand-alone reduction kernel: same slabs summed in the same
