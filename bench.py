@@ -284,12 +284,30 @@ def self_launch(n: int, argv, timeout_s=None, capture=False):
             return 2, None
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    # The bounded side job (capture) gets its own session = its own process group: on a timeout the launcher AND every rank it
+    # started are killed together (a hung RCCL call must not leave orphaned ranks holding the GPUs for whatever runs next).
+    # The top-level self-launch stays in the caller's process group, so whoever stops `python bench.py` stops the ranks too.
+    import signal
+    proc = subprocess.Popen(cmd, env=_launch_env(), stdout=subprocess.PIPE if capture else None, text=True, start_new_session=capture)
+
+    def stop():
+        try:
+            if capture:
+                os.killpg(proc.pid, signal.SIGKILL)
+            else:
+                proc.kill()
+        except ProcessLookupError:
+            pass
     try:
-        out = subprocess.run(cmd, env=_launch_env(), timeout=timeout_s, stdout=subprocess.PIPE if capture else None, text=True,
-                             start_new_session=capture)
-        return out.returncode, out.stdout
-    except subprocess.TimeoutExpired as exc:
-        return 124, (exc.stdout if isinstance(exc.stdout, str) else None)
+        out, _ = proc.communicate(timeout=timeout_s)
+        return proc.returncode, out
+    except subprocess.TimeoutExpired:
+        stop()
+        out, _ = proc.communicate()
+        return 124, out
+    except BaseException:
+        stop()
+        raise
 
 
 def collective_layout_job(n: int, args, timeout_s: int):

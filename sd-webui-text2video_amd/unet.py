@@ -735,7 +735,9 @@ class _Lowering:
             """n = LayerNorm{tag}(xin) (made by the op that produced xin).  Returns (x + attention, LayerNorm{next_norm} of it):
             the to_out GEMM writes the fp32 stream AND — fused into its epilogue where the tile holds whole rows — the next
             LayerNorm's fp16 output."""
-            if kind != "spatial" and self.fused_tattn and P.tattn_pixels_per_tile(F) >= 1 and inner % 64 == 0:
+            # (measured, b=2 x 24 frames: 63 vs 61 + 38 us at the 32x32 level, 55 vs 49 + 21 us at 16x16; at K = 1280 the 192x192
+            #  tile's main loop loses more than the fusion saves — 60 vs 43 + 13 us — so the 8x8 / 4x4 levels keep the pair)
+            if kind != "spatial" and self.fused_tattn and P.tattn_pixels_per_tile(F) >= 1 and inner % 64 == 0 and inner <= 640:
                 # temporal self-attention: QKV projection + attention in ONE launch (q / k / v never reach HBM)
                 a = P.alloc(Mrows, inner, "f16")
                 P.qkv_temporal_attention(f"{prefix}.attn{tag}.qkv_attn", n, self.w_qkv_heads(f"{prefix}.attn{tag}"), a, samples=B, frames=F,

@@ -89,3 +89,21 @@ def test_runner_layouts_multi_process_on_one_gpu(world, mode):
     # b = 1 per-role programs (other tiles / split-K than the b = 2 single-GPU forward): rounding-level differences only;
     # a wrong slice / halo / frame order is an O(100 %) error on the affected frames
     assert (d == 0).mean() > 0.85 and max(per_frame) < 0.02
+
+
+def test_bench_self_launch_one_device_rehearsal():
+    """VERDICT r02 #2 contract: `python bench.py --gpus N` with NO external launcher starts its own ranks and rank 0 prints the one
+    JSON line.  Rehearsal form (T2V_BENCH_ONE_DEVICE=1: the ranks share this box's single GPU over gloo — never a measurement):
+    2 ranks, the replicas headline of a short clip, no collective side job."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["T2V_BENCH_ONE_DEVICE"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--ddim-steps", "2",
+                          "--frames", "4", "--no-collective-job", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["config"]["layout"] == "replicas" and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["frames_per_video"] == 8 and "REHEARSAL" in d["data"] and d["config"]["rccl_communicators"] == []
