@@ -153,7 +153,9 @@ enum t2v_gather {
  * SOFTMAX: i: 0 rows, 1 cols, 2 ld_in, 3 ld_out; f: 0 scale; p: 0 in fp32, 1 out fp16
  * NCTHW_TO_CL: i: 0 B, 1 C, 2 F, 3 HW, 4 ld_out, 5 in dtype, 6 samples in the source (0 = B; fewer: output sample b reads
  *      source sample b % i[6] — the cond | uncond pair of a guided step shares x_t); f: 0 scale; p: 0 in, 1 out fp16,
- *      2 (optional) low-order fp16 image, same layout: out_lo = fp16(v - float(fp16(v))) — hi + lo operand split of a consumer GEMM
+ *      2 (optional) low-order fp16 image, same layout: out_lo = fp16(v - float(fp16(v))) — hi + lo operand split of a consumer GEMM;
+ *      i[7] = 1 (ld_out >= 2C): the low-order images are written into channels C .. 2C-1 of the same row instead (a consumer whose
+ *      weights repeat W for those channels computes (hi + lo) . W in one pass)
  * CL_TO_NCTHW: i: 0 B, 1 C, 2 F, 3 HW, 4 ld_in, 5 out dtype; p: 0 in fp32, 1 out
  * TIME_EMBED: i: 0 B, 1 dim; p: 0 t fp32 [B], 1 freqs fp32 [dim/2], 2 out fp16 [B,dim]
  * COPY2D: i: 0 rows, 1 cols, 2 ld_src, 3 ld_dst, 4 src dtype, 5 dst dtype, 6 act (0 none, 1 SiLU, 2 GELU(erf),

@@ -14,7 +14,7 @@ namespace {
 
 template <typename TIN>
 __global__ __launch_bounds__(256) void ncthw_to_cl_kernel(const TIN* in, f16* out, int B, int C, int F, int HW,
-                                                          int ld, float scale, int Bsrc, f16* out_lo) {
+                                                          int ld, float scale, int Bsrc, f16* out_lo, int lo_in_pad) {
   // one thread per output token; writes ld (>= C, multiple of 4) channels, zero padded.  Bsrc < B: the source holds
   // Bsrc samples and output sample b reads source sample b % Bsrc (the cond | uncond pair of a guided step shares x_t,
   // gaussian_sampler.py:161-162 — no torch.cat([x, x]) on the host)
@@ -31,6 +31,13 @@ __global__ __launch_bounds__(256) void ncthw_to_cl_kernel(const TIN* in, f16* ou
       const f16 hi = (f16)v;
       o[c] = hi;
       if (out_lo) out_lo[tkn * ld + c] = (f16)(v - (float)hi);      // low-order image: hi + lo carries the fp32 value (p[2])
+    }
+    if (lo_in_pad) {     // i[7]: the low-order images go into the padding channels C .. 2C-1 of the SAME row (ld >= 2C): a consumer
+                         // whose weights repeat W for those channels computes (hi + lo) . W in one pass
+      for (int c = 0; c < C; ++c) {
+        const float v = (float)in[(((size_t)bs * C + c) * F + f) * HW + pix] * scale;
+        o[C + c] = (f16)(v - (float)(f16)v);
+      }
     }
   }
 }
@@ -241,10 +248,12 @@ hipError_t t2v_launch_ncthw_to_cl(const t2v_op& op, hipStream_t s) {
   f16* out = reinterpret_cast<f16*>(op.p[1]);
   if (op.i[5] == T2V_F32)
     hipLaunchKernelGGL(ncthw_to_cl_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s,
-                       reinterpret_cast<const float*>(op.p[0]), out, B, C, F, HW, ld, op.f[0], Bsrc, reinterpret_cast<f16*>(op.p[2]));
+                       reinterpret_cast<const float*>(op.p[0]), out, B, C, F, HW, ld, op.f[0], Bsrc, reinterpret_cast<f16*>(op.p[2]),
+                       (op.i[7] != 0 && ld >= 2 * C) ? 1 : 0);
   else
     hipLaunchKernelGGL(ncthw_to_cl_kernel<f16>, dim3(grid_for(n)), dim3(256), 0, s,
-                       reinterpret_cast<const f16*>(op.p[0]), out, B, C, F, HW, ld, op.f[0], Bsrc, reinterpret_cast<f16*>(op.p[2]));
+                       reinterpret_cast<const f16*>(op.p[0]), out, B, C, F, HW, ld, op.f[0], Bsrc, reinterpret_cast<f16*>(op.p[2]),
+                       (op.i[7] != 0 && ld >= 2 * C) ? 1 : 0);
   return hipGetLastError();
 }
 

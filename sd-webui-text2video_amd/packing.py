@@ -52,6 +52,19 @@ def conv3x3(w: torch.Tensor, cin_pad: int = 0) -> torch.Tensor:
     return w.reshape(co, -1)
 
 
+def conv3x3_c8_dup(w: torch.Tensor) -> torch.Tensor:
+    """Stem conv [Co, 4, 3, 3] -> [Co, 9 * 8] with the 4 real input channels REPEATED in the 4 padding channels (k = tap * 8 + ci):
+    the entry op puts the low-order fp16 images of the latent there, so the one GEMM pass computes (x_hi + x_lo) . W."""
+    assert w.shape[1] == 4
+    return conv3x3(torch.cat([w, w], dim=1))
+
+
+def linear_dup(w: torch.Tensor) -> torch.Tensor:
+    """[N, K] -> [N, 2K] = [W | W]: consumer of an operand laid out [hi (K) | lo (K)] per row."""
+    w = linear(w)
+    return torch.cat([w, w], dim=1)
+
+
 def tconv3(w: torch.Tensor) -> torch.Tensor:
     """[Co, Ci, 3, 1, 1] -> [Co, 3*Ci] with k = (ci // 64) * 3*64 + kt * 64 + ci % 64 (Ci % 64 == 0)."""
     co, ci = w.shape[0], w.shape[1]

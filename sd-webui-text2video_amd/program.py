@@ -599,7 +599,7 @@ class Program:
         return self._emit(op)
 
     def ncthw_to_cl(self, name: str, src: Ref, src_dtype: str, out: Buf, *, B, C, F, HW, scale=1.0, src_batch: int = 0,
-                    lo: Optional[Buf] = None) -> Op:
+                    lo: Optional[Buf] = None, lo_in_pad: bool = False) -> Op:
         """src_batch (< B): the source holds that many samples, output sample b reads sample b % src_batch.
         lo: second fp16 output of the same layout holding fp16(v - fp16(v)) (hi + lo operand split of the consumer)."""
         assert src_batch == 0 or B % src_batch == 0
@@ -610,6 +610,9 @@ class Program:
         if lo is not None:
             assert (lo.rows, lo.cols, lo.ld, lo.dtype) == (out.rows, out.cols, out.ld, "f16")
             op.p[2] = lo.ref
+        if lo_in_pad:             # low-order images in the padding channels C .. 2C-1 of the same rows
+            assert out.ld >= 2 * C
+            op.i[7] = 1
         op.out = out
         return self._emit(op)
 

@@ -545,14 +545,14 @@ class _Lowering:
         self.x_batch = x_batch if 0 < x_batch < B else 0      # x holds fewer samples than the batch: sample b reads x[b % x_batch]
         self.precise = bool(getattr(net, "precise_operands", False))
         self.fused_tattn = bool(getattr(net, "fused_temporal_attention", False))
-        self.xin_lo = None
+        self.stem_dup = False
         self.P = Program(f"unet b{B} f{F} {H}x{W}")
         self.P.keep_taps = keep_taps
         self.packer = pk.WeightPacker()
         prefixes = tuple(getattr(net, "split_weight_prefixes", ()) or ())
         if prefixes:
             self.P.weight_lo = lambda ref: (Ref("weight", ref.off, self.packer.add_lo(ref.name))
-                                            if ref.name.startswith(prefixes) and ref.name.rsplit(":", 1)[-1] in ("lin", "c3", "t3", "qkv", "kv")
+                                            if ref.name.startswith(prefixes) and ref.name.rsplit(":", 1)[-1] in ("lin", "lin2", "c3", "c3d", "t3", "qkv", "kv")
                                             else None)
         self.emb_slices: Dict[str, Tuple[int, int]] = {}
         self.kv_slices: Dict[str, Tuple[int, int]] = {}
@@ -560,6 +560,12 @@ class _Lowering:
     # -- packed-weight declarations ------------------------------------------------------------
     def w_linear(self, key) -> Ref:
         return Ref("weight", 0, self.packer.add(key + ":lin", "f16", lambda sd, k=key: pk.pad_rows(pk.linear(sd[k + ".weight"]))))
+
+    def w_linear_dup(self, key) -> Ref:
+        return Ref("weight", 0, self.packer.add(key + ":lin2", "f16", lambda sd, k=key: pk.pad_rows(pk.linear_dup(sd[k + ".weight"]))))
+
+    def w_conv3_c8dup(self, key) -> Ref:
+        return Ref("weight", 0, self.packer.add(key + ":c3d", "f16", lambda sd, k=key: pk.pad_rows(pk.conv3x3_c8_dup(sd[k + ".weight"]))))
 
     def w_conv3(self, key, cin_pad=0) -> Ref:
         return Ref("weight", 0, self.packer.add(key + ":c3", "f16", lambda sd, k=key, c=cin_pad: pk.pad_rows(pk.conv3x3(sd[k + ".weight"], c))))
@@ -615,7 +621,7 @@ class _Lowering:
         return out
 
     def conv3(self, name, a: Buf, key, cout, h, w, *, stride=1, up=0, out_dtype="f32", rowbias=None,
-              residual=None, cin=None, dest: Optional[Buf] = None, a_lo: Optional[Buf] = None) -> Buf:
+              residual=None, cin=None, dest: Optional[Buf] = None, a_lo: Optional[Buf] = None, dup_c8: bool = False) -> Buf:
         """`dest`: write the result into this (sub-)buffer instead of a fresh allocation — the producers of the two
         halves of a skip-connection concat write straight into the concat buffer (no copy ops)."""
         cin = a.cols if cin is None else cin
@@ -624,7 +630,8 @@ class _Lowering:
         n = (cout + 3) // 4 * 4
         out = self._dest(dest, Mo, n, out_dtype)
         gather = L.GATHER_CONV3X3_C8 if cin == 8 else L.GATHER_CONV3X3
-        self.P.gemm(name, a, self.w_conv3(key, 8 if cin == 8 else 0), n, 9 * cin, out, bias=self.vec(key + ".bias"),
+        wref = self.w_conv3_c8dup(key) if dup_c8 else self.w_conv3(key, 8 if cin == 8 else 0)
+        self.P.gemm(name, a, wref, n, 9 * cin, out, bias=self.vec(key + ".bias"),
                     gather=gather, conv=dict(Hin=h, Win=w, Cin=cin, stride=stride, up=up, Hout=ho, Wout=wo),
                     rowbias=rowbias, rows_per_batch=self.F * ho * wo if rowbias is not None else 0,
                     residual=residual, a_lo=a_lo)
@@ -646,13 +653,19 @@ class _Lowering:
         b = self.gn(prefix + ".out_layers.0", h1, prefix + ".out_layers.0", per_frame=True, eps=1e-5, silu=True)
         P.free(h1)
         if cin != cout:
-            x16 = P.alloc(x.rows, cin, "f16")
-            x16lo = P.alloc(x.rows, cin, "f16") if self.precise else None
-            P.copy2d(prefix + ".skip.cast", x, x16, lo=x16lo)
             skip = P.alloc(x.rows, cout, "f32")
-            P.gemm(prefix + ".skip_connection", x16, self.w_linear(prefix + ".skip_connection"), cout, cin, skip,
-                   bias=self.vec(prefix + ".skip_connection.bias"), a_lo=x16lo)
-            P.free(x16, x16lo)
+            if self.precise:
+                # hi + lo operand split in ONE pass: rows [hi (cin) | lo (cin)], weights [W | W], K = 2 cin
+                x16 = P.alloc(x.rows, 2 * cin, "f16")
+                P.copy2d(prefix + ".skip.cast", x, x16.col_slice(0, cin), lo=x16.col_slice(cin, 2 * cin))
+                P.gemm(prefix + ".skip_connection", x16, self.w_linear_dup(prefix + ".skip_connection"), cout, 2 * cin, skip,
+                       bias=self.vec(prefix + ".skip_connection.bias"))
+            else:
+                x16 = P.alloc(x.rows, cin, "f16")
+                P.copy2d(prefix + ".skip.cast", x, x16)
+                P.gemm(prefix + ".skip_connection", x16, self.w_linear(prefix + ".skip_connection"), cout, cin, skip,
+                       bias=self.vec(prefix + ".skip_connection.bias"))
+            P.free(x16)
         else:
             skip = x
         h2 = self.conv3(prefix + ".out_layers.3", b, prefix + ".out_layers.3", cout, h, w, residual=skip)
@@ -962,17 +975,18 @@ class _Lowering:
 
         # ---- entry layout conversion: b c f h w -> tokens x 8 channels (4 real + 4 zero)
         xin = P.alloc(self.M(h, w), 8, "f16")
-        self.xin_lo = P.alloc(self.M(h, w), 8, "f16") if (self.precise and self.x_dt == "f32") else None
+        # precise operands: the low-order fp16 images of the 4 latent channels ride in the 4 padding channels of the 8-channel
+        # token rows, the stem's weights repeat W there — (x_hi + x_lo) . W in the one GEMM pass, no extra launch
+        self.stem_dup = self.precise and self.x_dt == "f32" and net.in_dim == 4
         P.ncthw_to_cl("x.to_tokens", Ref("ext", L.EXT_X), self.x_dt, xin, B=B, C=net.in_dim, F=F, HW=h * w, src_batch=self.x_batch,
-                      lo=self.xin_lo)
+                      lo_in_pad=self.stem_dup)
 
         def run_parts(prefix, parts, bare, x, h, w, dest=None):
             for i, (kind, cin, cout) in enumerate(parts):
                 p = prefix if bare else f"{prefix}.{i}"
                 d = dest if i == len(parts) - 1 else None         # the block's result goes straight into a concat buffer
                 if kind == "stem":
-                    y = self.conv3(p, x, p, cout, h, w, cin=8, dest=d, a_lo=self.xin_lo)
-                    P.free(self.xin_lo)
+                    y = self.conv3(p, x, p, cout, h, w, cin=8, dest=d, dup_c8=self.stem_dup)
                 elif kind == "res":
                     y = self.res_block(p, x, cin, cout, h, w, dest=d)
                 elif kind == "st":

@@ -242,17 +242,21 @@ class _LvdmLowering(_Lowering):
         return Ref("weight", 0, self.packer.add(key + ":c133", "f16", lambda sd, k=key, c=cin_pad:
                                                 pk.pad_rows(pk.conv3x3(sd[k + ".weight"][:, :, 0], c))))
 
+    def w_conv133_dup(self, key) -> Ref:
+        return Ref("weight", 0, self.packer.add(key + ":c133d", "f16", lambda sd, k=key: pk.pad_rows(pk.conv3x3_c8_dup(sd[k + ".weight"][:, :, 0]))))
+
     def table(self, key) -> Ref:
         return Ref("weight", 0, self.packer.add(key + ":tab", "f32", lambda sd, k=key: sd[k]))
 
     def conv133(self, name, a: Buf, key, cout, h, w, *, stride=1, up=0, out_dtype="f32", rowbias=None, residual=None, cin=None,
-                dest: Optional[Buf] = None, a_lo: Optional[Buf] = None) -> Buf:
+                dest: Optional[Buf] = None, a_lo: Optional[Buf] = None, dup_c8: bool = False) -> Buf:
         cin = a.cols if cin is None else cin
         ho, wo = (h * 2, w * 2) if up else ((h + 1) // 2 if stride == 2 else h, (w + 1) // 2 if stride == 2 else w)
         n = (cout + 3) // 4 * 4
         out = self._dest(dest, self.B * self.F * ho * wo, n, out_dtype)
         gather = L.GATHER_CONV3X3_C8 if cin == 8 else L.GATHER_CONV3X3
-        self.P.gemm(name, a, self.w_conv133(key, 8 if cin == 8 else 0), n, 9 * cin, out, bias=self.vec(key + ".bias"),
+        wref = self.w_conv133_dup(key) if dup_c8 else self.w_conv133(key, 8 if cin == 8 else 0)
+        self.P.gemm(name, a, wref, n, 9 * cin, out, bias=self.vec(key + ".bias"),
                     gather=gather, conv=dict(Hin=h, Win=w, Cin=cin, stride=stride, up=up, Hout=ho, Wout=wo),
                     rowbias=rowbias, rows_per_batch=self.F * ho * wo if rowbias is not None else 0, residual=residual, a_lo=a_lo)
         return out
@@ -268,13 +272,18 @@ class _LvdmLowering(_Lowering):
         b = self.gn(prefix + ".out_layers.0", h1, prefix + ".out_layers.0", per_frame=False, eps=1e-5, silu=True)
         P.free(h1)
         if cin != cout:
-            x16 = P.alloc(x.rows, cin, "f16")
-            x16lo = P.alloc(x.rows, cin, "f16") if self.precise else None         # hi + lo operand split (UNetSD.precise_operands)
-            P.copy2d(prefix + ".skip.cast", x, x16, lo=x16lo)
             skip = P.alloc(x.rows, cout, "f32")
-            P.gemm(prefix + ".skip_connection", x16, self.w_linear(prefix + ".skip_connection"), cout, cin, skip,
-                   bias=self.vec(prefix + ".skip_connection.bias"), a_lo=x16lo)
-            P.free(x16, x16lo)
+            if self.precise:         # hi + lo operand split in one pass (UNetSD.precise_operands): rows [hi | lo], weights [W | W]
+                x16 = P.alloc(x.rows, 2 * cin, "f16")
+                P.copy2d(prefix + ".skip.cast", x, x16.col_slice(0, cin), lo=x16.col_slice(cin, 2 * cin))
+                P.gemm(prefix + ".skip_connection", x16, self.w_linear_dup(prefix + ".skip_connection"), cout, 2 * cin, skip,
+                       bias=self.vec(prefix + ".skip_connection.bias"))
+            else:
+                x16 = P.alloc(x.rows, cin, "f16")
+                P.copy2d(prefix + ".skip.cast", x, x16)
+                P.gemm(prefix + ".skip_connection", x16, self.w_linear(prefix + ".skip_connection"), cout, cin, skip,
+                       bias=self.vec(prefix + ".skip_connection.bias"))
+            P.free(x16)
         else:
             skip = x
         out = self.conv133(prefix + ".out_layers.3", b, prefix + ".out_layers.3", cout, h, w, residual=skip, dest=dest)
@@ -439,17 +448,16 @@ class _LvdmLowering(_Lowering):
         P.free(ctx16)
 
         xin = P.alloc(self.M(h, w), 8, "f16")
-        self.xin_lo = P.alloc(xin.rows, 8, "f16") if (self.precise and self.x_dt == "f32") else None
+        self.stem_dup = self.precise and self.x_dt == "f32" and net.in_dim == 4
         P.ncthw_to_cl("x.to_tokens", Ref("ext", L.EXT_X), self.x_dt, xin, B=B, C=net.in_dim, F=F, HW=h * w, src_batch=self.x_batch,
-                      lo=self.xin_lo)
+                      lo_in_pad=self.stem_dup)
 
         def run_parts(prefix, parts, x, h, w, dest=None):
             for j, (kind, cin, cout) in enumerate(parts):
                 p = f"{prefix}.{j}"
                 d = dest if j == len(parts) - 1 else None
                 if kind == "stem":
-                    y = self.conv133(p, x, p, cout, h, w, cin=8, dest=d, a_lo=self.xin_lo)
-                    P.free(self.xin_lo)
+                    y = self.conv133(p, x, p, cout, h, w, cin=8, dest=d, dup_c8=self.stem_dup)
                 elif kind == "res":
                     y = self.res_block(p, x, cin, cout, h, w, dest=d)
                 elif kind == "st":

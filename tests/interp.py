@@ -234,6 +234,8 @@ class Interp:
             lo = self.mat(op.p[2], B * Fr * HW, ld, ld, torch.float16, ext)
             lo.zero_()
             self._st(lo[:, :C], v - v.half().float(), torch.float16)
+        if op.i[7] and ld >= 2 * C:                      # ... or in the padding channels of the same rows
+            self._st(out[:, C:2 * C], v - v.half().float(), torch.float16)
 
     # CL_TO_NCTHW --------------------------------------------------------------------------------------
     def _op7(self, op, ext):
