@@ -317,6 +317,8 @@ def collective_layout_job(n: int, args, timeout_s: int):
     mode = "pairs" if n == 2 else "tshard"
     argv = ["--gpus", str(n), "--parallel", mode, "--steps", "1", "--warmup", "1", "--ddim-steps", str(args.ddim_steps),
             "--height", str(args.height), "--width", str(args.width), "--no-cpu-baseline", "--also-batched", "0", "--no-collective-job"]
+    if args.frames:
+        argv += ["--frames", str(args.frames)]          # (rehearsals use short clips; default: 125 frames T-sharded, 24 per CFG pair)
     t0 = time.time()
     rc, out = self_launch(n, argv, timeout_s=timeout_s, capture=True)
     line = next((ln for ln in reversed((out or "").splitlines()) if ln.startswith("{")), None)
@@ -446,6 +448,7 @@ def main():
                     help="at N=1 with --videos 1: also time one pass with this many videos per batch and report it as "
                          "`batched` beside the headline (0 / 1 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the per-op roofline / calibration section (launch-path rehearsals only)")
     ap.add_argument("--parallel", default="auto", choices=["auto", "replicas", "pairs", "tshard"],
                     help="N>1 layout; auto = one 24-frame video per GPU (replicas; configs[1] at every N) as the headline, with the "
                          "collective layout of that N (pairs at N=2, ONE T-sharded 125-frame video for even N>=4) timed beside it as a "
@@ -587,7 +590,7 @@ def main():
         mode, frames = "replicas", args.frames or 24
         runner = build(mode, frames)
     cal_before = None
-    if rank == 0:
+    if rank == 0 and not args.no_roofline:
         try:
             cal_before = calibration_gemm(dev)
         except Exception:                          # noqa: BLE001
@@ -629,7 +632,7 @@ def main():
             result["replicas"] = {"value": None, "note": f"failed: {type(exc).__name__}: {exc}"}
 
     cal0 = None
-    if rank == 0:
+    if rank == 0 and not args.no_roofline:
         # ---- live roofline of the dominant kernel (HIP events on the launch stream) -------------
         try:
             cal0 = {"gemm_8192_tflops_after": calibration_gemm(dev), "smi_after": smi_snapshot()}

@@ -102,7 +102,7 @@ def test_bench_self_launch_one_device_rehearsal():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["T2V_BENCH_ONE_DEVICE"] = "1"
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--ddim-steps", "2",
-                          "--frames", "4", "--no-collective-job", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+                          "--frames", "4", "--no-collective-job", "--no-cpu-baseline", "--no-roofline"], capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["config"]["layout"] == "replicas" and d["scaling"] == "weak" and d["value"] > 0
