@@ -409,7 +409,30 @@ def main_lvdm(args):
                      "whole_video": {"tflop": round(video_tflop, 1), "tflops_per_gpu": round(video_tflop / (ms_per_step * 1e-3), 1),
                                      "frac": round(video_tflop / (ms_per_step * 1e-3) / MFMA_PEAK_TFLOPS, 4)}},
     }
-    print(json.dumps(result), flush=True)
+    emit(result)
+
+
+_REAL_STDOUT = None
+
+
+def claim_stdout():
+    """From here on file descriptor 1 carries NOTHING but the one JSON line: everything else a rank writes to stdout — the gloo /
+    RCCL banners of process-group creation ("[Gloo] Rank 0 is connected to ..."), progress bars, library notices — is sent to
+    stderr at the descriptor level (C++ libraries do not go through sys.stdout)."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    line = (json.dumps(obj) + "\n").encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, line)
 
 
 def choose_layout(world: int, requested: str, frames_arg: int = 0):
@@ -468,6 +491,8 @@ def main():
         cpu_baseline_worker(args.frames, args.ddim_steps)
         return
 
+    if args.gpus == 1 or "WORLD_SIZE" in os.environ:
+        claim_stdout()            # (the self-launching parent below keeps its stdout: its ranks inherit it and claim it themselves)
     if args.model == "lvdm":
         main_lvdm(args)
         return
@@ -489,7 +514,7 @@ def main():
             dist.all_reduce(v)
         assert world == args.gpus and int(v.item()) == world * (world + 1) // 2
         if rank == 0:
-            print(json.dumps({"launch_check": True, "n_gpus": world, "rank_sum": int(v.item())}), flush=True)
+            emit({"launch_check": True, "n_gpus": world, "rank_sum": int(v.item())})
         if world > 1:
             dist.destroy_process_group()
         return
@@ -707,7 +732,7 @@ def main():
             del runner
             torch.cuda.empty_cache()
             result["collective_layout"] = collective_layout_job(world, args, args.collective_timeout)
-        print(json.dumps(result), flush=True)
+        emit(result)
 
 
 if __name__ == "__main__":

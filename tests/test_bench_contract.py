@@ -1,4 +1,4 @@
-"""CPU: the committed bench line (profiles/r02_bench_n1.json, produced by `python bench.py` on an MI355X) carries every
+"""CPU: the committed bench line (profiles/r03_bench_n1.json, produced by `python bench.py` on an MI355X) carries every
 field of the measurement contract; bench.py's command line keeps the documented flags."""
 import json
 import os
@@ -9,7 +9,7 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_n1.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_n1.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -26,10 +26,22 @@ def test_committed_bench_line_has_the_contract_fields():
     wv = r["whole_video"]
     assert abs(wv["frac"] - wv["tflop"] / (d["ms_per_step"] * 1e-3) / d["n_gpus"] / r["peak"]) < 2e-3
     assert r["strict_bytes_per_launch"] < r["algorithmic_bytes_per_launch"] and abs(r["traffic_over_strict"] - r["traffic"] / r["strict_bytes_per_launch"]) < 1e-2
-    big = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_n1_125f.json")))
+    big = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_n1_125f.json")))
     assert "125f@256x256" in big["metric"] and "configs[2]" in big["config"]["workload"] and big["roofline"]["traffic"] is None
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
+    # round 3: box calibration either side of the timed region, the real reference's recorded CPU timing, the communicators used
+    cal = r["calibration"]
+    assert cal["gemm_8192_tflops_before"] > 300 and cal["gemm_8192_tflops_after"] > 300
+    ref = c["reference_recorded"]
+    assert ref["kind"] == "reference" and ref["value"] > 0 and ref["cores"] >= 1
+    assert d["config"]["rccl_communicators"] == []
+    lv = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_n1_lvdm.json")))
+    assert "VideoCrafter LVDM 16f@256x256" in lv["metric"] and "configs[4]" in lv["config"]["workload"] and lv["value"] > 0
+    for name, layout in (("r03_rehearsal_n4_one_gpu.json", "tshard"), ("r03_rehearsal_n2_one_gpu.json", "pairs")):
+        rh = json.load(open(os.path.join(ROOT, "profiles", name)))
+        assert rh["config"]["layout"] == "replicas" and rh["scaling"] == "weak" and "REHEARSAL" in rh["data"]
+        assert rh["collective_layout"]["layout"] == layout and rh["collective_layout"]["value"] > 0
 
 
 def test_bench_cli_flags():
