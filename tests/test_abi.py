@@ -137,3 +137,40 @@ def test_missing_rccl_is_an_error_code_not_a_crash(built_lib):
     assert out.returncode == 0, out.stderr[-2000:]
     line = next(ln for ln in out.stdout.splitlines() if ln.startswith("RC "))
     assert line.startswith("RC -5 -5 ") and "cannot dlopen librccl" in line and "/nonexistent/librccl.so.1" in line
+
+
+def test_validation_of_round3_records_without_gpu(built_lib):
+    """T2V_EPI_TATTN (fused QKV + temporal attention) records are validated before any launch: tile 10 and only tile 10, head-major
+    N = 192 * heads, 2 <= F <= 32, pixels * F <= 192, M = samples * ceil(HW / pixels) * 192, no bias / residual."""
+    h = ctypes.c_void_p()
+    ptr = 0x1000
+
+    def make(**kw):
+        op = (L.T2VOp * 1)()
+        op[0].kind = L.OP_GEMM
+        i = dict({0: 2 * 8 * 192, 1: 5 * 192, 2: 320, 3: 320, 4: 320, 5: 320, 7: L.GATHER_PLAIN, 8: 24, 9: 64, 10: 8, 16: L.EPI_TATTN, 17: L.F16, 19: 1, 22: 10})
+        i.update(kw.get("i", {}))
+        for k, v in i.items():
+            op[0].i[k] = v
+        op[0].f[1] = kw.get("scale", 0.125)
+        pp = {0: ptr, 1: ptr, 5: ptr}
+        pp.update(kw.get("p", {}))
+        for k, v in pp.items():
+            op[0].p[k] = v
+        return op
+
+    assert built_lib.t2v_plan_create(make(), 1, ctypes.byref(h)) == 0
+    built_lib.t2v_plan_destroy(h)
+    for bad, needle in ((dict(i={22: 8}), b"tile 10"), (dict(i={16: 0, 8: 0}), b"tile 10"), (dict(i={8: 40}), b"F <= 32"), (dict(i={10: 9}), b"pixels * F"),
+                        (dict(i={0: 192 * 15}), b"samples * ceil"), (dict(i={1: 5 * 192 + 64}), b"N = 192"), (dict(p={2: ptr}), b"no bias"),
+                        (dict(scale=0.0), b"positive scale"), (dict(i={17: L.F32}), b"fp16 out"), (dict(i={5: 256}), b"ldc")):
+        rc = built_lib.t2v_plan_create(make(**bad), 1, ctypes.byref(h))
+        msg = built_lib.t2v_last_error()
+        assert rc == -1 and needle in msg, (bad, rc, msg)
+    # copy2d: the low-order output exists for fp32 -> fp16 casts only
+    op = (L.T2VOp * 1)()
+    op[0].kind = L.OP_COPY2D
+    for k, v in enumerate((4, 8, 8, 8, L.F16, L.F16)):
+        op[0].i[k] = v
+    op[0].p[0], op[0].p[1], op[0].p[2] = ptr, ptr, ptr
+    assert built_lib.t2v_plan_create(op, 1, ctypes.byref(h)) == -1 and b"low-order" in built_lib.t2v_last_error()

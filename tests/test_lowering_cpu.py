@@ -284,3 +284,71 @@ def test_gemm_ln_option_fuses_on_the_192x320_tile_and_falls_back_elsewhere():
         assert rel_l2(got_out, want) < 1e-5
         ln = torch.nn.functional.layer_norm(got_out, (N,), gamma, beta, 1e-5)
         assert rel_l2(it.mat(n_out.ref, M, N, N, torch.float16, {}).float(), ln) < 1e-3
+
+
+def test_round3_lowering_options_fused_attention_and_precise_operands():
+    """Round 3 lowering switches, in the CPU interpreter (same op records the device executes):
+      * `fused_temporal_attention`: QKV projection + temporal attention as ONE record (T2V_EPI_TATTN, head-major weights) gives the
+        same forward as the QKV GEMM + attention pair (identical fp16 roundings: bit-equal in the interpreter) with fewer ops;
+      * `precise_operands`: the hi + lo split of the latent (lo in the padding channels, stem weights repeated) and of the
+        skip-convolution operands ([hi | lo] rows against [W | W], K doubled) lowers the error against the oracle on deployed weights;
+      * both switches are part of the program cache key."""
+    from oracle import torch_port as tp
+    cfg, m, sd, x, t, y = _tiny()
+    with torch.no_grad():
+        for p in m.parameters():
+            p.copy_(p.half().float())                      # deployed form: fp16-representable weights
+    sd16 = {k: v.clone() for k, v in m.state_dict().items()}
+    y16 = y.half().float()
+    ref = tp.unet_forward(sd16, cfg, x, t, y16)
+    res = {}
+    for fused, precise in ((True, True), (False, True), (True, False)):
+        m.fused_temporal_attention, m.precise_operands = fused, precise
+        comp = m._compile(2, 3, 16, 16, 7, "f32", "f32", "f32")
+        kinds = [op.i[16] for op in comp.prog.ops if op.kind == L.OP_GEMM]
+        n_tattn = kinds.count(L.EPI_TATTN)
+        assert (n_tattn > 0) == fused
+        if fused:
+            tat = next(op for op in comp.prog.ops if op.kind == L.OP_GEMM and op.i[16] == L.EPI_TATTN)
+            assert tat.i[22] == 10 and tat.i[8] == 3 and tat.i[10] == 12 and tat.i[0] % 192 == 0 and tat.i[1] % 192 == 0
+        dup = [op for op in comp.prog.ops if op.kind == L.OP_GEMM and op.name.endswith(".skip_connection")]
+        assert dup and all((op.p[1].name.endswith(":lin2")) == precise for op in dup)
+        stem = next(op for op in comp.prog.ops if op.name == "x.to_tokens")
+        assert stem.i[7] == int(precise)
+        it = Interp(comp.prog, comp.packer.materialise(m.state_dict(), "cpu"))
+        out = torch.empty(2, 4, 3, 16, 16)
+        it.run({L.EXT_X: x, L.EXT_T: t, L.EXT_CTX: y16, L.EXT_OUT: out})
+        res[(fused, precise)] = (out.clone(), len(comp.prog.ops), rel_l2(out, ref))
+    assert torch.equal(res[(True, True)][0], res[(False, True)][0])            # fusion changes no arithmetic
+    assert res[(True, True)][1] < res[(False, True)][1]                          # ... only the number of launches
+    assert res[(True, True)][2] < 0.93 * res[(True, False)][2], {k: v[2] for k, v in res.items()}   # measured 1.28e-3 vs 1.49e-3
+    keys = set()
+    for fused, precise in ((True, True), (False, True), (True, False)):
+        m.fused_temporal_attention, m.precise_operands = fused, precise
+        keys.add(m._program_key(2, 3, 16, 16, 7, torch.float32, torch.float32, torch.float32))
+    assert len(keys) == 3
+
+
+def test_round3_program_sync_words_come_first_and_gn_coop_flag():
+    """The device-side synchronisation words (split-K tickets + GroupNorm barrier) are the FIRST allocation of every program —
+    an allocation made later could alias memory an earlier op rewrites on every run — and GroupNorm records carry the single-pass
+    flag + barrier pointer unless the lowering is T-sharded / single-launch or T2V_GN_COOP=0 (Program.gn_coop)."""
+    from sd_webui_text2video_amd.program import Program, Ref
+    P = Program()
+    assert P._sync.ref.off == 0 and P._sync.rows == L.SYNC_INTS + L.SYNC_BARRIER_INTS
+    P.gn_fused_slice_bytes = 0
+    x, o = P.alloc(512, 320, "f32"), P.alloc(512, 320, "f16")
+    assert x.ref.off >= 4 * (L.SYNC_INTS + L.SYNC_BARRIER_INTS)
+    op = P.groupnorm("g", x, Ref("weight", 0, "g"), Ref("weight", 0, "b"), o, n_inst=2, eps=1e-5, silu=True)
+    assert op.i[15] == 1 and op.p[5].off == 4 * L.SYNC_INTS
+    P.gn_coop = False
+    op2 = P.groupnorm("g2", x, Ref("weight", 0, "g"), Ref("weight", 0, "b"), o, n_inst=2, eps=1e-5, silu=True)
+    assert op2.i[15] == 0 and op2.p[5].space == "null"
+    # split-K tickets are opt-in (measured slower than the reduction launch)
+    P.force_tile, P.target_cus = 0, 256
+    a, out = P.alloc(128, 2560, "f16"), P.alloc(128, 1280, "f32")
+    g = P.gemm("s", a, Ref("weight", 0, "w"), 1280, 2560, out)
+    assert g.i[19] > 1 and g.p[7].space == "null"
+    P.splitk_tickets = True
+    g2 = P.gemm("s2", a, Ref("weight", 0, "w"), 1280, 2560, out)
+    assert g2.i[19] > 1 and g2.p[7].off == 0
