@@ -73,7 +73,14 @@ class Probe(Interp):
             return torch.as_strided(self.shadow, tuple(shape), tuple(strides), ref.off // 2)
         return super().view(ref, shape, strides, dtype, ext)
 
+    round_inner = False      # experiment: the fp32 INNER residual stream of the transformer blocks (x1 / x2 / x3) stored as fp16
+
     def _st(self, view, value, dtype):
+        if self.round_inner and dtype == torch.float32 and self.cur.kind == L.OP_GEMM and self.nst == 0 and \
+                (self.cur.name.endswith(".to_out") or (self.cur.name.endswith(".proj_in"))):
+            self.nst += 1
+            view.copy_(value.half().float())
+            return
         if dtype == torch.float16 and view.dtype == torch.float32:          # a shadowed fp16 buffer
             cls = classify(self.cur)
             self.nst += 1
@@ -123,6 +130,12 @@ def main():
         return float(e.norm() / ref.norm()), it.seen
 
     base, seen = run()
+    if "inner16" in sys.argv:
+        Probe.round_inner = True
+        r16, _ = run()
+        Probe.round_inner = False
+        print(f"inner residual stream of the transformer blocks (proj_in / to_out outputs) stored as fp16: {base:.3e} -> {r16:.3e}", flush=True)
+        return
     classes = sorted(seen)
     if len(sys.argv) > 3:
         classes = [c for c in classes if c.startswith(sys.argv[3])]
