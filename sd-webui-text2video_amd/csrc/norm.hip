@@ -339,13 +339,18 @@ constexpr int GNC_THREADS = 512;
 // written with device-scope stores that their writers waited for before the __syncthreads below.
 constexpr int GNB_STRIDE = 32;                       // ints between level-1 counters (one 128-byte line each)
 constexpr int GNB_TOP = 8 * GNB_STRIDE, GNB_GEN = 9 * GNB_STRIDE;
-__device__ __forceinline__ void gn_grid_barrier(unsigned* bar, unsigned nwg) {
+#ifndef T2V_GN_GEN_AT_START
+#define T2V_GN_GEN_AT_START 1          // A/B switch (tools/build_variant.py): 0 = read the generation word right before arriving
+#endif
+// `gen` = the generation word as thread 0 read it at the START of the kernel (it cannot change before this workgroup arrives, and
+// reading it there takes one device-scope round trip off the chain between the statistics and the normalisation).
+__device__ __forceinline__ void gn_grid_barrier(unsigned* bar, unsigned nwg, unsigned gen) {
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned grp = blockIdx.x & 7u;
     const unsigned ngrp = nwg < 8u ? nwg : 8u;
     const unsigned in_grp = (nwg - grp + 7u) >> 3;                                   // workgroups b with b % 8 == grp
-    const unsigned gen = __hip_atomic_load(bar + GNB_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // read BEFORE arriving
+    if (!T2V_GN_GEN_AT_START) gen = __hip_atomic_load(bar + GNB_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     t2v_wait_vm0();
     bool release = false;
     if (__hip_atomic_fetch_add(bar + grp * GNB_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_grp - 1) {
@@ -381,6 +386,8 @@ __global__ __launch_bounds__(GNC_THREADS) void gn_coop_kernel(const T* __restric
   const int r0 = chunk * rc, r1 = min(rows, r0 + rc);
   const int c8 = cs * 8;
   const T* xb = x + (size_t)inst * rows * ld_in + c8;
+  unsigned gen0 = 0;
+  if (T2V_GN_GEN_AT_START && tid == 0) gen0 = __hip_atomic_load(bar + GNB_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   f32x8 v[KR];
   f32x8 s, q;
 #pragma unroll
@@ -423,7 +430,7 @@ __global__ __launch_bounds__(GNC_THREADS) void gn_coop_kernel(const T* __restric
       t2v_wait_vm0();                                                                // complete before this workgroup arrives
     }
   }
-  gn_grid_barrier(bar, gridDim.x);
+  gn_grid_barrier(bar, gridDim.x, gen0);
   {
     double ds = 0.0, dq = 0.0;
     if (g < groups) {
