@@ -300,24 +300,35 @@ class _LvdmLowering(_Lowering):
         scale = d ** -0.5
         M = x.rows
         n = self.gn(prefix + ".norm", x, prefix + ".norm", per_frame=False, eps=1e-6, silu=False)
-        cur = P.alloc(M, c, "f32")
-        P.gemm(prefix + ".proj_in", n, self.w_linear(prefix + ".proj_in"), c, c, cur, bias=self.vec(prefix + ".proj_in.bias"))
-        P.free(n)
         tb = prefix + ".transformer_blocks.0"
+        # LayerNorms as a second output of the GEMM that produces their input (fused into the epilogue of the 192x320 tile where
+        # the tile holds whole rows, C = 320: the 32x32 level; a separate LayerNorm op elsewhere — Program.gemm decides).  The
+        # T-sharded lowering keeps explicit LayerNorm ops (its temporal attentions normalise inside their K/V-gather form).
+        fuse = self.shard is None
+
+        def ln_of(tag) -> Optional[tuple]:
+            return self.ln_arg(f"{tb}.{tag}", P.alloc(M, c, "f16")) if fuse else None
 
         def layer_norm(tag, src: Buf) -> Buf:
             o = P.alloc(M, c, "f16")
             P.layernorm(f"{tb}.{tag}", src, self.vec(f"{tb}.{tag}.weight"), self.vec(f"{tb}.{tag}.bias"), o)
             return o
 
-        def out_proj(attn, a: Buf, res: Buf) -> Buf:
-            o = P.alloc(M, c, "f32")
-            P.gemm(f"{tb}.{attn}.to_out", a, self.w_linear(f"{tb}.{attn}.to_out.0"), c, c, o,
-                   bias=self.vec(f"{tb}.{attn}.to_out.0.bias"), residual=res)
-            P.free(a, res)
-            return o
+        cur = P.alloc(M, c, "f32")
+        ln = ln_of("norm1")
+        P.gemm(prefix + ".proj_in", n, self.w_linear(prefix + ".proj_in"), c, c, cur, bias=self.vec(prefix + ".proj_in.bias"), ln=ln)
+        P.free(n)
+        nxt = ln[3] if ln is not None else None          # LayerNorm(cur) for the next consumer, when already produced
 
-        def temporal_attn_sharded(attn, norm, src: Buf) -> Buf:
+        def out_proj(attn, a: Buf, res: Buf, next_norm: str):
+            o = P.alloc(M, c, "f32")
+            ln = ln_of(next_norm)
+            P.gemm(f"{tb}.{attn}.to_out", a, self.w_linear(f"{tb}.{attn}.to_out.0"), c, c, o,
+                   bias=self.vec(f"{tb}.{attn}.to_out.0.bias"), residual=res, ln=ln)
+            P.free(a, res)
+            return o, (ln[3] if ln is not None else None)
+
+        def temporal_attn_sharded(attn, norm, src: Buf, next_norm: str):
             """Queries = this rank's frames, keys / values = all frames of the clip (K/V projections all-gathered along T);
             the relative position of key s to local query t is s - (t + first frame of this slice)."""
             sh = self.shard
@@ -340,12 +351,12 @@ class _LvdmLowering(_Lowering):
                         rel_v=self.table(f"{tb}.{attn}.relative_position_v.embeddings_table"),
                         max_rel=net.temporal_length, q_offset=sh.offset)
             P.free(q, kv_all)
-            return out_proj(attn, a, src)
+            return out_proj(attn, a, src, next_norm)
 
-        def self_attn(attn, norm, src: Buf, temporal: bool) -> Buf:
+        def self_attn(attn, norm, src: Buf, nrm: Optional[Buf], temporal: bool, next_norm: str):
             if temporal and self.shard is not None:
-                return temporal_attn_sharded(attn, norm, src)
-            nrm = layer_norm(norm, src)
+                return temporal_attn_sharded(attn, norm, src, next_norm)
+            nrm = layer_norm(norm, src) if nrm is None else nrm
             qkv = P.alloc(M, 3 * c, "f16")
             P.gemm(f"{tb}.{attn}.qkv", nrm, self.w_qkv(f"{tb}.{attn}"), 3 * c, c, qkv)
             P.free(nrm)
@@ -364,12 +375,12 @@ class _LvdmLowering(_Lowering):
                             rel_v=self.table(f"{tb}.{attn}.relative_position_v.embeddings_table"),
                             max_rel=net.temporal_length)
             P.free(qkv)
-            return out_proj(attn, a, src)
+            return out_proj(attn, a, src, next_norm)
 
-        cur = self_attn("attn1", "norm1", cur, temporal=False)
-        cur = self_attn("attn1_tmp", "norm4", cur, temporal=True)
+        cur, nxt = self_attn("attn1", "norm1", cur, nxt, temporal=False, next_norm="norm4")
+        cur, nxt = self_attn("attn1_tmp", "norm4", cur, nxt, temporal=True, next_norm="norm2")
         # text cross-attention: K/V of all transformers come from ONE projection GEMM of the context
-        nrm = layer_norm("norm2", cur)
+        nrm = layer_norm("norm2", cur) if nxt is None else nxt
         q = P.alloc(M, c, "f16")
         P.gemm(f"{tb}.attn2.to_q", nrm, self.w_linear(f"{tb}.attn2.to_q"), c, c, q)
         P.free(nrm)
@@ -381,9 +392,9 @@ class _LvdmLowering(_Lowering):
                     nk=Lc, heads=heads, b_outer=B, b_inner=F, q_strides=(c, F * hw * c, hw * c), kv_strides=(kv.ld, Lc * kv.ld, 0),
                     o_strides=(c, F * hw * c, hw * c), scale=scale, head_dim=d)
         P.free(q)
-        cur = out_proj("attn2", a, cur)
-        cur = self_attn("attn2_tmp", "norm5", cur, temporal=True)
-        nrm = layer_norm("norm3", cur)
+        cur, nxt = out_proj("attn2", a, cur, "norm5")
+        cur, nxt = self_attn("attn2_tmp", "norm5", cur, nxt, temporal=True, next_norm="norm3")
+        nrm = layer_norm("norm3", cur) if nxt is None else nxt
         wg, bg = self.w_geglu(f"{tb}.ff.net.0.proj")
         g = P.alloc(M, 4 * c, "f16")
         P.gemm(f"{tb}.ff.geglu", nrm, wg, 8 * c, c, g, bias=bg, epi=L.EPI_GEGLU)
