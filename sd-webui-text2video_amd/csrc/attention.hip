@@ -437,6 +437,226 @@ __global__ __launch_bounds__(256) void seqattn_kernel(const SeqAttnParams p) {
   }
 }
 
+
+// ---- relative-position temporal attention on MFMA (round 3) -------------------------------------------------------------
+//   sim[t,s] = scale * (q[t].k[s] + q[t].Ek[s-t+R]),   out[t] = sum_s p[t,s] v[s] + sum_s p[t,s] Ev[s-t+R]
+// for the unclipped case R >= T-1 (the released model: 16 frames, R = 16), all T queries of a pixel.  The two relative terms
+// are GEMMs against the tables — QE^T = Ek . Q^T ([2T-1 relevant rows] x T) and O^T += Ev^T . Pskew^T — with a SKEW between
+// them and the score / probability matrices: entry (t, s) pairs with table row j = s - t + R.  The skew goes through LDS: QE^T
+// is written as [t][j] and read back at j = s - t + (T-1) by the lane that owns (t, s); the probabilities are written as rows
+// [zeros | p[t, 0..T) | zeros] and the B operand of the Ev product reads them at column s = j + t - (T-1), zeros outside.
+// One wave per (pixel, head), four per workgroup; the tables are staged once per workgroup as fp16 (exact for a .half()
+// model).  Q and K fragments come straight from global memory (16 B per lane), V is transposed through LDS.
+struct RelMfmaParams {
+  SeqAttnParams a;
+  int jbase;                  // first relevant table row: R - (T - 1)
+  int nblk;                   // 32-row blocks of relevant table rows: 1 (T <= 16) or 2
+};
+
+template <int D>
+__global__ __launch_bounds__(256) void relpos_mfma_kernel(const RelMfmaParams pp) {
+  const SeqAttnParams& p = pp.a;
+  constexpr int DK = (D + 15) / 16 * 16, NKK = DK / 16;
+  constexpr int DV = (D + 31) / 32 * 32, NDT = DV / 32;
+  constexpr int EK_PITCH = DK * 2 + 16;          // bytes per Ek row (fp16)
+  constexpr int EV_PITCH = 64 * 2 + 8;           // bytes per Ev^T row: 64 table-row slots
+  constexpr int VT_PITCH = 32 * 2 + 8;           // bytes per V^T row: 32 key slots
+  constexpr int QE_PITCH = 65;                   // floats per QE row (t): 64 slots + 1
+  constexpr int P_PITCH = 128;                   // halves per probability row: [32 zeros | 32 p | 64 zeros]
+  constexpr int WAVE_BYTES = DV * VT_PITCH + 32 * QE_PITCH * 4 + 32 * P_PITCH * 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char ssm[];
+  unsigned char* ekl = ssm;                                      // [64][EK_PITCH]
+  unsigned char* evt = ssm + 64 * EK_PITCH;                      // [DV][EV_PITCH]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  unsigned char* wbase = ssm + 64 * EK_PITCH + DV * EV_PITCH + wave * WAVE_BYTES;
+  unsigned char* vt = wbase;                                     // [DV][VT_PITCH]
+  float* qeb = reinterpret_cast<float*>(wbase + DV * VT_PITCH);  // [32][QE_PITCH]
+  f16* pb = reinterpret_cast<f16*>(wbase + DV * VT_PITCH + 32 * QE_PITCH * 4);   // [32][P_PITCH]
+  const int T = p.T, R = p.R;
+  const int nrows = 2 * R + 1;
+  // ---- tables (whole workgroup): Ek rows jbase .. jbase+63 as fp16 [slot][d]; Ev transposed [d][slot]
+  for (int u = tid; u < 64 * (DK / 8); u += 256) {
+    const int jl = u / (DK / 8), c = u - jl * (DK / 8);
+    const int j = jl + pp.jbase;
+    f16x8 val;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int d = c * 8 + e;
+      val[e] = (j < nrows && d < D) ? (f16)p.ek[(long)j * D + d] : (f16)0.f;
+    }
+    *reinterpret_cast<f16x8*>(ekl + jl * EK_PITCH + c * 16) = val;
+  }
+  for (int u = tid; u < DV * 64; u += 256) {
+    const int d = u >> 6, jl = u & 63;
+    const int j = jl + pp.jbase;
+    *reinterpret_cast<f16*>(evt + d * EV_PITCH + jl * 2) = (j < nrows && d < D) ? (f16)p.ev[(long)j * D + d] : (f16)0.f;
+  }
+  // zero this wave's probability rows once: the pads stay zero, the 32 middle slots are rewritten per item
+  for (int u = lane; u < 32 * P_PITCH / 8; u += 64) {
+    const f16x8 z = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+    reinterpret_cast<f16x8*>(pb)[u] = z;
+  }
+  __syncthreads();
+  const long item = (long)blockIdx.x * 4 + wave;
+  if (item >= p.n_items) return;                                 // wave-uniform; no workgroup barrier below
+  const int head = (int)(item % p.heads);
+  const long pos = item / p.heads;
+  const long bo = pos / p.b_inner, bi = pos % p.b_inner;
+  const f16* qb = p.q + bo * p.sq_out + bi * p.sq_in + head * D;
+  const f16* kb = p.k + bo * p.sk_out + bi * p.sk_in + head * D;
+  const f16* vb = p.v + bo * p.sk_out + bi * p.sk_in + head * D;
+  f16* ob = p.o + bo * p.so_out + bi * p.so_in + head * D;
+  const int frow = lane & 31, fhalf = lane >> 5;
+  // ---- V^T into LDS: unit = (key pair, 4 d)
+  for (int u = lane; u < 16 * (DV / 4); u += 64) {
+    const int kp = u / (DV / 4), dq = u - kp * (DV / 4);
+    const int key = 2 * kp;
+    const bool dok = dq * 4 < D;
+    f16x4 a, b;
+    if (dok && key < T) a = *reinterpret_cast<const f16x4*>(vb + (long)key * p.sk_seq + dq * 4);
+    else for (int e = 0; e < 4; ++e) a[e] = (f16)0.f;
+    if (dok && key + 1 < T) b = *reinterpret_cast<const f16x4*>(vb + (long)(key + 1) * p.sk_seq + dq * 4);
+    else for (int e = 0; e < 4; ++e) b[e] = (f16)0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      typedef f16 f16x2 __attribute__((ext_vector_type(2)));
+      f16x2 w = {a[e], b[e]};
+      *reinterpret_cast<f16x2*>(vt + (dq * 4 + e) * VT_PITCH + kp * 4) = w;
+    }
+  }
+  // ---- Q (B operand) and K (A operand) fragments from global
+  f16x8 qf[NKK], kf[NKK];
+#pragma unroll
+  for (int kk = 0; kk < NKK; ++kk) {
+    const int d0 = kk * 16 + fhalf * 8;
+    if (frow < T && d0 < D) {
+      qf[kk] = *reinterpret_cast<const f16x8*>(qb + (long)frow * p.sq_seq + d0);
+      kf[kk] = *reinterpret_cast<const f16x8*>(kb + (long)frow * p.sk_seq + d0);
+    } else {
+      for (int e = 0; e < 8; ++e) { qf[kk][e] = (f16)0.f; kf[kk][e] = (f16)0.f; }
+    }
+  }
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  // ---- S^T = K Q^T
+  f32x16 sc = zero16;
+#pragma unroll
+  for (int kk = 0; kk < NKK; ++kk) sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kk], qf[kk], sc, 0, 0, 0);
+  // ---- QE^T = Ek Q^T for the relevant table rows, written skew-ready as [t][slot]
+  for (int blk = 0; blk < pp.nblk; ++blk) {
+    f32x16 qe = zero16;
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+      const f16x8 ef = *reinterpret_cast<const f16x8*>(ekl + (blk * 32 + frow) * EK_PITCH + ((kk * 2 + fhalf) << 4));
+      qe = __builtin_amdgcn_mfma_f32_32x32x16_f16(ef, qf[kk], qe, 0, 0, 0);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g)                     // accumulator rows 8 g + 4 fhalf + {0..3} of this block, column t = frow
+#pragma unroll
+      for (int e = 0; e < 4; ++e) qeb[frow * QE_PITCH + blk * 32 + 8 * g + 4 * fhalf + e] = qe[4 * g + e];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");        // the same wave reads back below
+  // ---- scores + softmax for this lane's query t = frow
+  float mx = -INFINITY;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int key = (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+    float v = -INFINITY;
+    if (key < T && frow < T) v = sc[r] + qeb[frow * QE_PITCH + key - frow + (T - 1)];
+    sc[r] = v;
+    mx = fmaxf(mx, v);
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  if (frow >= T) mx = 0.f;
+  const float sl2 = p.scale * 1.44269504088896340736f;
+  const float neg_m = -mx * sl2;
+  float psum = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], sl2, neg_m));
+    sc[r] = pv;
+    psum += pv;
+  }
+  psum += __shfl_xor(psum, 32);
+  // probabilities (unnormalised) into this query's LDS row: slots 32 + key
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const f16x4 pw = {(f16)sc[4 * g], (f16)sc[4 * g + 1], (f16)sc[4 * g + 2], (f16)sc[4 * g + 3]};
+    *reinterpret_cast<f16x4*>(pb + frow * P_PITCH + 32 + 8 * g + 4 * fhalf) = pw;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  // ---- O^T = V^T P^T + Ev^T Pskew^T
+  f32x16 oacc[NDT];
+#pragma unroll
+  for (int d = 0; d < NDT; ++d) oacc[d] = zero16;
+#pragma unroll
+  for (int t2 = 0; t2 < 2; ++t2) {
+    f16x8 pf;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) pf[e] = (f16)sc[8 * t2 + e];
+    const int kofs = (t2 * 16 + 4 * fhalf) * 2;
+#pragma unroll
+    for (int d = 0; d < NDT; ++d) {
+      const unsigned char* vrow = vt + (d * 32 + frow) * VT_PITCH + kofs;
+      const f16x4 lo = *reinterpret_cast<const f16x4*>(vrow);
+      const f16x4 hi = *reinterpret_cast<const f16x4*>(vrow + 16);
+      const f16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, oacc[d], 0, 0, 0);
+    }
+  }
+  for (int u = 0; u < 2 * pp.nblk; ++u) {            // 16 table-row slots per step: slot = 16 u + 4 fhalf + (e & 3) + 8 (e >> 2)
+    f16x8 pf;
+    const f16* prow = pb + frow * P_PITCH + 32 + 16 * u + 4 * fhalf - (T - 1) + frow;     // column of slot e = 0 (s = slot + t - (T-1))
+#pragma unroll
+    for (int e = 0; e < 8; ++e) pf[e] = prow[(e & 3) + 8 * (e >> 2)];
+    const int jofs = (16 * u + 4 * fhalf) * 2;
+#pragma unroll
+    for (int d = 0; d < NDT; ++d) {
+      const unsigned char* erow = evt + (d * 32 + frow) * EV_PITCH + jofs;
+      const f16x4 lo = *reinterpret_cast<const f16x4*>(erow);
+      const f16x4 hi = *reinterpret_cast<const f16x4*>(erow + 16);
+      const f16x8 ef = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ef, pf, oacc[d], 0, 0, 0);
+    }
+  }
+  if (frow < T) {
+    const float inv = 1.0f / psum;
+    f16* orow = ob + (long)frow * p.so_seq;
+#pragma unroll
+    for (int d = 0; d < NDT; ++d)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const int col = d * 32 + 8 * qd + 4 * fhalf;
+        if (col < D) {
+          f16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (f16)(oacc[d][4 * qd + r] * inv);
+          *reinterpret_cast<f16x4*>(orow + col) = o;
+        }
+      }
+  }
+}
+
+template <int D>
+hipError_t launch_relpos_mfma(const SeqAttnParams& p, hipStream_t s) {
+  constexpr int DK = (D + 15) / 16 * 16, DV = (D + 31) / 32 * 32;
+  constexpr int lds = 64 * (DK * 2 + 16) + DV * (64 * 2 + 8) + 4 * (DV * (32 * 2 + 8) + 32 * 65 * 4 + 32 * 128 * 2);
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  RelMfmaParams pp;
+  pp.a = p;
+  pp.jbase = p.R - (p.T - 1);
+  pp.nblk = (2 * p.T - 1 > 32) ? 2 : 1;
+  auto kern = relpos_mfma_kernel<D>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)((p.n_items + 3) / 4)), dim3(256), lds, s, pp);
+  return hipGetLastError();
+}
+
 template <bool REL>
 hipError_t launch_seqattn(const t2v_op& op, hipStream_t s) {
   SeqAttnParams p;
@@ -456,6 +676,20 @@ hipError_t launch_seqattn(const t2v_op& op, hipStream_t s) {
   if (p.T <= 0 || p.T > 32 || p.Tq <= 0 || p.q_off < 0 || p.q_off + p.Tq > p.T || p.D <= 0 || p.D % 8 != 0 || p.D > 160 || p.n_items <= 0)
     return hipErrorInvalidValue;
   if (REL && (p.R < 0 || p.ek == nullptr || p.ev == nullptr)) return hipErrorInvalidValue;
+  if (REL && p.Tq == p.T && p.q_off == 0 && p.R >= p.T - 1 && p.R <= 31 && p.scale > 0.f) {
+    // the unclipped, unsharded form (the released model: 16 frames, R = 16): the MFMA kernel; everything else (clipped relative
+    // positions, a T-sharded clip's query slice, other head dims) keeps the VALU kernel below.  T2V_RELPOS_MFMA=0: A/B switch
+    static const bool use_mfma = [] { const char* e = getenv("T2V_RELPOS_MFMA"); return e ? atoi(e) != 0 : true; }();
+    if (use_mfma) {
+      switch (p.D) {
+        case 40: return launch_relpos_mfma<40>(p, s);
+        case 64: return launch_relpos_mfma<64>(p, s);
+        case 80: return launch_relpos_mfma<80>(p, s);
+        case 160: return launch_relpos_mfma<160>(p, s);
+        default: break;
+      }
+    }
+  }
   p.lds_per_wave = (3 * p.T * (p.D * 2 + 16) + p.T * (p.T + 1) * 4 + 15) / 16 * 16;
   const int lds = 4 * p.lds_per_wave;
   const dim3 grid((unsigned)((p.n_items + 3) / 4));

@@ -291,9 +291,13 @@ def test_attention_lvdm_head_dims(D, kind, B, F, hw, Lc):
     _check(it, got, o, 3e-3, f"attention {kind} d={D}")
 
 
-@pytest.mark.parametrize("D,T,R", [(40, 16, 16), (80, 16, 16), (160, 16, 16), (40, 24, 16), (64, 5, 2), (160, 32, 16)])
+@pytest.mark.parametrize("D,T,R", [(40, 16, 16), (80, 16, 16), (160, 16, 16), (40, 24, 16), (64, 5, 2), (160, 32, 16),
+                                   (40, 9, 16), (80, 16, 31), (64, 16, 20), (40, 17, 16), (40, 32, 31), (160, 20, 19)])
 def test_relpos_temporal_attention(D, T, R):
-    """LVDM TemporalCrossAttention with relative-position K / V terms (attention_temporal.py:107-144)."""
+    """LVDM TemporalCrossAttention with relative-position K / V terms (attention_temporal.py:107-144).  R >= T - 1 (no clipping:
+    the released model's 16 frames / R = 16 and the added shapes) runs the MFMA kernel (round 3: Q.Ek^T and P_skew.Ev as GEMMs
+    against the tables with an LDS skew), the clipped shapes the VALU kernel.  The tables are fp16-representable, as in a
+    `.half()` model (the MFMA kernel stages them as fp16)."""
     heads, B, hw = 8 if D < 160 else 2, 2, 12
     inner = heads * D
     M = B * T * hw
@@ -302,7 +306,7 @@ def test_relpos_temporal_attention(D, T, R):
     qkv, o = P.alloc(M, 3 * inner, "f16"), P.alloc(M, inner, "f16")
     ld = 3 * inner
     q, k, v = qkv.col_slice(0, inner), qkv.col_slice(inner, 2 * inner), qkv.col_slice(2 * inner, 3 * inner)
-    w = {"ek": torch.randn(2 * R + 1, D, generator=g) * 0.5, "ev": torch.randn(2 * R + 1, D, generator=g) * 0.5}
+    w = {"ek": (torch.randn(2 * R + 1, D, generator=g) * 0.5).half().float(), "ev": (torch.randn(2 * R + 1, D, generator=g) * 0.5).half().float()}
     P.attention("a", q.ref, k.ref, v.ref, o.ref, nq=T, nk=T, heads=heads, b_outer=B, b_inner=hw,
                 q_strides=(hw * ld, T * hw * ld, ld), kv_strides=(hw * ld, T * hw * ld, ld),
                 o_strides=(hw * inner, T * hw * inner, inner), scale=D ** -0.5, head_dim=D,
