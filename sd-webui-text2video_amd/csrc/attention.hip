@@ -676,11 +676,12 @@ hipError_t launch_seqattn(const t2v_op& op, hipStream_t s) {
   if (p.T <= 0 || p.T > 32 || p.Tq <= 0 || p.q_off < 0 || p.q_off + p.Tq > p.T || p.D <= 0 || p.D % 8 != 0 || p.D > 160 || p.n_items <= 0)
     return hipErrorInvalidValue;
   if (REL && (p.R < 0 || p.ek == nullptr || p.ev == nullptr)) return hipErrorInvalidValue;
-  if (REL && p.Tq == p.T && p.q_off == 0 && p.R >= p.T - 1 && p.R <= 31 && p.scale > 0.f) {
-    // the unclipped, unsharded form (the released model: 16 frames, R = 16): the MFMA kernel; everything else (clipped relative
-    // positions, a T-sharded clip's query slice, other head dims) keeps the VALU kernel below.  T2V_RELPOS_MFMA=0: A/B switch
-    static const bool use_mfma = [] { const char* e = getenv("T2V_RELPOS_MFMA"); return e ? atoi(e) != 0 : true; }();
-    if (use_mfma) {
+  if (REL && op.i[17] != 0 && p.Tq == p.T && p.q_off == 0 && p.R >= p.T - 1 && p.R <= 31 && p.scale > 0.f) {
+    // i[17]: the MFMA kernel for the unclipped, unsharded form (the released model: 16 frames, R = 16).  Correct (op tests against
+    // the interpreter and the explicit formula), but MEASURED SLOWER than the VALU kernel below on the VideoCrafter step (2.25 vs
+    // 1.65 ms for the 32 launches): its LDS footprint (tables + skew buffers, ~100 KB per 4-wave workgroup) leaves 4 waves per CU
+    // against 24, and every workgroup re-stages the tables for four 16x16 problems.  Kept as an opt-in (T2V_RELPOS_MFMA=1).
+    {
       switch (p.D) {
         case 40: return launch_relpos_mfma<40>(p, s);
         case 64: return launch_relpos_mfma<64>(p, s);

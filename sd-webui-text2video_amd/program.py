@@ -564,7 +564,7 @@ class Program:
     def attention(self, name: str, q: Ref, k: Ref, v: Ref, o: Ref, *, out_buf: Optional[Buf] = None, nq: int, nk: int, heads: int,
                   b_outer: int, b_inner: int, q_strides, kv_strides, o_strides, scale: float, head_dim: int = 64,
                   rel_k: Optional[Ref] = None, rel_v: Optional[Ref] = None, max_rel: int = 0, causal: bool = False,
-                  q_offset: int = 0) -> Op:
+                  q_offset: int = 0, relpos_mfma: Optional[bool] = None) -> Op:
         """softmax(q k^T scale) v over strided (sequence, outer, inner) batches.  With rel_k / rel_v (fp32
         [2*max_rel+1, head_dim] tables) the LVDM relative-position temporal attention op is emitted instead."""
         assert head_dim in (40, 64, 80, 160) or rel_k is not None
@@ -574,6 +574,8 @@ class Program:
         if rel_k is not None:
             assert nk <= 32 and 0 <= q_offset and q_offset + nq <= nk and head_dim % 8 == 0
             op.i[15], op.i[16] = max_rel, q_offset
+            # MFMA variant of the relative-position kernel: opt-in (measured slower than the VALU kernel, csrc/attention.hip)
+            op.i[17] = int(os.environ.get("T2V_RELPOS_MFMA", "0") != "0" if relpos_mfma is None else relpos_mfma)
             op.p[4], op.p[5] = rel_k, rel_v
             assert not causal
         elif causal:

@@ -291,13 +291,15 @@ def test_attention_lvdm_head_dims(D, kind, B, F, hw, Lc):
     _check(it, got, o, 3e-3, f"attention {kind} d={D}")
 
 
+@pytest.mark.parametrize("mfma", [False, True])
 @pytest.mark.parametrize("D,T,R", [(40, 16, 16), (80, 16, 16), (160, 16, 16), (40, 24, 16), (64, 5, 2), (160, 32, 16),
                                    (40, 9, 16), (80, 16, 31), (64, 16, 20), (40, 17, 16), (40, 32, 31), (160, 20, 19)])
-def test_relpos_temporal_attention(D, T, R):
-    """LVDM TemporalCrossAttention with relative-position K / V terms (attention_temporal.py:107-144).  R >= T - 1 (no clipping:
-    the released model's 16 frames / R = 16 and the added shapes) runs the MFMA kernel (round 3: Q.Ek^T and P_skew.Ev as GEMMs
-    against the tables with an LDS skew), the clipped shapes the VALU kernel.  The tables are fp16-representable, as in a
-    `.half()` model (the MFMA kernel stages them as fp16)."""
+def test_relpos_temporal_attention(D, T, R, mfma):
+    """LVDM TemporalCrossAttention with relative-position K / V terms (attention_temporal.py:107-144): the VALU kernel (default)
+    and, with `relpos_mfma=True` (t2v_op.i[17]) where R >= T - 1 (no clipping: the released model's 16 frames / R = 16 and the
+    added shapes), the MFMA kernel of round 3 (Q.Ek^T and P_skew.Ev as GEMMs against the tables with an LDS skew; the clipped
+    shapes fall through to the VALU kernel).  The tables are fp16-representable, as in a `.half()` model (the MFMA kernel stages
+    them as fp16)."""
     heads, B, hw = 8 if D < 160 else 2, 2, 12
     inner = heads * D
     M = B * T * hw
@@ -310,14 +312,14 @@ def test_relpos_temporal_attention(D, T, R):
     P.attention("a", q.ref, k.ref, v.ref, o.ref, nq=T, nk=T, heads=heads, b_outer=B, b_inner=hw,
                 q_strides=(hw * ld, T * hw * ld, ld), kv_strides=(hw * ld, T * hw * ld, ld),
                 o_strides=(hw * inner, T * hw * inner, inner), scale=D ** -0.5, head_dim=D,
-                rel_k=Ref("weight", 0, "ek"), rel_v=Ref("weight", 0, "ev"), max_rel=R)
-    assert P.ops[0].kind == L.OP_RELPOS_ATTN
+                rel_k=Ref("weight", 0, "ek"), rel_v=Ref("weight", 0, "ev"), max_rel=R, relpos_mfma=mfma)
+    assert P.ops[0].kind == L.OP_RELPOS_ATTN and P.ops[0].i[17] == int(mfma)
 
     def init(it):
         fill(it, qkv, g, 1.2)
         fill(it, o, g, 3.0)
     it, got, _, _ = run_both(P, w, {}, init)
-    _check(it, got, o, 2e-3, f"relpos attention d={D} T={T}")
+    _check(it, got, o, 2e-3, f"relpos attention d={D} T={T} mfma={mfma}")
 
 
 def test_attention_peaked_softmax():
