@@ -323,8 +323,10 @@ class Program:
         conv = conv or {}
         M = out.rows if m is None else m
         if a_lo is not None:
-            # hi + lo ACTIVATION split (the weights are exact fp16): t = A_lo.W (+ residual) in fp32, then the normal GEMM on
-            # A_hi with t as its residual — the operand reaches the MFMA with ~22 bits instead of 11 (precise_operands, unet.py)
+            # hi + lo ACTIVATION split as TWO passes (the weights are exact fp16): t = A_lo.W (+ residual) in fp32, then the normal
+            # GEMM on A_hi with t as its residual — the operand reaches the MFMA with ~22 bits instead of 11.  General form (any
+            # gather); the lowerings use the ONE-pass forms instead where the layout allows it (rows [hi | lo] against [W | W]
+            # for the 1x1 skip convolutions, lo in the padding channels for the stem: unet.py `precise_operands`)
             assert a_lo.dtype == "f16" and (a_lo.rows, a_lo.cols, a_lo.ld) == (a.rows, a.cols, a.ld) and epi == L.EPI_NONE and ln is None
             t_lo = self.alloc(M, n, "f32")
             self.gemm(name + ".a_lo", a_lo, w, n, k, t_lo, ldw=ldw, gather=gather, conv=conv, residual=residual, m=m,

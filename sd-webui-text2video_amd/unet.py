@@ -621,7 +621,7 @@ class _Lowering:
         return out
 
     def conv3(self, name, a: Buf, key, cout, h, w, *, stride=1, up=0, out_dtype="f32", rowbias=None,
-              residual=None, cin=None, dest: Optional[Buf] = None, a_lo: Optional[Buf] = None, dup_c8: bool = False) -> Buf:
+              residual=None, cin=None, dest: Optional[Buf] = None, dup_c8: bool = False) -> Buf:
         """`dest`: write the result into this (sub-)buffer instead of a fresh allocation — the producers of the two
         halves of a skip-connection concat write straight into the concat buffer (no copy ops)."""
         cin = a.cols if cin is None else cin
@@ -634,7 +634,7 @@ class _Lowering:
         self.P.gemm(name, a, wref, n, 9 * cin, out, bias=self.vec(key + ".bias"),
                     gather=gather, conv=dict(Hin=h, Win=w, Cin=cin, stride=stride, up=up, Hout=ho, Wout=wo),
                     rowbias=rowbias, rows_per_batch=self.F * ho * wo if rowbias is not None else 0,
-                    residual=residual, a_lo=a_lo)
+                    residual=residual)
         return out
 
     def _dest(self, dest: Optional[Buf], rows, cols, dtype) -> Buf:

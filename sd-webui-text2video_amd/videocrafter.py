@@ -249,7 +249,7 @@ class _LvdmLowering(_Lowering):
         return Ref("weight", 0, self.packer.add(key + ":tab", "f32", lambda sd, k=key: sd[k]))
 
     def conv133(self, name, a: Buf, key, cout, h, w, *, stride=1, up=0, out_dtype="f32", rowbias=None, residual=None, cin=None,
-                dest: Optional[Buf] = None, a_lo: Optional[Buf] = None, dup_c8: bool = False) -> Buf:
+                dest: Optional[Buf] = None, dup_c8: bool = False) -> Buf:
         cin = a.cols if cin is None else cin
         ho, wo = (h * 2, w * 2) if up else ((h + 1) // 2 if stride == 2 else h, (w + 1) // 2 if stride == 2 else w)
         n = (cout + 3) // 4 * 4
@@ -258,7 +258,7 @@ class _LvdmLowering(_Lowering):
         wref = self.w_conv133_dup(key) if dup_c8 else self.w_conv133(key, 8 if cin == 8 else 0)
         self.P.gemm(name, a, wref, n, 9 * cin, out, bias=self.vec(key + ".bias"),
                     gather=gather, conv=dict(Hin=h, Win=w, Cin=cin, stride=stride, up=up, Hout=ho, Wout=wo),
-                    rowbias=rowbias, rows_per_batch=self.F * ho * wo if rowbias is not None else 0, residual=residual, a_lo=a_lo)
+                    rowbias=rowbias, rows_per_batch=self.F * ho * wo if rowbias is not None else 0, residual=residual)
         return out
 
     def res_block(self, prefix, x: Buf, cin, cout, h, w, dest: Optional[Buf] = None) -> Buf:

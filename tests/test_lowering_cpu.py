@@ -352,3 +352,35 @@ def test_round3_program_sync_words_come_first_and_gn_coop_flag():
     P.splitk_tickets = True
     g2 = P.gemm("s2", a, Ref("weight", 0, "w"), 1280, 2560, out)
     assert g2.i[19] > 1 and g2.p[7].off == 0
+
+
+def test_hi_lo_operand_split_two_pass_and_one_pass_forms():
+    """`Program.gemm(a_lo=...)` (two passes: A_lo.W into an fp32 temporary, then A_hi.W + bias + that temporary) and the one-pass
+    form the lowerings use ([hi | lo] rows against [W | W]) both recover the fp32 operand: against the exact fp32 product they are
+    ~1000x closer than the single fp16 operand, and they agree with each other to fp32 rounding."""
+    from sd_webui_text2video_amd import packing as pk
+    from sd_webui_text2video_amd.program import Program, Ref
+    g = torch.Generator().manual_seed(3)
+    M, K, N = 96, 128, 64
+    x = torch.randn(M, K, generator=g) * 3.0
+    wt = (torch.randn(N, K, generator=g) / K ** 0.5).half()
+    bias = torch.randn(N, generator=g)
+    w = {"w": wt, "w2": pk.linear_dup(wt.float()).half(), "b": bias}
+    P = Program()
+    xs = P.alloc(M, K, "f32")
+    hi, lo = P.alloc(M, K, "f16"), P.alloc(M, K, "f16")
+    both = P.alloc(M, 2 * K, "f16")
+    o1, o2, o3 = P.alloc(M, N, "f32"), P.alloc(M, N, "f32"), P.alloc(M, N, "f32")
+    P.copy2d("cast", xs, hi, lo=lo)
+    P.copy2d("cast2", xs, both.col_slice(0, K), lo=both.col_slice(K, 2 * K))
+    P.gemm("plain", hi, Ref("weight", 0, "w"), N, K, o1, bias=Ref("weight", 0, "b"))
+    P.gemm("two_pass", hi, Ref("weight", 0, "w"), N, K, o2, bias=Ref("weight", 0, "b"), a_lo=lo)
+    P.gemm("one_pass", both, Ref("weight", 0, "w2"), N, 2 * K, o3, bias=Ref("weight", 0, "b"))
+    assert [op.name for op in P.ops if op.kind == L.OP_GEMM] == ["plain", "two_pass.a_lo", "two_pass", "one_pass"]
+    it = Interp(P, w, poison=False)
+    it.mat(xs.ref, M, K, K, torch.float32, {}).copy_(x)
+    it.run({})
+    exact = x.double() @ wt.double().t() + bias.double()
+    from harness import read
+    e1, e2, e3 = (rel_l2(read(it, o).double(), exact) for o in (o1, o2, o3))
+    assert e1 > 1e-4 and e2 < 2e-6 and e3 < 2e-6 and rel_l2(read(it, o2), read(it, o3)) < 1e-6, (e1, e2, e3)
