@@ -231,7 +231,7 @@ class UNetSD(nn.Module):
         # Precision (on by default): the fp32 -> fp16 operand casts whose rounding error reaches the output un-normalised — the
         # latent at the entry and the residual stream in front of the 1x1 skip convolutions — are emitted as hi + lo fp16
         # images and their (small) GEMMs run twice: 23 % of the activation-rounding error variance of a forward for ~15 extra
-        # launches and +1.5 % FLOPs (tools/precision_probe.py; DESIGN.md "Precision").  Part of the program cache key.
+        # launches and +1.5 % FLOPs (tests/precision_probe.py; DESIGN.md "Precision").  Part of the program cache key.
         self.precise_operands = True
         # TemporalTransformer self-attention as ONE launch per attention (QKV projection + attention of every pixel's frame
         # sequence in the GEMM epilogue, T2V_EPI_TATTN): Q / K / V never reach HBM.  Clips of 2..32 frames; longer clips (and the

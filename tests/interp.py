@@ -57,7 +57,7 @@ class Interp:
 
     def _st(self, view, value, dtype):
         """Store `value` into an output view of logical type `dtype` (fp16 buffers hold fp16-rounded values).  One hook for
-        every fp16 write, so that tools/precision_probe.py can switch the rounding of chosen tensors off."""
+        every fp16 write, so that tests/precision_probe.py can switch the rounding of chosen tensors off."""
         view.copy_(value.to(dtype))
 
     # ---- execution -----------------------------------------------------------------------------

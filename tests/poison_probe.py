@@ -1,6 +1,6 @@
 """Diagnostic (GPU): run a denoise program op by op over an arena pre-filled with NaN bit patterns and report the first op
 whose output contains a NaN — i.e. an op that reads arena bytes no earlier op wrote (harmless with zero-filled fresh
-memory, fatal with recycled memory).   python tools/poison_probe.py [vae|unet|lvdm]"""
+memory, fatal with recycled memory).   python tests/poison_probe.py [vae|unet|lvdm]"""
 import ctypes
 import os
 import sys

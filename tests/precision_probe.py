@@ -7,10 +7,10 @@ class of tensors the fp16 rounding at the store is switched off (the consumer th
 operand split delivers), everything else stays fp16.  Error is rel-L2 against the fp32 oracle port on the DEPLOYED weights
 (`w.half().float()`, t2v_pipeline.py:103-104), i.e. the comparison of the `*_w16.npz` goldens.
 
-    python tools/precision_probe.py [tiny|small] [frames]
+    python tests/precision_probe.py [tiny|small] [frames]
 
 Output: baseline, every class switched off alone (gain), everything but one class (what that class alone costs), cumulative
-greedy order.  CPU only; test infrastructure (imports oracle/ and tests/interp.py)."""
+order.  CPU only; TEST INFRASTRUCTURE (a script, not collected by pytest; lives in tests/ because it imports oracle/ and interp.py)."""
 import os
 import sys
 
@@ -18,7 +18,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from interp import Interp  # noqa: E402
 from oracle import configs, synth, torch_port as tp  # noqa: E402
 from sd_webui_text2video_amd import _lib as L  # noqa: E402
