@@ -85,8 +85,9 @@ class Communicator:
         if index == 0:
             L.check(lib.t2v_comm_unique_id(buf))
         box = [bytes(buf.raw)]
-        if len(ranks) > 1:
-            dist.broadcast_object_list(box, src=ranks[0], group=group, device=torch.device(device))
+        if len(ranks) > 1:      # the id travels over the group itself (host tensors for a gloo group)
+            dist.broadcast_object_list(box, src=ranks[0], group=group,
+                                       device=torch.device("cpu") if _host_staged(group) else torch.device(device))
         handle = ctypes.c_void_p()
         L.check(lib.t2v_comm_create(box[0], len(ranks), index, ctypes.byref(handle)))
         self.handle, self._lib, self.size = handle, lib, len(ranks)
@@ -121,8 +122,10 @@ class TShard:
 
     def communicator(self, device) -> Optional[Communicator]:
         """The in-library communicator for programs on `device`; None = run the exchanges from the host through
-        torch.distributed (CPU / gloo groups, or T2V_COLLECTIVES=host)."""
-        if torch.device(device).type != "cuda" or os.environ.get("T2V_COLLECTIVES", "library") == "host" or _host_staged(self.group):
+        torch.distributed (CPU / gloo groups, or T2V_COLLECTIVES=host).  T2V_COLLECTIVES=library forces the library communicator
+        even over a gloo group (tests: several ranks on ONE GPU with T2V_RCCL_SONAME pointing at tests/fake_rccl)."""
+        mode = os.environ.get("T2V_COLLECTIVES", "auto")
+        if torch.device(device).type != "cuda" or mode == "host" or (_host_staged(self.group) and mode != "library"):
             return None
         if self._comm is None:
             self._comm = Communicator(self.group, self.ranks, self.index, device)

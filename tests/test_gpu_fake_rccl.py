@@ -1,0 +1,72 @@
+"""GPU (-m gpu), ONE device: csrc/comm.hip under a REAL multi-process run.
+
+The build environment only has 1-GPU boxes and RCCL refuses several ranks on one device, so the RCCL entry points are
+provided by tests/fake_rccl (shared-memory stand-in with RCCL's documented semantics for ncclAllGather and grouped
+ncclSend / ncclRecv; selected with T2V_RCCL_SONAME — the library resolves RCCL with dlopen).  2, 3 and 4 processes share
+cuda:0; each lowers the T-sharded tiny UNet (uneven slices), runs the forward with the exchanges inside the library — which
+bytes go to which peer at which offsets is exactly what csrc/comm.hip computes — and then the same records through
+parallel.ShardedExecutor (torch.distributed over gloo): the results must be bit-identical, and the gathered frames must match the
+unsharded forward.  What this cannot cover is RCCL itself (tests/test_gpu_rccl.py does, on >= 2 GPUs)."""
+import json
+import os
+import shutil
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+FAKE_SRC = os.path.join(HERE, "fake_rccl", "fake_rccl.cpp")
+FAKE_LIB = os.path.join(HERE, "fake_rccl", "libfakerccl.so")
+
+
+@pytest.fixture(scope="module")
+def fake_rccl():
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available to build tests/fake_rccl")
+    if not os.path.exists(FAKE_LIB) or os.path.getmtime(FAKE_LIB) < os.path.getmtime(FAKE_SRC):
+        subprocess.run([hipcc, "-O2", "-std=c++17", "-fPIC", "-shared", FAKE_SRC, "-o", FAKE_LIB, "-lrt"], check=True)
+    return FAKE_LIB
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world,frames", [(2, 5), (3, 7), (4, 10)])      # 5 = 3 + 2, 7 = 3 + 3 + 1, 10 = 3 + 3 + 3 + 1
+def test_library_collectives_multi_process_one_gpu(fake_rccl, world, frames):
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = {**os.environ, "RANK": str(r), "WORLD_SIZE": str(world), "LOCAL_RANK": str(r), "MASTER_ADDR": "127.0.0.1",
+               "MASTER_PORT": str(port), "T2V_TEST_FRAMES": str(frames), "T2V_TEST_BACKEND": "gloo", "T2V_TEST_ONE_DEVICE": "1",
+               "T2V_RCCL_SONAME": fake_rccl, "T2V_GN_COOP": "0"}        # several processes on one GPU: no grid-barrier kernels
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "rccl_worker.py")], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = []
+    try:
+        for p in procs:
+            out, _ = p.communicate(timeout=420)
+            outs.append(out)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    results = []
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{out[-3000:]}"
+        results.append(json.loads(next(ln for ln in out.splitlines() if ln.startswith("RESULT "))[7:]))
+    print(f"library collectives over tests/fake_rccl, {world} processes on one GPU: {results[0]}")
+    for res in results:
+        assert res["lib_vs_host_equal"] and res["rerun_equal"] and res["n_collectives"] > 100
+        assert res["halo"] == 88 and res["allgather"] >= 105
+    if 64 % world == 0:
+        assert results[0]["alltoall"] > 0          # frame <-> pixel resharding of the TemporalTransformers
+    assert results[0]["rel_l2_vs_unsharded"] < 4e-3
