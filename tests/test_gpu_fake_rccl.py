@@ -40,7 +40,12 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,frames", [(2, 5), (3, 7), (4, 10)])      # 5 = 3 + 2, 7 = 3 + 3 + 1, 10 = 3 + 3 + 3 + 1
+# 5 = 3 + 2 (resharded TemporalTransformers: all-to-alls), 7 = 3 + 3 + 1 (64 pixels % 3 != 0: K/V all-gathers instead);
+# 10 = 3 + 3 + 3 + 1 on 4 processes passes too (profiles/r03_parity_measurements.txt) and runs with T2V_TEST_FULL=1 (80 s per case)
+CASES = [(2, 5), (3, 7)] + ([(4, 10)] if os.environ.get("T2V_TEST_FULL") == "1" else [])
+
+
+@pytest.mark.parametrize("world,frames", CASES)
 def test_library_collectives_multi_process_one_gpu(fake_rccl, world, frames):
     port = _free_port()
     procs = []
