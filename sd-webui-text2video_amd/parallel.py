@@ -4,7 +4,7 @@ The reference has exactly one collective — sample-level data parallelism whose
 all-gathered (scripts/videocrafter/lvdm/utils/dist_utils.py:13-19, sample_text2video.py:123-125)
 — and two sequential UNet calls per guided step (gaussian_sampler.py:161-162).  Layouts here:
 
-  * T-axis (frame) sharding x CFG pair (north_star's layout; default for N >= 4): world = 2 roles x R frame slices.
+  * T-axis (frame) sharding x CFG pair (north_star's layout; even N >= 4, mode "tshard"): world = 2 roles x R frame slices.
     The clip's frames are split contiguously over the R ranks of a role (slices of ceil(F / R) frames, a shorter last
     one: 125 = 32 + 32 + 32 + 29); all spatial work is frame-local, and before each temporal op the lowering inserts
     an exchange op into the denoise program (program.py: T2V_OP_ALLGATHER of GroupNorm statistics, T2V_OP_HALO_EXCHANGE of
