@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define T2V_ABI_VERSION 2
+#define T2V_ABI_VERSION 3   /* 3 (round 3): T2V_EPI_TATTN + tile 10, GROUPNORM i[15] / p[5], GEMM p[7] tickets, RELPOS i[17], low-order outputs of the cast ops, T2V_SYNC_* */
 
 /* error codes */
 #define T2V_OK 0

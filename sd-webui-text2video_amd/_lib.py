@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("T2V_LIB_PATH") or os.path.join(_HERE, "libt2v_hip.so")   # T2V_LIB_PATH: A/B builds of the same ABI (tools/build_variant.py)
 
 # ---- mirrors of include/t2v_hip.h (checked against the header by tests/test_abi.py) -------
-ABI_VERSION = 2
+ABI_VERSION = 3
 OP_GEMM, OP_GROUPNORM, OP_LAYERNORM, OP_ATTENTION, OP_SOFTMAX = 1, 2, 3, 4, 5
 OP_NCTHW_TO_CL, OP_CL_TO_NCTHW, OP_TIME_EMBED, OP_COPY2D, OP_DDIM_STEP, OP_MEMSET = 6, 7, 8, 9, 10, 11
 OP_LINCOMB = 12
