@@ -478,7 +478,7 @@ def main():
                          "separate job; pairs / tshard make the collective layout the headline")
     ap.add_argument("--no-collective-job", action="store_true",
                     help="N>1, --parallel auto: skip the separate job that times the collective layout beside the headline")
-    ap.add_argument("--collective-timeout", type=int, default=int(os.environ.get("T2V_BENCH_COLLECTIVE_TIMEOUT", 420)),
+    ap.add_argument("--collective-timeout", type=int, default=int(os.environ.get("T2V_BENCH_COLLECTIVE_TIMEOUT", 180)),
                     help="seconds the separate collective-layout job may take before it is abandoned (reported, headline unaffected)")
     ap.add_argument("--model", default="modelscope", choices=["modelscope", "lvdm"],
                     help="modelscope (default; configs[1]-[3]) or lvdm = VideoCrafter, BASELINE.json configs[4]: 16 frames @256x256 through "
@@ -728,7 +728,9 @@ def main():
         want_job = (world > 1 and requested == "auto" and not args.no_collective_job and (world == 2 or world % 2 == 0)
                     and os.environ.get("T2V_BENCH_COLLECTIVE_JOB", "1") != "0")
         if want_job:
-            # the other ranks are leaving; this rank's own buffers can go too before the N-rank job starts
+            # the other ranks are leaving; this rank's own buffers can go too before the N-rank job starts.  The headline is
+            # complete at this point: keep a copy on stderr in case whoever runs us loses patience with the side job
+            print("[bench] headline before the collective-layout job: " + json.dumps(result), file=sys.stderr, flush=True)
             del runner
             torch.cuda.empty_cache()
             result["collective_layout"] = collective_layout_job(world, args, args.collective_timeout)
