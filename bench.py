@@ -646,8 +646,9 @@ def main():
     if world > 1 and os.environ.get("T2V_BENCH_ONE_DEVICE") == "1":
         result["data"] = "synthetic; REHEARSAL: all ranks on one GPU over gloo — not a measurement"
     result["config"]["rccl_communicators"] = runner.communicators() if hasattr(runner, "communicators") else []
-    if world > 1 and mode != "replicas":
-        # the collective-free layout beside the headline: every GPU its own 24-frame video (configs[1] per GPU)
+    if world > 1 and mode != "replicas" and not args.no_collective_job:
+        # the collective-free layout beside the headline: every GPU its own 24-frame video (configs[1] per GPU).  (Not inside the
+        # bounded side job of a default run, which passes --no-collective-job: there the replicas number IS the parent's headline.)
         try:
             rep = build("replicas", 24, videos=1)
             el = timed(rep, 1, 1)
