@@ -26,7 +26,8 @@
 extern "C" {
 #endif
 
-#define T2V_ABI_VERSION 3   /* 3 (round 3): T2V_EPI_TATTN + tile 10, GROUPNORM i[15] / p[5], GEMM p[7] tickets, RELPOS i[17], low-order outputs of the cast ops, T2V_SYNC_* */
+#define T2V_ABI_VERSION 4   /* 4 (round 4): t2v_async_status, t2v_sync_reset, T2V_ERR_ASYNC (bounded grid barrier of the single-pass GroupNorm);
+                               3 (round 3): T2V_EPI_TATTN + tile 10, GROUPNORM i[15] / p[5], GEMM p[7] tickets, RELPOS i[17], low-order outputs of the cast ops, T2V_SYNC_* */
 
 /* error codes */
 #define T2V_OK 0
@@ -35,6 +36,7 @@ extern "C" {
 #define T2V_ERR_LAUNCH (-3)
 #define T2V_ERR_NO_DEVICE (-4)
 #define T2V_ERR_COMM (-5)      /* RCCL not loadable / communicator call failed */
+#define T2V_ERR_ASYNC (-6)     /* a kernel of an EARLIER run raised a fault (bounded grid barrier timed out): that run's results are invalid */
 
 /* ---- op kinds ------------------------------------------------------------------------- */
 enum t2v_op_kind {
@@ -103,7 +105,8 @@ enum t2v_gather {
 /* Device-side synchronisation words a program may hand to its ops: T2V_SYNC_INTS int32 arrival counters for the split-K fold
  * (GEMM p[7]) followed by T2V_SYNC_BARRIER_INTS more for the two-level grid barrier of the single-pass GroupNorm (GROUPNORM
  * p[5] points at the first of them).  All zero before the first launch; the kernels leave them zero (counters) or monotonic
- * (barrier generation).  They must not alias any buffer an op of the program writes. */
+ * (barrier generation).  They must not alias any buffer an op of the program writes.  t2v_sync_reset() zeroes the region on a
+ * stream (call it when the program is bound to an arena, before the first run — never while a run is in flight). */
 #define T2V_SYNC_INTS 4096
 #define T2V_SYNC_BARRIER_INTS 512
 
@@ -208,6 +211,16 @@ int t2v_abi_version(void);
 const char* t2v_last_error(void);
 /* fills name (<= len bytes), number of CUs and total HBM bytes of the current HIP device */
 int t2v_device_info(char* name, int len, int* compute_units, uint64_t* hbm_bytes);
+
+/* Asynchronous faults.  The single-pass GroupNorm synchronises its workgroups with a grid barrier; the library only launches it when
+ * the occupancy API says the whole grid is co-resident, and the wait is bounded: a workgroup that sees no release within 0.25 s
+ * (another client of the device holds compute units) raises a flag in host-mapped memory and falls through instead of hanging the
+ * device.  The run in flight then produced invalid results; the NEXT t2v_run_ops / t2v_plan_run* call returns T2V_ERR_ASYNC (once)
+ * and the three-launch GroupNorm is used for the rest of the process.  t2v_async_status() reports the same condition without running
+ * anything (call it after synchronising the stream at the end of a job): T2V_OK or T2V_ERR_ASYNC. */
+int t2v_async_status(void);
+/* zero the T2V_SYNC_INTS + T2V_SYNC_BARRIER_INTS int32 words at `sync_words` on `stream` */
+int t2v_sync_reset(void* sync_words, void* stream);
 
 /* Execute `n` ops in order on `stream` (a hipStream_t; null = default stream). */
 int t2v_run_ops(const t2v_op* ops, int n, const uint64_t* ext, int n_ext, void* stream);

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("T2V_LIB_PATH") or os.path.join(_HERE, "libt2v_hip.so")   # T2V_LIB_PATH: A/B builds of the same ABI (tools/build_variant.py)
 
 # ---- mirrors of include/t2v_hip.h (checked against the header by tests/test_abi.py) -------
-ABI_VERSION = 3
+ABI_VERSION = 4
 OP_GEMM, OP_GROUPNORM, OP_LAYERNORM, OP_ATTENTION, OP_SOFTMAX = 1, 2, 3, 4, 5
 OP_NCTHW_TO_CL, OP_CL_TO_NCTHW, OP_TIME_EMBED, OP_COPY2D, OP_DDIM_STEP, OP_MEMSET = 6, 7, 8, 9, 10, 11
 OP_LINCOMB = 12
@@ -33,6 +33,7 @@ EXPORTS = [
     "t2v_plan_num_ops", "t2v_plan_run", "t2v_plan_run_timed", "t2v_plan_destroy",
     "t2v_unet_forward", "t2v_vae_decode", "t2v_ddim_step",
     "t2v_comm_unique_id", "t2v_comm_create", "t2v_comm_size", "t2v_comm_destroy", "t2v_plan_set_comm",
+    "t2v_async_status", "t2v_sync_reset",
 ]
 
 
@@ -82,6 +83,8 @@ def load():
     lib.t2v_comm_destroy.argtypes = [vp]
     lib.t2v_comm_destroy.restype = None
     lib.t2v_plan_set_comm.argtypes = [vp, vp]
+    lib.t2v_async_status.restype = ctypes.c_int
+    lib.t2v_sync_reset.argtypes = [vp, vp]
     if lib.t2v_abi_version() != ABI_VERSION:
         raise T2VError(f"libt2v_hip.so ABI {lib.t2v_abi_version()} != binding {ABI_VERSION}; rebuild")
     _lib = lib
@@ -92,6 +95,12 @@ def check(rc: int):
     if rc != 0:
         msg = load().t2v_last_error()
         raise T2VError(f"libt2v_hip error {rc}: {msg.decode() if msg else '?'}")
+
+
+def async_status():
+    """Raise T2VError if a kernel of an earlier run raised an asynchronous fault (include/t2v_hip.h: t2v_async_status) —
+    call after synchronising at the end of a job (a video, a decode): the job's results are invalid if this raises."""
+    check(load().t2v_async_status())
 
 
 def device_info():

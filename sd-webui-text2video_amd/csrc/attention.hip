@@ -647,11 +647,10 @@ hipError_t launch_relpos_mfma(const SeqAttnParams& p, hipStream_t s) {
   pp.jbase = p.R - (p.T - 1);
   pp.nblk = (2 * p.T - 1 > 32) ? 2 : 1;
   auto kern = relpos_mfma_kernel<D>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  static t2v_device_flags attr_set;       // per (instantiation, device)
+  {
+    const hipError_t e = t2v_set_dynamic_lds(reinterpret_cast<const void*>(kern), lds, attr_set, s);
     if (e != hipSuccess) return e;
-    attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)((p.n_items + 3) / 4)), dim3(256), lds, s, pp);
   return hipGetLastError();
@@ -696,11 +695,10 @@ hipError_t launch_seqattn(const t2v_op& op, hipStream_t s) {
   const dim3 grid((unsigned)((p.n_items + 3) / 4));
   const int tb = (p.T + 7) / 8;
   auto go = [&](auto kern) -> hipError_t {
-    static bool attr_set = false;      // one flag per instantiation (the lambda is instantiated per kernel type)
-    if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static t2v_device_flags attr_set;      // per (instantiation, device); the lambda is instantiated per kernel type
+    {
+      const hipError_t e = t2v_set_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024, attr_set, s);
       if (e != hipSuccess) return e;
-      attr_set = true;
     }
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
     return hipGetLastError();

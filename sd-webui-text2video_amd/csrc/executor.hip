@@ -253,6 +253,11 @@ hipError_t launch_op(const t2v_op& op, hipStream_t s) {
 }
 
 int run_resolved(const t2v_op* ops, int n, const uint64_t* ext, int n_ext, hipStream_t s, float* ms, t2v_comm* comm = nullptr) {
+  {
+    // a kernel of an EARLIER run gave up at a grid barrier (norm.hip): that run's results are invalid — say so now, once
+    std::string why;
+    if (t2v_async_fault_consume(&why)) return fail(T2V_ERR_ASYNC, why);
+  }
   std::vector<hipEvent_t> ev;
   if (ms) {
     ev.resize(n + 1);
@@ -324,6 +329,19 @@ int t2v_device_info(char* name, int len, int* compute_units, uint64_t* hbm_bytes
   }
   if (compute_units) *compute_units = prop.multiProcessorCount;
   if (hbm_bytes) *hbm_bytes = (uint64_t)prop.totalGlobalMem;
+  return T2V_OK;
+}
+
+int t2v_async_status(void) {
+  std::string why;
+  if (t2v_async_fault_consume(&why)) return fail(T2V_ERR_ASYNC, why);
+  return T2V_OK;
+}
+
+int t2v_sync_reset(void* sync_words, void* stream) {
+  if (!sync_words) return fail(T2V_ERR_BAD_ARG, "null sync words");
+  const hipError_t e = hipMemsetAsync(sync_words, 0, sizeof(int32_t) * (T2V_SYNC_INTS + T2V_SYNC_BARRIER_INTS), reinterpret_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail(T2V_ERR_LAUNCH, std::string("hipMemsetAsync of the sync words failed: ") + hipGetErrorString(e));
   return T2V_OK;
 }
 

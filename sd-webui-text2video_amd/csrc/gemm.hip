@@ -343,29 +343,29 @@ hipError_t launch_tile(const GemmParams& pin, hipStream_t s) {
   switch (p.gather) {
     case T2V_GATHER_PLAIN: {
       auto k = gemm_kernel<BM, BN, WM, WN, T2V_GATHER_PLAIN>;
-      static bool once0 = false;
-      if (!once0) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds); once0 = true; }
+      static t2v_device_flags once0;
+      (void)t2v_set_dynamic_lds(reinterpret_cast<const void*>(k), lds, once0, s);
       hipLaunchKernelGGL(k, grid, block, lds, s, p);
       break;
     }
     case T2V_GATHER_CONV3X3: {
       auto k = gemm_kernel<BM, BN, WM, WN, T2V_GATHER_CONV3X3>;
-      static bool once1 = false;
-      if (!once1) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds); once1 = true; }
+      static t2v_device_flags once1;
+      (void)t2v_set_dynamic_lds(reinterpret_cast<const void*>(k), lds, once1, s);
       hipLaunchKernelGGL(k, grid, block, lds, s, p);
       break;
     }
     case T2V_GATHER_TCONV3: {
       auto k = gemm_kernel<BM, BN, WM, WN, T2V_GATHER_TCONV3>;
-      static bool once2 = false;
-      if (!once2) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds); once2 = true; }
+      static t2v_device_flags once2;
+      (void)t2v_set_dynamic_lds(reinterpret_cast<const void*>(k), lds, once2, s);
       hipLaunchKernelGGL(k, grid, block, lds, s, p);
       break;
     }
     case T2V_GATHER_CONV3X3_C8: {
       auto k = gemm_kernel<BM, BN, WM, WN, T2V_GATHER_CONV3X3_C8>;
-      static bool once3 = false;
-      if (!once3) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds); once3 = true; }
+      static t2v_device_flags once3;
+      (void)t2v_set_dynamic_lds(reinterpret_cast<const void*>(k), lds, once3, s);
       hipLaunchKernelGGL(k, grid, block, lds, s, p);
       break;
     }

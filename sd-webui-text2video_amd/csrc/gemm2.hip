@@ -628,11 +628,10 @@ hipError_t launch_cfg_gather(const GemmParams& p, hipStream_t s) {
                           : STAGES * (BM + BN) * BK * 2 + 1024;
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   auto k = gemm2_kernel<WM, WN, TM, TN, BK, STAGES, MINW, GATHER, PP, LN, TAT>;
-  static bool attr_set = false;     // once per instantiation (the call costs microseconds on the host)
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  static t2v_device_flags attr_set;     // once per (instantiation, device): the call costs microseconds on the host
+  {
+    const hipError_t e = t2v_set_dynamic_lds(reinterpret_cast<const void*>(k), lds, attr_set, s);
     if (e != hipSuccess) return e;
-    attr_set = true;
   }
   hipLaunchKernelGGL(k, dim3(tiles, p.splitk > 1 ? p.splitk : 1), dim3(WM * WN * 64), lds, s, p);
   return hipGetLastError();

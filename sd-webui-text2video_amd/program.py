@@ -687,10 +687,17 @@ class BoundProgram:
     """A Program whose symbolic pointers are resolved against a device arena and weight
     tensors, compiled into a `t2v_plan`."""
 
-    def __init__(self, prog: Program, arena_ptr: int, weight_ptrs: Dict[str, int], ops: Optional[List[Op]] = None, comm=None):
-        """`comm`: a parallel.Communicator (t2v_comm over RCCL) — required to RUN a program that holds collective ops."""
+    def __init__(self, prog: Program, arena_ptr: int, weight_ptrs: Dict[str, int], ops: Optional[List[Op]] = None, comm=None,
+                 reset_sync: Optional[bool] = None, stream: int = 0):
+        """`comm`: a parallel.Communicator (t2v_comm over RCCL) — required to RUN a program that holds collective ops.
+        `reset_sync` (default: when the WHOLE program is bound, i.e. `ops` is None): zero the program's device-side sync words
+        (split-K tickets, GroupNorm grid-barrier counters) in this arena on `stream` — the kernels' contract is "all zero before
+        the first launch", and the arena may be recycled or randomly filled memory (tools/, benchmarks).  Never done for a
+        sub-list of ops: those are bound while other plans of the same program may be in flight."""
         self.prog = prog
         lib = L.load()
+        if arena_ptr and ((ops is None) if reset_sync is None else reset_sync):
+            L.check(lib.t2v_sync_reset(ctypes.c_void_p(arena_ptr + prog._sync.ref.off), ctypes.c_void_p(stream)))
         ops = prog.ops if ops is None else ops
         self.ops = ops
         self.comm = comm

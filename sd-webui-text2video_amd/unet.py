@@ -235,8 +235,9 @@ class UNetSD(nn.Module):
         self.precise_operands = True
         # TemporalTransformer self-attention as ONE launch per attention (QKV projection + attention of every pixel's frame
         # sequence in the GEMM epilogue, T2V_EPI_TATTN): Q / K / V never reach HBM.  Clips of 2..32 frames; longer clips (and the
-        # K/V-gather form of a T-sharded clip) keep the projection GEMM + attention kernel pair.  Part of the program cache key.
-        self.fused_temporal_attention = os.environ.get("T2V_FUSED_TATTN", "1") != "0"
+        # K/V-gather form of a T-sharded clip) keep the projection GEMM + attention kernel pair, and so do clips whose sequences fill
+        # less than 144 of the tile's 192 rows (fewer than 12 frames) unless the option is "force".  Part of the program cache key.
+        self.fused_temporal_attention = {"0": False, "force": "force"}.get(os.environ.get("T2V_FUSED_TATTN", "1"), True)
         self.t_shard = None           # parallel.TShard: this rank holds a contiguous slice of the clip's frames
         self.auto_refresh = True      # re-check parameter versions on every forward (~1 ms); the sampler
                                       # turns this off inside its loop after one explicit refresh
@@ -450,7 +451,7 @@ class UNetSD(nn.Module):
     def _lowering_options(self) -> tuple:
         """Lowering switches that change the program (part of the cache key)."""
         return ((("precise",),) if getattr(self, "precise_operands", False) else ()) + \
-            ((("tattn",),) if getattr(self, "fused_temporal_attention", False) else ())
+            ((("tattn", str(self.fused_temporal_attention)),) if getattr(self, "fused_temporal_attention", False) else ())
 
     def forward_cfg_pair(self, x, t, ctx_pair, context_token=None):
         """One guided step's two evaluations (gaussian_sampler.py:161-162) as ONE forward: x [V,4,F,h,w] is read twice by
@@ -513,18 +514,19 @@ class _Compiled:
         # zero weights) must not hold NaN bit patterns of recycled allocator blocks
         self.arena = torch.zeros(self.prog.arena.high + 256, dtype=torch.uint8, device=device)
         wptr = {k: v.data_ptr() for k, v in packed.items()}
+        st = torch.cuda.current_stream(device).cuda_stream       # the bind-time reset of the sync words is ordered with the first run
         if any(op.kind in COLLECTIVE_KINDS for op in self.prog.ops):
             if t_shard is None:
                 raise L.T2VError("a T-sharded program needs the T group (UNetSD.t_shard)")
             comm = t_shard.communicator(device)
             if comm is not None:
-                self.bound = BoundProgram(self.prog, self.arena.data_ptr(), wptr, comm=comm)
+                self.bound = BoundProgram(self.prog, self.arena.data_ptr(), wptr, comm=comm, stream=st)
             else:
                 from .parallel import ShardedExecutor
                 self.bound = ShardedExecutor(self.prog, self.arena, t_shard,
                                              lambda ops: BoundProgram(self.prog, self.arena.data_ptr(), wptr, ops=ops))
         else:
-            self.bound = BoundProgram(self.prog, self.arena.data_ptr(), wptr)
+            self.bound = BoundProgram(self.prog, self.arena.data_ptr(), wptr, stream=st)
 
 
 # ------------------------------------------------------------------------------------------
@@ -750,7 +752,13 @@ class _Lowering:
             LayerNorm's fp16 output."""
             # (measured, b=2 x 24 frames: 63 vs 61 + 38 us at the 32x32 level, 55 vs 49 + 21 us at 16x16; at K = 1280 the 192x192
             #  tile's main loop loses more than the fusion saves — 60 vs 43 + 13 us — so the 8x8 / 4x4 levels keep the pair)
-            if kind != "spatial" and self.fused_tattn and P.tattn_pixels_per_tile(F) >= 1 and inner % 64 == 0 and inner <= 640:
+            #  The tile holds min(12, 192 // F) pixels x F frames: below 144 of its 192 rows (clips shorter than 12 frames: 50 % at 8 frames,
+            #  25 % at 4) the padding rows cost more MFMA time than the fusion saves, and the projection + attention pair is kept; so it is
+            #  when this attention's weights are hi + lo split (`split_weight_prefixes`: the fused op has no second weight pass).
+            split_here = bool(self.net.split_weight_prefixes) and f"{prefix}.attn{tag}".startswith(tuple(self.net.split_weight_prefixes))
+            min_rows = 1 if getattr(self.net, "fused_temporal_attention", False) == "force" else 144      # "force": tests of short clips
+            if kind != "spatial" and self.fused_tattn and P.tattn_pixels_per_tile(F) * F >= min_rows and inner % 64 == 0 and inner <= 640 \
+                    and not split_here:
                 # temporal self-attention: QKV projection + attention in ONE launch (q / k / v never reach HBM)
                 a = P.alloc(Mrows, inner, "f16")
                 P.qkv_temporal_attention(f"{prefix}.attn{tag}.qkv_attn", n, self.w_qkv_heads(f"{prefix}.attn{tag}"), a, samples=B, frames=F,
