@@ -9,15 +9,21 @@ A "step" is ONE whole video through the hot path behind the reference's entry po
 classifier-free guidance 9, eta 0; cond+uncond batched => 50 b=2 UNet forwards + 50 fused
 update kernels) + batched VAE decode of all frames + uint8 conversion, all on device
 (inputs — noise, conditioning, weights — are resident in HBM before the timed region).
-Workload, every N: BASELINE.json configs[1] — ModelScope t2v fp16, 24 frames @256x256, one video per GPU in flight
-(`replicas`: videos are independent objects, no data-path collective; weak scaling, so the per-N values are comparable).
+Workload: BASELINE.json configs[1] — ModelScope t2v fp16, 24 frames @256x256 (the clip BASELINE.json's metric names).
+N = 1: one video on the GPU (cond + uncond batched as b=2).
+N > 1 (round 4): the headline is north_star's FRAME-PARALLEL layout — ONE clip on all N GPUs, strong scaling:
+N = 2 the CFG pair (cond | uncond forwards on 2 GPUs, eps all-gather per step), even N >= 4 the clip's frames sharded along T
+over N/2 GPUs x the CFG pair, the exchanges inside a UNet forward executed by the library over its own RCCL communicator
+(csrc/comm.hip).  That layout has never run on more than one GPU in the build environment, so it is measured FIRST, by rank 0,
+as its own N-rank job under a timeout (own process group, killed as a group): >= 1 warm-up + K timed videos of the 24-frame
+clip, then of configs[2]'s 125-frame clip (`clip_125f`), after a first-forward self-check (library collectives bit-equal to
+the host executor the gloo tests pin).  If that job exits 0 its line IS this run's line (`scaling: "strong"`,
+`config.layout: "pairs" | "tshard"`, `rccl_communicators` filled) and the N ranks then time `replicas` — one independent
+24-frame video per GPU, no data-path collective — as the side figure.  If it fails or times out, `replicas` (weak scaling) is
+the headline and `config.layout_fallback` carries the reason: a hang of the RCCL path can cost the strong-scaling figure, never
+the run.  Odd N > 1 has no collective layout: replicas.  `--parallel replicas | pairs | tshard` select a layout explicitly.
 `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment launches its own N ranks (re-exec under
 torch.distributed.run on 127.0.0.1, the reference's launcher does the same: scripts/videocrafter/ddp_wrapper.py:9-13).
-Beside the headline, rank 0 then times the COLLECTIVE layout of that N as a separate N-rank job under a timeout and reports
-it as `collective_layout`: N = 2 — one video per CFG pair (eps all-gather per step); even N >= 4 — configs[2], ONE 125-frame
-video, frames sharded along T over N/2 GPUs x the CFG pair, exchanges executed by the library over its own RCCL communicators
-(north_star's layout; `--parallel tshard` makes it the headline).  It runs in its own job so that a failure or hang of the
-RCCL path can never take the headline measurement down with it.
 Weights are random-init of the exact ModelScope architecture (no checkpoints offline).
 
 Prints ONE JSON line (rank 0) with the driver's fields plus
@@ -272,7 +278,7 @@ def _launch_env():
     return env
 
 
-def self_launch(n: int, argv, timeout_s=None, capture=False):
+def self_launch(n: int, argv, timeout_s=None, capture=False, stderr_path=None):
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, one process per GPU, under
     torch.distributed.run on 127.0.0.1 (ddp_wrapper.py:9-13 does the same for the reference's VideoCrafter sampling).
     -> (exit code, stdout or None)."""
@@ -288,7 +294,9 @@ def self_launch(n: int, argv, timeout_s=None, capture=False):
     # started are killed together (a hung RCCL call must not leave orphaned ranks holding the GPUs for whatever runs next).
     # The top-level self-launch stays in the caller's process group, so whoever stops `python bench.py` stops the ranks too.
     import signal
-    proc = subprocess.Popen(cmd, env=_launch_env(), stdout=subprocess.PIPE if capture else None, text=True, start_new_session=capture)
+    errf = open(stderr_path, "w") if stderr_path else None      # the bounded job's stderr: kept for the fallback's `reason`
+    proc = subprocess.Popen(cmd, env=_launch_env(), stdout=subprocess.PIPE if capture else None, stderr=errf, text=True,
+                            start_new_session=capture)
 
     def stop():
         try:
@@ -311,25 +319,67 @@ def self_launch(n: int, argv, timeout_s=None, capture=False):
 
 
 def collective_layout_job(n: int, args, timeout_s: int):
-    """The collective layout of N GPUs (pairs at N = 2, T-shard x CFG pair for even N >= 4) as its OWN N-rank job, bounded by a
-    timeout: a failure or hang of the RCCL path is reported, it cannot take the headline down.  Called by rank 0 after the
-    headline job's process group is gone (the other ranks have released their GPUs' queues; memory is not a constraint)."""
+    """The frame-parallel layout of N GPUs (pairs at N = 2, T-shard x CFG pair for even N >= 4) as its OWN N-rank job, bounded
+    by a timeout: a failure or hang of the RCCL path is reported, it cannot take the run down.  Called by rank 0 BEFORE the
+    outer job's ranks touch their GPUs.  -> {"ok": True, "line": <the job's JSON line>, ...} | {"ok": False, "reason": ...}."""
+    import tempfile
     mode = "pairs" if n == 2 else "tshard"
-    argv = ["--gpus", str(n), "--parallel", mode, "--steps", "1", "--warmup", "1", "--ddim-steps", str(args.ddim_steps),
-            "--height", str(args.height), "--width", str(args.width), "--no-cpu-baseline", "--also-batched", "0", "--no-collective-job"]
+    argv = ["--gpus", str(n), "--parallel", mode, "--steps", str(args.steps), "--warmup", str(max(1, args.warmup)),
+            "--ddim-steps", str(args.ddim_steps), "--height", str(args.height), "--width", str(args.width), "--no-cpu-baseline",
+            "--also-batched", "0", "--no-collective-job", "--also-frames", str(args.also_frames)]
     if args.frames:
-        argv += ["--frames", str(args.frames)]          # (rehearsals use short clips; default: 125 frames T-sharded, 24 per CFG pair)
+        argv += ["--frames", str(args.frames)]
+    err_path = os.path.join(tempfile.gettempdir(), f"t2v_bench_collective_{os.getpid()}.err")
     t0 = time.time()
-    rc, out = self_launch(n, argv, timeout_s=timeout_s, capture=True)
+    rc, out = self_launch(n, argv, timeout_s=timeout_s, capture=True, stderr_path=err_path)
+    job_s = round(time.time() - t0, 1)
+    tail = ""
+    try:
+        with open(err_path) as fh:
+            txt = fh.read()
+        sys.stderr.write(txt)                      # the job's diagnostics stay visible in this run's stderr
+        keep = [ln for ln in txt.splitlines() if ln.strip() and "Warning" not in ln]
+        marked = [ln for ln in keep if "[bench]" in ln or "Error" in ln or "error" in ln]
+        tail = " | ".join((marked or keep)[-3:])[-600:]
+        os.remove(err_path)
+    except OSError:
+        pass
     line = next((ln for ln in reversed((out or "").splitlines()) if ln.startswith("{")), None)
     if rc == 0 and line:
-        d = json.loads(line)
-        return {"layout": mode, "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "scaling": d["scaling"],
-                "metric": d["metric"], "frames_per_video": d["config"]["frames_per_video"], "parallelism": d["config"]["parallelism"],
-                "rccl_communicators": d["config"].get("rccl_communicators"), "whole_video": d.get("roofline", {}).get("whole_video"),
-                "job_s": round(time.time() - t0, 1), "note": "separate N-rank job after the headline; not the headline"}
-    return {"layout": mode, "value": None, "exit_code": rc, "job_s": round(time.time() - t0, 1),
-            "note": ("timed out" if rc == 124 else "failed") + f" (limit {timeout_s}s); the headline is unaffected"}
+        return {"ok": True, "layout": mode, "line": json.loads(line), "job_s": job_s, "timeout_s": timeout_s}
+    why = f"timed out after {timeout_s}s" if rc == 124 else (f"exit code {rc}" if rc != 0 else "printed no JSON line")
+    return {"ok": False, "layout": mode, "exit_code": rc, "job_s": job_s, "timeout_s": timeout_s, "reason": f"{why}: {tail}" if tail else why}
+
+
+def _handoff_path():
+    """Where rank 0 publishes the collective job's result to the other ranks of THIS launch (one node: a local file; the ranks
+    share their parent — the launcher agent — and the rendezvous port)."""
+    import tempfile
+    return os.path.join(tempfile.gettempdir(), f"t2v_bench_handoff_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}.json")
+
+
+def collective_first(world: int, rank: int, args, t_start: float):
+    """Every rank returns the same dict: rank 0 runs `collective_layout_job` while the others wait (idle, no GPU context yet)."""
+    path = _handoff_path()
+    if rank == 0:
+        try:
+            res = collective_layout_job(world, args, args.collective_timeout)
+        except Exception as exc:                    # noqa: BLE001 — the other ranks are waiting for SOME answer
+            res = {"ok": False, "layout": "pairs" if world == 2 else "tshard", "reason": f"launcher failed: {type(exc).__name__}: {exc}"}
+        with open(path + ".tmp", "w") as fh:
+            json.dump(res, fh)
+        os.replace(path + ".tmp", path)
+        return res
+    deadline = time.time() + args.collective_timeout + 180
+    while time.time() < deadline:
+        try:
+            if os.path.getmtime(path) >= t_start - 5:
+                with open(path) as fh:
+                    return json.load(fh)
+        except (OSError, ValueError):
+            pass
+        time.sleep(0.5)
+    return {"ok": False, "layout": "pairs" if world == 2 else "tshard", "reason": "rank 0 never published the collective job's result"}
 
 
 LVDM_UNET_TFLOP_16F = 3.302     # SURVEY App. B: UNetModel.forward, 16 frames @256x256 (2*MAC, conv + matmul)
@@ -436,17 +486,22 @@ def emit(obj):
 
 
 def choose_layout(world: int, requested: str, frames_arg: int = 0):
-    """-> (layout, frames per video).  auto: configs[1] at every N — one 24-frame video per GPU (cond + uncond batched as b=2):
-    `single` on one GPU, `replicas` on N (weak scaling, the per-N values are comparable).  `--parallel pairs | tshard` select the
-    collective layouts explicitly (tshard = configs[2], ONE 125-frame video, frames sharded along T over world / 2 GPUs x the CFG
-    pair — north_star's layout); under auto they are timed beside the headline as a separate job (`collective_layout`).
-    `--frames` overrides the frame count only."""
+    """-> (layout of THIS job's ranks, frames per video).  The clip is configs[1]'s 24 frames in every layout (BASELINE.json's
+    metric names it; configs[2]'s 125-frame clip is timed beside it: `--also-frames`).  auto: `single` on one GPU; on N > 1 the
+    frame-parallel layout is measured first as its own bounded job (`collective_first`) and THIS job's ranks run `replicas` — the
+    side figure, or the headline if that job failed.  `--parallel pairs | tshard | replicas` select a layout explicitly (tshard:
+    ONE clip, frames sharded along T over world / 2 GPUs x the CFG pair — north_star's layout).  `--frames` overrides the clip."""
     mode = requested
     if mode == "auto":
         mode = "single" if world == 1 else "replicas"
     if world == 1:
         mode = "single"
-    return mode, (frames_arg or (125 if mode == "tshard" else 24))
+    return mode, (frames_arg or 24)
+
+
+def collective_layout_of(world: int):
+    """The frame-parallel layout `auto` measures first at this N (None: there is none — odd N, one GPU)."""
+    return "pairs" if world == 2 else ("tshard" if world >= 4 and world % 2 == 0 else None)
 
 
 BASELINE_CONFIGS = {(24, 256, 256): "BASELINE.json configs[1]", (125, 256, 256): "BASELINE.json configs[2]",
@@ -454,13 +509,15 @@ BASELINE_CONFIGS = {(24, 256, 256): "BASELINE.json configs[1]", (125, 256, 256):
 
 
 def main():
+    t_start = time.time()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2, help="timed videos")
+    ap.add_argument("--steps", type=int, default=3, help="timed videos")
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--frames", type=int, default=0,
-                    help="frames per video; default 24 (configs[1]) for N <= 2 and the replicas layout, 125 (configs[2]) for the "
-                         "T-sharded layout of N >= 4")
+    ap.add_argument("--frames", type=int, default=0, help="frames per video; default 24 (configs[1], the clip BASELINE.json's metric names)")
+    ap.add_argument("--also-frames", type=int, default=-1,
+                    help="N > 1, frame-parallel layouts: also time a clip of this many frames in the same job and report it as `clip_125f` "
+                         "(default: 125 = configs[2]; with --frames: skipped; 0 = skip)")
     ap.add_argument("--height", type=int, default=256)
     ap.add_argument("--width", type=int, default=256)
     ap.add_argument("--ddim-steps", type=int, default=50)
@@ -473,13 +530,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-op roofline / calibration section (launch-path rehearsals only)")
     ap.add_argument("--parallel", default="auto", choices=["auto", "replicas", "pairs", "tshard"],
-                    help="N>1 layout; auto = one 24-frame video per GPU (replicas; configs[1] at every N) as the headline, with the "
-                         "collective layout of that N (pairs at N=2, ONE T-sharded 125-frame video for even N>=4) timed beside it as a "
-                         "separate job; pairs / tshard make the collective layout the headline")
+                    help="N>1 layout; auto = the frame-parallel layout of that N (pairs at N=2, T-shard x CFG pair for even N>=4: ONE clip on "
+                         "all GPUs) measured first as its own bounded job and reported as the headline, `replicas` (one video per GPU) "
+                         "beside it — or as the headline, with the reason, if that job fails; replicas / pairs / tshard force a layout")
     ap.add_argument("--no-collective-job", action="store_true",
-                    help="N>1, --parallel auto: skip the separate job that times the collective layout beside the headline")
-    ap.add_argument("--collective-timeout", type=int, default=int(os.environ.get("T2V_BENCH_COLLECTIVE_TIMEOUT", 180)),
-                    help="seconds the separate collective-layout job may take before it is abandoned (reported, headline unaffected)")
+                    help="N>1, --parallel auto: do not run the bounded frame-parallel job; the headline is replicas")
+    ap.add_argument("--collective-timeout", type=int, default=int(os.environ.get("T2V_BENCH_COLLECTIVE_TIMEOUT", 600)),
+                    help="seconds the bounded frame-parallel job may take before it is abandoned (then: replicas headline + reason)")
     ap.add_argument("--model", default="modelscope", choices=["modelscope", "lvdm"],
                     help="modelscope (default; configs[1]-[3]) or lvdm = VideoCrafter, BASELINE.json configs[4]: 16 frames @256x256 through "
                          "sample_text2video (1 GPU; reported beside the headline, never the driver's default line)")
@@ -487,6 +544,8 @@ def main():
     ap.add_argument("--launch-check", action="store_true",
                     help="only check the launch path: ranks rendezvous over gloo, all-reduce their ranks, rank 0 prints one JSON line (no GPU)")
     args = ap.parse_args()
+    if args.also_frames < 0:
+        args.also_frames = 0 if args.frames else 125
     if args.cpu_baseline_worker:
         cpu_baseline_worker(args.frames, args.ddim_steps)
         return
@@ -518,6 +577,19 @@ def main():
         if world > 1:
             dist.destroy_process_group()
         return
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+
+    # ---- N > 1, auto: the frame-parallel layout FIRST, as its own bounded N-rank job (rank 0 launches it; nobody here has touched a GPU yet)
+    requested = args.parallel
+    coll = None
+    if (world > 1 and requested == "auto" and not args.no_collective_job and collective_layout_of(world) is not None
+            and os.environ.get("T2V_BENCH_COLLECTIVE_JOB", "1") != "0"):
+        coll = collective_first(world, rank, args, t_start)
+        if rank == 0:
+            print(f"[bench] frame-parallel job ({coll.get('layout')}): " + ("ok, " + json.dumps({k: coll['line'][k] for k in ('value', 'ms_per_step')})
+                                                                              if coll.get("ok") else "FAILED — " + str(coll.get("reason"))),
+                  file=sys.stderr, flush=True)
+
     ctl = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -525,17 +597,17 @@ def main():
         # RCCL (device buffers staged through the host, parallel.all_gather_into) — never a measurement configuration
         one_device = os.environ.get("T2V_BENCH_ONE_DEVICE") == "1"
         if one_device:
-            # several processes share the GPU: the single-pass GroupNorm's grid barrier needs all its workgroups resident,
-            # which more than two concurrent processes cannot guarantee -> three-launch path in the rehearsal
+            # several processes share the GPU: the single-pass GroupNorm's grid barrier wants an otherwise idle device (its wait is
+            # bounded — a co-tenant costs a reported fault, not a hang — but the rehearsal should not trip it) -> three-launch path
             os.environ.setdefault("T2V_GN_COOP", "0")
         dist.init_process_group(backend="gloo" if one_device else "nccl")      # "nccl" is RCCL on ROCm
         ctl = dist.new_group(backend="gloo")         # control plane (layout agreement), never on the data path
         if one_device:
             local_rank = 0
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
+    from sd_webui_text2video_amd import _lib as L
     from sd_webui_text2video_amd import configs
     from sd_webui_text2video_amd import parallel, pipeline, unet as U, vae as V
 
@@ -550,7 +622,6 @@ def main():
     cond = torch.randn(1, 77, 1024, generator=g).half().to(dev)
     uncond = torch.randn(1, 77, 1024, generator=g).half().to(dev)
 
-    requested = args.parallel
     mode, frames = choose_layout(world, requested, args.frames)
 
     def build(mode_, frames_, videos=args.videos):
@@ -582,6 +653,7 @@ def main():
             out_ = runner_(cond, uncond, 1234 + i)
         sync()
         el = time.perf_counter() - t0
+        L.async_status()                           # a kernel that gave up at a grid barrier invalidates the timing: fail loudly
         if world > 1:
             tmax = torch.tensor([el], device=dev, dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -589,45 +661,67 @@ def main():
         assert out_ is not None and out_.dtype == torch.uint8
         return el
 
-    fallback = None
-    runner = None
-    err = ""
+    # ---- this job's own layout: first pass (lowering, weight packing, communicator set-up) + the frame-parallel self-check
+    runner, err, self_check = None, "", None
     try:
         runner = build(mode, frames)
-        if os.environ.get("T2V_BENCH_INJECT_FAILURE") in ("all", str(rank)):   # rehearsal hook: exercise the collective fallback
+        if os.environ.get("T2V_BENCH_INJECT_FAILURE") in ("all", str(rank)) and mode in ("pairs", "tshard"):   # rehearsal hook
             raise RuntimeError("injected failure (T2V_BENCH_INJECT_FAILURE)")
-        runner(cond, uncond, 999)                  # first pass: lowering, weight packing, communicator set-up
+        if hasattr(runner, "self_check"):
+            # first forward of the T-sharded UNet twice: exchanges inside the library (RCCL on the launch stream) vs the host
+            # executor the gloo tests pin — bit-equal on every rank, or nothing is timed
+            self_check = runner.self_check(cond)
+            if not self_check.get("ok", False):
+                raise RuntimeError(f"frame-parallel self-check failed: {self_check}")
+        runner(cond, uncond, 999)
         sync()
         ok = True
     except Exception as exc:                       # noqa: BLE001 — reported, never silent (below)
         ok, err = False, f"{type(exc).__name__}: {exc}"
     if not all_ok(ok):
-        # An explicitly requested layout that breaks fails the run.  Under `auto` every rank switches TOGETHER to the
-        # collective-free layout and the JSON line says so (requested vs. actual layout + the first error seen here).
-        # (This covers failures every rank sees at the same point — a missing library, an unsupported shape.  A failure
-        # on SOME ranks while the others already wait inside a collective cannot be agreed on: the job then ends with
-        # the process-group timeout, an explicit failure, never a silent change of what is measured.)
-        if requested != "auto" or world == 1:
-            raise RuntimeError(f"layout {mode!r} failed on rank {rank}: {err or 'another rank failed'}")
-        fallback = {"requested_layout": mode, "reason": err or "failure on another rank"}
-        print(f"[bench] rank {rank}: layout {mode!r} failed ({fallback['reason']}); all ranks switch to replicas", file=sys.stderr, flush=True)
-        net.t_shard = None
-        mode, frames = "replicas", args.frames or 24
-        runner = build(mode, frames)
+        # Layouts are explicit in this job (auto's own ranks run replicas, which has no collective to fail): a layout that breaks
+        # fails the job — the OUTER run, which launched it under a timeout, then reports replicas with this as the reason.
+        print(f"[bench] rank {rank}: layout {mode!r} failed: {err or 'failure on another rank'}", file=sys.stderr, flush=True)
+        raise RuntimeError(f"layout {mode!r} failed on rank {rank}: {err or 'another rank failed'}")
+    side_only = bool(coll is not None and coll.get("ok"))     # the headline already exists: this job's replicas pass is the side figure
     cal_before = None
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and not args.no_roofline and not side_only:
         try:
             cal_before = calibration_gemm(dev)
         except Exception:                          # noqa: BLE001
             cal_before = None
-    elapsed = timed(runner, args.warmup, args.steps)
+    n_warm, n_steps = (1, min(args.steps, 2)) if side_only else (args.warmup, args.steps)
+    elapsed = timed(runner, n_warm, n_steps)
 
-    total_frames = runner.frames_per_video_all_ranks * args.steps
+    total_frames = runner.frames_per_video_all_ranks * n_steps
     value = total_frames / elapsed
-    ms_per_step = elapsed / args.steps * 1e3
+    ms_per_step = elapsed / n_steps * 1e3
     geom = (frames, args.height, args.width)
     named = BASELINE_CONFIGS.get(geom, "not a BASELINE.json configuration") if args.ddim_steps == 50 else \
         f"{BASELINE_CONFIGS.get(geom, 'custom geometry')} with {args.ddim_steps} instead of 50 steps"
+    rehearsal = world > 1 and os.environ.get("T2V_BENCH_ONE_DEVICE") == "1"
+
+    if side_only:
+        # ---- the frame-parallel job's line IS the line; this job adds the replicas figure --------------------------------
+        result = coll["line"]
+        result["config"]["layout_requested"] = requested
+        result["replicas"] = {"value": round(value, 4), "unit": "frames/s", "ms_per_step": round(ms_per_step, 2), "scaling": "weak",
+                              "videos_in_flight": world, "steps": n_steps, "warmup": n_warm,
+                              "note": "one independent 24-frame video per GPU (no data-path collective), timed by the N ranks of the outer job "
+                                      "after the frame-parallel job; not the headline"}
+        result["collective_job"] = {"layout": coll["layout"], "job_s": coll["job_s"], "timeout_s": coll["timeout_s"],
+                                    "note": "the headline was measured FIRST, by its own N-rank job under this timeout (own process group, "
+                                            "killed as a group on expiry); had it failed, replicas would be the headline with the reason"}
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            try:
+                os.remove(_handoff_path())
+            except OSError:
+                pass
+            emit(result)
+        return
 
     result = {
         "metric": f"denoised frames/sec (UNet+VAE), ModelScope {frames}f@{args.width}x{args.height}",
@@ -641,21 +735,38 @@ def main():
                    "frames_per_video": runner.frames_per_video_all_ranks, "videos_per_batch": args.videos,
                    "layout": mode, "layout_requested": requested, "parallelism": runner.describe},
     }
-    if fallback is not None:
-        result["config"]["layout_fallback"] = fallback
-    if world > 1 and os.environ.get("T2V_BENCH_ONE_DEVICE") == "1":
+    if coll is not None:          # the frame-parallel job ran and failed: replicas is the headline, and the line says why
+        result["config"]["layout_fallback"] = {"requested_layout": coll.get("layout"), "reason": coll.get("reason"),
+                                               "exit_code": coll.get("exit_code"), "job_s": coll.get("job_s"),
+                                               "timeout_s": coll.get("timeout_s")}
+    if self_check is not None:
+        result["config"]["self_check"] = self_check
+    if rehearsal:
         result["data"] = "synthetic; REHEARSAL: all ranks on one GPU over gloo — not a measurement"
     result["config"]["rccl_communicators"] = runner.communicators() if hasattr(runner, "communicators") else []
-    if world > 1 and mode != "replicas" and not args.no_collective_job:
-        # the collective-free layout beside the headline: every GPU its own 24-frame video (configs[1] per GPU).  (Not inside the
-        # bounded side job of a default run, which passes --no-collective-job: there the replicas number IS the parent's headline.)
+
+    if world > 1 and mode in ("pairs", "tshard") and args.also_frames and args.also_frames != frames:
+        # configs[2]'s clip (125 frames) in the same layout, same job: 1 warm-up + K timed videos
+        key, ok2, note = ("clip_125f" if args.also_frames == 125 else "clip_other"), True, ""
         try:
-            rep = build("replicas", 24, videos=1)
-            el = timed(rep, 1, 1)
-            result["replicas"] = {"value": round(rep.frames_per_video_all_ranks / el, 4), "unit": "frames/s", "ms_per_step": round(el * 1e3, 2),
-                                  "note": "one independent 24-frame video per GPU (no data-path collective); not the headline"}
-        except Exception as exc:                   # noqa: BLE001
-            result["replicas"] = {"value": None, "note": f"failed: {type(exc).__name__}: {exc}"}
+            net.t_shard = None
+            big = build(mode, args.also_frames, videos=1)
+            big(cond, uncond, 998)
+            sync()
+            el = timed(big, 1, args.steps)
+            bgeom = (args.also_frames, args.height, args.width)
+            result[key] = {
+                "frames_per_video": args.also_frames, "value": round(args.also_frames * args.steps / el, 4), "unit": "frames/s",
+                "ms_per_step": round(el / args.steps * 1e3, 2), "steps": args.steps, "warmup": 1, "scaling": "strong",
+                "workload": BASELINE_CONFIGS.get(bgeom, "custom geometry") if args.ddim_steps == 50 else
+                f"{BASELINE_CONFIGS.get(bgeom, 'custom geometry')} with {args.ddim_steps} instead of 50 steps",
+                "parallelism": big.describe}
+            del big
+        except Exception as exc:                   # noqa: BLE001 — the headline stands; the side clip says what happened
+            ok2, note = False, f"{type(exc).__name__}: {exc}"
+            print(f"[bench] rank {rank}: {args.also_frames}-frame clip failed: {note}", file=sys.stderr, flush=True)
+        if not all_ok(ok2):
+            result[key] = {"frames_per_video": args.also_frames, "value": None, "note": "failed: " + (note or "on another rank")}
 
     cal0 = None
     if rank == 0 and not args.no_roofline:
@@ -692,6 +803,7 @@ def main():
             "unet_step_ms_events": round(step_ms, 3),
             "unet_step_tflops_all_kernels": round(prog.total_flops() / (step_ms * 1e-3) / 1e12, 1),
             "unet_step_frac_of_peak": round(prog.total_flops() / (step_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+            "geometry": f"one rank's UNet forward in this layout WITHOUT its exchanges: b={runner.unet_batch}, {F_loc} frames",
             "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 --pmc, profiles/r0N_pmc_traffic.json)",
             # box calibration either side of the timed region: the same kernel family on an 8192^3 fp16 GEMM (random data)
             "calibration": {"gemm_8192_tflops_before": cal_before, **(cal0 or {}),
@@ -726,15 +838,10 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        want_job = (world > 1 and requested == "auto" and not args.no_collective_job and (world == 2 or world % 2 == 0)
-                    and os.environ.get("T2V_BENCH_COLLECTIVE_JOB", "1") != "0")
-        if want_job:
-            # the other ranks are leaving; this rank's own buffers can go too before the N-rank job starts.  The headline is
-            # complete at this point: keep a copy on stderr in case whoever runs us loses patience with the side job
-            print("[bench] headline before the collective-layout job: " + json.dumps(result), file=sys.stderr, flush=True)
-            del runner
-            torch.cuda.empty_cache()
-            result["collective_layout"] = collective_layout_job(world, args, args.collective_timeout)
+        try:
+            os.remove(_handoff_path())
+        except OSError:
+            pass
         emit(result)
 
 

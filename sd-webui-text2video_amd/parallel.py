@@ -378,6 +378,57 @@ class _TShardRunner:
                 {"kind": f"torch.distributed {dist.get_backend()} world group (uint8 frame gather)", "size": self.topo.world}]
 
     @torch.no_grad()
+    def self_check(self, cond) -> dict:
+        """First forward of the T-sharded UNet, twice, on the same seeded inputs: (1) the production path — the exchanges are ops of
+        the denoise program executed by the library over its own RCCL communicator (csrc/comm.hip) — and (2) the same op records
+        through `ShardedExecutor`, whose collectives go through torch.distributed (the path the gloo CPU tests pin against the
+        unsharded forward).  Both must be BIT-equal on every rank; bench.py times nothing if they are not (a wrong
+        answer must not be timed).  Collective: every rank of the job calls it."""
+        from .program import BoundProgram
+        net, topo, dev = self.pipe.sd_model, self.topo, self.pipe.device
+        spec = topo.spec
+        g = torch.Generator().manual_seed(4242)                    # the same clip on every rank; each takes its slice
+        x = torch.randn(1, 4, self.frames_total, self.height // 8, self.width // 8, generator=g)
+        x = x[:, :, spec.offset:spec.offset + spec.frames].contiguous().to(dev)
+        t = torch.tensor([500.0], device=dev)
+        c = cond.to(dev)
+        saved_env = os.environ.get("T2V_COLLECTIVES")
+        net.t_shard = topo.tshard
+        try:
+            out_lib = net(x, t, c).clone()
+            comp = next(cmp for key, cmp in net._programs.items() if spec in key)
+            n_coll = sum(1 for op in comp.prog.ops if op.kind in COLLECTIVE_KINDS)
+            in_library = isinstance(comp.bound, BoundProgram) and comp.bound.comm is not None
+            equal = True
+            if in_library:
+                keep_bound, keep_arena = comp.bound, comp.arena
+                os.environ["T2V_COLLECTIVES"] = "host"
+                comp.bound = None                                   # re-bind: fresh arena, exchanges from the host
+                out_host = net(x, t, c).clone()
+                assert isinstance(comp.bound, ShardedExecutor)
+                torch.cuda.synchronize(dev)
+                equal = bool(torch.equal(out_lib, out_host)) and bool(torch.isfinite(out_lib.float()).all())
+                comp.bound, comp.arena = keep_bound, keep_arena     # the timed runs use the library path again
+                comp.ctx_token = comp.ctx_bound = None
+        finally:
+            net.t_shard = None
+            if saved_env is None:
+                os.environ.pop("T2V_COLLECTIVES", None)
+            else:
+                os.environ["T2V_COLLECTIVES"] = saved_env
+        flag = torch.tensor([0 if equal else 1], dtype=torch.int32)
+        if _host_staged(None):
+            dist.all_reduce(flag)
+        else:
+            flag = flag.to(dev)
+            dist.all_reduce(flag)
+        ok = int(flag.item()) == 0
+        return {"ok": ok, "collective_ops_per_forward": n_coll,
+                "compared": ("library communicator (RCCL on the launch stream) vs host executor (torch.distributed): bit-equal on every rank"
+                             if in_library else "exchanges already run through the host executor in this set-up (gloo group): nothing to compare"),
+                "in_library": bool(in_library)}
+
+    @torch.no_grad()
     def __call__(self, cond, uncond, seed):
         pipe, topo = self.pipe, self.topo
         dev = pipe.device

@@ -71,12 +71,83 @@ def test_bench_refuses_more_gpus_than_the_node_has():
 
 
 def test_layout_choice_is_comparable_across_n():
-    """the headline workload is configs[1] at every N (one 24-frame video per GPU); the collective layouts are
-    explicit choices (and timed beside the headline as their own job)."""
+    """The clip is configs[1]'s 24 frames in every layout (BASELINE.json's metric names it), so the per-N values are comparable.
+    Round 4: under `auto` the frame-parallel layout of that N is measured first as its own bounded job and is the
+    headline; the outer job's own ranks run replicas (side figure / fallback)."""
     sys.path.insert(0, ROOT)
     import bench
     assert bench.choose_layout(1, "auto") == ("single", 24)
     for n in (2, 3, 4, 8):
         assert bench.choose_layout(n, "auto") == ("replicas", 24)
-    assert bench.choose_layout(8, "tshard") == ("tshard", 125) and bench.choose_layout(2, "pairs") == ("pairs", 24)
-    assert bench.choose_layout(8, "tshard", 64) == ("tshard", 64)
+    assert bench.choose_layout(8, "tshard") == ("tshard", 24) and bench.choose_layout(2, "pairs") == ("pairs", 24)
+    assert bench.choose_layout(8, "tshard", 125) == ("tshard", 125)
+    assert [bench.collective_layout_of(n) for n in (1, 2, 3, 4, 5, 6, 8)] == [None, "pairs", None, "tshard", None, "tshard", "tshard"]
+
+
+def _args(**kw):
+    import argparse
+    base = dict(steps=3, warmup=1, ddim_steps=50, height=256, width=256, frames=0, also_frames=125, collective_timeout=5)
+    base.update(kw)
+    return argparse.Namespace(**base)
+
+
+def test_frame_parallel_job_result_and_fallback_reason(monkeypatch, tmp_path):
+    """Round 4: the frame-parallel layout is measured by its own bounded job; its JSON line becomes the headline,
+    a failure / timeout becomes `layout_fallback.reason` (with the job's last diagnostics), never an exception."""
+    sys.path.insert(0, ROOT)
+    import bench
+    seen = {}
+
+    def fake_ok(n, argv, timeout_s=None, capture=False, stderr_path=None):
+        seen["argv"], seen["timeout"] = list(argv), timeout_s
+        open(stderr_path, "w").write("[Gloo] banner\n")
+        return 0, 'noise\n{"value": 55.5, "ms_per_step": 432.1, "config": {"layout": "tshard"}}\n'
+    monkeypatch.setattr(bench, "self_launch", fake_ok)
+    res = bench.collective_layout_job(8, _args(), 77)
+    assert res["ok"] and res["layout"] == "tshard" and res["line"]["value"] == 55.5 and res["timeout_s"] == 77
+    a = seen["argv"]
+    assert a[a.index("--parallel") + 1] == "tshard" and a[a.index("--steps") + 1] == "3" and a[a.index("--warmup") + 1] == "1"
+    assert a[a.index("--also-frames") + 1] == "125" and "--no-collective-job" in a and "--frames" not in a and seen["timeout"] == 77
+    assert bench.collective_layout_job(2, _args(warmup=0), 5)["layout"] == "pairs"
+    assert seen["argv"][seen["argv"].index("--warmup") + 1] == "1"          # the bounded job always warms up at least once
+
+    def fake_timeout(n, argv, timeout_s=None, capture=False, stderr_path=None):
+        open(stderr_path, "w").write("UserWarning: x\n[bench] rank 3: layout 'tshard' failed: RuntimeError: ncclAllGather: unhandled system error\n")
+        return 124, ""
+    monkeypatch.setattr(bench, "self_launch", fake_timeout)
+    res = bench.collective_layout_job(4, _args(), 9)
+    assert not res["ok"] and res["exit_code"] == 124 and "timed out after 9s" in res["reason"] and "ncclAllGather" in res["reason"]
+
+    def fake_crash(n, argv, timeout_s=None, capture=False, stderr_path=None):
+        open(stderr_path, "w").write("")
+        return 1, "{not json"
+    monkeypatch.setattr(bench, "self_launch", fake_crash)
+    res = bench.collective_layout_job(4, _args(), 9)
+    assert not res["ok"] and res["reason"].startswith("exit code 1")
+
+
+HANDOFF_WORKER = r'''
+import json, os, sys, time
+sys.path.insert(0, sys.argv[1])
+import bench
+rank = int(sys.argv[2])
+import argparse
+args = argparse.Namespace(collective_timeout=20)
+if rank == 0:
+    def job(world, a, timeout):
+        time.sleep(1.0)
+        return {"ok": True, "layout": "tshard", "line": {"value": 12.5}, "job_s": 1.0, "timeout_s": timeout}
+    bench.collective_layout_job = job
+print("RES " + json.dumps(bench.collective_first(4, rank, args, time.time())), flush=True)
+'''
+
+
+def test_every_rank_gets_the_frame_parallel_jobs_result():
+    """rank 0 runs the bounded job while the other ranks of the launch wait for the hand-off file (same parent, same port)."""
+    env = dict(os.environ, MASTER_PORT="29791")
+    procs = [subprocess.Popen([sys.executable, "-c", HANDOFF_WORKER, ROOT, str(r)], stdout=subprocess.PIPE, text=True, env=env) for r in (1, 2, 0)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    res = [json.loads(next(ln for ln in o.splitlines() if ln.startswith("RES "))[4:]) for o in outs]
+    assert all(r == res[0] for r in res) and res[0]["ok"] and res[0]["line"]["value"] == 12.5
+    import tempfile
+    os.remove(os.path.join(tempfile.gettempdir(), f"t2v_bench_handoff_{os.getpid()}_29791.json"))
