@@ -125,6 +125,8 @@ enum t2v_gather {
  *         10 = 192x192 on 12 waves, T2V_EPI_TATTN only),
  *      23 tconv halo (input rows are [clip][F+2][HW]: one halo frame either side, T-sharding);
  *         for CONV3X3: 1 = zero padding (0,1,0,1) instead of (1,1,1,1) (LDM encoder Downsample, taps at +0..+2)
+ *      PLAIN gather only: 11 = 1 -> hi + lo fp16 output (fp16 out, plain epilogue, ldc >= 2N): out[m, N + n] = fp16(v - float(fp16(v)))
+ *         beside out[m, n] = fp16(v) — a consumer GEMM over rows [hi | lo] with weights [W | W] (K = 2N) sees v with ~22 bits;
  *      PLAIN gather only: 8 = 1 -> fused LayerNorm second output (tile 8, N == 320, fp32 out, no split-K): p[7] fp16 [M, i[9]] =
  *         LayerNorm(out row, eps f[0]) * gamma + beta with p[3] = fp32 [2N] gamma | beta (instead of a row bias)
  *   p: 0 A fp16, 1 W fp16 [N,K], 2 bias fp32 [N] (or [M] if bias_along_m), 3 rowbias fp32
@@ -139,6 +141,8 @@ enum t2v_gather {
  *      15 single-PASS cooperative variant allowed (phase 0, groups <= 32, p[5] given): grid <= one workgroup per CU, the tensor
  *         is read once into registers, statistics meet at a grid barrier (p[5] = T2V_SYNC_BARRIER_INTS zero-initialised uint32 words); the library
  *         uses it when the instance chunks fit (else the launches above on the same scratch);
+ *      16 = 1 (phases 0 / 2, ld_out >= 2C): hi + lo operand split — the low-order fp16 image fp16(y - float(fp16(y))) of every output
+ *         value goes to column C + c of the same output row (consumer: a GEMM with K = 2C against weights [W | W]);
  *      scratch, phase 0: block partials [n_inst][nblk][groups][2] fp64, then {mean, rstd} fp32;  phases 1 / 2: gathered parts
  *      [nparts][n_inst][groups][2] fp64 (phase 1 folds this rank's block partials into its part; ALLGATHER of
  *      n_inst*groups*16 bytes per part), then this rank's block partials, then {mean, rstd};

@@ -79,6 +79,10 @@ int validate_op(const t2v_op& op, int idx) {
         if (op.i[5] < (N / 192) * 64 || op.i[5] % 4 != 0) return bad("fused temporal attention: ldc < heads * 64");
         return 0;
       }
+      if (g == T2V_GATHER_PLAIN && op.i[11] == 1) {       // hi + lo fp16 output
+        if (op.i[17] != T2V_F16 || op.i[16] != T2V_EPI_NONE || op.i[8] == 1 || op.i[5] < 2 * N)
+          return bad("hi + lo output: fp16 out, plain epilogue, no fused LayerNorm, ldc >= 2 N");
+      }
       if (g == T2V_GATHER_PLAIN && op.i[8] == 1) {
         if (op.i[22] != 8 || N != 320 || op.i[19] > 1 || op.i[16] != T2V_EPI_NONE || op.i[17] != T2V_F32 || op.i[18] != 0 || op.i[20] != 0 ||
             K % 64 != 0)
@@ -96,6 +100,7 @@ int validate_op(const t2v_op& op, int idx) {
       if (phase < 0 || phase > 2 || op.i[10] < 0 || op.i[10] >= nparts) return bad("bad GroupNorm phase / part");
       if (op.i[13] != 0 && op.i[13] < op.i[1]) return bad("rows of the largest part < rows");
       if (op.i[12] != 0 && (phase != 0 || (C / groups) % 4 != 0)) return bad("single-launch GroupNorm: phase 0, (C/groups) % 4 == 0");
+      if (op.i[16] != 0 && (phase == 1 || op.i[7] < 2 * C)) return bad("GroupNorm low-order output: not for the statistics-only phase, ld_out >= 2 C");
       if (op.p[0] == 0 || op.p[1] == 0 || op.p[2] == 0 || op.p[4] == 0 || (phase != 1 && op.p[3] == 0)) return bad("null GroupNorm pointer");
       return 0;
     }
@@ -209,6 +214,7 @@ hipError_t launch_op(const t2v_op& op, hipStream_t s) {
       p.out = reinterpret_cast<void*>(op.p[5]);
       p.ws = reinterpret_cast<float*>(op.p[6]);
       p.halo = op.i[23];
+      p.out_lo = (p.gather == T2V_GATHER_PLAIN && op.i[11] == 1) ? 1 : 0;
       const int tile = op.i[22];
       if (p.epi == T2V_EPI_TATTN) {                              // fused QKV projection + temporal attention (tile 10)
         p.F = op.i[8]; p.HW = op.i[9]; p.tpix = op.i[10];

@@ -70,7 +70,12 @@ __device__ __forceinline__ void epi_store(const GemmParams& p, int m, int n, flo
     *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n) = o;
   } else {
     f16x4 o = {(f16)v0, (f16)v1, (f16)v2, (f16)v3};
-    *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(p.out) + (size_t)m * p.ldc + n) = o;
+    f16* dst = reinterpret_cast<f16*>(p.out) + (size_t)m * p.ldc + n;
+    *reinterpret_cast<f16x4*>(dst) = o;
+    if (p.out_lo) {       // low-order image of the rounding, beside the row's N values (GemmParams::out_lo)
+      const f16x4 l = {(f16)(v0 - (float)o[0]), (f16)(v1 - (float)o[1]), (f16)(v2 - (float)o[2]), (f16)(v3 - (float)o[3])};
+      *reinterpret_cast<f16x4*>(dst + p.N) = l;
+    }
   }
 }
 

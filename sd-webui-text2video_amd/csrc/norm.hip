@@ -166,7 +166,7 @@ template <typename T, bool SILU>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ finals,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        f16* __restrict__ out, int rows, int C, int ld_in, int ld_out,
-                                                       int groups) {
+                                                       int groups, int lo_off) {
   extern __shared__ float sh[];   // scale[C], shift[C]
   float* sc = sh;
   float* sf = sh + C;
@@ -204,14 +204,16 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     for (int k = 0; k < GN_UNROLL; ++k) {
       const int rk = r0 + k * R;
       if (rk < rows) {
-        f16x8 o;
+        f16x8 o, l;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           float y = v[k][e] * a[e] + b[e];
           if (SILU) y = t2v_silu(y);
           o[e] = (f16)y;
+          l[e] = (f16)(y - (float)o[e]);
         }
         *reinterpret_cast<f16x8*>(ob + (size_t)rk * ld_out + c8) = o;
+        if (lo_off) *reinterpret_cast<f16x8*>(ob + (size_t)rk * ld_out + lo_off + c8) = l;     // hi + lo operand split (op.i[16])
       }
     }
   }
@@ -240,7 +242,7 @@ template <> struct Load4<f16> {
 template <typename T, bool SILU>
 __global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, f16* __restrict__ out, int rows,
-                                                               int C, int ld_in, int ld_out, int groups, float eps) {
+                                                               int C, int ld_in, int ld_out, int groups, float eps, int lo_off) {
   __shared__ double red[2 * (GNF_THREADS / 64)];
   __shared__ float stat[2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -304,14 +306,16 @@ __global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(const T* __restri
     for (int k = 0; k < GNF_UNROLL; ++k) {
       const int rk = r + k * R;
       if (rk < rows) {
-        f16x4 o;
+        f16x4 o, l;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float y = v[k][e] * sc[e] + sf[e];
           if (SILU) y = t2v_silu(y);
           o[e] = (f16)y;
+          l[e] = (f16)(y - (float)o[e]);
         }
         *reinterpret_cast<f16x4*>(ob + (size_t)rk * ld_out) = o;
+        if (lo_off) *reinterpret_cast<f16x4*>(ob + (size_t)rk * ld_out + lo_off) = l;
       }
     }
   }
@@ -389,7 +393,7 @@ template <typename T, bool SILU, int KR>
 __global__ __launch_bounds__(GNC_THREADS) void gn_coop_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, f16* __restrict__ out, double* partials,
                                                               unsigned* bar, unsigned* fault, int rows, int C, int ld_in, int ld_out,
-                                                              int groups, int nchunk, int rc, double inv_n, float eps) {
+                                                              int groups, int nchunk, int rc, double inv_n, float eps, int lo_off) {
   extern __shared__ float sh[];            // phase 1: parked sums [2][R][C]; phase 2: scale[C] | shift[C]
   __shared__ float stat[2 * 32];           // {mean, rstd} per group (groups <= 32)
   const int tid = threadIdx.x;
@@ -493,14 +497,16 @@ __global__ __launch_bounds__(GNC_THREADS) void gn_coop_kernel(const T* __restric
   for (int k = 0; k < KR; ++k) {
     const int r = r0 + rr + k * R;
     if (r < r1) {
-      f16x8 o;
+      f16x8 o, l;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         float y = v[k][e] * a[e] + b[e];
         if (SILU) y = t2v_silu(y);
         o[e] = (f16)y;
+        l[e] = (f16)(y - (float)o[e]);
       }
       *reinterpret_cast<f16x8*>(ob + (size_t)r * ld_out) = o;
+      if (lo_off) *reinterpret_cast<f16x8*>(ob + (size_t)r * ld_out + lo_off) = l;
     }
   }
 }
@@ -546,14 +552,14 @@ bool coop_fits(K kernel, int nwg, size_t lds, hipStream_t s, int* cache) {
 template <typename T, bool SILU>
 bool gn_coop_launch(int kr, dim3 grid, size_t lds, hipStream_t s, const T* x, const float* gamma, const float* beta, f16* out,
                     double* partials, unsigned* bar, int rows, int C, int ld_in, int ld_out, int groups, int nchunk, int rc, double inv_n,
-                    float eps) {
+                    float eps, int lo_off) {
 #define GNC_CASE(K)                                                                                                              \
   case K: {                                                                                                                      \
     static int occ[T2V_MAX_DEVICES] = {};                                                                                        \
     auto kern = gn_coop_kernel<T, SILU, K>;                                                                                      \
     if (!coop_fits(kern, (int)grid.x, lds, s, occ)) return false;                                                                \
     hipLaunchKernelGGL(kern, grid, dim3(GNC_THREADS), lds, s, x, gamma, beta, out, partials, bar, g_coop.fault, rows, C, ld_in,   \
-                       ld_out, groups, nchunk, rc, inv_n, eps);                                                                  \
+                       ld_out, groups, nchunk, rc, inv_n, eps, lo_off);                                                          \
     return true;                                                                                                                 \
   }
   switch (kr) {
@@ -730,6 +736,8 @@ hipError_t t2v_launch_groupnorm(const t2v_op& op, hipStream_t s) {
   const float* beta = reinterpret_cast<const float*>(op.p[2]);
   f16* out = reinterpret_cast<f16*>(op.p[3]);
   const bool fused = op.i[12] != 0;
+  const int lo_off = op.i[16] != 0 ? C : 0;        // hi + lo operand split: low-order images at columns C .. 2C-1 of the output rows
+  if (lo_off && (phase == 1 || ld_out < 2 * C)) return hipErrorInvalidValue;
   if (fused && (phase != 0 || (C / groups) % 4 != 0 || (C / groups) / 4 > GNF_THREADS)) return hipErrorInvalidValue;
   // single-pass cooperative variant: the smallest rows-per-thread count whose grid still fits one workgroup per CU
   int coop_kr = 0, coop_rc = 0, coop_nchunk = 0;
@@ -747,16 +755,16 @@ hipError_t t2v_launch_groupnorm(const t2v_op& op, hipStream_t s) {
       unsigned* bar = reinterpret_cast<unsigned*>(op.p[5]);
       const dim3 grid(n_inst * coop_nchunk);
       const bool done = silu ? gn_coop_launch<T, true>(coop_kr, grid, ldsc, s, x, gamma, beta, out, partials, bar, rows, C, ld_in, ld_out, groups,
-                                                       coop_nchunk, coop_rc, inv_n, op.f[0])
+                                                       coop_nchunk, coop_rc, inv_n, op.f[0], lo_off)
                              : gn_coop_launch<T, false>(coop_kr, grid, ldsc, s, x, gamma, beta, out, partials, bar, rows, C, ld_in, ld_out, groups,
-                                                        coop_nchunk, coop_rc, inv_n, op.f[0]);
+                                                        coop_nchunk, coop_rc, inv_n, op.f[0], lo_off);
       if (done) return;             // else: not provably co-resident (or a fault was raised earlier) -> the three launches below
     }
     if (fused) {
       if (silu) hipLaunchKernelGGL((gn_fused_kernel<T, true>), dim3(groups * n_inst), dim3(GNF_THREADS), 0, s, x, gamma, beta, out, rows,
-                                   C, ld_in, ld_out, groups, op.f[0]);
+                                   C, ld_in, ld_out, groups, op.f[0], lo_off);
       else hipLaunchKernelGGL((gn_fused_kernel<T, false>), dim3(groups * n_inst), dim3(GNF_THREADS), 0, s, x, gamma, beta, out, rows, C,
-                              ld_in, ld_out, groups, op.f[0]);
+                              ld_in, ld_out, groups, op.f[0], lo_off);
       return;
     }
     if (phase != 2)
@@ -770,8 +778,8 @@ hipError_t t2v_launch_groupnorm(const t2v_op& op, hipStream_t s) {
       const int rpa = R * GN_UNROLL;    // rows per normalise workgroup
       const dim3 g3((rows + rpa - 1) / rpa, n_inst);
       const size_t lds3 = 2 * (size_t)C * sizeof(float);
-      if (silu) hipLaunchKernelGGL((gn_apply_kernel<T, true>), g3, dim3(256), lds3, s, x, finals, gamma, beta, out, rows, C, ld_in, ld_out, groups);
-      else hipLaunchKernelGGL((gn_apply_kernel<T, false>), g3, dim3(256), lds3, s, x, finals, gamma, beta, out, rows, C, ld_in, ld_out, groups);
+      if (silu) hipLaunchKernelGGL((gn_apply_kernel<T, true>), g3, dim3(256), lds3, s, x, finals, gamma, beta, out, rows, C, ld_in, ld_out, groups, lo_off);
+      else hipLaunchKernelGGL((gn_apply_kernel<T, false>), g3, dim3(256), lds3, s, x, finals, gamma, beta, out, rows, C, ld_in, ld_out, groups, lo_off);
     }
   };
   if (in_dt == T2V_F32) run(reinterpret_cast<const float*>(op.p[0]));

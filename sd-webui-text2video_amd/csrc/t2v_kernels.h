@@ -46,6 +46,9 @@ struct GemmParams {
   // split-K without a reduction launch (EPI_NONE): one arrival counter per output tile (T2V_SYNC_INTS ints, all zero between
   // launches); the LAST workgroup of a tile to arrive folds the slabs in split order and runs the fused epilogue
   int* tickets;
+  // hi + lo fp16 output (PLAIN gather, fp16 out, EPI_NONE): out[m, N + n] = fp16(v - float(fp16(v))) beside out[m, n] = fp16(v) — the
+  // consumer GEMM reads rows [hi | lo] against weights [W | W] (K doubled) and so sees the value with ~22 bits (precise_operands)
+  int out_lo;
 };
 
 
@@ -231,7 +234,12 @@ __device__ __forceinline__ void t2v_epilogue_rows(const GemmParams& p, const f32
             *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n) = v;
           } else {
             f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
-            *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(p.out) + (size_t)m * p.ldc + n) = o;
+            f16* dst = reinterpret_cast<f16*>(p.out) + (size_t)m * p.ldc + n;
+            *reinterpret_cast<f16x4*>(dst) = o;
+            if (p.out_lo) {
+              const f16x4 l = {(f16)(v[0] - (float)o[0]), (f16)(v[1] - (float)o[1]), (f16)(v[2] - (float)o[2]), (f16)(v[3] - (float)o[3])};
+              *reinterpret_cast<f16x4*>(dst + p.N) = l;
+            }
           }
         }
       }
@@ -291,7 +299,12 @@ __device__ __forceinline__ void t2v_epilogue_rows(const GemmParams& p, const f32
           *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n) = v;
         } else {
           f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
-          *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(p.out) + (size_t)m * p.ldc + n) = o;
+          f16* dst = reinterpret_cast<f16*>(p.out) + (size_t)m * p.ldc + n;
+          *reinterpret_cast<f16x4*>(dst) = o;
+          if (p.out_lo) {
+            const f16x4 l = {(f16)(v[0] - (float)o[0]), (f16)(v[1] - (float)o[1]), (f16)(v[2] - (float)o[2]), (f16)(v[3] - (float)o[3])};
+            *reinterpret_cast<f16x4*>(dst + p.N) = l;
+          }
         }
       }
     }

@@ -314,9 +314,11 @@ class Program:
              rowbias: Optional[Buf] = None, rows_per_batch: int = 0, residual: Optional[Buf] = None,
              epi: int = L.EPI_NONE, act: int = 0, bias_along_m: bool = False, m: Optional[int] = None,
              allow_splitk: bool = True, halo: bool = False, ln: Optional[tuple] = None, step_invariant: bool = False,
-             a_lo: Optional[Buf] = None) -> Op:
+             a_lo: Optional[Buf] = None, out_lo: bool = False) -> Op:
         """out[M, n_out] = epi(gather(a)[M, k] @ w[n, k]^T).  conv['pad_after_only'] (3x3, stride 2): zero padding
         (0,1,0,1) instead of 1 on every side.
+        out_lo (fp16 `out` that is the left half of a [M, 2n] buffer): also write the low-order image fp16(v - fp16(v)) at columns
+        n .. 2n-1 of the same rows — the consumer GEMM runs on the [hi | lo] rows against [W | W] (precise_operands).
         ln = (gamma|beta Ref (fp32 [2n]), gamma Ref, beta Ref, ln_out Buf fp16, eps): LayerNorm of the fp32 result rows as a second
         output.  Fused into the GEMM epilogue when the op runs on the 192x320 tile with whole rows (n == 320, no split-K:
         the 32x32-level C -> C linears); otherwise a separate LayerNorm op follows."""
@@ -365,6 +367,9 @@ class Program:
         I[20] = 1 if bias_along_m else 0
         I[21] = rowbias.ld if rowbias is not None else 0
         I[23] = 1 if (halo or conv.get("pad_after_only")) else 0
+        if out_lo:
+            assert gather == L.GATHER_PLAIN and out.dtype == "f16" and epi == L.EPI_NONE and ln is None and out.ld >= 2 * n
+            I[11] = 1
         assert not (conv.get("pad_after_only") and (gather != L.GATHER_CONV3X3 or conv.get("up")))
         op.p[0], op.p[1], op.p[2] = a.ref, w, bias
         op.p[3] = rowbias.ref if rowbias is not None else NULL
@@ -437,13 +442,16 @@ class Program:
         return self._emit(op)
 
     def groupnorm(self, name: str, x: Buf, gamma: Ref, beta: Ref, out: Buf, *, n_inst: int, eps: float,
-                  silu: bool, groups: int = 32, shard: Optional[TShardSpec] = None) -> Op:
+                  silu: bool, groups: int = 32, shard: Optional[TShardSpec] = None, lo: bool = False) -> Op:
         """GroupNorm(+SiLU).  With `shard` (cross-frame statistics of a T-sharded clip; n_inst = 1) the op is split
         into: statistics (this rank's partials) -> all-gather of the fp64 partials over the T group ->
         ordered fold of all parts + normalise; every rank ends up with bit-identical statistics.  Each rank folds its own
         block partials first, so a part is one {sum, sum of squares} pair per group: 512 bytes per instance, whatever the
-        slice lengths (uneven slices need no special care)."""
+        slice lengths (uneven slices need no special care).
+        lo: `out` is the left half of a [rows, 2C] buffer; the low-order fp16 image of every output value goes to columns C .. 2C-1
+        (hi + lo operand split of the consuming GEMM, precise_operands)."""
         rows = x.rows // n_inst
+        assert not lo or out.ld >= 2 * x.cols
         assert rows * n_inst == x.rows and out.dtype == "f16" and x.cols % 4 == 0
         nparts, part = (shard.size, shard.index) if shard is not None else (1, 0)
         rows_total = rows * nparts
@@ -469,6 +477,8 @@ class Program:
             op.i[0:12] = [n_inst, rows, x.cols, x.ld, groups, _DT[x.dtype], int(silu), out.ld, phase, nparts, part, rpb]
             if shard is not None:
                 op.i[14] = rows_total
+            if lo and phase != 1:
+                op.i[16] = 1
             op.f[0] = eps
             op.p[0:5] = [x.ref, gamma, beta, out.ref, scratch.ref]
             return op

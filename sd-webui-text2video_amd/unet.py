@@ -232,7 +232,10 @@ class UNetSD(nn.Module):
         # latent at the entry and the residual stream in front of the 1x1 skip convolutions — are emitted as hi + lo fp16
         # images and their (small) GEMMs run twice: 23 % of the activation-rounding error variance of a forward for ~15 extra
         # launches and +1.5 % FLOPs (tests/precision_probe.py; DESIGN.md "Precision").  Part of the program cache key.
-        self.precise_operands = True
+        # Round 4 adds the next two classes of that ranking: the GroupNorm output in front of every transformer's proj_in and the
+        # feed-forward output x4 in front of proj_out (rows [hi | lo] written by the producing kernel, K doubled in the C -> C
+        # linear that consumes them).  "r3" = the round-3 subset only (A/B).
+        self.precise_operands = {"0": False, "r3": "r3"}.get(os.environ.get("T2V_PRECISE", "1"), True)
         # TemporalTransformer self-attention as ONE launch per attention (QKV projection + attention of every pixel's frame
         # sequence in the GEMM epilogue, T2V_EPI_TATTN): Q / K / V never reach HBM.  Clips of 2..32 frames; longer clips (and the
         # K/V-gather form of a T-sharded clip) keep the projection GEMM + attention kernel pair, and so do clips whose sequences fill
@@ -450,7 +453,7 @@ class UNetSD(nn.Module):
 
     def _lowering_options(self) -> tuple:
         """Lowering switches that change the program (part of the cache key)."""
-        return ((("precise",),) if getattr(self, "precise_operands", False) else ()) + \
+        return ((("precise", str(self.precise_operands)),) if getattr(self, "precise_operands", False) else ()) + \
             ((("tattn", str(self.fused_temporal_attention)),) if getattr(self, "fused_temporal_attention", False) else ())
 
     def forward_cfg_pair(self, x, t, ctx_pair, context_token=None):
@@ -546,6 +549,11 @@ class _Lowering:
         self.x_dt, self.out_dt, self.ctx_dt = x_dt, out_dt, ctx_dt
         self.x_batch = x_batch if 0 < x_batch < B else 0      # x holds fewer samples than the batch: sample b reads x[b % x_batch]
         self.precise = bool(getattr(net, "precise_operands", False))
+        # round 4: the two next classes of the operand ranking (DESIGN.md "Precision") — GroupNorm -> proj_in and x4 -> proj_out.
+        # Their consumers are the C -> C linears (HBM-bound at the 32x32 level: a doubled K costs bytes, not MFMA time)
+        level = getattr(net, "precise_operands", False)
+        self.precise_gn = self.precise and level != "r3"
+        self.precise_ff = self.precise and level != "r3"
         self.fused_tattn = bool(getattr(net, "fused_temporal_attention", False))
         self.stem_dup = False
         self.P = Program(f"unet b{B} f{F} {H}x{W}")
@@ -562,6 +570,11 @@ class _Lowering:
     # -- packed-weight declarations ------------------------------------------------------------
     def w_linear(self, key) -> Ref:
         return Ref("weight", 0, self.packer.add(key + ":lin", "f16", lambda sd, k=key: pk.pad_rows(pk.linear(sd[k + ".weight"]))))
+
+    def w_proj(self, key, copies: int) -> Ref:
+        """Linear weights for an operand stored as `copies` column blocks (1: plain; 2: rows [hi | lo] -> [W | W])."""
+        assert copies in (1, 2)
+        return self.w_linear(key) if copies == 1 else self.w_linear_dup(key)
 
     def w_linear_dup(self, key) -> Ref:
         return Ref("weight", 0, self.packer.add(key + ":lin2", "f16", lambda sd, k=key: pk.pad_rows(pk.linear_dup(sd[k + ".weight"]))))
@@ -615,12 +628,19 @@ class _Lowering:
         return self.B * self.F * h * w
 
     # -- building blocks ------------------------------------------------------------------------
-    def gn(self, name, x: Buf, key, *, per_frame: bool, eps, silu, out: Optional[Buf] = None) -> Buf:
-        out = self.P.alloc(x.rows, x.cols, "f16") if out is None else out
+    def gn(self, name, x: Buf, key, *, per_frame: bool, eps, silu, out: Optional[Buf] = None, lo: bool = False) -> Buf:
+        """lo (precise_operands): the result is a [rows, 2C] buffer of rows [hi | lo] — fp16(y) and the low-order image of that
+        rounding — for a consumer GEMM with weights [W | W] (K = 2C)."""
+        if lo:
+            assert out is None
+            full = self.P.alloc(x.rows, 2 * x.cols, "f16")
+            out = full.col_slice(0, x.cols)
+        else:
+            full = out = self.P.alloc(x.rows, x.cols, "f16") if out is None else out
         n_inst = self.B * self.F if per_frame else self.B
         self.P.groupnorm(name, x, self.vec(key + ".weight"), self.vec(key + ".bias"), out, n_inst=n_inst, eps=eps, silu=silu,
-                         shard=None if per_frame else self.shard)
-        return out
+                         shard=None if per_frame else self.shard, lo=lo)
+        return full
 
     def conv3(self, name, a: Buf, key, cout, h, w, *, stride=1, up=0, out_dtype="f32", rowbias=None,
               residual=None, cin=None, dest: Optional[Buf] = None, dup_c8: bool = False) -> Buf:
@@ -828,25 +848,32 @@ class _Lowering:
         g = P.alloc(Mrows, 4 * inner, "f16")
         P.gemm(f"{prefix}.ff.geglu", n, wg, 8 * inner, inner, g, bias=bg, epi=L.EPI_GEGLU)
         P.free(n)
-        x4 = P.alloc(Mrows, inner, "f16")
-        P.gemm(f"{prefix}.ff.net.2", g, self.w_linear(f"{prefix}.ff.net.2"), inner, 4 * inner, x4,
-               bias=self.vec(f"{prefix}.ff.net.2.bias"), residual=x3)
+        # x4 = x3 + FF feeds proj_out as an fp16 operand: with precise_operands it is stored as rows [hi | lo] (the low-order image
+        # of the fp16 rounding beside the value) and proj_out runs with K doubled against [W | W]
+        if self.precise_ff:
+            x4 = P.alloc(Mrows, 2 * inner, "f16")
+            P.gemm(f"{prefix}.ff.net.2", g, self.w_linear(f"{prefix}.ff.net.2"), inner, 4 * inner, x4.col_slice(0, inner),
+                   bias=self.vec(f"{prefix}.ff.net.2.bias"), residual=x3, out_lo=True)
+        else:
+            x4 = P.alloc(Mrows, inner, "f16")
+            P.gemm(f"{prefix}.ff.net.2", g, self.w_linear(f"{prefix}.ff.net.2"), inner, 4 * inner, x4,
+                   bias=self.vec(f"{prefix}.ff.net.2.bias"), residual=x3)
         P.free(g, x3)
         return x4
 
     def spatial_transformer(self, prefix, x: Buf, c, h, w, dest: Optional[Buf] = None) -> Buf:
         P = self.P
         heads = c // 64
-        n = self.gn(prefix + ".norm", x, prefix + ".norm", per_frame=True, eps=1e-6, silu=False)
+        n = self.gn(prefix + ".norm", x, prefix + ".norm", per_frame=True, eps=1e-6, silu=False, lo=self.precise_gn)
         x1 = P.alloc(x.rows, c, "f32")
         n1 = P.alloc(x.rows, c, "f16")
         tb = prefix + ".transformer_blocks.0"
-        P.gemm(prefix + ".proj_in", n, self.w_linear(prefix + ".proj_in"), c, c, x1, bias=self.vec(prefix + ".proj_in.bias"),
+        P.gemm(prefix + ".proj_in", n, self.w_proj(prefix + ".proj_in", n.cols // c), c, n.cols, x1, bias=self.vec(prefix + ".proj_in.bias"),
                ln=self.ln_arg(tb + ".norm1", n1))
         P.free(n)
         x4 = self.transformer_block(tb, x1, n1, c, heads, "spatial", h, w)
         out = self._dest(dest, x.rows, c, "f32")
-        P.gemm(prefix + ".proj_out", x4, self.w_linear(prefix + ".proj_out"), c, c, out,
+        P.gemm(prefix + ".proj_out", x4, self.w_proj(prefix + ".proj_out", x4.cols // c), c, x4.cols, out,
                bias=self.vec(prefix + ".proj_out.bias"), residual=x)
         P.free(x4)
         return out
@@ -856,16 +883,16 @@ class _Lowering:
         inner = heads * 64
         if self.shard is not None and (h * w) % self.shard.size == 0:
             return self.temporal_transformer_resharded(prefix, x, c, heads, h, w, dest)
-        n = self.gn(prefix + ".norm", x, prefix + ".norm", per_frame=False, eps=1e-6, silu=False)
+        n = self.gn(prefix + ".norm", x, prefix + ".norm", per_frame=False, eps=1e-6, silu=False, lo=self.precise_gn)
         x1 = P.alloc(x.rows, inner, "f32")
         tb = prefix + ".transformer_blocks.0"
         n1 = None if self.shard is not None else P.alloc(x.rows, inner, "f16")
-        P.gemm(prefix + ".proj_in", n, self.w_linear(prefix + ".proj_in"), inner, c, x1, bias=self.vec(prefix + ".proj_in.bias"),
+        P.gemm(prefix + ".proj_in", n, self.w_proj(prefix + ".proj_in", n.cols // c), inner, n.cols, x1, bias=self.vec(prefix + ".proj_in.bias"),
                ln=None if n1 is None else self.ln_arg(tb + ".norm1", n1))
         P.free(n)
         x4 = self.transformer_block(tb, x1, n1, inner, heads, "temporal", h, w)
         out = self._dest(dest, x.rows, c, "f32")
-        P.gemm(prefix + ".proj_out", x4, self.w_linear(prefix + ".proj_out"), c, inner, out,
+        P.gemm(prefix + ".proj_out", x4, self.w_proj(prefix + ".proj_out", x4.cols // inner), c, x4.cols, out,
                bias=self.vec(prefix + ".proj_out.bias"), residual=x)
         P.free(x4)
         return out
@@ -898,7 +925,7 @@ class _Lowering:
         P.free(xp)
         x4 = self.transformer_block(tb, x1, n1, inner, heads, "temporal", h, w, geom=(Ft, hwr))
         yp = P.alloc(Ft * hwr, c, "f32")
-        P.gemm(prefix + ".proj_out", x4, self.w_linear(prefix + ".proj_out"), c, inner, yp, bias=self.vec(prefix + ".proj_out.bias"))
+        P.gemm(prefix + ".proj_out", x4, self.w_proj(prefix + ".proj_out", x4.cols // inner), c, x4.cols, yp, bias=self.vec(prefix + ".proj_out.bias"))
         P.free(x4)
         # ---- pixels -> frames: frames of slice q (rows [q*cb*hwr, ...) of yp) go to rank q; then unpack + residual
         back = P.alloc(R * Fl * hwr, c, "f32")

@@ -143,6 +143,9 @@ class Interp:
                 res = res + self.mat(op.p[4], M, N, ldr, torch.float32, ext)
         out = self.mat(op.p[5], M, n_out, ldc, _TD[I[17]], ext)
         self._st(out, res, _TD[I[17]])
+        if gather == L.GATHER_PLAIN and I[11] == 1:          # hi + lo fp16 output: the rounding's low-order image beside the row
+            lo_view = self.view(op.p[5].shifted(2 * N), (M, N), (ldc, 1), torch.float16, ext)
+            self._st(lo_view, res.float() - res.half().float(), torch.float16)
         if epi != L.EPI_GEGLU and gather == L.GATHER_PLAIN and I[8] == 1:
             gb = self.view(op.p[3], (2 * N,), (1,), torch.float32, ext)
             y = F.layer_norm(res.float(), (N,), gb[:N], gb[N:], op.f[0])
@@ -175,6 +178,9 @@ class Interp:
         if silu:
             y = F.silu(y)
         self._st(self.mat(op.p[3], n_inst * rows, C, ld_out, torch.float16, ext), y, torch.float16)
+        if op.i[16]:                                           # low-order image of the fp16 rounding at columns C .. 2C-1
+            lo_view = self.view(op.p[3].shifted(2 * C), (n_inst * rows, C), (ld_out, 1), torch.float16, ext)
+            self._st(lo_view, y.float() - y.half().float(), torch.float16)
 
     # LAYERNORM ----------------------------------------------------------------------------------------
     def _op3(self, op, ext):

@@ -84,7 +84,9 @@ class Probe(Interp):
         if dtype == torch.float16 and view.dtype == torch.float32:          # a shadowed fp16 buffer
             cls = classify(self.cur)
             self.nst += 1
-            if self.nst == 2 and self.cur.kind in (L.OP_COPY2D, L.OP_NCTHW_TO_CL):
+            is_lo = self.cur.kind in (L.OP_COPY2D, L.OP_NCTHW_TO_CL) or (self.cur.kind == L.OP_GROUPNORM and self.cur.i[16]) or \
+                (self.cur.kind == L.OP_GEMM and self.cur.i[7] == L.GATHER_PLAIN and self.cur.i[11] == 1 and self.cur.i[16] == L.EPI_NONE)
+            if self.nst == 2 and is_lo:
                 # the low-order image of a hi + lo cast (precise_operands): carries nothing when the hi store is already exact
                 view.copy_(value.float() * 0 if cls in self.exact else value.half().float())
                 return

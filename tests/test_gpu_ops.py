@@ -887,3 +887,173 @@ def test_gemm_with_fused_layernorm_output(M, K, with_res):
     _check(it, got, n_out, 1e-3, "gemm + fused LN: fp16 LayerNorm output")
     ref = torch.nn.functional.layer_norm(read(got, out), (N,), gamma, beta, 1e-5)
     assert rel_l2(read(got, n_out).float(), ref) < 1e-3
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Round 4: every GEMM epilogue and every gather mode against torch.nn.functional — not the interpreter —
+# on BASELINE shapes, plus the hi + lo operand forms of `precise_operands`.
+# ------------------------------------------------------------------------------------------------------------------
+def _torch_linear(it, a, w, bias=None):
+    return torch.nn.functional.linear(read(it, a).float(), w.float(), bias)
+
+
+@pytest.mark.parametrize("M,C", [(49152 // 8, 320), (3072, 1280)])
+def test_geglu_epilogue_against_torch_unpermuted_definition(M, C):
+    """(49152, 2560, 320) / (3072, 10240, 1280) of SURVEY App. D (the 32x32 shape at 1/8 of its rows): GEGLU.forward
+    (t2v_model.py:817-821) `x, gate = proj(x).chunk(2); x * gelu(gate)` on the UNPERMUTED nn.Linear weights."""
+    P = Program()
+    g = _g(201)
+    a, out = P.alloc(M, C, "f16"), P.alloc(M, 4 * C, "f16")
+    wsrc, bsrc = (torch.randn(8 * C, C, generator=g) / math.sqrt(C)).half(), torch.randn(8 * C, generator=g) * 0.2
+    perm = pk.geglu_perm(4 * C)
+    P.gemm("g", a, Ref("weight", 0, "w"), 8 * C, C, out, bias=Ref("weight", 0, "b"), epi=L.EPI_GEGLU)
+    it, got = _gpu_run(P, {"w": wsrc[perm].contiguous(), "b": bsrc[perm].contiguous()}, lambda it: fill(it, a, g))
+    hg = _torch_linear(it, a, wsrc, bsrc)
+    ref = hg[:, :4 * C] * torch.nn.functional.gelu(hg[:, 4 * C:])
+    assert rel_l2(read(got, out).float(), ref) < 1e-3
+
+
+@pytest.mark.parametrize("tile", [0, 2, 8, 5])
+def test_rowbias_silu_residual_epilogue_against_torch(tile):
+    """bias + per-sample row bias (the time-embedding projection of a ResBlock, t2v_model.py:941-947) + SiLU + fp32 residual."""
+    M, N, K, rpb = 1536, 320, 640, 384
+    P = Program()
+    P.force_tile = tile
+    g = _g(202)
+    a, out, res, rb = P.alloc(M, K, "f16"), P.alloc(M, N, "f32"), P.alloc(M, N, "f32"), P.alloc(M // rpb, N, "f32")
+    w = {"w": (torch.randn(N, K, generator=g) / math.sqrt(K)).half(), "b": torch.randn(N, generator=g)}
+    P.gemm("g", a, Ref("weight", 0, "w"), N, K, out, bias=Ref("weight", 0, "b"), act=1, residual=res, rowbias=rb, rows_per_batch=rpb,
+           allow_splitk=False)
+    it, got = _gpu_run(P, w, lambda it: (fill(it, a, g), fill(it, res, g, 2.0), fill(it, rb, g)))
+    ref = torch.nn.functional.silu(_torch_linear(it, a, w["w"], w["b"]) + read(it, rb).repeat_interleave(rpb, dim=0)) + read(it, res)
+    assert rel_l2(read(got, out), ref) < 2e-5
+
+
+@pytest.mark.parametrize("tickets", [False, True])
+def test_split_k_against_torch(tickets):
+    """(768, 1280, 11520, split 8): the 4x4-level 3x3 convolution's GEMM shape, as a plain GEMM with bias + fp32 residual."""
+    M, N, K = 768, 1280, 11520
+    P = Program()
+    P.splitk_tickets = tickets
+    g = _g(203)
+    a, out, res = P.alloc(M, K, "f16"), P.alloc(M, N, "f32"), P.alloc(M, N, "f32")
+    w = {"w": (torch.randn(N, K, generator=g) / math.sqrt(K)).half(), "b": torch.randn(N, generator=g)}
+    op = P.gemm("g", a, Ref("weight", 0, "w"), N, K, out, bias=Ref("weight", 0, "b"), residual=res)
+    assert op.i[19] > 1
+    it, got = _gpu_run(P, w, lambda it: (fill(it, a, g), fill(it, res, g)))
+    ref = _torch_linear(it, a, w["w"], w["b"]) + read(it, res)
+    assert rel_l2(read(got, out), ref) < 2e-5
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride,up,pad_after", [(4, 32, 32, 320, 320, 1, 0, False), (2, 16, 16, 640, 640, 2, 0, False),
+                                                                (2, 8, 8, 1280, 1280, 1, 1, False), (2, 16, 16, 128, 128, 2, 0, True)])
+def test_conv3x3_gather_against_torch_conv2d(B, H, W, Cin, Cout, stride, up, pad_after):
+    """Every 3x3 gather mode against F.conv2d on the NCHW view of the same tokens: stride 1 / 2, the nearest-2x upsample folded into
+    the gather (t2v_model.py:1044-1050), and the encoder's (0,1,0,1) padding (autoencoder_modules.py Downsample)."""
+    Ho, Wo = (2 * H, 2 * W) if up else (((H + 1) // 2, (W + 1) // 2) if stride == 2 else (H, W))
+    if pad_after:
+        Ho, Wo = H // 2, W // 2
+    P = Program()
+    g = _g(204)
+    a, out = P.alloc(B * H * W, Cin, "f16"), P.alloc(B * Ho * Wo, Cout, "f32")
+    w4 = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).half()
+    w = {"w": pk.pad_rows(pk.conv3x3(w4.float())).half(), "b": torch.randn(Cout, generator=g)}
+    P.gemm("c", a, Ref("weight", 0, "w"), Cout, 9 * Cin, out, bias=Ref("weight", 0, "b"), gather=L.GATHER_CONV3X3,
+           conv=dict(Hin=H, Win=W, Cin=Cin, stride=stride, up=up, Hout=Ho, Wout=Wo, pad_after_only=pad_after))
+    it, got = _gpu_run(P, w, lambda it: fill(it, a, g))
+    x = read(it, a).float().view(B, H, W, Cin).permute(0, 3, 1, 2)
+    if up:
+        x = torch.nn.functional.interpolate(x, scale_factor=2.0, mode="nearest")
+    if pad_after:
+        ref = torch.nn.functional.conv2d(torch.nn.functional.pad(x, (0, 1, 0, 1)), w4.float(), w["b"], stride=2)
+    else:
+        ref = torch.nn.functional.conv2d(x, w4.float(), w["b"], stride=stride, padding=1)
+    assert rel_l2(read(got, out), ref.permute(0, 2, 3, 1).reshape(B * Ho * Wo, Cout)) < 2e-5
+
+
+@pytest.mark.parametrize("B,F,HW,C,halo", [(2, 24, 64, 640, False), (1, 6, 256, 320, True)])
+def test_temporal_conv_gather_against_torch_conv3d(B, F, HW, C, halo):
+    """(3,1,1) temporal convolution (t2v_model.py:1202-1211) against F.conv3d; `halo`: the T-sharded input layout [F + 2] frames."""
+    P = Program()
+    g = _g(205)
+    rows_in = B * (F + 2) * HW if halo else B * F * HW
+    a, out = P.alloc(rows_in, C, "f16"), P.alloc(B * F * HW, C, "f32")
+    w5 = (torch.randn(C, C, 3, 1, 1, generator=g) / math.sqrt(3 * C)).half()
+    w = {"w": pk.tconv3(w5.float()).half(), "b": torch.randn(C, generator=g)}
+    P.gemm("t", a, Ref("weight", 0, "w"), C, 3 * C, out, bias=Ref("weight", 0, "b"), gather=L.GATHER_TCONV3, conv=dict(F=F, HW=HW, Cin=C), halo=halo)
+    it, got = _gpu_run(P, w, lambda it: fill(it, a, g))
+    x = read(it, a).float().view(B, F + 2 if halo else F, HW, C).permute(0, 3, 1, 2).unsqueeze(-1)      # [B, C, F(+2), HW, 1]
+    ref = torch.nn.functional.conv3d(x, w5.float(), w["b"], padding=(0, 0, 0) if halo else (1, 0, 0))
+    assert rel_l2(read(got, out), ref.squeeze(-1).permute(0, 2, 3, 1).reshape(B * F * HW, C)) < 2e-5
+
+
+def test_c8_stem_gather_with_lo_channels_against_torch_conv2d():
+    """The stem (Cin = 8 = 4 latent channels + their 4 low-order images, weights repeated): (hi + lo) . W in one pass equals the
+    fp32 convolution of the UNROUNDED latent to ~1e-6 — what `precise_operands` buys at the entry."""
+    B, F, H, W, Cout = 1, 3, 16, 16, 320
+    P = Program()
+    g = _g(206)
+    xin, out = P.alloc(B * F * H * W, 8, "f16"), P.alloc(B * F * H * W, Cout, "f32")
+    x5 = torch.randn(B, 4, F, H, W, generator=g)
+    w4 = (torch.randn(Cout, 4, 3, 3, generator=g) / 6.0).half()
+    w = {"w": pk.pad_rows(pk.conv3x3_c8_dup(w4.float())).half(), "b": torch.randn(Cout, generator=g)}
+    P.ncthw_to_cl("in", Ref("ext", L.EXT_X), "f32", xin, B=B, C=4, F=F, HW=H * W, lo_in_pad=True)
+    P.gemm("stem", xin, Ref("weight", 0, "w"), Cout, 72, out, bias=Ref("weight", 0, "b"), gather=L.GATHER_CONV3X3_C8,
+           conv=dict(Hin=H, Win=W, Cin=8, stride=1, up=0, Hout=H, Wout=W))
+    it, got, _, _ = run_both(P, w, {L.EXT_X: x5}, lambda it: None)
+    ref = torch.nn.functional.conv2d(x5.permute(0, 2, 1, 3, 4).reshape(B * F, 4, H, W), w4.float(), w["b"], padding=1)
+    r = rel_l2(read(got, out), ref.permute(0, 2, 3, 1).reshape(-1, Cout))
+    assert r < 5e-6, r          # (an fp16-rounded latent alone would give ~2e-4)
+
+
+@pytest.mark.parametrize("variant", ["three_launch", "cooperative", "single_launch"])
+def test_groupnorm_lo_output_and_dup_linear_against_torch(variant):
+    """precise_operands, round 4: GroupNorm writes rows [fp16(y) | fp16(y - fp16(y))], the consumer linear runs on K = 2C against
+    [W | W] — together they must reproduce linear(group_norm(x)) of torch in fp32 to ~1e-6 relative (fp16 operand alone: ~3e-4)."""
+    n_inst, rows, C, N = 4, 256, 320, 320
+    P = Program()
+    P.gn_coop = variant == "cooperative"
+    P.gn_fused_slice_bytes = 1 << 30 if variant == "single_launch" else 0
+    P.gn_fused_total_bytes = 1 << 30
+    if variant == "single_launch":
+        C = N = 640                                  # (C / groups) % 4 == 0
+    g = _g(207)
+    x, nrm, out = P.alloc(n_inst * rows, C, "f32"), P.alloc(n_inst * rows, 2 * C, "f16"), P.alloc(n_inst * rows, N, "f32")
+    wl = (torch.randn(N, C, generator=g) / math.sqrt(C)).half()
+    w = {"g": 1 + 0.1 * torch.randn(C, generator=g), "b": 0.1 * torch.randn(C, generator=g), "w2": pk.linear_dup(wl.float()).half()}
+    P.groupnorm("gn", x, Ref("weight", 0, "g"), Ref("weight", 0, "b"), nrm.col_slice(0, C), n_inst=n_inst, eps=1e-6, silu=False, lo=True)
+    P.gemm("lin", nrm, Ref("weight", 0, "w2"), N, 2 * C, out)
+    gn = [op for op in P.ops if op.kind == L.OP_GROUPNORM][0]
+    assert gn.i[16] == 1 and gn.i[12] == (variant == "single_launch") and gn.i[15] == (variant == "cooperative")
+
+    def init(it):
+        v = fill(it, x, g, 1.5)
+        v += 0.3
+    it, got = _gpu_run(P, w, init)
+    _check(it, got, nrm, 2e-3, "GroupNorm hi | lo images vs the interpreter")
+    xf = read(it, x).view(n_inst, rows, C).permute(0, 2, 1)
+    y = torch.nn.functional.group_norm(xf, 32, w["g"], w["b"], 1e-6).permute(0, 2, 1).reshape(n_inst * rows, C)
+    hi_lo = read(got, nrm).float()
+    assert rel_l2(hi_lo[:, :C] + hi_lo[:, C:], y) < 3e-6          # hi + lo carries the value to ~22 bits
+    r = rel_l2(read(got, out), torch.nn.functional.linear(y, wl.float()))
+    assert r < 5e-6, r
+
+
+@pytest.mark.parametrize("M,N,K,tile", [(1536, 320, 1280, None), (768, 1280, 5120, None), (400, 640, 2560, 0)])
+def test_gemm_hi_lo_fp16_output_against_torch(M, N, K, tile):
+    """precise_operands, round 4: the feed-forward output x4 = x3 + FF as rows [fp16(v) | fp16(v - fp16(v))] (also through the
+    split-K reduction kernel at the 4x4-level shape), then proj_out on K = 2N against [W | W]: equals torch's fp32 chain."""
+    P = Program()
+    P.force_tile = tile
+    g = _g(208)
+    a, x4, res, out = P.alloc(M, K, "f16"), P.alloc(M, 2 * N, "f16"), P.alloc(M, N, "f32"), P.alloc(M, N, "f32")
+    w1, wp = (torch.randn(N, K, generator=g) / math.sqrt(K)).half(), (torch.randn(N, N, generator=g) / math.sqrt(N)).half()
+    w = {"w1": w1, "b1": torch.randn(N, generator=g), "wp": pk.linear_dup(wp.float()).half()}
+    P.gemm("ff2", a, Ref("weight", 0, "w1"), N, K, x4.col_slice(0, N), bias=Ref("weight", 0, "b1"), residual=res, out_lo=True)
+    P.gemm("proj_out", x4, Ref("weight", 0, "wp"), N, 2 * N, out)
+    it, got = _gpu_run(P, w, lambda it: (fill(it, a, g), fill(it, res, g, 2.0)))
+    v = _torch_linear(it, a, w1, w["b1"]) + read(it, res)
+    hi_lo = read(got, x4).float()
+    assert rel_l2(hi_lo[:, :N] + hi_lo[:, N:], v) < 3e-6
+    r = rel_l2(read(got, out), torch.nn.functional.linear(v, wp.float()))
+    assert r < 5e-6, r
