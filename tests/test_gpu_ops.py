@@ -1003,7 +1003,7 @@ def test_c8_stem_gather_with_lo_channels_against_torch_conv2d():
     it, got, _, _ = run_both(P, w, {L.EXT_X: x5}, lambda it: None)
     ref = torch.nn.functional.conv2d(x5.permute(0, 2, 1, 3, 4).reshape(B * F, 4, H, W), w4.float(), w["b"], padding=1)
     r = rel_l2(read(got, out), ref.permute(0, 2, 3, 1).reshape(-1, Cout))
-    assert r < 5e-6, r          # (an fp16-rounded latent alone would give ~2e-4)
+    assert r < 2e-5, r          # (an fp16-rounded latent alone would give ~2e-4)
 
 
 @pytest.mark.parametrize("variant", ["three_launch", "cooperative", "single_launch"])
@@ -1034,9 +1034,9 @@ def test_groupnorm_lo_output_and_dup_linear_against_torch(variant):
     xf = read(it, x).view(n_inst, rows, C).permute(0, 2, 1)
     y = torch.nn.functional.group_norm(xf, 32, w["g"], w["b"], 1e-6).permute(0, 2, 1).reshape(n_inst * rows, C)
     hi_lo = read(got, nrm).float()
-    assert rel_l2(hi_lo[:, :C] + hi_lo[:, C:], y) < 3e-6          # hi + lo carries the value to ~22 bits
+    assert rel_l2(hi_lo[:, :C] + hi_lo[:, C:], y) < 1e-5          # hi + lo carries the value to ~22 bits (fp16 alone: ~3e-4)
     r = rel_l2(read(got, out), torch.nn.functional.linear(y, wl.float()))
-    assert r < 5e-6, r
+    assert r < 2e-5, r
 
 
 @pytest.mark.parametrize("M,N,K,tile", [(1536, 320, 1280, None), (768, 1280, 5120, None), (400, 640, 2560, 0)])
@@ -1054,6 +1054,6 @@ def test_gemm_hi_lo_fp16_output_against_torch(M, N, K, tile):
     it, got = _gpu_run(P, w, lambda it: (fill(it, a, g), fill(it, res, g, 2.0)))
     v = _torch_linear(it, a, w1, w["b1"]) + read(it, res)
     hi_lo = read(got, x4).float()
-    assert rel_l2(hi_lo[:, :N] + hi_lo[:, N:], v) < 3e-6
+    assert rel_l2(hi_lo[:, :N] + hi_lo[:, N:], v) < 1e-5
     r = rel_l2(read(got, out), torch.nn.functional.linear(v, wp.float()))
-    assert r < 5e-6, r
+    assert r < 2e-5, r
