@@ -23,9 +23,12 @@ from sd_webui_text2video_amd import samplers, vae as V
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 DEV = "cuda:0"
-# gates against the deployed-weights goldens (north_star: 1e-3 rel-L2 on identical inputs; VERDICT r02 #1: forward <= 1.5e-3)
-GATE_FWD_W16 = 1.5e-3
+# gates against the deployed-weights goldens (north_star: 1e-3 rel-L2 on identical inputs).  Round 4: single
+# forwards <= 1.2e-3 (measured <= ~0.9e-3 with the round-4 operand splits), 50-step outputs <= 1.0e-3; the few-step sampling runs
+# (5 / 10 steps: the trajectory has not contracted yet and CFG amplifies each step's error) <= 1.5e-3.
+GATE_FWD_W16 = 1.2e-3
 GATE_VIDEO_W16 = 1.0e-3
+GATE_FEWSTEP_W16 = 1.5e-3
 
 
 def _gold(name):
@@ -89,7 +92,7 @@ def test_c1_24f_sampling_10_and_50_steps_and_frames(modelscope_full_fp16, vae16)
         if _gold16("modelscope_24f.npz") is not None:
             ra = rel_l2(x0[steps].float().cpu(), torch.from_numpy(_gold16("modelscope_24f.npz")[f"sampler_x0_{steps}"]))
             print(f"configs[1] {steps}-step DDIM_Gaussian CFG 9 vs the reference on the DEPLOYED weights: x0 rel-L2 {ra:.3e}")
-            assert ra < (GATE_FWD_W16 if steps == 10 else GATE_VIDEO_W16)
+            assert ra < (GATE_FEWSTEP_W16 if steps == 10 else GATE_VIDEO_W16)
     # frames 0 / 23 of the 50-step video: VAE decode + tensor2vid as ONE program, against the reference's uint8 frames
     z = (x0[50][:, :, [0, 23]] / configs.SCALE_FACTOR).permute(0, 2, 1, 3, 4).reshape(2, 4, 32, 32)
     u8 = vae16.decode_to_uint8(z, videos=1).cpu().numpy()
@@ -207,9 +210,71 @@ def test_c4_lvdm_16f_ddim_and_decode():
         if g16 is not None:
             ra = rel_l2(x0.float().cpu(), torch.from_numpy(g16[f"ddim_x0_{steps}"]))
             print(f"configs[4] VideoCrafter 16f, {steps}-step lvdm DDIM vs the reference on the DEPLOYED weights: x0 rel-L2 {ra:.3e}")
-            assert ra < GATE_FWD_W16
+            assert ra < (GATE_FEWSTEP_W16 if steps == 10 else GATE_VIDEO_W16)
     img = ld.decode_first_stage(torch.from_numpy(gold["ddim_x0_50"])[:, :, 0:1].to(DEV).half()).float().cpu()
     img = img.reshape(-1, 3, 256, 256)[0:1]
     rv = rel_l2(img[:, :, ::2, ::2], torch.from_numpy(gold["vae_img_frame0"]))
     print(f"configs[4] decode_first_stage of the reference latent, fp16 weights: rel-L2 {rv:.3e}")
     assert rv < 1.8e-3                            # measured 1.15e-3
+
+
+def _need(name):
+    path = os.path.join(GOLD, name)
+    if not os.path.exists(path):
+        pytest.skip(f"{name} not generated (tests/golden/make_golden_full.py w16 c1s c3s c2s)")
+    return np.load(path)
+
+
+@pytest.mark.parametrize("name", ["DDIM", "UniPC"])
+def test_c1_other_samplers_full_size(modelscope_full_fp16, name):
+    """VERDICT r03 missing #4: the other two samplers at the FULL configs[1] size — 10-step "DDIM" (LDM DDIMSampler,
+    ddim/sampler.py:110-220) and 10-step "UniPC" (uni_pc/uni_pc.py:683-743) latents of the 1.41 B model, 24 frames @256x256, CFG 9,
+    against the reference's own Txt2VideoSampler on the deployed weights."""
+    net, betas = modelscope_full_fp16
+    gold = _need("modelscope_24f_samplers_w16.npz")
+    _, cond, uncond = synth.synth_inputs(24, 256, 256)
+    smp = samplers.Txt2VideoSampler(net, torch.device(DEV), betas=betas, sampler_name=name)
+    smp.progress = False
+    _, nz, shape = smp.get_noise(1, 4, 24, 256, 256, seed=1234)
+    x0 = smp.sample_loop(steps=10, strength=None, conditioning=cond.to(DEV).half(), unconditional_conditioning=uncond.to(DEV).half(),
+                         batch_size=1, shape=shape, noise=nz, guidance_scale=9.0, eta=0.0, sampler_name=name)
+    r = rel_l2(x0.float().cpu(), torch.from_numpy(gold[f"{name.lower()}_x0_10"]))
+    print(f"configs[1] 24f, 10-step {name} CFG 9 vs the reference's own sampler on the DEPLOYED weights: x0 rel-L2 {r:.3e}")
+    assert r < GATE_FEWSTEP_W16
+
+
+def test_c3_zeroscope_xl_sampled_output_5_steps(modelscope_full_fp16):
+    """VERDICT r03 missing #2: an OUTPUT of configs[3]'s geometry — the 5-step DDIM_Gaussian CFG 9 latent of a 4-frame clip at
+    1024x576 (latent 72x128, 9216-token spatial attention) — against the reference's sampler on the deployed weights."""
+    net, betas = modelscope_full_fp16
+    gold = _need("zeroscope_xl_s5_w16.npz")
+    _, cond, uncond = synth.synth_inputs(4, 576, 1024)
+    smp = samplers.Txt2VideoSampler(net, torch.device(DEV), betas=betas, sampler_name="DDIM_Gaussian")
+    smp.progress = False
+    _, nz, shape = smp.get_noise(1, 4, 4, 576, 1024, seed=1234)
+    x0 = smp.sample_loop(steps=5, strength=None, conditioning=cond.to(DEV).half(), unconditional_conditioning=uncond.to(DEV).half(),
+                         batch_size=1, shape=shape, noise=nz, guidance_scale=9.0, eta=0.0, sampler_name="DDIM_Gaussian")
+    r = rel_l2(x0.float().cpu(), torch.from_numpy(gold["sampler_x0_5"]))
+    print(f"configs[3] ZeroScope-XL geometry, 4f, 5-step DDIM_Gaussian CFG 9 vs the reference on the DEPLOYED weights: x0 rel-L2 {r:.3e}")
+    assert r < GATE_FEWSTEP_W16
+
+
+def test_c2_125f_sampled_output_10_steps(modelscope_full_fp16):
+    """VERDICT r03 missing #2: an OUTPUT of configs[2] — the 10-step DDIM_Gaussian CFG 9 latent of the 125-frame clip (frames at
+    the slice edges of the 4-way T split and both clip ends) — against the reference's sampler on the deployed weights."""
+    net, betas = modelscope_full_fp16
+    gold = _need("modelscope_125f_s10_w16.npz")
+    frames = [int(f) for f in gold["frames"]]
+    _, cond, uncond = synth.synth_inputs(125, 256, 256)
+    smp = samplers.Txt2VideoSampler(net, torch.device(DEV), betas=betas, sampler_name="DDIM_Gaussian")
+    smp.progress = False
+    _, nz, shape = smp.get_noise(1, 4, 125, 256, 256, seed=1234)
+    x0 = smp.sample_loop(steps=10, strength=None, conditioning=cond.to(DEV).half(), unconditional_conditioning=uncond.to(DEV).half(),
+                         batch_size=1, shape=shape, noise=nz, guidance_scale=9.0, eta=0.0, sampler_name="DDIM_Gaussian").float().cpu()
+    want = torch.from_numpy(gold["sampler_x0_10_frames"])
+    r = rel_l2(x0[:, :, frames], want)
+    worst = max(rel_l2(x0[:, :, f], want[:, :, k]) for k, f in enumerate(frames))
+    print(f"configs[2] 125f, 10-step DDIM_Gaussian CFG 9 vs the reference on the DEPLOYED weights: x0 rel-L2 {r:.3e} over frames {frames}, "
+          f"worst single frame {worst:.3e}")
+    assert abs(float(x0.std()) - float(gold["x0_std"])) < 3e-3 * float(gold["x0_std"])
+    assert r < GATE_FEWSTEP_W16 and worst < 1.15 * GATE_FEWSTEP_W16
