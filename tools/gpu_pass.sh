@@ -1,0 +1,68 @@
+#!/bin/bash
+# One GPU-box pass made of named stages (round 4; replaces the per-session gpu_r3_*.sh scripts):
+#   gpurun --timeout 1500 -- 'bash tools/gpu_pass.sh ops fault parity ab smoke rehearsal bench'
+# Every stage writes its logs under gpurun_out/<tag>_* (tag = $T2V_PASS_TAG, default "p") and prints a short digest.
+set -u
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+TAG=${T2V_PASS_TAG:-p}
+PYT="python -m pytest -q --tb=short -p no:cacheprovider"
+digest() { grep -E "passed|failed|FAILED|ERROR|error" "$1" | tail -n "${2:-6}" | cut -c1-300; }
+
+stage_ops() {       # the op-level tests that changed or are new this round
+  timeout 900 $PYT tests/test_gpu_ops.py -x -k "torch or lo_output or hi_lo or groupnorm or epilogue or split_k or tattn or temporal_attention" > gpurun_out/${TAG}_ops.log 2>&1
+  echo "ops exit $?"; digest gpurun_out/${TAG}_ops.log
+}
+stage_opsall() {
+  timeout 1500 $PYT tests/test_gpu_ops.py > gpurun_out/${TAG}_opsall.log 2>&1; echo "ops(all) exit $?"; digest gpurun_out/${TAG}_opsall.log
+}
+stage_fault() {
+  timeout 400 $PYT tests/test_gpu_gn_fault.py -rP > gpurun_out/${TAG}_fault.log 2>&1; echo "gn fault exit $?"; grep -E "FAULT_OK|passed|failed" gpurun_out/${TAG}_fault.log | tail -n 3
+}
+stage_parity() {    # the full-size goldens that the round-4 operand splits are meant to move
+  timeout 1500 $PYT tests/test_gpu_fullsize.py -rP -k "${T2V_PARITY_K:-c1_24f_forward or c3_zeroscope_xl_forward_72x128 or c4 or c1_other or c3_zeroscope_xl_sampled or c2_125f_forward}" > gpurun_out/${TAG}_parity.log 2>&1
+  echo "parity exit $?"; grep -E "rel-L2|identical" gpurun_out/${TAG}_parity.log | cut -c1-220; digest gpurun_out/${TAG}_parity.log 3
+}
+stage_parityall() {
+  timeout 2400 $PYT tests/test_gpu_fullsize.py tests/test_gpu_videocrafter.py -rP > gpurun_out/${TAG}_parityall.log 2>&1
+  echo "parity(all) exit $?"; grep -E "rel-L2|identical" gpurun_out/${TAG}_parityall.log | cut -c1-220; digest gpurun_out/${TAG}_parityall.log 3
+}
+prof() {            # name, then env assignments
+  name=$1; shift
+  env "$@" timeout 300 python tools/profile_unet.py > gpurun_out/${TAG}_prof_$name.log 2>&1
+  echo "== profile $name"; sed -n 4,5p gpurun_out/${TAG}_prof_$name.log; grep -E "^(gemm|groupnorm|attention|layernorm|copy2d)" gpurun_out/${TAG}_prof_$name.log | awk '{printf "   %-14s %8s ms %5s\n", $1, $2, $4}'
+  cp gpurun_out/unet_ops_b2_f24_32x32.json gpurun_out/${TAG}_ops_$name.json 2>/dev/null
+}
+stage_ab() {        # same-box A/B of the per-op UNet step: default | round-3 operand splits only | three-launch GroupNorm | default again
+  prof default T2V_X=0
+  prof precise_r3 T2V_PRECISE=r3
+  prof nocoop T2V_GN_COOP=0
+  prof default2 T2V_X=0
+}
+stage_smoke() {
+  timeout 400 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${TAG}_smoke.log 2>&1; echo "smoke exit $?"; grep smoke gpurun_out/${TAG}_smoke.log | tail -n 5
+}
+stage_rehearsal() { bash tools/gpu_rehearsal.sh; }
+stage_bench() {
+  timeout -k 10 900 python bench.py > gpurun_out/${TAG}_bench_n1.json 2> gpurun_out/${TAG}_bench_n1.err; echo "bench exit $?"; cut -c1-330 gpurun_out/${TAG}_bench_n1.json
+  python - <<PY
+import json
+try:
+    d = json.loads([l for l in open("gpurun_out/${TAG}_bench_n1.json") if l.startswith("{")][-1]); r = d["roofline"]
+    print({k: r[k] for k in ("achieved", "frac", "unet_step_ms_events", "unet_step_frac_of_peak")}, r["whole_video"], r["calibration"].get("gemm_8192_tflops_before"), d.get("batched", {}).get("value"), d["cpu_baseline"]["value"])
+except Exception as e:
+    print("bench line:", e)
+PY
+}
+stage_multiproc() {
+  timeout 1200 $PYT tests/test_gpu_multiproc.py tests/test_gpu_fake_rccl.py tests/test_gpu_boundary.py -rP > gpurun_out/${TAG}_multiproc.log 2>&1; echo "multiproc exit $?"; grep -E "identical|passed|failed" gpurun_out/${TAG}_multiproc.log | tail -n 8 | cut -c1-250
+}
+stage_e2e() {
+  timeout 1500 $PYT tests/test_gpu_e2e.py tests/test_gpu_text_encoder.py tests/test_gpu_videocrafter.py > gpurun_out/${TAG}_e2e.log 2>&1; echo "e2e exit $?"; digest gpurun_out/${TAG}_e2e.log
+}
+stage_suite() {     # what the driver runs at round end
+  timeout -k 10 2400 python -m pytest tests -m gpu -q -rP --tb=short -p no:cacheprovider > gpurun_out/${TAG}_pytest_gpu.log 2>&1; echo "pytest -m gpu exit $?"; digest gpurun_out/${TAG}_pytest_gpu.log 12
+}
+for st in "$@"; do
+  t0=$(date +%s); echo "######## stage $st"; stage_$st; echo "######## $st took $(( $(date +%s) - t0 )) s"
+done
