@@ -339,7 +339,7 @@ def collective_layout_job(n: int, args, timeout_s: int):
             txt = fh.read()
         sys.stderr.write(txt)                      # the job's diagnostics stay visible in this run's stderr
         keep = [ln for ln in txt.splitlines() if ln.strip() and "Warning" not in ln]
-        marked = [ln for ln in keep if "[bench]" in ln or "Error" in ln or "error" in ln]
+        marked = [ln for ln in keep if "[bench]" in ln] or [ln for ln in keep if ("Error" in ln or "error" in ln) and "traceback" not in ln]
         tail = " | ".join((marked or keep)[-3:])[-600:]
         os.remove(err_path)
     except OSError:

@@ -65,7 +65,7 @@ int validate_op(const t2v_op& op, int idx) {
       if (op.i[16] == T2V_EPI_GEGLU && (N % 32 != 0 || op.i[17] != T2V_F16)) return bad("GEGLU needs N % 32 == 0, fp16 out");
       if (op.i[19] > 1 && op.p[6] == 0) return bad("split-K without workspace");
       if (op.p[3] != 0 && op.i[15] <= 0 && !(g == T2V_GATHER_PLAIN && op.i[8] == 1)) return bad("rowbias without rows_per_batch");
-      if (op.i[22] < 0 || op.i[22] > 10) return bad("unknown tile id");
+      if (op.i[22] < 0 || op.i[22] > 11) return bad("unknown tile id");
       if ((op.i[16] == T2V_EPI_TATTN) != (op.i[22] == 10)) return bad("tile 10 is the fused QKV + temporal attention tile (T2V_EPI_TATTN), and only that");
       if (op.i[16] == T2V_EPI_TATTN) {
         const int F = op.i[8], HW = op.i[9], tpix = op.i[10];
@@ -84,9 +84,9 @@ int validate_op(const t2v_op& op, int idx) {
           return bad("hi + lo output: fp16 out, plain epilogue, no fused LayerNorm, ldc >= 2 N");
       }
       if (g == T2V_GATHER_PLAIN && op.i[8] == 1) {
-        if (op.i[22] != 8 || N != 320 || op.i[19] > 1 || op.i[16] != T2V_EPI_NONE || op.i[17] != T2V_F32 || op.i[18] != 0 || op.i[20] != 0 ||
+        if ((op.i[22] != 8 && op.i[22] != 11) || N != 320 || op.i[19] > 1 || op.i[16] != T2V_EPI_NONE || op.i[17] != T2V_F32 || op.i[18] != 0 || op.i[20] != 0 ||
             K % 64 != 0)
-          return bad("fused LayerNorm output needs the 192x320 tile, N == 320, fp32 out, no split-K / activation");
+          return bad("fused LayerNorm output needs a whole-row tile (192x320 or 128x320), N == 320, fp32 out, no split-K / activation");
         if (op.p[3] == 0 || op.p[7] == 0 || op.i[9] < N || op.i[9] % 4 != 0) return bad("fused LayerNorm output: gamma|beta, output pointer or leading dimension");
         // the epilogue moves whole f32x4 / f16x4 groups without tail guards
         if (op.i[5] < N || (op.p[4] != 0 && (op.i[6] < N || op.i[6] % 4 != 0))) return bad("fused LayerNorm output: ldc / ldr must be >= N and multiples of 4");
@@ -233,7 +233,7 @@ hipError_t launch_op(const t2v_op& op, hipStream_t s) {
         p.ln_eps = op.f[0];
       }
       // the large-tile kernel advances its source pointers by whole k-tiles: needs K % BK == 0
-      if (tile >= 1 && tile <= 9 && p.gather != T2V_GATHER_CONV3X3_C8 && p.K % 64 == 0) return t2v_launch_gemm2(p, tile, s);
+      if (tile >= 1 && tile <= 11 && tile != 10 && p.gather != T2V_GATHER_CONV3X3_C8 && p.K % 64 == 0) return t2v_launch_gemm2(p, tile, s);
       return t2v_launch_gemm(p, s);
     }
     case T2V_OP_GROUPNORM: return t2v_launch_groupnorm(op, s);

@@ -666,7 +666,7 @@ hipError_t launch_cfg(const GemmParams& pin, hipStream_t s) {
         break;
       }
       if (p.epi == T2V_EPI_TATTN) return hipErrorInvalidValue;
-      if constexpr (WM == 6 && WN == 2 && TM == 1 && TN == 5 && !PP) {
+      if constexpr ((WM == 6 || WM == 4) && WN == 2 && TM == 1 && TN == 5 && !PP) {      // whole-row tiles: 192x320 / 128x320
         if (p.ln_out != nullptr) {
           e = launch_cfg_gather<WM, WN, TM, TN, BK, STAGES, MINW, T2V_GATHER_PLAIN, PP, true>(p, s);
           break;
@@ -688,7 +688,7 @@ hipError_t launch_cfg(const GemmParams& pin, hipStream_t s) {
 
 }  // namespace
 
-// tile ids (t2v_op.i[22]):  1 = 256x256, 2 = 256x320, 8 = 192x320 / 9 = 192x256 (12 waves), 3 = 128x256 (8 waves), 4 / 5 = 128x128 with a 4-deep ring
+// tile ids (t2v_op.i[22]):  1 = 256x256, 2 = 256x320, 8 = 192x320 / 9 = 192x256 (12 waves), 11 = 128x320 (8 waves), 3 = 128x256 (8 waves), 4 / 5 = 128x128 with a 4-deep ring
 // (few-row levels: latency-bound, keep 96 KiB per CU in flight) — 64-wide k-tiles
 // (full 128-byte lines per row = one conv reduction chunk), 2-3 stage ring, one workgroup per CU.
 hipError_t t2v_launch_gemm2(const GemmParams& p, int tile, hipStream_t s) {
@@ -701,6 +701,8 @@ hipError_t t2v_launch_gemm2(const GemmParams& p, int tile, hipStream_t s) {
     case 8: return launch_cfg<6, 2, 1, 5, 64, 2, 3>(p, s);   // 192x320, 12 waves (3 per SIMD), 2 x 64 KiB: M = 49152 -> exactly 256 workgroups
     case 9: return launch_cfg<6, 2, 1, 4, 64, 2, 3>(p, s);   // 192x256, 12 waves, 2 x 56 KiB (N = 256 * j where 256-row grids fill badly)
     case 10: return launch_cfg<6, 2, 1, 3, 64, 2, 3>(p, s);  // 192x192, 12 waves: fused QKV projection + temporal attention (T2V_EPI_TATTN only)
+    case 11: return launch_cfg<4, 2, 1, 5, 64, 2, 2>(p, s);  // 128x320, 8 waves (2 per SIMD), 2 x 56 KiB: M = 32768 (VideoCrafter, 16 frames) -> exactly
+                                                             // 256 workgroups where 192-row tiles make 171; also the b = 1 per-GPU shapes (M = 24576 -> 192)
     case 6: return launch_cfg<2, 4, 4, 2, 64, 2, 2, true>(p, s);   // 256x256 ping-pong (two staggered wave groups)
     case 7:                                                         // 256x320 ping-pong
       if (p.gather == T2V_GATHER_CONV3X3 && p.up) return launch_cfg<4, 2, 2, 5, 64, 2, 2>(p, s);   // (upsample gather: register budget)

@@ -229,6 +229,12 @@ class Program:
             # the 256-row grid is a few, badly filled waves
             if n % 320 == 0 and math.ceil(M / 256) * (n // 320) <= 640 and os.environ.get("T2V_TILE8", "1") != "0":
                 tile = 8
+                # 128x320 on 8 waves (tile 11, round 4): VideoCrafter's M = 32768 makes 171 / 513 workgroups of 192 rows for N = 320 / 960
+                # (0.67 of the last wave of CUs) and exactly 256 / 768 of 128 rows; M = 49152 never gets here (192 rows fill it)
+                w8, w11 = math.ceil(M / 192) * (n // 320), math.ceil(M / 128) * (n // 320)
+                fill = lambda wgs: wgs / (math.ceil(wgs / cus) * cus)
+                if fill(w11) > fill(w8) + 0.05 and os.environ.get("T2V_TILE11", "1") != "0":
+                    tile = 11
             elif tile == 1 and n % 256 == 0 and os.environ.get("T2V_TILE8", "1") != "0":
                 # the stem TemporalTransformer (inner = 512): 192 x 2 tiles of 256x256 = 384 workgroups, 192x256 gives 512
                 w1, w9 = math.ceil(M / 256) * (n // 256), math.ceil(M / 192) * (n // 256)
@@ -240,6 +246,8 @@ class Program:
                 # one CFG role per GPU (pairs / T-shard layouts: M = 24576): 192x256 on 12 waves gives 128 x ceil(N / 256)
                 # workgroups; measured (SWEEP_BATCH=1 tools/gemm_sweep.py L0) +7 % QKV, +9 % feed-forward, +13 % temporal conv
                 tile = 9
+                if n % 320 == 0 and os.environ.get("T2V_TILE11_B1", "0") != "0":
+                    tile = 11          # 128x320: no padded columns (N = 320 on 256-wide tiles wastes 37 %); opt-in until swept (SWEEP_BATCH=1)
             elif gather == L.GATHER_CONV3X3 and k >= 2560 and n % 320 == 0:
                 tile = self._fill_choice(M, n, k) if allow_splitk else 2
             elif n >= 2560:
@@ -267,7 +275,7 @@ class Program:
             bm, bn, bk = 128, (64 if (n % 128 != 0 and n % 128 <= 64) else 128), 64
         else:
             bm, bn, bk = {1: (256, 256, 64), 2: (256, 320, 64), 3: (128, 256, 64), 4: (128, 128, 64), 5: (128, 128, 64),
-                          6: (256, 256, 64), 7: (256, 320, 64), 8: (192, 320, 64), 9: (192, 256, 64)}[tile]
+                          6: (256, 256, 64), 7: (256, 320, 64), 8: (192, 320, 64), 9: (192, 256, 64), 11: (128, 320, 64)}[tile]
         tiles = math.ceil(M / bm) * math.ceil(n / bn)
         kt = math.ceil(k / bk)
         split = 1
@@ -314,9 +322,11 @@ class Program:
              rowbias: Optional[Buf] = None, rows_per_batch: int = 0, residual: Optional[Buf] = None,
              epi: int = L.EPI_NONE, act: int = 0, bias_along_m: bool = False, m: Optional[int] = None,
              allow_splitk: bool = True, halo: bool = False, ln: Optional[tuple] = None, step_invariant: bool = False,
-             a_lo: Optional[Buf] = None, out_lo: bool = False) -> Op:
+             a_lo: Optional[Buf] = None, out_lo: bool = False, k_alg: Optional[int] = None) -> Op:
         """out[M, n_out] = epi(gather(a)[M, k] @ w[n, k]^T).  conv['pad_after_only'] (3x3, stride 2): zero padding
         (0,1,0,1) instead of 1 on every side.
+        k_alg: the reduction length that counts as ALGORITHMIC work (Op.flops = 2 M n k_alg) when `k` repeats operand columns — the
+        [hi | lo] x [W | W] forms of precise_operands run 2 k_alg deep but compute the reference's k_alg-deep product.
         out_lo (fp16 `out` that is the left half of a [M, 2n] buffer): also write the low-order image fp16(v - fp16(v)) at columns
         n .. 2n-1 of the same rows — the consumer GEMM runs on the [hi | lo] rows against [W | W] (precise_operands).
         ln = (gamma|beta Ref (fp32 [2n]), gamma Ref, beta Ref, ln_out Buf fp16, eps): LayerNorm of the fp32 result rows as a second
@@ -385,7 +395,7 @@ class Program:
         if ln is not None:
             gb, gamma, beta, ln_out, ln_eps = ln
             assert out.dtype == "f32" and ln_out.dtype == "f16" and ln_out.cols == n and ln_out.rows >= M
-            ln_fused = (tile == 8 and split == 1 and n == 320 and gather == L.GATHER_PLAIN and epi == L.EPI_NONE and act == 0
+            ln_fused = (tile in (8, 11) and split == 1 and n == 320 and gather == L.GATHER_PLAIN and epi == L.EPI_NONE and act == 0
                         and rowbias is None and not bias_along_m and k % 64 == 0 and os.environ.get("T2V_LN_FUSE", "1") != "0")
             if ln_fused:
                 I[8], I[9] = 1, ln_out.ld
@@ -397,7 +407,7 @@ class Program:
             op.p[6] = ws.ref
             if self.splitk_tickets and epi == L.EPI_NONE and not ln_fused:
                 op.p[7] = self.sync_ref("tickets")     # the last-arriving workgroup of a tile folds the slabs: no reduction launch
-        op.flops = 2.0 * M * n * k
+        op.flops = 2.0 * M * n * (k if k_alg is None else k_alg)
         op.out = out
         op.meta = dict(M=M, N=n, K=k, gather=gather, conv=dict(conv), epi=epi, split=split, tile=tile, halo=halo, ln=int(ln_fused))
         if step_invariant:

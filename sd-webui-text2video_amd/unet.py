@@ -234,8 +234,9 @@ class UNetSD(nn.Module):
         # launches and +1.5 % FLOPs (tests/precision_probe.py; DESIGN.md "Precision").  Part of the program cache key.
         # Round 4 adds the next two classes of that ranking: the GroupNorm output in front of every transformer's proj_in and the
         # feed-forward output x4 in front of proj_out (rows [hi | lo] written by the producing kernel, K doubled in the C -> C
-        # linear that consumes them).  "r3" = the round-3 subset only (A/B).
-        self.precise_operands = {"0": False, "r3": "r3"}.get(os.environ.get("T2V_PRECISE", "1"), True)
+        # linear that consumes them) — at the input-resolution level, where the probe puts their whole gain; "all" = at every level
+        # (+0.7 ms per step for ~1 % less error), "r3" = the round-3 subset only (A/B).
+        self.precise_operands = {"0": False, "r3": "r3", "all": "all"}.get(os.environ.get("T2V_PRECISE", "1"), True)
         # TemporalTransformer self-attention as ONE launch per attention (QKV projection + attention of every pixel's frame
         # sequence in the GEMM epilogue, T2V_EPI_TATTN): Q / K / V never reach HBM.  Clips of 2..32 frames; longer clips (and the
         # K/V-gather form of a T-sharded clip) keep the projection GEMM + attention kernel pair, and so do clips whose sequences fill
@@ -551,9 +552,13 @@ class _Lowering:
         self.precise = bool(getattr(net, "precise_operands", False))
         # round 4: the two next classes of the operand ranking (DESIGN.md "Precision") — GroupNorm -> proj_in and x4 -> proj_out.
         # Their consumers are the C -> C linears (HBM-bound at the 32x32 level: a doubled K costs bytes, not MFMA time)
+        # Measured on MI355X (same box): every doubled C -> C linear costs ~12 us at every level (+1.04 ms per step for all 66), and the
+        # probe by level (tests/precision_probe.py ... levels) puts 9.7 of the 10 % / 10.7 of the 13 % of these two classes' gain at
+        # the INPUT resolution (its 11 + 11 sites) -> by default only the transformers of the top level are split; "all" = every level
         level = getattr(net, "precise_operands", False)
         self.precise_gn = self.precise and level != "r3"
         self.precise_ff = self.precise and level != "r3"
+        self.precise_all_levels = level == "all"
         self.fused_tattn = bool(getattr(net, "fused_temporal_attention", False))
         self.stem_dup = False
         self.P = Program(f"unet b{B} f{F} {H}x{W}")
@@ -570,6 +575,10 @@ class _Lowering:
     # -- packed-weight declarations ------------------------------------------------------------
     def w_linear(self, key) -> Ref:
         return Ref("weight", 0, self.packer.add(key + ":lin", "f16", lambda sd, k=key: pk.pad_rows(pk.linear(sd[k + ".weight"]))))
+
+    def precise_at(self, flag: bool, h: int, w: int) -> bool:
+        """Is a round-4 operand split (flag) applied at the level whose frames are h x w?"""
+        return bool(flag) and (self.precise_all_levels or (h == self.H and w == self.W))
 
     def w_proj(self, key, copies: int) -> Ref:
         """Linear weights for an operand stored as `copies` column blocks (1: plain; 2: rows [hi | lo] -> [W | W])."""
@@ -681,7 +690,7 @@ class _Lowering:
                 x16 = P.alloc(x.rows, 2 * cin, "f16")
                 P.copy2d(prefix + ".skip.cast", x, x16.col_slice(0, cin), lo=x16.col_slice(cin, 2 * cin))
                 P.gemm(prefix + ".skip_connection", x16, self.w_linear_dup(prefix + ".skip_connection"), cout, 2 * cin, skip,
-                       bias=self.vec(prefix + ".skip_connection.bias"))
+                       bias=self.vec(prefix + ".skip_connection.bias"), k_alg=cin)
             else:
                 x16 = P.alloc(x.rows, cin, "f16")
                 P.copy2d(prefix + ".skip.cast", x, x16)
@@ -850,7 +859,7 @@ class _Lowering:
         P.free(n)
         # x4 = x3 + FF feeds proj_out as an fp16 operand: with precise_operands it is stored as rows [hi | lo] (the low-order image
         # of the fp16 rounding beside the value) and proj_out runs with K doubled against [W | W]
-        if self.precise_ff:
+        if self.precise_at(self.precise_ff, h, w):
             x4 = P.alloc(Mrows, 2 * inner, "f16")
             P.gemm(f"{prefix}.ff.net.2", g, self.w_linear(f"{prefix}.ff.net.2"), inner, 4 * inner, x4.col_slice(0, inner),
                    bias=self.vec(f"{prefix}.ff.net.2.bias"), residual=x3, out_lo=True)
@@ -864,17 +873,17 @@ class _Lowering:
     def spatial_transformer(self, prefix, x: Buf, c, h, w, dest: Optional[Buf] = None) -> Buf:
         P = self.P
         heads = c // 64
-        n = self.gn(prefix + ".norm", x, prefix + ".norm", per_frame=True, eps=1e-6, silu=False, lo=self.precise_gn)
+        n = self.gn(prefix + ".norm", x, prefix + ".norm", per_frame=True, eps=1e-6, silu=False, lo=self.precise_at(self.precise_gn, h, w))
         x1 = P.alloc(x.rows, c, "f32")
         n1 = P.alloc(x.rows, c, "f16")
         tb = prefix + ".transformer_blocks.0"
         P.gemm(prefix + ".proj_in", n, self.w_proj(prefix + ".proj_in", n.cols // c), c, n.cols, x1, bias=self.vec(prefix + ".proj_in.bias"),
-               ln=self.ln_arg(tb + ".norm1", n1))
+               ln=self.ln_arg(tb + ".norm1", n1), k_alg=c)
         P.free(n)
         x4 = self.transformer_block(tb, x1, n1, c, heads, "spatial", h, w)
         out = self._dest(dest, x.rows, c, "f32")
         P.gemm(prefix + ".proj_out", x4, self.w_proj(prefix + ".proj_out", x4.cols // c), c, x4.cols, out,
-               bias=self.vec(prefix + ".proj_out.bias"), residual=x)
+               bias=self.vec(prefix + ".proj_out.bias"), residual=x, k_alg=c)
         P.free(x4)
         return out
 
@@ -883,17 +892,17 @@ class _Lowering:
         inner = heads * 64
         if self.shard is not None and (h * w) % self.shard.size == 0:
             return self.temporal_transformer_resharded(prefix, x, c, heads, h, w, dest)
-        n = self.gn(prefix + ".norm", x, prefix + ".norm", per_frame=False, eps=1e-6, silu=False, lo=self.precise_gn)
+        n = self.gn(prefix + ".norm", x, prefix + ".norm", per_frame=False, eps=1e-6, silu=False, lo=self.precise_at(self.precise_gn, h, w))
         x1 = P.alloc(x.rows, inner, "f32")
         tb = prefix + ".transformer_blocks.0"
         n1 = None if self.shard is not None else P.alloc(x.rows, inner, "f16")
         P.gemm(prefix + ".proj_in", n, self.w_proj(prefix + ".proj_in", n.cols // c), inner, n.cols, x1, bias=self.vec(prefix + ".proj_in.bias"),
-               ln=None if n1 is None else self.ln_arg(tb + ".norm1", n1))
+               ln=None if n1 is None else self.ln_arg(tb + ".norm1", n1), k_alg=c)
         P.free(n)
         x4 = self.transformer_block(tb, x1, n1, inner, heads, "temporal", h, w)
         out = self._dest(dest, x.rows, c, "f32")
         P.gemm(prefix + ".proj_out", x4, self.w_proj(prefix + ".proj_out", x4.cols // inner), c, x4.cols, out,
-               bias=self.vec(prefix + ".proj_out.bias"), residual=x)
+               bias=self.vec(prefix + ".proj_out.bias"), residual=x, k_alg=inner)
         P.free(x4)
         return out
 
@@ -925,7 +934,8 @@ class _Lowering:
         P.free(xp)
         x4 = self.transformer_block(tb, x1, n1, inner, heads, "temporal", h, w, geom=(Ft, hwr))
         yp = P.alloc(Ft * hwr, c, "f32")
-        P.gemm(prefix + ".proj_out", x4, self.w_proj(prefix + ".proj_out", x4.cols // inner), c, x4.cols, yp, bias=self.vec(prefix + ".proj_out.bias"))
+        P.gemm(prefix + ".proj_out", x4, self.w_proj(prefix + ".proj_out", x4.cols // inner), c, x4.cols, yp, bias=self.vec(prefix + ".proj_out.bias"),
+               k_alg=inner)
         P.free(x4)
         # ---- pixels -> frames: frames of slice q (rows [q*cb*hwr, ...) of yp) go to rank q; then unpack + residual
         back = P.alloc(R * Fl * hwr, c, "f32")

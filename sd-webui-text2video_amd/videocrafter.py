@@ -277,7 +277,7 @@ class _LvdmLowering(_Lowering):
                 x16 = P.alloc(x.rows, 2 * cin, "f16")
                 P.copy2d(prefix + ".skip.cast", x, x16.col_slice(0, cin), lo=x16.col_slice(cin, 2 * cin))
                 P.gemm(prefix + ".skip_connection", x16, self.w_linear_dup(prefix + ".skip_connection"), cout, 2 * cin, skip,
-                       bias=self.vec(prefix + ".skip_connection.bias"))
+                       bias=self.vec(prefix + ".skip_connection.bias"), k_alg=cin)
             else:
                 x16 = P.alloc(x.rows, cin, "f16")
                 P.copy2d(prefix + ".skip.cast", x, x16)
@@ -299,7 +299,7 @@ class _LvdmLowering(_Lowering):
         heads, d = net.num_heads, c // net.num_heads
         scale = d ** -0.5
         M = x.rows
-        n = self.gn(prefix + ".norm", x, prefix + ".norm", per_frame=False, eps=1e-6, silu=False, lo=self.precise_gn)
+        n = self.gn(prefix + ".norm", x, prefix + ".norm", per_frame=False, eps=1e-6, silu=False, lo=self.precise_at(self.precise_gn, h, w))
         tb = prefix + ".transformer_blocks.0"
         # LayerNorms as a second output of the GEMM that produces their input (fused into the epilogue of the 192x320 tile where
         # the tile holds whole rows, C = 320: the 32x32 level; a separate LayerNorm op elsewhere — Program.gemm decides).  The
@@ -316,7 +316,8 @@ class _LvdmLowering(_Lowering):
 
         cur = P.alloc(M, c, "f32")
         ln = ln_of("norm1")
-        P.gemm(prefix + ".proj_in", n, self.w_proj(prefix + ".proj_in", n.cols // c), c, n.cols, cur, bias=self.vec(prefix + ".proj_in.bias"), ln=ln)
+        P.gemm(prefix + ".proj_in", n, self.w_proj(prefix + ".proj_in", n.cols // c), c, n.cols, cur, bias=self.vec(prefix + ".proj_in.bias"), ln=ln,
+               k_alg=c)
         P.free(n)
         nxt = ln[3] if ln is not None else None          # LayerNorm(cur) for the next consumer, when already produced
 
@@ -399,7 +400,7 @@ class _LvdmLowering(_Lowering):
         g = P.alloc(M, 4 * c, "f16")
         P.gemm(f"{tb}.ff.geglu", nrm, wg, 8 * c, c, g, bias=bg, epi=L.EPI_GEGLU)
         P.free(nrm)
-        if self.precise_ff:          # x4 as rows [hi | lo], proj_out against [W | W] (unet.py transformer_block)
+        if self.precise_at(self.precise_ff, h, w):          # x4 as rows [hi | lo], proj_out against [W | W] (unet.py transformer_block)
             x4 = P.alloc(M, 2 * c, "f16")
             P.gemm(f"{tb}.ff.net.2", g, self.w_linear(f"{tb}.ff.net.2"), c, 4 * c, x4.col_slice(0, c), bias=self.vec(f"{tb}.ff.net.2.bias"),
                    residual=cur, out_lo=True)
@@ -409,7 +410,7 @@ class _LvdmLowering(_Lowering):
         P.free(g, cur)
         out = self._dest(dest, M, c, "f32")
         P.gemm(prefix + ".proj_out", x4, self.w_proj(prefix + ".proj_out", x4.cols // c), c, x4.cols, out, bias=self.vec(prefix + ".proj_out.bias"),
-               residual=x)
+               residual=x, k_alg=c)
         P.free(x4)
         return out
 

@@ -25,7 +25,17 @@ from sd_webui_text2video_amd import _lib as L  # noqa: E402
 from sd_webui_text2video_amd import unet as U  # noqa: E402
 
 
+BY_LEVEL = False       # "levels" on the command line: the round-4 classes are split by resolution level (rows of the tensor)
+
+
 def classify(op) -> str:
+    c = _classify(op)
+    if BY_LEVEL and op.out is not None:
+        return f"{c}@{op.out.rows}"
+    return c
+
+
+def _classify(op) -> str:
     """Class of the fp16 tensor an op writes (by op kind / name)."""
     n = op.name
     if op.kind == L.OP_GROUPNORM:
@@ -36,7 +46,7 @@ def classify(op) -> str:
         return "gn.resblock"                  # GN+SiLU -> 3x3 conv operand (incl. the head)
     if op.kind == L.OP_LAYERNORM:
         return "ln"
-    if op.kind == L.OP_ATTENTION:
+    if op.kind in (L.OP_ATTENTION, L.OP_RELPOS_ATTN):
         return "attn.out"
     if op.kind == L.OP_NCTHW_TO_CL:
         return "x.latent"
@@ -102,6 +112,13 @@ class Probe(Interp):
 
 
 def main():
+    global BY_LEVEL
+    if "levels" in sys.argv:
+        BY_LEVEL = True
+        sys.argv.remove("levels")
+    fast = "fast" in sys.argv           # only the "this class exact alone" column
+    if fast:
+        sys.argv.remove("fast")
     which = sys.argv[1] if len(sys.argv) > 1 else "tiny"
     F = int(sys.argv[2]) if len(sys.argv) > 2 else 4
     cfg = dict(configs.TINY_UNET)
@@ -109,7 +126,13 @@ def main():
     if which == "small":           # same topology, wider: closer to the full model's K (error averages down with K)
         cfg.update(dim=128)
     torch.manual_seed(0)
-    net = U.UNetSD(**cfg, init_weights=False)
+    lvdm = which == "lvdm"         # VideoCrafter topology (SpatialTemporalTransformer: 4 attentions + 5 LayerNorms per block, rel-pos)
+    if lvdm:
+        from sd_webui_text2video_amd import videocrafter as VC
+        cfg, hw = dict(configs.TINY_LVDM_UNET), 8
+        net = VC.UNetModel(**cfg, init_weights=False)
+    else:
+        net = U.UNetSD(**cfg, init_weights=False)
     synth.load_synth(net, seed=0)
     with torch.no_grad():
         for p in net.parameters():
@@ -119,7 +142,7 @@ def main():
     x = torch.randn(1, 4, F, hw, hw, generator=g)
     y = torch.randn(1, 7, cfg["context_dim"], generator=g).half().float()
     t = torch.tensor([801.0])
-    ref = tp.unet_forward(sd, cfg, x, t.long(), y)
+    ref = tp.lvdm_unet_forward(sd, cfg, x, t.long(), y) if lvdm else tp.unet_forward(sd, cfg, x, t.long(), y)
     net16 = net.half()
     comp = net16._compile(1, F, hw, hw, 7, "f32", "f16", "f16")
     weights = comp.packer.materialise(net16.state_dict(), "cpu")
@@ -147,9 +170,11 @@ def main():
     alone = {}
     for c in classes:
         r1, _ = run({c})
-        r2, _ = run(set(sorted(seen)) - {c})
+        r2 = float("nan") if fast else run(set(sorted(seen)) - {c})[0]
         alone[c] = r1
         print(f"{c:16s} {seen[c]:6d} {r1:12.3e} {100 * (1 - r1 / base):7.1f}% {r2:20.3e}", flush=True)
+    if fast:
+        return
     rall, _ = run(set(sorted(seen)))
     print(f"every class exact: {rall:.3e} (floor: fp16 eps output + fp32 accumulation order)")
     print(f"every class exact: {rall:.3e}", flush=True)

@@ -13,7 +13,7 @@ from sd_webui_text2video_amd.program import Buf, Program, Ref
 
 pytestmark = pytest.mark.gpu
 
-GEMM2_TILES = [1, 2, 3, 4, 5, 6, 7, 8, 9]     # csrc/gemm2.hip configurations (t2v_op.i[22])
+GEMM2_TILES = [1, 2, 3, 4, 5, 6, 7, 8, 9, 11]     # csrc/gemm2.hip configurations (t2v_op.i[22])
 
 
 def _g(seed=0):
@@ -861,13 +861,14 @@ def test_relpos_attention_against_explicit_formula(D, T, Tq, off, R):
     assert rel_l2(read(got, o).float(), ref.permute(2, 0, 1, 3).reshape(Tq * hw, inner)) < 2e-3
 
 
+@pytest.mark.parametrize("tile", [8, 11])
 @pytest.mark.parametrize("M,K,with_res", [(400, 320, True), (192 * 3 + 5, 1280, True), (77, 64, False), (4096, 320, True)])
-def test_gemm_with_fused_layernorm_output(M, K, with_res):
+def test_gemm_with_fused_layernorm_output(M, K, with_res, tile):
     """192x320 tile with whole rows (N == 320): the epilogue writes the fp32 stream AND LayerNorm(row) * gamma + beta (fp16) —
     checked against the interpreter and against torch.nn.functional.layer_norm of the device's own fp32 output."""
     N = 320
     P = Program()
-    P.force_tile = 8
+    P.force_tile = tile
     g = _g(150 + M)
     a, out, n_out = P.alloc(M, K, "f16"), P.alloc(M, N, "f32"), P.alloc(M, N, "f16", ld=N + 8)
     res = P.alloc(M, N, "f32") if with_res else None
@@ -876,7 +877,7 @@ def test_gemm_with_fused_layernorm_output(M, K, with_res):
          "gb": torch.cat([gamma, beta])}
     op = P.gemm("g", a, Ref("weight", 0, "w"), N, K, out, bias=Ref("weight", 0, "b"), residual=res, allow_splitk=False,
                 ln=(Ref("weight", 0, "gb"), Ref("weight", 0, "g"), Ref("weight", 0, "be"), n_out, 1e-5))
-    assert op.i[22] == 8 and op.i[8] == 1 and len(P.ops) == 1          # fused: no separate LayerNorm op
+    assert op.i[22] == tile and op.i[8] == 1 and len(P.ops) == 1          # fused: no separate LayerNorm op
 
     def init(it):
         fill(it, a, g)

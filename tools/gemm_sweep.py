@@ -13,7 +13,7 @@ from sd_webui_text2video_amd.program import BoundProgram, Program, Ref  # noqa: 
 
 dev = torch.device("cuda:0")
 # (label, gather, M, N, K, conv)
-F = 24
+F = int(os.environ.get("SWEEP_FRAMES", "24"))      # 16 + SWEEP_BATCH=2: VideoCrafter's M = 32768
 B = int(os.environ.get("SWEEP_BATCH", "2"))      # 2 = cond+uncond batched (1 GPU); 1 = one CFG role per GPU (N >= 2)
 SHAPES = []
 for (C, hw, lvl) in [(320, 32, "L0"), (640, 16, "L1"), (1280, 8, "L2"), (1280, 4, "L3")]:
@@ -33,8 +33,8 @@ for label, gather, M, N, K, conv, epi in SHAPES:
     if only and only not in label:
         continue
     res = []
-    for tile in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9):
-        if tile in (2, 7, 8) and N % 320 != 0:
+    for tile in (0, 1, 2, 3, 4, 5, 8, 9, 11):
+        if tile in (2, 7, 8, 11) and N % 320 != 0:
             continue
         splits = [1]
         P0 = Program(); P0.force_tile = tile

@@ -33,11 +33,28 @@ prof() {            # name, then env assignments
   echo "== profile $name"; sed -n 4,5p gpurun_out/${TAG}_prof_$name.log; grep -E "^(gemm|groupnorm|attention|layernorm|copy2d)" gpurun_out/${TAG}_prof_$name.log | awk '{printf "   %-14s %8s ms %5s\n", $1, $2, $4}'
   cp gpurun_out/unet_ops_b2_f24_32x32.json gpurun_out/${TAG}_ops_$name.json 2>/dev/null
 }
-stage_ab() {        # same-box A/B of the per-op UNet step: default | round-3 operand splits only | three-launch GroupNorm | default again
+stage_ab() {        # same-box A/B of the per-op UNet step: default | round-3 operand splits only | round-4 splits at every level | default again
   prof default T2V_X=0
   prof precise_r3 T2V_PRECISE=r3
-  prof nocoop T2V_GN_COOP=0
+  prof precise_all T2V_PRECISE=all
   prof default2 T2V_X=0
+}
+stage_lvdm() {      # configs[4]: bench line + step profile with the 128x320 tile (default) and without
+  timeout 400 python bench.py --model lvdm --steps 2 --warmup 1 > gpurun_out/${TAG}_bench_lvdm.json 2> gpurun_out/${TAG}_bench_lvdm.err; echo "bench lvdm exit $?"; cut -c1-200 gpurun_out/${TAG}_bench_lvdm.json
+  T2V_TILE11=0 timeout 400 python bench.py --model lvdm --steps 2 --warmup 1 > gpurun_out/${TAG}_bench_lvdm_notile11.json 2> gpurun_out/${TAG}_bench_lvdm_notile11.err; echo "bench lvdm (no tile 11) exit $?"; cut -c1-200 gpurun_out/${TAG}_bench_lvdm_notile11.json
+  python - <<PY
+import json
+for n in ("bench_lvdm", "bench_lvdm_notile11"):
+    try:
+        d = json.loads([l for l in open("gpurun_out/${TAG}_%s.json" % n) if l.startswith("{")][-1]); r = d["roofline"]
+        print(n, d["value"], {k: r[k] for k in ("achieved", "frac", "unet_step_ms_events", "unet_step_frac_of_peak")}, r["whole_video"]["frac"])
+    except Exception as e:
+        print(n, "no line:", e)
+PY
+}
+stage_sweep() {     # tile sweeps of the shapes the 128x320 tile is meant for: VideoCrafter (16 frames, b = 2) and one CFG role per GPU (b = 1)
+  SWEEP_FRAMES=16 timeout 500 python tools/gemm_sweep.py L0 > gpurun_out/${TAG}_sweep_L0_f16.txt 2>&1; cat gpurun_out/${TAG}_sweep_L0_f16.txt | cut -c1-330
+  SWEEP_BATCH=1 timeout 500 python tools/gemm_sweep.py L0 > gpurun_out/${TAG}_sweep_L0_b1.txt 2>&1; cat gpurun_out/${TAG}_sweep_L0_b1.txt | cut -c1-330
 }
 stage_smoke() {
   timeout 400 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${TAG}_smoke.log 2>&1; echo "smoke exit $?"; grep smoke gpurun_out/${TAG}_smoke.log | tail -n 5
