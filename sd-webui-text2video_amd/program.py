@@ -246,8 +246,11 @@ class Program:
                 # one CFG role per GPU (pairs / T-shard layouts: M = 24576): 192x256 on 12 waves gives 128 x ceil(N / 256)
                 # workgroups; measured (SWEEP_BATCH=1 tools/gemm_sweep.py L0) +7 % QKV, +9 % feed-forward, +13 % temporal conv
                 tile = 9
-                if n % 320 == 0 and os.environ.get("T2V_TILE11_B1", "0") != "0":
-                    tile = 11          # 128x320: no padded columns (N = 320 on 256-wide tiles wastes 37 %); opt-in until swept (SWEEP_BATCH=1)
+                if n == 320 and os.environ.get("T2V_TILE11", "1") != "0":
+                    # 128x320 on 8 waves: 192 workgroups, no padded columns (N = 320 on 256-wide tiles wastes 37 %); measured
+                    # (SWEEP_BATCH=1 tools/gemm_sweep.py L0, round 4): ff2 497 vs 461 TF/s, conv3x3 681 vs 598, tconv 442 vs 419, C -> C
+                    # 216 vs 213; N = 960 stays on 192x256 (324 vs 263)
+                    tile = 11
             elif gather == L.GATHER_CONV3X3 and k >= 2560 and n % 320 == 0:
                 tile = self._fill_choice(M, n, k) if allow_splitk else 2
             elif n >= 2560:

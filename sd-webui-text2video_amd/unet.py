@@ -222,7 +222,7 @@ class UNetSD(nn.Module):
         # Storage type of tensors that are consumed ONLY by a GroupNorm (ResBlock's first conv output
         # and the three inner temporal-conv outputs): "f16" halves their HBM traffic (what the
         # reference's .half() path stores everywhere), "f32" keeps them in the fp32 stream.
-        self.norm_input_dtype = "f16"
+        self.norm_input_dtype = os.environ.get("T2V_NORM_INPUT", "f16")
         self.context_token = None     # one-shot hint consumed by the next forward (see forward_cfg_pair)
         # Precision option (off by default): weights whose packed-image name starts with one of these prefixes are applied as
         # hi + lo fp16 images in two MFMA passes (fp32 weights only; e.g. ("input_blocks.0", "input_blocks.1") — the blocks

@@ -126,10 +126,12 @@ def main():
     if which == "small":           # same topology, wider: closer to the full model's K (error averages down with K)
         cfg.update(dim=128)
     torch.manual_seed(0)
-    lvdm = which == "lvdm"         # VideoCrafter topology (SpatialTemporalTransformer: 4 attentions + 5 LayerNorms per block, rel-pos)
+    lvdm = which.startswith("lvdm")     # VideoCrafter topology (SpatialTemporalTransformer: 4 attentions + 5 LayerNorms per block, rel-pos)
+    if which == "full":                 # the RELEASED ModelScope width / depth (1.41 B) on a small clip: the per-config table VERDICT r03 asks for
+        cfg = dict(configs.MODELSCOPE_UNET)
     if lvdm:
         from sd_webui_text2video_amd import videocrafter as VC
-        cfg, hw = dict(configs.TINY_LVDM_UNET), 8
+        cfg, hw = (dict(configs.LVDM_UNET), 16) if which == "lvdmfull" else (dict(configs.TINY_LVDM_UNET), 8)      # lvdmfull: released 0.96 B config
         net = VC.UNetModel(**cfg, init_weights=False)
     else:
         net = U.UNetSD(**cfg, init_weights=False)

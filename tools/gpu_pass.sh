@@ -52,6 +52,18 @@ for n in ("bench_lvdm", "bench_lvdm_notile11"):
         print(n, "no line:", e)
 PY
 }
+stage_lvdmx() {     # configs[4] parity + bench under the heavier precision settings (every level split, fp32 GroupNorm-only tensors)
+  for cfg in "T2V_PRECISE=all" "T2V_PRECISE=all T2V_NORM_INPUT=f32" "T2V_NORM_INPUT=f32"; do
+    tag=$(echo $cfg | tr ' =' '__')
+    env $cfg timeout 900 $PYT tests/test_gpu_fullsize.py -rP -k "c4" > gpurun_out/${TAG}_c4_$tag.log 2>&1
+    echo "== $cfg"; grep -E "DEPLOYED" gpurun_out/${TAG}_c4_$tag.log | cut -c1-200
+    env $cfg timeout 400 python bench.py --model lvdm --steps 2 --warmup 1 2>/dev/null | python -c "import json,sys; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('   bench', d['value'], d['roofline']['unet_step_ms_events'])"
+  done
+}
+stage_sweep12() {   # does the 128x320 tile win anywhere at the 16x16 / 8x8 levels (b = 2)?
+  timeout 600 python tools/gemm_sweep.py L1 > gpurun_out/${TAG}_sweep_L1.txt 2>&1; cut -c1-400 gpurun_out/${TAG}_sweep_L1.txt
+  timeout 600 python tools/gemm_sweep.py L2 > gpurun_out/${TAG}_sweep_L2.txt 2>&1; cut -c1-400 gpurun_out/${TAG}_sweep_L2.txt
+}
 stage_sweep() {     # tile sweeps of the shapes the 128x320 tile is meant for: VideoCrafter (16 frames, b = 2) and one CFG role per GPU (b = 1)
   SWEEP_FRAMES=16 timeout 500 python tools/gemm_sweep.py L0 > gpurun_out/${TAG}_sweep_L0_f16.txt 2>&1; cat gpurun_out/${TAG}_sweep_L0_f16.txt | cut -c1-330
   SWEEP_BATCH=1 timeout 500 python tools/gemm_sweep.py L0 > gpurun_out/${TAG}_sweep_L0_b1.txt 2>&1; cat gpurun_out/${TAG}_sweep_L0_b1.txt | cut -c1-330
