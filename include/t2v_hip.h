@@ -82,6 +82,10 @@ enum t2v_gather {
                              M = samples * ceil(HW / i[10]) * 192 (tile rows, not tokens); out fp16 [samples*F*HW, ldc]:
                              softmax(q k^T f[1]) v of every pixel's frame sequence, head h at columns 64 h .. 64 h + 63 */
 
+#define T2V_EPI_STATS 3   /* = T2V_EPI_NONE, and p[7] (fp32 [ceil(M/32)][2][N]) receives per 32-row strip the column sums and sums of squares of the
+                             STORED result (after bias / row bias / activation / residual; fp16 outputs: of the rounded values) — the input of a
+                             GROUPNORM phase 3, which then needs no pass over the tensor for its statistics.  No split-K, no fused LayerNorm. */
+
 /* dtype tags */
 #define T2V_F16 0
 #define T2V_F32 1
@@ -134,7 +138,8 @@ enum t2v_gather {
  *      7 split-K (epilogue NONE): T2V_SYNC_INTS zeroed int32 tile tickets -> the last workgroup of a tile to arrive folds the
  *        slabs in split order and applies the epilogue (no reduction launch); 0 -> a reduction kernel follows
  * GROUPNORM: i: 0 n_inst, 1 rows_per_inst, 2 C, 3 ld_in, 4 groups, 5 in dtype, 6 silu,
- *      7 ld_out, 8 phase (0 whole op | 1 statistics only | 2 fold gathered parts + normalise),
+ *      7 ld_out, 8 phase (0 whole op | 1 statistics only | 2 fold gathered parts + normalise | 3 statistics from the producing GEMM:
+ *         p[6] = its T2V_EPI_STATS strips fp32 [n_inst * rows / 32][2][i[17]], rows % 32 == 0 — a fold of the strips + ONE apply pass),
  *      9 nparts, 10 this rank's part, 11 rows per workgroup (0: T2V_GN_ROWS_PER_BLOCK; sizes the scratch),
  *      12 single-launch variant (phase 0 only, (C/groups) % 4 == 0): one workgroup per (instance, group);
  *      14 rows of the whole instance over all parts (0 = rows * nparts; T-sharded clips with uneven slices);
@@ -146,7 +151,7 @@ enum t2v_gather {
  *      scratch, phase 0: block partials [n_inst][nblk][groups][2] fp64, then {mean, rstd} fp32;  phases 1 / 2: gathered parts
  *      [nparts][n_inst][groups][2] fp64 (phase 1 folds this rank's block partials into its part; ALLGATHER of
  *      n_inst*groups*16 bytes per part), then this rank's block partials, then {mean, rstd};
- *      f: 0 eps;  p: 0 x, 1 gamma, 2 beta, 3 out fp16, 4 scratch, 5 grid-barrier words (i[15])
+ *      f: 0 eps;  p: 0 x, 1 gamma, 2 beta, 3 out fp16, 4 scratch, 5 grid-barrier words (i[15]), 6 producer strips (phase 3)
  * LAYERNORM: i: 0 M, 1 C, 2 ld_in, 3 ld_out, 4 workgroup cap (0 = 2048; rows beyond 4 x cap are walked grid-stride); f: 0 eps;
  *      p: 0 x fp32, 1 gamma, 2 beta, 3 out fp16
  * ATTENTION: i: 0 nq, 1 nk, 2 heads, 3 batch_outer, 4 batch_inner, 5..7 q strides (seq,

@@ -19,7 +19,7 @@ OP_EMBED_ROWS = 14
 OP_TO_UINT8, OP_ALLGATHER, OP_HALO_EXCHANGE = 15, 16, 17
 OP_RESHARD_ROWS, OP_ALLTOALL = 18, 19
 GATHER_PLAIN, GATHER_CONV3X3, GATHER_TCONV3, GATHER_CONV3X3_C8 = 0, 1, 2, 3
-EPI_NONE, EPI_GEGLU, EPI_TATTN = 0, 1, 2
+EPI_NONE, EPI_GEGLU, EPI_TATTN, EPI_STATS = 0, 1, 2, 3
 F16, F32 = 0, 1
 EXT_SLOTS = 16
 EXT_X, EXT_T, EXT_CTX, EXT_OUT, EXT_XT, EXT_XT_OUT, EXT_NOISE, EXT_EPS = 1, 2, 3, 4, 5, 6, 7, 8

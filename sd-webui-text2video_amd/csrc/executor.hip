@@ -63,6 +63,9 @@ int validate_op(const t2v_op& op, int idx) {
       if (g == T2V_GATHER_TCONV3 && (op.i[8] <= 0 || op.i[9] <= 0 || M % (op.i[8] * op.i[9]) != 0))
         return bad("M not a multiple of F*HW");
       if (op.i[16] == T2V_EPI_GEGLU && (N % 32 != 0 || op.i[17] != T2V_F16)) return bad("GEGLU needs N % 32 == 0, fp16 out");
+      if (op.i[16] == T2V_EPI_STATS && (op.p[7] == 0 || op.i[19] > 1 || (g == T2V_GATHER_PLAIN && op.i[8] == 1)))
+        return bad("column statistics (T2V_EPI_STATS): strips pointer p[7], no split-K, no fused LayerNorm");
+      if (op.i[16] < 0 || op.i[16] > T2V_EPI_STATS) return bad("unknown epilogue");
       if (op.i[19] > 1 && op.p[6] == 0) return bad("split-K without workspace");
       if (op.p[3] != 0 && op.i[15] <= 0 && !(g == T2V_GATHER_PLAIN && op.i[8] == 1)) return bad("rowbias without rows_per_batch");
       if (op.i[22] < 0 || op.i[22] > 11) return bad("unknown tile id");
@@ -97,7 +100,8 @@ int validate_op(const t2v_op& op, int idx) {
       const int C = op.i[2], groups = op.i[4], phase = op.i[8], nparts = op.i[9] > 0 ? op.i[9] : 1;
       if (op.i[0] <= 0 || op.i[1] <= 0 || C <= 0 || groups <= 0) return bad("empty GroupNorm");
       if (C % groups != 0 || C % 8 != 0 || op.i[3] % 8 != 0 || op.i[7] % 8 != 0 || groups > 256) return bad("GroupNorm needs C % groups == 0, C / ld % 8 == 0, groups <= 256");
-      if (phase < 0 || phase > 2 || op.i[10] < 0 || op.i[10] >= nparts) return bad("bad GroupNorm phase / part");
+      if (phase < 0 || phase > 3 || op.i[10] < 0 || op.i[10] >= nparts) return bad("bad GroupNorm phase / part");
+      if (phase == 3 && (op.p[6] == 0 || op.i[1] % 32 != 0 || op.i[17] < C || nparts != 1)) return bad("GroupNorm phase 3: producer strips p[6], rows % 32 == 0, strip row length i[17] >= C");
       if (op.i[13] != 0 && op.i[13] < op.i[1]) return bad("rows of the largest part < rows");
       if (op.i[12] != 0 && (phase != 0 || (C / groups) % 4 != 0)) return bad("single-launch GroupNorm: phase 0, (C/groups) % 4 == 0");
       if (op.i[16] != 0 && (phase == 1 || op.i[7] < 2 * C)) return bad("GroupNorm low-order output: not for the statistics-only phase, ld_out >= 2 C");
@@ -204,6 +208,7 @@ hipError_t launch_op(const t2v_op& op, hipStream_t s) {
       p.Cin = op.i[10]; p.stride = op.i[11]; p.up = op.i[12]; p.Hout = op.i[13]; p.Wout = op.i[14];
       p.rows_per_batch = op.i[15] > 0 ? op.i[15] : 1;
       p.epi = op.i[16]; p.out_f32 = op.i[17] == T2V_F32; p.act = op.i[18];
+      if (p.epi == T2V_EPI_STATS) { p.epi = T2V_EPI_NONE; p.stats = reinterpret_cast<float*>(op.p[7]); }   // (validated: no split-K -> p[7] is not a ticket buffer)
       p.splitk = op.i[19] > 1 ? op.i[19] : 1;
       p.bias_m = op.i[20]; p.ldrb = op.i[21];
       p.A = reinterpret_cast<const f16*>(op.p[0]);

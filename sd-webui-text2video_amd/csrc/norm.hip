@@ -159,6 +159,33 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* partials
   }
 }
 
+// Phase 3 — statistics from the producing GEMM's epilogue (T2V_EPI_STATS): strips[(inst * nstrips + s)][0 | 1][c] = sum / sum of squares
+// of one 32-row strip of column c.  One wave per (instance, group) folds nstrips x cpg pairs in a fixed order in fp64 -> {mean, rstd}.
+__global__ __launch_bounds__(256) void gn_finalize_strips_kernel(const float* __restrict__ strips, float* finals, int n_inst, int nstrips,
+                                                                 int groups, int cpg, int ldn, double inv_n, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (idx >= n_inst * groups) return;
+  const int inst = idx / groups, g = idx - inst * groups;
+  const float* base = strips + (size_t)inst * nstrips * 2 * ldn + g * cpg;
+  const int total = nstrips * cpg;
+  double s = 0.0, q = 0.0;
+  for (int u = lane; u < total; u += 64) {
+    const int st = u / cpg, c = u - st * cpg;
+    const float* p = base + (size_t)st * 2 * ldn + c;
+    s += (double)p[0];
+    q += (double)p[ldn];
+  }
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+  if (lane == 0) {
+    const double m = s * inv_n;
+    double var = q * inv_n - m * m;
+    var = var < 0.0 ? 0.0 : var;
+    finals[2 * idx] = (float)m;
+    finals[2 * idx + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
 // Launch 2 — grid (ceil(rows / (R*GN_UNROLL)), n_inst), same thread layout.  The workgroup first builds
 // scale[c] = rstd*gamma[c] and shift[c] = beta[c] - mean*scale[c] for the instance in LDS; every thread then
 // normalises GN_UNROLL rows of its 8 channels per column unit (16-byte loads issued together, 16-byte stores).
@@ -715,16 +742,18 @@ hipError_t t2v_launch_groupnorm(const t2v_op& op, hipStream_t s) {
   const int phase = op.i[8], nparts = op.i[9] > 0 ? op.i[9] : 1, part = op.i[10];
   const int rpb = op.i[11] > 0 ? op.i[11] : T2V_GN_ROWS_PER_BLOCK;
   if (C % 8 != 0 || ld_in % 8 != 0 || ld_out % 8 != 0 || C % groups != 0 || groups > 256 || n_inst <= 0 || rows <= 0 ||
-      op.p[4] == 0 || part < 0 || part >= nparts || phase < 0 || phase > 2)
+      op.p[4] == 0 || part < 0 || part >= nparts || phase < 0 || phase > 3)
     return hipErrorInvalidValue;
+  if (phase == 3 && (op.p[6] == 0 || rows % 32 != 0 || op.i[17] < C || nparts != 1)) return hipErrorInvalidValue;
   // T-sharded clips (phase 1 / 2): every rank folds ITS OWN block partials to one {sum, sum of squares} pair per
   // (instance, group) — 512 bytes per instance — and only those are all-gathered; phase 2 sums the parts in rank order
   // (every rank: same values, same order => bit-identical statistics) over the rows of the whole clip (i[14]).
   const long rows_total = op.i[14] > 0 ? (long)op.i[14] : (long)rows * nparts;
   const int nblk = (rows + rpb - 1) / rpb;
-  const size_t part_len = phase == 0 ? (size_t)n_inst * nblk * groups * 2 : (size_t)n_inst * groups * 2;   // doubles per gathered part
+  const bool whole = phase == 0 || phase == 3;         // scratch layout of an unsharded op: [block partials][finals]
+  const size_t part_len = whole ? (size_t)n_inst * nblk * groups * 2 : (size_t)n_inst * groups * 2;        // doubles per gathered part
   double* partials = reinterpret_cast<double*>(op.p[4]);
-  double* local = phase == 0 ? partials : partials + part_len * nparts;                                    // block partials of this rank
+  double* local = whole ? partials : partials + part_len * nparts;                                         // block partials of this rank
   float* finals = reinterpret_cast<float*>(local + (size_t)n_inst * nblk * groups * 2);
   const dim3 g1(nblk, n_inst);
   const int cv = C / 8;
@@ -767,14 +796,18 @@ hipError_t t2v_launch_groupnorm(const t2v_op& op, hipStream_t s) {
                               ld_in, ld_out, groups, op.f[0], lo_off);
       return;
     }
-    if (phase != 2)
+    if (phase == 3)
+      hipLaunchKernelGGL(gn_finalize_strips_kernel, dim3(g2), dim3(256), 0, s, reinterpret_cast<const float*>(op.p[6]), finals, n_inst, rows / 32,
+                         groups, C / groups, op.i[17], inv_n, op.f[0]);
+    else if (phase != 2)
       hipLaunchKernelGGL(gn_stats_kernel<T>, g1, dim3(256), lds, s, x, local, rows, C, ld_in, groups, rpb);
     if (phase == 1)
       hipLaunchKernelGGL(gn_finalize_kernel, dim3(g2), dim3(256), 0, s, local, finals, n_inst, nblk, groups, 0.0, 0.f, 1,
                          partials + part_len * part);
     if (phase != 1) {
-      hipLaunchKernelGGL(gn_finalize_kernel, dim3(g2), dim3(256), 0, s, partials, finals, n_inst, phase == 0 ? nblk : 1, groups,
-                         inv_n, op.f[0], nparts, static_cast<double*>(nullptr));
+      if (phase != 3)
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3(g2), dim3(256), 0, s, partials, finals, n_inst, phase == 0 ? nblk : 1, groups,
+                           inv_n, op.f[0], nparts, static_cast<double*>(nullptr));
       const int rpa = R * GN_UNROLL;    // rows per normalise workgroup
       const dim3 g3((rows + rpa - 1) / rpa, n_inst);
       const size_t lds3 = 2 * (size_t)C * sizeof(float);

@@ -49,6 +49,10 @@ struct GemmParams {
   // hi + lo fp16 output (PLAIN gather, fp16 out, EPI_NONE): out[m, N + n] = fp16(v - float(fp16(v))) beside out[m, n] = fp16(v) — the
   // consumer GEMM reads rows [hi | lo] against weights [W | W] (K doubled) and so sees the value with ~22 bits (precise_operands)
   int out_lo;
+  // Column statistics of the stored result for a GroupNorm that consumes it (T2V_EPI_STATS; no split-K): stats[m / 32][0][n] = sum over
+  // the 32-row strip of out[m, n], stats[m / 32][1][n] = sum of squares — fp32 [ceil(M / 32)][2][N].  The GroupNorm then needs no
+  // statistics pass over the tensor (and no grid barrier): a small fold of the strips + one apply pass (norm.hip, phase 3).
+  float* stats;
 };
 
 
@@ -203,6 +207,7 @@ __device__ __forceinline__ void t2v_epilogue_rows(const GemmParams& p, const f32
     const int mt = m_wave + a * 32;
     const int nt = n_wave + b * 32;
     if (mt < p.M && nt < p.N) {                                // wave-uniform
+      f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};   // T2V_EPI_STATS: this lane's 4 rows x 4 columns of the block
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const f32x4 v = {acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
@@ -232,6 +237,7 @@ __device__ __forceinline__ void t2v_epilogue_rows(const GemmParams& p, const f32
           if (has_res) v += rcur[i];
           if (p.out_f32) {
             *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n) = v;
+            if (p.stats) { ssum += v; ssq += v * v; }
           } else {
             f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
             f16* dst = reinterpret_cast<f16*>(p.out) + (size_t)m * p.ldc + n;
@@ -240,7 +246,23 @@ __device__ __forceinline__ void t2v_epilogue_rows(const GemmParams& p, const f32
               const f16x4 l = {(f16)(v[0] - (float)o[0]), (f16)(v[1] - (float)o[1]), (f16)(v[2] - (float)o[2]), (f16)(v[3] - (float)o[3])};
               *reinterpret_cast<f16x4*>(dst + p.N) = l;
             }
+            if (p.stats) {                                       // statistics of the STORED (fp16-rounded) values: what the GroupNorm normalises
+              const f32x4 sv = {(float)o[0], (float)o[1], (float)o[2], (float)o[3]};
+              ssum += sv; ssq += sv * sv;
+            }
           }
+        }
+      }
+      if (p.stats) {                                             // wave-uniform
+        // the 8 lanes with the same (lane & 7) hold the other rows of these 4 columns: fixed butterfly over lane bits 3, 4, 5
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { ssum[e] += __shfl_xor(ssum[e], o); ssq[e] += __shfl_xor(ssq[e], o); }
+        if (lane < 8 && ncol) {
+          float* st = p.stats + (size_t)(mt >> 5) * 2 * p.N + n;
+          *reinterpret_cast<f32x4*>(st) = ssum;
+          *reinterpret_cast<f32x4*>(st + p.N) = ssq;
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -325,9 +325,12 @@ class Program:
              rowbias: Optional[Buf] = None, rows_per_batch: int = 0, residual: Optional[Buf] = None,
              epi: int = L.EPI_NONE, act: int = 0, bias_along_m: bool = False, m: Optional[int] = None,
              allow_splitk: bool = True, halo: bool = False, ln: Optional[tuple] = None, step_invariant: bool = False,
-             a_lo: Optional[Buf] = None, out_lo: bool = False, k_alg: Optional[int] = None) -> Op:
+             a_lo: Optional[Buf] = None, out_lo: bool = False, k_alg: Optional[int] = None, stats: Optional[Buf] = None) -> Op:
         """out[M, n_out] = epi(gather(a)[M, k] @ w[n, k]^T).  conv['pad_after_only'] (3x3, stride 2): zero padding
         (0,1,0,1) instead of 1 on every side.
+        stats (fp32 [ceil(M / 32), 2 n]): the epilogue also writes per 32-row strip the column sums / sums of squares of the stored
+        result (T2V_EPI_STATS) for a GroupNorm that consumes it (`groupnorm(..., stats=)`); honoured when the op runs without split-K
+        (op.meta["stats"] says whether it was).
         k_alg: the reduction length that counts as ALGORITHMIC work (Op.flops = 2 M n k_alg) when `k` repeats operand columns — the
         [hi | lo] x [W | W] forms of precise_operands run 2 k_alg deep but compute the reference's k_alg-deep product.
         out_lo (fp16 `out` that is the left half of a [M, 2n] buffer): also write the low-order image fp16(v - fp16(v)) at columns
@@ -404,6 +407,11 @@ class Program:
                 I[8], I[9] = 1, ln_out.ld
                 op.f[0] = ln_eps
                 op.p[3], op.p[7] = gb, ln_out.ref
+        with_stats = stats is not None and split == 1 and epi == L.EPI_NONE and not ln_fused and ln is None
+        if with_stats:
+            assert stats.dtype == "f32" and stats.rows >= -(-M // 32) and stats.ld == 2 * n
+            I[16] = L.EPI_STATS
+            op.p[7] = stats.ref
         ws = None
         if split > 1:
             ws = self.alloc(split * M, n, "f32")
@@ -412,7 +420,8 @@ class Program:
                 op.p[7] = self.sync_ref("tickets")     # the last-arriving workgroup of a tile folds the slabs: no reduction launch
         op.flops = 2.0 * M * n * (k if k_alg is None else k_alg)
         op.out = out
-        op.meta = dict(M=M, N=n, K=k, gather=gather, conv=dict(conv), epi=epi, split=split, tile=tile, halo=halo, ln=int(ln_fused))
+        op.meta = dict(M=M, N=n, K=k, gather=gather, conv=dict(conv), epi=epi, split=split, tile=tile, halo=halo, ln=int(ln_fused),
+                       stats=int(with_stats))
         if step_invariant:
             op.meta["step_invariant"] = True      # (also set on the .w_lo pass above: both halves of a split weight are skipped together)
         self._emit(op)
@@ -455,14 +464,16 @@ class Program:
         return self._emit(op)
 
     def groupnorm(self, name: str, x: Buf, gamma: Ref, beta: Ref, out: Buf, *, n_inst: int, eps: float,
-                  silu: bool, groups: int = 32, shard: Optional[TShardSpec] = None, lo: bool = False) -> Op:
+                  silu: bool, groups: int = 32, shard: Optional[TShardSpec] = None, lo: bool = False, stats: Optional[Buf] = None) -> Op:
         """GroupNorm(+SiLU).  With `shard` (cross-frame statistics of a T-sharded clip; n_inst = 1) the op is split
         into: statistics (this rank's partials) -> all-gather of the fp64 partials over the T group ->
         ordered fold of all parts + normalise; every rank ends up with bit-identical statistics.  Each rank folds its own
         block partials first, so a part is one {sum, sum of squares} pair per group: 512 bytes per instance, whatever the
         slice lengths (uneven slices need no special care).
         lo: `out` is the left half of a [rows, 2C] buffer; the low-order fp16 image of every output value goes to columns C .. 2C-1
-        (hi + lo operand split of the consuming GEMM, precise_operands)."""
+        (hi + lo operand split of the consuming GEMM, precise_operands).
+        stats: the T2V_EPI_STATS strips written by the GEMM that produced `x` (fp32 [x.rows / 32, 2 C]): the op folds them (phase 3)
+        instead of reading the tensor for its statistics — two small launches, no grid barrier."""
         rows = x.rows // n_inst
         assert not lo or out.ld >= 2 * x.cols
         assert rows * n_inst == x.rows and out.dtype == "f16" and x.cols % 4 == 0
@@ -496,7 +507,15 @@ class Program:
             op.p[0:5] = [x.ref, gamma, beta, out.ref, scratch.ref]
             return op
 
-        if nparts == 1:
+        if nparts == 1 and stats is not None:
+            assert rows % 32 == 0 and stats.ld == 2 * x.cols and stats.rows * 32 >= x.rows
+            op = make(3, "")
+            op.i[17] = x.cols
+            op.p[6] = stats.ref
+            op.meta = dict(n_inst=n_inst, rows=rows, C=x.cols, dt=x.dtype, fused=0, coop=0, strips=1)
+            op.out = out
+            self._emit(op)
+        elif nparts == 1:
             op = make(0, "")
             # small statistics slices (16x16 / 8x8 / 4x4 levels): one launch, one workgroup per (instance, group)
             cpg = x.cols // groups

@@ -223,6 +223,10 @@ class UNetSD(nn.Module):
         # and the three inner temporal-conv outputs): "f16" halves their HBM traffic (what the
         # reference's .half() path stores everywhere), "f32" keeps them in the fp32 stream.
         self.norm_input_dtype = os.environ.get("T2V_NORM_INPUT", "f16")
+        # GroupNorm statistics as a by-product of the GEMM that produces the normalised tensor (T2V_EPI_STATS strips, round 4): the
+        # ResBlock's conv -> norm pairs and the temporal-conv chain then run "fold strips + apply" instead of the statistics pass /
+        # the single-pass kernel with its grid barrier.  Part of the program cache key.
+        self.gn_producer_stats = os.environ.get("T2V_GN_STRIPS", "1") != "0"
         self.context_token = None     # one-shot hint consumed by the next forward (see forward_cfg_pair)
         # Precision option (off by default): weights whose packed-image name starts with one of these prefixes are applied as
         # hi + lo fp16 images in two MFMA passes (fp32 weights only; e.g. ("input_blocks.0", "input_blocks.1") — the blocks
@@ -454,7 +458,8 @@ class UNetSD(nn.Module):
 
     def _lowering_options(self) -> tuple:
         """Lowering switches that change the program (part of the cache key)."""
-        return ((("precise", str(self.precise_operands)),) if getattr(self, "precise_operands", False) else ()) + \
+        return ((("nostrips",),) if not getattr(self, "gn_producer_stats", True) else ()) + \
+            ((("precise", str(self.precise_operands)),) if getattr(self, "precise_operands", False) else ()) + \
             ((("tattn", str(self.fused_temporal_attention)),) if getattr(self, "fused_temporal_attention", False) else ())
 
     def forward_cfg_pair(self, x, t, ctx_pair, context_token=None):
@@ -559,6 +564,9 @@ class _Lowering:
         self.precise_gn = self.precise and level != "r3"
         self.precise_ff = self.precise and level != "r3"
         self.precise_all_levels = level == "all"
+        # GroupNorm statistics from the producing GEMM's epilogue (ResBlock conv -> norm, the temporal-conv chain): on by default
+        self.gn_strips = bool(getattr(net, "gn_producer_stats", True))
+        self.last_stats: Optional[Buf] = None
         self.fused_tattn = bool(getattr(net, "fused_temporal_attention", False))
         self.stem_dup = False
         self.P = Program(f"unet b{B} f{F} {H}x{W}")
@@ -637,7 +645,8 @@ class _Lowering:
         return self.B * self.F * h * w
 
     # -- building blocks ------------------------------------------------------------------------
-    def gn(self, name, x: Buf, key, *, per_frame: bool, eps, silu, out: Optional[Buf] = None, lo: bool = False) -> Buf:
+    def gn(self, name, x: Buf, key, *, per_frame: bool, eps, silu, out: Optional[Buf] = None, lo: bool = False,
+           stats: Optional[Buf] = None) -> Buf:
         """lo (precise_operands): the result is a [rows, 2C] buffer of rows [hi | lo] — fp16(y) and the low-order image of that
         rounding — for a consumer GEMM with weights [W | W] (K = 2C)."""
         if lo:
@@ -647,12 +656,24 @@ class _Lowering:
         else:
             full = out = self.P.alloc(x.rows, x.cols, "f16") if out is None else out
         n_inst = self.B * self.F if per_frame else self.B
+        shard = None if per_frame else self.shard
+        if stats is not None and (shard is not None or (x.rows // n_inst) % 32 != 0):
+            stats = None                  # (a T-sharded cross-frame norm exchanges its own partials; strips are 32 rows)
         self.P.groupnorm(name, x, self.vec(key + ".weight"), self.vec(key + ".bias"), out, n_inst=n_inst, eps=eps, silu=silu,
-                         shard=None if per_frame else self.shard, lo=lo)
+                         shard=shard, lo=lo, stats=stats)
         return full
 
+    def strips_for(self, rows: int, n: int, inst_rows: int) -> Optional[Buf]:
+        """Buffer for the column statistics a GEMM's epilogue leaves for the GroupNorm that consumes its output (T2V_EPI_STATS:
+        fp32 [rows / 32][2][n]) — round 4, VERDICT r03 next #4: that GroupNorm then needs neither a statistics pass over the
+        tensor nor a grid barrier.  None when the option is off or the consumer's statistics instances (`inst_rows` rows each) are
+        not whole 32-row strips."""
+        if not self.gn_strips or inst_rows % 32 != 0:
+            return None
+        return self.P.alloc(-(-rows // 32), 2 * n, "f32")
+
     def conv3(self, name, a: Buf, key, cout, h, w, *, stride=1, up=0, out_dtype="f32", rowbias=None,
-              residual=None, cin=None, dest: Optional[Buf] = None, dup_c8: bool = False) -> Buf:
+              residual=None, cin=None, dest: Optional[Buf] = None, dup_c8: bool = False, stats: Optional[Buf] = None) -> Buf:
         """`dest`: write the result into this (sub-)buffer instead of a fresh allocation — the producers of the two
         halves of a skip-connection concat write straight into the concat buffer (no copy ops)."""
         cin = a.cols if cin is None else cin
@@ -662,10 +683,11 @@ class _Lowering:
         out = self._dest(dest, Mo, n, out_dtype)
         gather = L.GATHER_CONV3X3_C8 if cin == 8 else L.GATHER_CONV3X3
         wref = self.w_conv3_c8dup(key) if dup_c8 else self.w_conv3(key, 8 if cin == 8 else 0)
-        self.P.gemm(name, a, wref, n, 9 * cin, out, bias=self.vec(key + ".bias"),
-                    gather=gather, conv=dict(Hin=h, Win=w, Cin=cin, stride=stride, up=up, Hout=ho, Wout=wo),
-                    rowbias=rowbias, rows_per_batch=self.F * ho * wo if rowbias is not None else 0,
-                    residual=residual)
+        op = self.P.gemm(name, a, wref, n, 9 * cin, out, bias=self.vec(key + ".bias"),
+                         gather=gather, conv=dict(Hin=h, Win=w, Cin=cin, stride=stride, up=up, Hout=ho, Wout=wo),
+                         rowbias=rowbias, rows_per_batch=self.F * ho * wo if rowbias is not None else 0,
+                         residual=residual, stats=stats)
+        self.last_stats = stats if (stats is not None and op.meta.get("stats")) else None     # None: the op ran with split-K
         return out
 
     def _dest(self, dest: Optional[Buf], rows, cols, dtype) -> Buf:
@@ -678,11 +700,12 @@ class _Lowering:
         P = self.P
         a = self.gn(prefix + ".in_layers.0", x, prefix + ".in_layers.0", per_frame=True, eps=1e-5, silu=True)
         e0, e1 = self.emb_slices[prefix]
+        st = self.strips_for(x.rows, cout, h * w)
         h1 = self.conv3(prefix + ".in_layers.2", a, prefix + ".in_layers.2", cout, h, w,
-                        rowbias=self.emb_out.col_slice(e0, e1), out_dtype=self.net.norm_input_dtype)
+                        rowbias=self.emb_out.col_slice(e0, e1), out_dtype=self.net.norm_input_dtype, stats=st)
         P.free(a)
-        b = self.gn(prefix + ".out_layers.0", h1, prefix + ".out_layers.0", per_frame=True, eps=1e-5, silu=True)
-        P.free(h1)
+        b = self.gn(prefix + ".out_layers.0", h1, prefix + ".out_layers.0", per_frame=True, eps=1e-5, silu=True, stats=self.last_stats)
+        P.free(h1, st)
         if cin != cout:
             skip = P.alloc(x.rows, cout, "f32")
             if self.precise:
@@ -699,7 +722,9 @@ class _Lowering:
             P.free(x16)
         else:
             skip = x
-        h2 = self.conv3(prefix + ".out_layers.3", b, prefix + ".out_layers.3", cout, h, w, residual=skip)
+        st = self.strips_for(x.rows, cout, self.F * h * w) if self.shard is None else None
+        h2 = self.conv3(prefix + ".out_layers.3", b, prefix + ".out_layers.3", cout, h, w, residual=skip, stats=st)
+        st_live = self.last_stats
         P.free(b)
         if skip is not x:
             P.free(skip)
@@ -708,7 +733,9 @@ class _Lowering:
         tp = prefix + ".temopral_conv"
         for name, idx in (("conv1", 2), ("conv2", 3), ("conv3", 3), ("conv4", 3)):
             if self.shard is None:
-                nrm = self.gn(f"{tp}.{name}.0", t, f"{tp}.{name}.0", per_frame=False, eps=1e-5, silu=True)
+                nrm = self.gn(f"{tp}.{name}.0", t, f"{tp}.{name}.0", per_frame=False, eps=1e-5, silu=True, stats=st_live)
+                P.free(st)
+                st = st_live = None
             else:
                 # T-sharded: normalised activations go into a buffer with one halo frame either side;
                 # neighbours fill the halos (zeros at the two ends of the clip = the conv's zero padding)
@@ -726,9 +753,12 @@ class _Lowering:
                 P.free(t)
             t = self._dest(dest, h2.rows, cout, "f32") if name == "conv4" else P.alloc(h2.rows, cout, self.net.norm_input_dtype)
             key = f"{tp}.{name}.{idx}"
-            P.gemm(key, nrm, self.w_tconv(key), cout, 3 * cout, t, bias=self.vec(key + ".bias"),
-                   gather=L.GATHER_TCONV3, conv=dict(F=self.F, HW=h * w, Cin=cout),
-                   residual=h2 if name == "conv4" else None, halo=self.shard is not None)
+            if name != "conv4" and self.shard is None:
+                st = self.strips_for(h2.rows, cout, self.F * h * w)            # conv1 .. conv3 feed the next cross-frame GroupNorm
+            op = P.gemm(key, nrm, self.w_tconv(key), cout, 3 * cout, t, bias=self.vec(key + ".bias"),
+                        gather=L.GATHER_TCONV3, conv=dict(F=self.F, HW=h * w, Cin=cout),
+                        residual=h2 if name == "conv4" else None, halo=self.shard is not None, stats=st if name != "conv4" else None)
+            st_live = st if (st is not None and name != "conv4" and op.meta.get("stats")) else None
             P.free(nrm)
         P.free(h2)
         return t

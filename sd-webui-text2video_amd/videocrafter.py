@@ -249,16 +249,17 @@ class _LvdmLowering(_Lowering):
         return Ref("weight", 0, self.packer.add(key + ":tab", "f32", lambda sd, k=key: sd[k]))
 
     def conv133(self, name, a: Buf, key, cout, h, w, *, stride=1, up=0, out_dtype="f32", rowbias=None, residual=None, cin=None,
-                dest: Optional[Buf] = None, dup_c8: bool = False) -> Buf:
+                dest: Optional[Buf] = None, dup_c8: bool = False, stats: Optional[Buf] = None) -> Buf:
         cin = a.cols if cin is None else cin
         ho, wo = (h * 2, w * 2) if up else ((h + 1) // 2 if stride == 2 else h, (w + 1) // 2 if stride == 2 else w)
         n = (cout + 3) // 4 * 4
         out = self._dest(dest, self.B * self.F * ho * wo, n, out_dtype)
         gather = L.GATHER_CONV3X3_C8 if cin == 8 else L.GATHER_CONV3X3
         wref = self.w_conv133_dup(key) if dup_c8 else self.w_conv133(key, 8 if cin == 8 else 0)
-        self.P.gemm(name, a, wref, n, 9 * cin, out, bias=self.vec(key + ".bias"),
-                    gather=gather, conv=dict(Hin=h, Win=w, Cin=cin, stride=stride, up=up, Hout=ho, Wout=wo),
-                    rowbias=rowbias, rows_per_batch=self.F * ho * wo if rowbias is not None else 0, residual=residual)
+        op = self.P.gemm(name, a, wref, n, 9 * cin, out, bias=self.vec(key + ".bias"),
+                         gather=gather, conv=dict(Hin=h, Win=w, Cin=cin, stride=stride, up=up, Hout=ho, Wout=wo),
+                         rowbias=rowbias, rows_per_batch=self.F * ho * wo if rowbias is not None else 0, residual=residual, stats=stats)
+        self.last_stats = stats if (stats is not None and op.meta.get("stats")) else None
         return out
 
     def res_block(self, prefix, x: Buf, cin, cout, h, w, dest: Optional[Buf] = None) -> Buf:
@@ -266,11 +267,12 @@ class _LvdmLowering(_Lowering):
         P = self.P
         a = self.gn(prefix + ".in_layers.0", x, prefix + ".in_layers.0", per_frame=False, eps=1e-5, silu=True)
         e0, e1 = self.emb_slices[prefix]
+        st = self.strips_for(x.rows, cout, self.F * h * w)       # column statistics from the conv's epilogue for the norm that follows (unet.py)
         h1 = self.conv133(prefix + ".in_layers.2", a, prefix + ".in_layers.2", cout, h, w,
-                          rowbias=self.emb_out.col_slice(e0, e1), out_dtype=self.net.norm_input_dtype)
+                          rowbias=self.emb_out.col_slice(e0, e1), out_dtype=self.net.norm_input_dtype, stats=st)
         P.free(a)
-        b = self.gn(prefix + ".out_layers.0", h1, prefix + ".out_layers.0", per_frame=False, eps=1e-5, silu=True)
-        P.free(h1)
+        b = self.gn(prefix + ".out_layers.0", h1, prefix + ".out_layers.0", per_frame=False, eps=1e-5, silu=True, stats=self.last_stats)
+        P.free(h1, st)
         if cin != cout:
             skip = P.alloc(x.rows, cout, "f32")
             if self.precise:         # hi + lo operand split in one pass (UNetSD.precise_operands): rows [hi | lo], weights [W | W]

@@ -125,6 +125,9 @@ class Interp:
             else:
                 acc = acc + self.view(op.p[2], (N,), (1,), torch.float32, ext)[None, :]
         epi = I[16]
+        want_stats = epi == L.EPI_STATS
+        if want_stats:
+            epi = L.EPI_NONE
         if epi == L.EPI_GEGLU:
             a = acc.view(M, N // 16, 2, 8)
             val, gate = a[:, :, 0, :].reshape(M, N // 2), a[:, :, 1, :].reshape(M, N // 2)
@@ -143,6 +146,15 @@ class Interp:
                 res = res + self.mat(op.p[4], M, N, ldr, torch.float32, ext)
         out = self.mat(op.p[5], M, n_out, ldc, _TD[I[17]], ext)
         self._st(out, res, _TD[I[17]])
+        if want_stats:       # per 32-row strip: column sums / sums of squares of the STORED values -> fp32 [ceil(M / 32)][2][N]
+            stored = self.mat(op.p[5], M, n_out, ldc, _TD[I[17]], ext).float()
+            ns = -(-M // 32)
+            pad = torch.zeros(ns * 32, N)
+            pad[:M] = stored
+            strips = pad.view(ns, 32, N)
+            sv = self.view(op.p[7], (ns, 2, N), (2 * N, N, 1), torch.float32, ext)
+            sv[:, 0] = strips.sum(dim=1)
+            sv[:, 1] = (strips * strips).sum(dim=1)
         if gather == L.GATHER_PLAIN and I[11] == 1:          # hi + lo fp16 output: the rounding's low-order image beside the row
             lo_view = self.view(op.p[5].shifted(2 * N), (M, N), (ldc, 1), torch.float16, ext)
             self._st(lo_view, res.float() - res.half().float(), torch.float16)
@@ -158,7 +170,11 @@ class Interp:
         cpg = C // groups
         x = self.mat(op.p[0], n_inst * rows, C, ld_in, _TD[in_dt], ext).double().view(n_inst, rows, groups, cpg)
         rows_total = op.i[14] if op.i[14] > 0 else rows * nparts
-        if phase == 0:
+        if phase == 3:       # statistics from the producing GEMM's strips (T2V_EPI_STATS)
+            ldn = op.i[17]
+            sv = self.view(op.p[6], (n_inst, rows // 32, 2, groups, cpg), (rows // 32 * 2 * ldn, 2 * ldn, ldn, cpg, 1), torch.float32, ext).double()
+            s1, s2, n = sv[:, :, 0].sum(dim=(1, 3)), sv[:, :, 1].sum(dim=(1, 3)), rows * cpg
+        elif phase == 0:
             s1, s2, n = x.sum(dim=(1, 3)), (x * x).sum(dim=(1, 3)), rows * cpg
         else:
             # scratch head: gathered fp64 {sum, sum of squares} [nparts][n_inst][groups][2] (each rank folds its own block

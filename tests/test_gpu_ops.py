@@ -1058,3 +1058,48 @@ def test_gemm_hi_lo_fp16_output_against_torch(M, N, K, tile):
     assert rel_l2(hi_lo[:, :N] + hi_lo[:, N:], v) < 1e-5
     r = rel_l2(read(got, out), torch.nn.functional.linear(v, wp.float()))
     assert r < 2e-5, r
+
+
+@pytest.mark.parametrize("kind,tile", [("conv", None), ("tconv", None), ("plain", 0), ("plain", 8), ("plain", 2)])
+@pytest.mark.parametrize("per_frame,out_dt", [(True, "f16"), (False, "f32")])
+def test_groupnorm_from_producer_strips_against_torch(kind, tile, per_frame, out_dt):
+    """Round 4: the GEMM that produces a GroupNorm's input leaves per-32-row-strip column sums / sums of squares of
+    its STORED result (T2V_EPI_STATS), the GroupNorm folds them (phase 3) and normalises in one pass — no statistics pass, no grid
+    barrier.  Checked against torch: conv / linear -> (fp16 rounding) -> group_norm -> SiLU."""
+    B, F, H, W, C = 2, 3, 8, 8, 128
+    M = B * F * H * W
+    P = Program()
+    P.force_tile = tile
+    g = _g(300)
+    res = P.alloc(M, C, "f32") if out_dt == "f32" else None
+    y, st, out = P.alloc(M, C, out_dt), P.alloc(M // 32, 2 * C, "f32"), P.alloc(M, C, "f16")
+    w = {"b": torch.randn(C, generator=g), "g": 1 + 0.1 * torch.randn(C, generator=g), "be": 0.1 * torch.randn(C, generator=g)}
+    if kind == "conv":
+        a = P.alloc(M, C, "f16")
+        w4 = (torch.randn(C, C, 3, 3, generator=g) / math.sqrt(9 * C)).half()
+        w["w"] = pk.conv3x3(w4.float()).half()
+        op = P.gemm("c", a, Ref("weight", 0, "w"), C, 9 * C, y, bias=Ref("weight", 0, "b"), gather=L.GATHER_CONV3X3,
+                    conv=dict(Hin=H, Win=W, Cin=C, stride=1, up=0, Hout=H, Wout=W), residual=res, stats=st, allow_splitk=False)
+    elif kind == "tconv":
+        a = P.alloc(M, C, "f16")
+        w5 = (torch.randn(C, C, 3, 1, 1, generator=g) / math.sqrt(3 * C)).half()
+        w["w"] = pk.tconv3(w5.float()).half()
+        op = P.gemm("t", a, Ref("weight", 0, "w"), C, 3 * C, y, bias=Ref("weight", 0, "b"), gather=L.GATHER_TCONV3, conv=dict(F=F, HW=H * W, Cin=C),
+                    residual=res, stats=st, allow_splitk=False)
+    else:
+        a = P.alloc(M, 2 * C, "f16")
+        w["w"] = (torch.randn(C, 2 * C, generator=g) / math.sqrt(2 * C)).half()
+        op = P.gemm("l", a, Ref("weight", 0, "w"), C, 2 * C, y, bias=Ref("weight", 0, "b"), residual=res, stats=st, allow_splitk=False)
+    assert op.i[16] == L.EPI_STATS and op.meta["stats"] == 1
+    gn = P.groupnorm("gn", y, Ref("weight", 0, "g"), Ref("weight", 0, "be"), out, n_inst=B * F if per_frame else B, eps=1e-5, silu=True, stats=st)
+    assert gn.i[8] == 3 and len(P.ops) == 2
+    it, got = _gpu_run(P, w, lambda it: (fill(it, a, g), res is not None and fill(it, res, g, 2.0)))
+    _check(it, got, st, 2e-5, "strips vs the interpreter")
+    _check(it, got, out, 1e-3, "GroupNorm from strips vs the interpreter")
+    stored = read(got, y).float()                                      # the device's own GEMM result (fp16-rounded or fp32)
+    s = read(got, st).view(M // 32, 2, C)
+    assert rel_l2(s[:, 0], stored.view(M // 32, 32, C).sum(dim=1)) < 1e-5
+    assert rel_l2(s[:, 1], (stored * stored).view(M // 32, 32, C).sum(dim=1)) < 1e-5
+    n_inst = B * F if per_frame else B
+    ref = torch.nn.functional.silu(torch.nn.functional.group_norm(stored.view(n_inst, M // n_inst, C).permute(0, 2, 1), 32, w["g"], w["be"], 1e-5))
+    assert rel_l2(read(got, out).float(), ref.permute(0, 2, 1).reshape(M, C)) < 1e-3

@@ -10,7 +10,7 @@ PYT="python -m pytest -q --tb=short -p no:cacheprovider"
 digest() { grep -E "passed|failed|FAILED|ERROR|error" "$1" | tail -n "${2:-6}" | cut -c1-300; }
 
 stage_ops() {       # the op-level tests that changed or are new this round
-  timeout 900 $PYT tests/test_gpu_ops.py -x -k "torch or lo_output or hi_lo or groupnorm or epilogue or split_k or tattn or temporal_attention" > gpurun_out/${TAG}_ops.log 2>&1
+  timeout 900 $PYT tests/test_gpu_ops.py -x -k "torch or lo_output or hi_lo or groupnorm or epilogue or split_k or tattn or temporal_attention or strips or layernorm" > gpurun_out/${TAG}_ops.log 2>&1
   echo "ops exit $?"; digest gpurun_out/${TAG}_ops.log
 }
 stage_opsall() {
@@ -38,6 +38,12 @@ stage_ab() {        # same-box A/B of the per-op UNet step: default | round-3 op
   prof precise_r3 T2V_PRECISE=r3
   prof precise_all T2V_PRECISE=all
   prof default2 T2V_X=0
+}
+stage_abgn() {      # same-box A/B: GroupNorm statistics from the producing GEMM's epilogue (default) vs the statistics pass / cooperative kernel
+  prof strips T2V_X=0
+  prof nostrips T2V_GN_STRIPS=0
+  prof strips2 T2V_X=0
+  prof nostrips2 T2V_GN_STRIPS=0
 }
 stage_lvdm() {      # configs[4]: bench line + step profile with the 128x320 tile (default) and without
   timeout 400 python bench.py --model lvdm --steps 2 --warmup 1 > gpurun_out/${TAG}_bench_lvdm.json 2> gpurun_out/${TAG}_bench_lvdm.err; echo "bench lvdm exit $?"; cut -c1-200 gpurun_out/${TAG}_bench_lvdm.json
