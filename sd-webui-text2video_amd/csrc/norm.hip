@@ -186,6 +186,37 @@ __global__ __launch_bounds__(256) void gn_finalize_strips_kernel(const float* __
   }
 }
 
+// The same fold with a whole workgroup per (instance, group), for instances of many strips (cross-frame statistics: 768 strips x 10
+// channels at the 32x32 level — one wave per pair walked them in 120 dependent-latency rounds, 46 us; 256 threads keep ~60 independent
+// loads each in flight).  Thread t takes strips t, t + 256, ...; fixed reduction order (wave xor-tree, then the 4 waves in order).
+__global__ __launch_bounds__(256) void gn_finalize_strips_wg_kernel(const float* __restrict__ strips, float* finals, int nstrips, int groups,
+                                                                    int cpg, int ldn, double inv_n, float eps) {
+  __shared__ double red[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int idx = blockIdx.x, inst = idx / groups, g = idx - inst * groups;
+  const float* base = strips + (size_t)inst * nstrips * 2 * ldn + g * cpg;
+  double s = 0.0, q = 0.0;
+  for (int st = tid; st < nstrips; st += 256) {
+    const float* p = base + (size_t)st * 2 * ldn;
+    float fs = 0.f, fq = 0.f;
+    for (int c = 0; c < cpg; ++c) { fs += p[c]; fq += p[ldn + c]; }
+    s += (double)fs;
+    q += (double)fq;
+  }
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+  if (lane == 0) { red[2 * wave] = s; red[2 * wave + 1] = q; }
+  __syncthreads();
+  if (tid == 0) {
+    double a = 0.0, b = 0.0;
+    for (int w = 0; w < 4; ++w) { a += red[2 * w]; b += red[2 * w + 1]; }
+    const double m = a * inv_n;
+    double var = b * inv_n - m * m;
+    var = var < 0.0 ? 0.0 : var;
+    finals[2 * idx] = (float)m;
+    finals[2 * idx + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
 // Launch 2 — grid (ceil(rows / (R*GN_UNROLL)), n_inst), same thread layout.  The workgroup first builds
 // scale[c] = rstd*gamma[c] and shift[c] = beta[c] - mean*scale[c] for the instance in LDS; every thread then
 // normalises GN_UNROLL rows of its 8 channels per column unit (16-byte loads issued together, 16-byte stores).
@@ -796,7 +827,10 @@ hipError_t t2v_launch_groupnorm(const t2v_op& op, hipStream_t s) {
                               ld_in, ld_out, groups, op.f[0], lo_off);
       return;
     }
-    if (phase == 3)
+    if (phase == 3 && (long)(rows / 32) * (C / groups) > 1024)
+      hipLaunchKernelGGL(gn_finalize_strips_wg_kernel, dim3(n_inst * groups), dim3(256), 0, s, reinterpret_cast<const float*>(op.p[6]), finals,
+                         rows / 32, groups, C / groups, op.i[17], inv_n, op.f[0]);
+    else if (phase == 3)
       hipLaunchKernelGGL(gn_finalize_strips_kernel, dim3(g2), dim3(256), 0, s, reinterpret_cast<const float*>(op.p[6]), finals, n_inst, rows / 32,
                          groups, C / groups, op.i[17], inv_n, op.f[0]);
     else if (phase != 2)

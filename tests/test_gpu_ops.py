@@ -1103,3 +1103,21 @@ def test_groupnorm_from_producer_strips_against_torch(kind, tile, per_frame, out
     n_inst = B * F if per_frame else B
     ref = torch.nn.functional.silu(torch.nn.functional.group_norm(stored.view(n_inst, M // n_inst, C).permute(0, 2, 1), 32, w["g"], w["be"], 1e-5))
     assert rel_l2(read(got, out).float(), ref.permute(0, 2, 1).reshape(M, C)) < 1e-3
+
+
+def test_groupnorm_from_strips_many_strips_per_instance():
+    """The workgroup-per-(instance, group) fold of phase 3 (instances of > 1024 strip x channel pairs: the cross-frame norms)."""
+    n_inst, rows, C, K = 2, 1536, 1280, 256
+    M = n_inst * rows
+    P = Program()
+    g = _g(301)
+    a, y, st, out = P.alloc(M, K, "f16"), P.alloc(M, C, "f16"), P.alloc(M // 32, 2 * C, "f32"), P.alloc(M, C, "f16")
+    w = {"w": (torch.randn(C, K, generator=g) / math.sqrt(K)).half(), "b": torch.randn(C, generator=g),
+         "g": 1 + 0.1 * torch.randn(C, generator=g), "be": 0.1 * torch.randn(C, generator=g)}
+    op = P.gemm("l", a, Ref("weight", 0, "w"), C, K, y, bias=Ref("weight", 0, "b"), stats=st, allow_splitk=False)
+    assert op.meta["stats"] == 1
+    P.groupnorm("gn", y, Ref("weight", 0, "g"), Ref("weight", 0, "be"), out, n_inst=n_inst, eps=1e-5, silu=True, stats=st)
+    it, got = _gpu_run(P, w, lambda it: fill(it, a, g))
+    stored = read(got, y).float()
+    ref = torch.nn.functional.silu(torch.nn.functional.group_norm(stored.view(n_inst, rows, C).permute(0, 2, 1), 32, w["g"], w["be"], 1e-5))
+    assert rel_l2(read(got, out).float(), ref.permute(0, 2, 1).reshape(M, C)) < 1e-3
