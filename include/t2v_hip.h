@@ -126,7 +126,7 @@ enum t2v_gather {
  *      17 out dtype, 18 act (0 none, 1 SiLU), 19 split_k, 20 bias_along_m, 21 ldrb,
  *      22 tile (0 = 128x128-class kernel; 1 256x256, 2 256x320, 3 128x256 (8 waves, 3-stage ring), 4 / 5 128x128 with a 4-deep
  *         ring on 4 / 8 waves, 6 / 7 = 1 / 2 with the two-group ping-pong schedule, 8 / 9 192x320 / 192x256 on 12 waves,
- *         10 = 192x192 on 12 waves, T2V_EPI_TATTN only; 11 = 128x320 on 8 waves),
+ *         10 = 192x192 on 12 waves, T2V_EPI_TATTN only; 11 = 128x320 on 8 waves, 12 = 64x64 on 4 waves with a 4-deep ring),
  *      23 tconv halo (input rows are [clip][F+2][HW]: one halo frame either side, T-sharding);
  *         for CONV3X3: 1 = zero padding (0,1,0,1) instead of (1,1,1,1) (LDM encoder Downsample, taps at +0..+2)
  *      PLAIN gather only: 11 = 1 -> hi + lo fp16 output (fp16 out, plain epilogue, ldc >= 2N): out[m, N + n] = fp16(v - float(fp16(v)))

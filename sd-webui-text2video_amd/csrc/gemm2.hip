@@ -701,6 +701,8 @@ hipError_t t2v_launch_gemm2(const GemmParams& p, int tile, hipStream_t s) {
     case 8: return launch_cfg<6, 2, 1, 5, 64, 2, 3>(p, s);   // 192x320, 12 waves (3 per SIMD), 2 x 64 KiB: M = 49152 -> exactly 256 workgroups
     case 9: return launch_cfg<6, 2, 1, 4, 64, 2, 3>(p, s);   // 192x256, 12 waves, 2 x 56 KiB (N = 256 * j where 256-row grids fill badly)
     case 10: return launch_cfg<6, 2, 1, 3, 64, 2, 3>(p, s);  // 192x192, 12 waves: fused QKV projection + temporal attention (T2V_EPI_TATTN only)
+    case 12: return launch_cfg<2, 2, 1, 1, 64, 4, 2>(p, s);  // 64x64, 4 waves, 4 x 16 KiB (2 workgroups per CU): the 4x4 level (M = 768) as 240 tiles with the
+                                                             // FULL reduction each — no split-K slabs, no reduction launch (experiment, round 4)
     case 11: return launch_cfg<4, 2, 1, 5, 64, 2, 2>(p, s);  // 128x320, 8 waves (2 per SIMD), 2 x 56 KiB: M = 32768 (VideoCrafter, 16 frames) -> exactly
                                                              // 256 workgroups where 192-row tiles make 171; also the b = 1 per-GPU shapes (M = 24576 -> 192)
     case 6: return launch_cfg<2, 4, 4, 2, 64, 2, 2, true>(p, s);   // 256x256 ping-pong (two staggered wave groups)

@@ -274,11 +274,16 @@ class Program:
                 tile = 2 if (M >= 4096 and n % 320 == 0) else 3
             else:
                 tile = 5                               # 128x128, 4-deep ring: 96 KiB per CU in flight
+                if M <= 1024 and n <= 1280 and k <= 1280 and os.environ.get("T2V_TILE12", "1") != "0":
+                    # the 4x4 level's C -> C linears (768, 1280, 1280): 64x64 tiles with the FULL reduction = 240 workgroups, no
+                    # split-K slabs and no reduction launch: 201 vs 146 TF/s (tools/gemm_sweep.py L3, round 4); longer K / wider N
+                    # stay on the split-K configurations (ff2 381 vs 341, conv3x3 525 vs 410, qkv 365 vs 331)
+                    tile = 12
         if tile == 0:
             bm, bn, bk = 128, (64 if (n % 128 != 0 and n % 128 <= 64) else 128), 64
         else:
             bm, bn, bk = {1: (256, 256, 64), 2: (256, 320, 64), 3: (128, 256, 64), 4: (128, 128, 64), 5: (128, 128, 64),
-                          6: (256, 256, 64), 7: (256, 320, 64), 8: (192, 320, 64), 9: (192, 256, 64), 11: (128, 320, 64)}[tile]
+                          6: (256, 256, 64), 7: (256, 320, 64), 8: (192, 320, 64), 9: (192, 256, 64), 11: (128, 320, 64), 12: (64, 64, 64)}[tile]
         tiles = math.ceil(M / bm) * math.ceil(n / bn)
         kt = math.ceil(k / bk)
         split = 1
@@ -289,6 +294,8 @@ class Program:
                     split = max(1, min(round(2 * cus / tiles), kt // 16, 32))
                 elif tiles < 0.5 * cus:
                     split = max(1, min(round(2 * cus / tiles), kt // 8, 32))
+            elif tile == 12:
+                split = 1
             elif tile in (3, 4, 5) and not forced:
                 split = max(1, min(cus // tiles, kt // 8, 8))
             elif tiles < 0.6 * cus:

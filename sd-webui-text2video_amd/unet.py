@@ -226,7 +226,9 @@ class UNetSD(nn.Module):
         # GroupNorm statistics as a by-product of the GEMM that produces the normalised tensor (T2V_EPI_STATS strips, round 4): the
         # ResBlock's conv -> norm pairs and the temporal-conv chain then run "fold strips + apply" instead of the statistics pass /
         # the single-pass kernel with its grid barrier.  Part of the program cache key.
-        self.gn_producer_stats = os.environ.get("T2V_GN_STRIPS", "1") != "0"
+        # MEASURED SLOWER than the single-pass kernel it replaces (same box, round 4: 31.8 vs 25.2 us at the 32x32 level, 22.9 vs 18.8 us at
+        # 8x8, GroupNorm 3.40 vs 3.21 ms per step) — two launches cost what one grid barrier costs — so it is OFF by default.
+        self.gn_producer_stats = os.environ.get("T2V_GN_STRIPS", "0") != "0"
         self.context_token = None     # one-shot hint consumed by the next forward (see forward_cfg_pair)
         # Precision option (off by default): weights whose packed-image name starts with one of these prefixes are applied as
         # hi + lo fp16 images in two MFMA passes (fp32 weights only; e.g. ("input_blocks.0", "input_blocks.1") — the blocks
@@ -458,7 +460,7 @@ class UNetSD(nn.Module):
 
     def _lowering_options(self) -> tuple:
         """Lowering switches that change the program (part of the cache key)."""
-        return ((("nostrips",),) if not getattr(self, "gn_producer_stats", True) else ()) + \
+        return ((("strips",),) if getattr(self, "gn_producer_stats", False) else ()) + \
             ((("precise", str(self.precise_operands)),) if getattr(self, "precise_operands", False) else ()) + \
             ((("tattn", str(self.fused_temporal_attention)),) if getattr(self, "fused_temporal_attention", False) else ())
 
@@ -564,8 +566,8 @@ class _Lowering:
         self.precise_gn = self.precise and level != "r3"
         self.precise_ff = self.precise and level != "r3"
         self.precise_all_levels = level == "all"
-        # GroupNorm statistics from the producing GEMM's epilogue (ResBlock conv -> norm, the temporal-conv chain): on by default
-        self.gn_strips = bool(getattr(net, "gn_producer_stats", True))
+        # GroupNorm statistics from the producing GEMM's epilogue (ResBlock conv -> norm, the temporal-conv chain): opt-in (measured slower)
+        self.gn_strips = bool(getattr(net, "gn_producer_stats", False))
         self.last_stats: Optional[Buf] = None
         self.fused_tattn = bool(getattr(net, "fused_temporal_attention", False))
         self.stem_dup = False

@@ -392,7 +392,7 @@ def test_hi_lo_operand_split_two_pass_and_one_pass_forms():
 
 
 def test_round4_groupnorm_statistics_from_the_producing_gemm():
-    """`gn_producer_stats` (default on): the ResBlock's conv -> GroupNorm pairs and the temporal-conv chain carry T2V_EPI_STATS strips
+    """`gn_producer_stats` (opt-in: measured slower than the single-pass kernel): the ResBlock's conv -> GroupNorm pairs and the temporal-conv chain carry T2V_EPI_STATS strips
     from the GEMM's epilogue to a phase-3 GroupNorm.  In the interpreter (same records the device executes) the forward agrees with the
     statistics-pass lowering to fp32 rounding, split-K producers keep the old form, and the switch is part of the program key."""
     from oracle import torch_port as tp

@@ -33,7 +33,7 @@ for label, gather, M, N, K, conv, epi in SHAPES:
     if only and only not in label:
         continue
     res = []
-    for tile in (0, 1, 2, 3, 4, 5, 8, 9, 11):
+    for tile in (0, 1, 2, 3, 4, 5, 8, 9, 11, 12):
         if tile in (2, 7, 8, 11) and N % 320 != 0:
             continue
         splits = [1]

@@ -70,6 +70,9 @@ stage_sweep12() {   # does the 128x320 tile win anywhere at the 16x16 / 8x8 leve
   timeout 600 python tools/gemm_sweep.py L1 > gpurun_out/${TAG}_sweep_L1.txt 2>&1; cut -c1-400 gpurun_out/${TAG}_sweep_L1.txt
   timeout 600 python tools/gemm_sweep.py L2 > gpurun_out/${TAG}_sweep_L2.txt 2>&1; cut -c1-400 gpurun_out/${TAG}_sweep_L2.txt
 }
+stage_sweep3() {    # the 4x4 level (M = 768): 64x64 tiles with the full reduction (tile 12) against the split-K configurations
+  timeout 600 python tools/gemm_sweep.py L3 > gpurun_out/${TAG}_sweep_L3.txt 2>&1; cut -c1-700 gpurun_out/${TAG}_sweep_L3.txt
+}
 stage_sweep() {     # tile sweeps of the shapes the 128x320 tile is meant for: VideoCrafter (16 frames, b = 2) and one CFG role per GPU (b = 1)
   SWEEP_FRAMES=16 timeout 500 python tools/gemm_sweep.py L0 > gpurun_out/${TAG}_sweep_L0_f16.txt 2>&1; cat gpurun_out/${TAG}_sweep_L0_f16.txt | cut -c1-330
   SWEEP_BATCH=1 timeout 500 python tools/gemm_sweep.py L0 > gpurun_out/${TAG}_sweep_L0_b1.txt 2>&1; cat gpurun_out/${TAG}_sweep_L0_b1.txt | cut -c1-330
