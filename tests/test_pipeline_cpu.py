@@ -120,7 +120,8 @@ def test_bench_layout_choice_and_byte_counts():
     assert bench.choose_layout(1, "auto") == ("single", 24)                  # N = 1 stays configs[1]
     # round 3: the headline workload is configs[1] on every GPU at every N; collective layouts are explicit
     assert bench.choose_layout(2, "auto") == ("replicas", 24) and bench.choose_layout(2, "pairs") == ("pairs", 24)
-    assert bench.choose_layout(4, "auto") == ("replicas", 24) and bench.choose_layout(8, "tshard") == ("tshard", 125)   # configs[2]
+    # round 4: the clip is configs[1]'s 24 frames in every layout (configs[2]'s 125-frame clip is timed beside it: --also-frames)
+    assert bench.choose_layout(4, "auto") == ("replicas", 24) and bench.choose_layout(8, "tshard") == ("tshard", 24)
     assert bench.choose_layout(3, "auto") == ("replicas", 24)
     assert bench.choose_layout(8, "replicas") == ("replicas", 24) and bench.choose_layout(8, "tshard", 48) == ("tshard", 48)
     assert bench.choose_layout(1, "tshard") == ("single", 24)
