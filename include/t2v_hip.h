@@ -156,11 +156,13 @@ enum t2v_gather {
  *      p: 0 x fp32, 1 gamma, 2 beta, 3 out fp16
  * ATTENTION: i: 0 nq, 1 nk, 2 heads, 3 batch_outer, 4 batch_inner, 5..7 q strides (seq,
  *      outer, inner), 8..10 k/v strides, 11..13 out strides (elements; head h at +head_dim*h),
- *      14 head_dim (0 = 64), 15 causal (1: key s visible to query t iff s <= t);  f: 0 scale; p: 0 q, 1 k, 2 v, 3 out (all fp16)
+ *      14 head_dim (0 = 64), 15 causal (1: key s visible to query t iff s <= t), 16 low-order output offset (elements, 0 = none): also
+ *      store fp16(o - float(fp16(o))) at out + i[16] — rows [hi | lo] for a K-doubled output projection;  f: 0 scale; p: 0 q, 1 k, 2 v, 3 out (all fp16)
  * RELPOS_ATTN: i: as ATTENTION with nk == frames of the clip (<= 32), 14 head_dim (multiple of 8, <= 160),
  *      15 max relative position R, 16 q_off: the nq queries are frames [q_off, q_off + nq) of the clip (nq == nk, q_off == 0
  *      unless the clip is T-sharded: then s - t below is s - (t + q_off)); 17 = 1: use the MFMA kernel where it applies (nq == nk,
- *      q_off == 0, nk - 1 <= R <= 31, head_dim 40 | 64 | 80 | 160; the relative tables are staged as fp16) — else the VALU kernel;  f: 0 scale;  p: 0 q, 1 k, 2 v, 3 out (fp16), 4 Ek fp32 [2R+1, head_dim],
+ *      q_off == 0, nk - 1 <= R <= 31, head_dim 40 | 64 | 80 | 160; the relative tables are staged as fp16) — else the VALU kernel;
+ *      18 low-order output offset (as ATTENTION i[16]);  f: 0 scale;  p: 0 q, 1 k, 2 v, 3 out (fp16), 4 Ek fp32 [2R+1, head_dim],
  *      5 Ev fp32 [2R+1, head_dim]:  sim[t,s] = scale * q[t].(k[s] + Ek[clip(s-t)]),
  *      out[t] = sum_s softmax_s(sim)[t,s] * (v[s] + Ev[clip(s-t)])   (attention_temporal.py:107-144)
  * SOFTMAX: i: 0 rows, 1 cols, 2 ld_in, 3 ld_out; f: 0 scale; p: 0 in fp32, 1 out fp16

@@ -35,6 +35,7 @@ struct AttnParams {
   long so_seq, so_out, so_in;
   float scale_log2;
   int causal;   // 1: key s is visible to query t only if s <= t (CLIP text towers)
+  int lo_off;   // != 0: also store fp16(o - float(fp16(o))) at o + lo_off (elements): rows [hi | lo] for a K-doubled to_out (precise_operands)
 };
 
 // KT = keys per LDS tile: 64, or 32 for sequences of <= 32 keys (temporal attention over the frames of one pixel:
@@ -270,10 +271,15 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnParams p) {
       for (int qd = 0; qd < 4; ++qd) {
         const int col = d * 32 + 8 * qd + 4 * fhalf;
         if (col < D) {
-          f16x4 o;
+          f16x4 o, lo;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = (f16)(oacc[d][4 * qd + r] * inv);
+          for (int r = 0; r < 4; ++r) {
+            const float val = oacc[d][4 * qd + r] * inv;
+            o[r] = (f16)val;
+            lo[r] = (f16)(val - (float)o[r]);
+          }
           *reinterpret_cast<f16x4*>(orow + col) = o;
+          if (p.lo_off) *reinterpret_cast<f16x4*>(orow + p.lo_off + col) = lo;
         }
       }
   }
@@ -298,6 +304,7 @@ struct SeqAttnParams {
   long sk_seq, sk_out, sk_in;
   long so_seq, so_out, so_in;
   float scale;
+  int lo_off;                                              // as AttnParams::lo_off
 };
 
 __device__ __forceinline__ f32x8 ld_f32x8(const float* p) {
@@ -429,10 +436,11 @@ __global__ __launch_bounds__(256) void seqattn_kernel(const SeqAttnParams p) {
           for (int j = 0; j < 8; ++j) o[j] += pv * (float)vv[j];
         }
       }
-      f16x8 oh;
+      f16x8 oh, ol;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) oh[j] = (f16)o[j];
+      for (int j = 0; j < 8; ++j) { oh[j] = (f16)o[j]; ol[j] = (f16)(o[j] - (float)oh[j]); }
       *reinterpret_cast<f16x8*>(ob + (long)t * p.so_seq + c * 8) = oh;
+      if (p.lo_off) *reinterpret_cast<f16x8*>(ob + p.lo_off + (long)t * p.so_seq + c * 8) = ol;
     }
   }
 }
@@ -628,10 +636,15 @@ __global__ __launch_bounds__(256) void relpos_mfma_kernel(const RelMfmaParams pp
       for (int qd = 0; qd < 4; ++qd) {
         const int col = d * 32 + 8 * qd + 4 * fhalf;
         if (col < D) {
-          f16x4 o;
+          f16x4 o, lo;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = (f16)(oacc[d][4 * qd + r] * inv);
+          for (int r = 0; r < 4; ++r) {
+            const float val = oacc[d][4 * qd + r] * inv;
+            o[r] = (f16)val;
+            lo[r] = (f16)(val - (float)o[r]);
+          }
           *reinterpret_cast<f16x4*>(orow + col) = o;
+          if (p.lo_off) *reinterpret_cast<f16x4*>(orow + p.lo_off + col) = lo;
         }
       }
   }
@@ -672,6 +685,7 @@ hipError_t launch_seqattn(const t2v_op& op, hipStream_t s) {
   p.sk_seq = op.i[8]; p.sk_out = op.i[9]; p.sk_in = op.i[10];
   p.so_seq = op.i[11]; p.so_out = op.i[12]; p.so_in = op.i[13];
   p.scale = op.f[0];
+  p.lo_off = REL ? op.i[18] : 0;
   if (p.T <= 0 || p.T > 32 || p.Tq <= 0 || p.q_off < 0 || p.q_off + p.Tq > p.T || p.D <= 0 || p.D % 8 != 0 || p.D > 160 || p.n_items <= 0)
     return hipErrorInvalidValue;
   if (REL && (p.R < 0 || p.ek == nullptr || p.ev == nullptr)) return hipErrorInvalidValue;
@@ -751,6 +765,8 @@ hipError_t t2v_launch_attention(const t2v_op& op, hipStream_t s) {
   p.so_seq = op.i[11]; p.so_out = op.i[12]; p.so_in = op.i[13];
   p.scale_log2 = op.f[0] * 1.44269504088896340736f;
   p.causal = op.i[15] != 0;
+  p.lo_off = op.i[16];
+  if (p.lo_off < 0) return hipErrorInvalidValue;
   if (p.nq <= 0 || p.nk <= 0 || !(op.f[0] > 0.f)) return hipErrorInvalidValue;
   const int nbatch = p.b_outer * p.b_inner;
   const int hd = op.i[14] > 0 ? op.i[14] : 64;

@@ -120,6 +120,7 @@ int validate_op(const t2v_op& op, int idx) {
       for (int k = 5; k <= 13; ++k)
         if (op.i[k] < 0) return bad("negative attention stride");
       if (op.i[15] != 0 && op.i[0] != op.i[1]) return bad("causal attention needs nq == nk");
+      if (op.i[16] < 0) return bad("negative low-order output offset");
       if (!(op.f[0] > 0.f)) return bad("attention scale must be > 0");
       if (op.p[0] == 0 || op.p[1] == 0 || op.p[2] == 0 || op.p[3] == 0) return bad("null attention pointer");
       return 0;
@@ -128,7 +129,7 @@ int validate_op(const t2v_op& op, int idx) {
       if (op.i[1] <= 0 || op.i[1] > 32 || op.i[0] <= 0 || op.i[16] < 0 || op.i[16] + op.i[0] > op.i[1])
         return bad("relative-position attention needs nk <= 32 and queries [q_off, q_off + nq) inside the keys");
       if (op.i[14] <= 0 || op.i[14] % 8 != 0 || op.i[14] > 160) return bad("relative-position attention head_dim: multiple of 8, <= 160");
-      if (op.i[2] <= 0 || op.i[3] <= 0 || op.i[4] <= 0 || op.i[15] < 0) return bad("empty relative-position attention");
+      if (op.i[2] <= 0 || op.i[3] <= 0 || op.i[4] <= 0 || op.i[15] < 0 || op.i[18] < 0) return bad("empty relative-position attention");
       for (int k = 5; k <= 13; ++k)
         if (op.i[k] < 0) return bad("negative attention stride");
       for (int k = 0; k < 6; ++k)

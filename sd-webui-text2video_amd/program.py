@@ -294,7 +294,7 @@ class Program:
                     split = max(1, min(round(2 * cus / tiles), kt // 16, 32))
                 elif tiles < 0.5 * cus:
                     split = max(1, min(round(2 * cus / tiles), kt // 8, 32))
-            elif tile == 12:
+            elif tile == 12 and not forced:
                 split = 1
             elif tile in (3, 4, 5) and not forced:
                 split = max(1, min(cus // tiles, kt // 8, 8))
@@ -615,9 +615,11 @@ class Program:
     def attention(self, name: str, q: Ref, k: Ref, v: Ref, o: Ref, *, out_buf: Optional[Buf] = None, nq: int, nk: int, heads: int,
                   b_outer: int, b_inner: int, q_strides, kv_strides, o_strides, scale: float, head_dim: int = 64,
                   rel_k: Optional[Ref] = None, rel_v: Optional[Ref] = None, max_rel: int = 0, causal: bool = False,
-                  q_offset: int = 0, relpos_mfma: Optional[bool] = None) -> Op:
+                  q_offset: int = 0, relpos_mfma: Optional[bool] = None, lo_off: int = 0) -> Op:
         """softmax(q k^T scale) v over strided (sequence, outer, inner) batches.  With rel_k / rel_v (fp32
-        [2*max_rel+1, head_dim] tables) the LVDM relative-position temporal attention op is emitted instead."""
+        [2*max_rel+1, head_dim] tables) the LVDM relative-position temporal attention op is emitted instead.
+        lo_off (elements): also store the low-order fp16 image of every output value at o + lo_off (rows [hi | lo] for a K-doubled
+        output projection, precise_operands)."""
         assert head_dim in (40, 64, 80, 160) or rel_k is not None
         op = Op(L.OP_ATTENTION if rel_k is None else L.OP_RELPOS_ATTN, name)
         op.i[0:5] = [nq, nk, heads, b_outer, b_inner]
@@ -628,10 +630,13 @@ class Program:
             # MFMA variant of the relative-position kernel: opt-in (measured slower than the VALU kernel, csrc/attention.hip)
             op.i[17] = int(os.environ.get("T2V_RELPOS_MFMA", "0") != "0" if relpos_mfma is None else relpos_mfma)
             op.p[4], op.p[5] = rel_k, rel_v
+            op.i[18] = lo_off
             assert not causal
         elif causal:
             assert nq == nk
             op.i[15] = 1
+        if rel_k is None:
+            op.i[16] = lo_off
         op.i[5:8] = list(q_strides)
         op.i[8:11] = list(kv_strides)
         op.i[11:14] = list(o_strides)

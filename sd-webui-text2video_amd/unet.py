@@ -243,6 +243,12 @@ class UNetSD(nn.Module):
         # linear that consumes them) — at the input-resolution level, where the probe puts their whole gain; "all" = at every level
         # (+0.7 ms per step for ~1 % less error), "r3" = the round-3 subset only (A/B).
         self.precise_operands = {"0": False, "r3": "r3", "all": "all"}.get(os.environ.get("T2V_PRECISE", "1"), True)
+        # Two more classes of the same ranking, OFF for ModelScope (its outputs are inside north_star's 1e-3 without them; +0.4 / +0.6 ms
+        # per step) and ON for videocrafter.UNetModel, whose 50-step output needs them (1.09e-3 -> below 1e-3; DESIGN.md "Precision"):
+        # the attention output in front of to_out (input-resolution level) and the fp32 -> fp16 cast in front of the Down / Upsample
+        # convolutions, both as rows [hi | lo] against [W | W].  Part of the program cache key.
+        self.precise_attn_out = os.environ.get("T2V_PRECISE_ATTN", "0") != "0"
+        self.precise_resample = os.environ.get("T2V_PRECISE_RESAMPLE", "0") != "0"
         # TemporalTransformer self-attention as ONE launch per attention (QKV projection + attention of every pixel's frame
         # sequence in the GEMM epilogue, T2V_EPI_TATTN): Q / K / V never reach HBM.  Clips of 2..32 frames; longer clips (and the
         # K/V-gather form of a T-sharded clip) keep the projection GEMM + attention kernel pair, and so do clips whose sequences fill
@@ -461,6 +467,7 @@ class UNetSD(nn.Module):
     def _lowering_options(self) -> tuple:
         """Lowering switches that change the program (part of the cache key)."""
         return ((("strips",),) if getattr(self, "gn_producer_stats", False) else ()) + \
+            ((("pattn",),) if getattr(self, "precise_attn_out", False) else ()) + ((("presample",),) if getattr(self, "precise_resample", False) else ()) + \
             ((("precise", str(self.precise_operands)),) if getattr(self, "precise_operands", False) else ()) + \
             ((("tattn", str(self.fused_temporal_attention)),) if getattr(self, "fused_temporal_attention", False) else ())
 
@@ -566,6 +573,8 @@ class _Lowering:
         self.precise_gn = self.precise and level != "r3"
         self.precise_ff = self.precise and level != "r3"
         self.precise_all_levels = level == "all"
+        self.precise_attn = self.precise and bool(getattr(net, "precise_attn_out", False))
+        self.precise_rs = self.precise and bool(getattr(net, "precise_resample", False))
         # GroupNorm statistics from the producing GEMM's epilogue (ResBlock conv -> norm, the temporal-conv chain): opt-in (measured slower)
         self.gn_strips = bool(getattr(net, "gn_producer_stats", False))
         self.last_stats: Optional[Buf] = None
@@ -603,6 +612,10 @@ class _Lowering:
 
     def w_conv3(self, key, cin_pad=0) -> Ref:
         return Ref("weight", 0, self.packer.add(key + ":c3", "f16", lambda sd, k=key, c=cin_pad: pk.pad_rows(pk.conv3x3(sd[k + ".weight"], c))))
+
+    def w_conv3_hilo(self, key) -> Ref:
+        """3x3 conv weights for an operand of 2 Cin channels = [hi (Cin) | lo (Cin)]: [W | W] along the input channels."""
+        return Ref("weight", 0, self.packer.add(key + ":c3hl", "f16", lambda sd, k=key: pk.pad_rows(pk.conv3x3(torch.cat([sd[k + ".weight"]] * 2, dim=1)))))
 
     def w_tconv(self, key) -> Ref:
         return Ref("weight", 0, self.packer.add(key + ":t3", "f16", lambda sd, k=key: pk.tconv3(sd[k + ".weight"])))
@@ -675,7 +688,8 @@ class _Lowering:
         return self.P.alloc(-(-rows // 32), 2 * n, "f32")
 
     def conv3(self, name, a: Buf, key, cout, h, w, *, stride=1, up=0, out_dtype="f32", rowbias=None,
-              residual=None, cin=None, dest: Optional[Buf] = None, dup_c8: bool = False, stats: Optional[Buf] = None) -> Buf:
+              residual=None, cin=None, dest: Optional[Buf] = None, dup_c8: bool = False, stats: Optional[Buf] = None,
+              hilo: bool = False) -> Buf:
         """`dest`: write the result into this (sub-)buffer instead of a fresh allocation — the producers of the two
         halves of a skip-connection concat write straight into the concat buffer (no copy ops)."""
         cin = a.cols if cin is None else cin
@@ -684,11 +698,11 @@ class _Lowering:
         n = (cout + 3) // 4 * 4
         out = self._dest(dest, Mo, n, out_dtype)
         gather = L.GATHER_CONV3X3_C8 if cin == 8 else L.GATHER_CONV3X3
-        wref = self.w_conv3_c8dup(key) if dup_c8 else self.w_conv3(key, 8 if cin == 8 else 0)
+        wref = self.w_conv3_hilo(key) if hilo else (self.w_conv3_c8dup(key) if dup_c8 else self.w_conv3(key, 8 if cin == 8 else 0))
         op = self.P.gemm(name, a, wref, n, 9 * cin, out, bias=self.vec(key + ".bias"),
                          gather=gather, conv=dict(Hin=h, Win=w, Cin=cin, stride=stride, up=up, Hout=ho, Wout=wo),
                          rowbias=rowbias, rows_per_batch=self.F * ho * wo if rowbias is not None else 0,
-                         residual=residual, stats=stats)
+                         residual=residual, stats=stats, k_alg=9 * cin // 2 if hilo else None)
         self.last_stats = stats if (stats is not None and op.meta.get("stats")) else None     # None: the op ran with split-K
         return out
 
@@ -982,9 +996,15 @@ class _Lowering:
 
     def resample(self, prefix, attr, x: Buf, c, h, w, *, up, dest: Optional[Buf] = None) -> Buf:
         P = self.P
-        x16 = P.alloc(x.rows, c, "f16")
-        P.copy2d(prefix + ".cast", x, x16)
-        out = self.conv3(f"{prefix}.{attr}", x16, f"{prefix}.{attr}", c, h, w, stride=1 if up else 2, up=1 if up else 0, dest=dest)
+        if self.precise_rs and c % 64 == 0:
+            # the stream's fp16 cast as rows [hi | lo] (2c channels), the convolution on K = 9 * 2c against [W | W]
+            x16 = P.alloc(x.rows, 2 * c, "f16")
+            P.copy2d(prefix + ".cast", x, x16.col_slice(0, c), lo=x16.col_slice(c, 2 * c))
+            out = self.conv3(f"{prefix}.{attr}", x16, f"{prefix}.{attr}", c, h, w, stride=1 if up else 2, up=1 if up else 0, dest=dest, hilo=True)
+        else:
+            x16 = P.alloc(x.rows, c, "f16")
+            P.copy2d(prefix + ".cast", x, x16)
+            out = self.conv3(f"{prefix}.{attr}", x16, f"{prefix}.{attr}", c, h, w, stride=1 if up else 2, up=1 if up else 0, dest=dest)
         P.free(x16)
         return out
 

@@ -331,14 +331,23 @@ class _VaeLowering:
                    bias_along_m=True, allow_splitk=False)
             q_i = qk.row_slice(rows.start, rows.stop).col_slice(0, c)
             k_i = qk.row_slice(rows.start, rows.stop).col_slice(c, 2 * c)
-            s = P.alloc(hw, hw, "f32")
-            P.gemm(f"{p}.qk^T.{img}", q_i, k_i.ref, hw, c, s, ldw=k_i.ld, allow_splitk=False)
-            pm = P.alloc(hw, hw, "f16")
-            P.softmax(f"{p}.softmax.{img}", s, pm, float(int(c) ** (-0.5)))
-            P.free(s)
-            P.gemm(f"{p}.pv.{img}", pm, vt.ref, c, hw, out_attn.row_slice(rows.start, rows.stop), ldw=vt.ld,
-                   allow_splitk=False)
-            P.free(pm, vt)
+            # Scores are materialised per QUERY BLOCK, never for the whole image (round 4): at 1024x576 (9216
+            # tokens) the [hw, hw] fp32 matrix was 340 MB + 170 MB of fp16 probabilities per frame; a block of `bq` query rows is
+            # 38 + 19 MB, re-used by every block and every frame (the arena of the 24-frame decode shrinks accordingly).  Softmax rows
+            # are independent, so the result is bit-identical to the one-shot form.  (A fused flash kernel at d = 512 was sized again:
+            # DESIGN.md §5 — single pass needs the 128-query x 512 O tile spread over 8 waves with K / V ping-ponged through one LDS
+            # buffer each; the two-pass form recomputes Q K^T per 128-wide O slice = 3x the FLOPs of this GEMM form.)
+            bq = hw if hw <= 4096 else next(b for b in (1152, 1024, 768, 512, 256, hw) if hw % b == 0)
+            for q0 in range(0, hw, bq):
+                s = P.alloc(bq, hw, "f32")
+                P.gemm(f"{p}.qk^T.{img}.{q0}", q_i.row_slice(q0, q0 + bq), k_i.ref, hw, c, s, ldw=k_i.ld, allow_splitk=False)
+                pm = P.alloc(bq, hw, "f16")
+                P.softmax(f"{p}.softmax.{img}.{q0}", s, pm, float(int(c) ** (-0.5)))
+                P.free(s)
+                P.gemm(f"{p}.pv.{img}.{q0}", pm, vt.ref, c, hw, out_attn.row_slice(rows.start + q0, rows.start + q0 + bq), ldw=vt.ld,
+                       allow_splitk=False)
+                P.free(pm)
+            P.free(vt)
         P.free(nrm, qk)
         out = P.alloc(x.rows, c, "f32")
         P.gemm(p + ".proj_out", out_attn, self.w_linear(p + ".proj_out"), c, c, out, bias=self.vec(p + ".proj_out.bias"),

@@ -232,6 +232,9 @@ class Interp:
         if rel:
             o = o + torch.einsum("abhts,tsd->abhtd", p, ev[idx])
         self._st(v(op.p[3], nq, so), o, torch.float16)
+        lo_off = op.i[18] if rel else op.i[16]
+        if lo_off:                                             # low-order image of the fp16 rounding at out + lo_off elements
+            self._st(v(op.p[3].shifted(2 * lo_off), nq, so), o.float() - o.half().float(), torch.float16)
 
     def _op13(self, op, ext):
         self._op4(op, ext, rel=True)

@@ -95,6 +95,7 @@ class Probe(Interp):
             cls = classify(self.cur)
             self.nst += 1
             is_lo = self.cur.kind in (L.OP_COPY2D, L.OP_NCTHW_TO_CL) or (self.cur.kind == L.OP_GROUPNORM and self.cur.i[16]) or \
+                (self.cur.kind == L.OP_ATTENTION and self.cur.i[16]) or (self.cur.kind == L.OP_RELPOS_ATTN and self.cur.i[18]) or \
                 (self.cur.kind == L.OP_GEMM and self.cur.i[7] == L.GATHER_PLAIN and self.cur.i[11] == 1 and self.cur.i[16] == L.EPI_NONE)
             if self.nst == 2 and is_lo:
                 # the low-order image of a hi + lo cast (precise_operands): carries nothing when the hi store is already exact

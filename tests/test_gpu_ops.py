@@ -1121,3 +1121,79 @@ def test_groupnorm_from_strips_many_strips_per_instance():
     stored = read(got, y).float()
     ref = torch.nn.functional.silu(torch.nn.functional.group_norm(stored.view(n_inst, rows, C).permute(0, 2, 1), 32, w["g"], w["be"], 1e-5))
     assert rel_l2(read(got, out).float(), ref.permute(0, 2, 1).reshape(M, C)) < 1e-3
+
+
+@pytest.mark.parametrize("kind,D", [("spatial", 64), ("spatial", 40), ("cross", 80), ("relpos", 40), ("relpos", 160)])
+def test_attention_lo_output_and_dup_to_out_against_torch(kind, D):
+    """precise_operands (VideoCrafter default): the attention kernels also store the low-order fp16 image of every output value
+    (rows [hi | lo]), to_out runs on K = 2C against [W | W]: hi + lo reproduces the fp32 attention output to ~22 bits."""
+    heads, B, F, hw, Lc, R = 2, 1, 4, 48, 11, 16
+    inner = heads * D
+    M = B * F * hw
+    P = Program()
+    g = _g(400 + D)
+    scale = D ** -0.5
+    qkv, a, out = P.alloc(M, 3 * inner, "f16"), P.alloc(M, 2 * inner, "f16"), P.alloc(M, inner, "f32")
+    ld, lo = 3 * inner, 2 * inner
+    q, k, v = qkv.col_slice(0, inner), qkv.col_slice(inner, 2 * inner), qkv.col_slice(2 * inner, 3 * inner)
+    wl = (torch.randn(inner, inner, generator=g) / math.sqrt(inner)).half()
+    w = {"w2": pk.linear_dup(wl.float()).half(), "ek": 0.3 * torch.randn(2 * R + 1, D, generator=g), "ev": 0.3 * torch.randn(2 * R + 1, D, generator=g)}
+    bufs = [qkv]
+    if kind == "spatial":
+        P.attention("a", q.ref, k.ref, v.ref, a.ref, nq=hw, nk=hw, heads=heads, b_outer=B * F, b_inner=1, q_strides=(ld, hw * ld, 0),
+                    kv_strides=(ld, hw * ld, 0), o_strides=(lo, hw * lo, 0), scale=scale, head_dim=D, lo_off=inner)
+    elif kind == "cross":
+        kv = P.alloc(B * Lc, 2 * inner, "f16")
+        bufs.append(kv)
+        P.attention("a", q.ref, kv.col_slice(0, inner).ref, kv.col_slice(inner, 2 * inner).ref, a.ref, nq=hw, nk=Lc, heads=heads, b_outer=B,
+                    b_inner=F, q_strides=(ld, F * hw * ld, hw * ld), kv_strides=(kv.ld, Lc * kv.ld, 0), o_strides=(lo, F * hw * lo, hw * lo),
+                    scale=scale, head_dim=D, lo_off=inner)
+    else:
+        P.attention("a", q.ref, k.ref, v.ref, a.ref, nq=F, nk=F, heads=heads, b_outer=B, b_inner=hw, q_strides=(hw * ld, F * hw * ld, ld),
+                    kv_strides=(hw * ld, F * hw * ld, ld), o_strides=(hw * lo, F * hw * lo, lo), scale=scale, head_dim=D,
+                    rel_k=Ref("weight", 0, "ek"), rel_v=Ref("weight", 0, "ev"), max_rel=R, lo_off=inner)
+    P.gemm("to_out", a, Ref("weight", 0, "w2"), inner, 2 * inner, out)
+    it, got = _gpu_run(P, w, lambda it: [fill(it, b, g, 1.0) for b in bufs])
+    _check(it, got, a, 3e-3, "attention hi | lo vs the interpreter")
+    qf, kf, vf = read(it, q).float(), read(it, k).float(), read(it, v).float()
+    if kind == "spatial":
+        sh = lambda t: t.view(B * F, hw, heads, D).transpose(1, 2)
+        ref = torch.nn.functional.scaled_dot_product_attention(sh(qf), sh(kf), sh(vf)).transpose(1, 2).reshape(M, inner)
+    elif kind == "cross":
+        kvf = read(it, bufs[1]).float()
+        qs = qf.view(B, F, hw, heads, D).permute(0, 1, 3, 2, 4)
+        ks = kvf[:, :inner].view(B, 1, Lc, heads, D).permute(0, 1, 3, 2, 4).expand(B, F, heads, Lc, D)
+        vs = kvf[:, inner:].view(B, 1, Lc, heads, D).permute(0, 1, 3, 2, 4).expand(B, F, heads, Lc, D)
+        ref = torch.nn.functional.scaled_dot_product_attention(qs, ks, vs).permute(0, 1, 3, 2, 4).reshape(M, inner)
+    else:
+        sh = lambda t: t.view(B, F, hw, heads, D).permute(0, 2, 3, 1, 4)                       # [B, hw, h, F, D]
+        idx = (torch.arange(F)[None, :] - torch.arange(F)[:, None]).clamp(-R, R) + R
+        sim = (torch.einsum("bphtd,bphsd->bphts", sh(qf), sh(kf)) + torch.einsum("bphtd,tsd->bphts", sh(qf), w["ek"][idx])) * scale
+        pr = sim.softmax(dim=-1)
+        o = torch.einsum("bphts,bphsd->bphtd", pr, sh(vf)) + torch.einsum("bphts,tsd->bphtd", pr, w["ev"][idx])
+        ref = o.permute(0, 3, 1, 2, 4).reshape(M, inner)
+    hi_lo = read(got, a).float()
+    r_hi, r_sum = rel_l2(hi_lo[:, :inner], ref), rel_l2(hi_lo[:, :inner] + hi_lo[:, inner:], ref)
+    assert r_hi < 2e-3 and r_sum < 0.5 * r_hi + 2e-4, (r_hi, r_sum)        # the sum is closer than the fp16 value (P itself is fp16 inside the kernels)
+    want = torch.nn.functional.linear(hi_lo[:, :inner] + hi_lo[:, inner:], wl.float())
+    assert rel_l2(read(got, out), want) < 2e-5
+
+
+def test_conv3x3_on_hi_lo_channel_blocks_against_torch():
+    """precise_operands (VideoCrafter default): the fp32 stream in front of a Down / Upsample convolution is cast to rows [hi | lo]
+    (2 Cin channels) and the 3x3 convolution runs against [W | W]: equals F.conv2d on the UNROUNDED fp32 input to ~1e-5."""
+    B, H, W, Cin, Cout = 2, 8, 8, 64, 128
+    M = B * H * W
+    P = Program()
+    g = _g(410)
+    x, x16, out = P.alloc(M, Cin, "f32"), P.alloc(M, 2 * Cin, "f16"), P.alloc(M // 4, Cout, "f32")
+    w4 = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).half()
+    w = {"w": pk.conv3x3(torch.cat([w4.float()] * 2, dim=1)).half(), "b": torch.randn(Cout, generator=g)}
+    P.copy2d("cast", x, x16.col_slice(0, Cin), lo=x16.col_slice(Cin, 2 * Cin))
+    P.gemm("down", x16, Ref("weight", 0, "w"), Cout, 9 * 2 * Cin, out, bias=Ref("weight", 0, "b"), gather=L.GATHER_CONV3X3,
+           conv=dict(Hin=H, Win=W, Cin=2 * Cin, stride=2, up=0, Hout=H // 2, Wout=W // 2), k_alg=9 * Cin)
+    it, got = _gpu_run(P, w, lambda it: fill(it, x, g, 2.0))
+    xin = read(it, x).view(B, H, W, Cin).permute(0, 3, 1, 2)
+    ref = torch.nn.functional.conv2d(xin, w4.float(), w["b"], stride=2, padding=1).permute(0, 2, 3, 1).reshape(M // 4, Cout)
+    r = rel_l2(read(got, out), ref)
+    assert r < 2e-5, r

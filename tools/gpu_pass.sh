@@ -101,6 +101,26 @@ stage_e2e() {
 stage_suite() {     # what the driver runs at round end
   timeout -k 10 2400 python -m pytest tests -m gpu -q -rP --tb=short -p no:cacheprovider > gpurun_out/${TAG}_pytest_gpu.log 2>&1; echo "pytest -m gpu exit $?"; digest gpurun_out/${TAG}_pytest_gpu.log 12
 }
+stage_roundend() {  # the measurements that go to profiles/r04_*: rocprofv3 kernel stats + PMC traffic + MFMA utilisation on this build, the other
+                    # BASELINE geometries, per-kind step profiles, the stages either side of the loop
+  R=$GRAFT_REPO_ROOT
+  bash tools/gpu_profile.sh > gpurun_out/gpu_profile.out 2>&1; tail -n 14 gpurun_out/gpu_profile.out | cut -c1-200
+  cd /tmp
+  rm -rf $R/gpurun_out/pmc_mfma
+  timeout 420 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_mfma -- python $R/tools/pmc_target.py 2 > $R/gpurun_out/pmc_mfma.log 2>&1; echo "mfma pmc exit $?"
+  cd $R
+  python tools/pmc_generic_post.py gpurun_out/pmc_mfma > gpurun_out/pmc_mfma_counters.txt 2>&1
+  python tools/mfma_util_post.py gpurun_out/pmc_mfma_counters.txt > gpurun_out/mfma_utilisation_unet.txt 2>&1; tail -n 3 gpurun_out/mfma_utilisation_unet.txt
+  find gpurun_out/pmc_mfma -name "*.csv" -size +20M -delete
+  timeout 600 python bench.py --frames 125 --steps 1 --warmup 1 --no-cpu-baseline --also-batched 0 > gpurun_out/bench_n1_125f.json 2> gpurun_out/bench_n1_125f.err; echo "bench125 exit $?"; cut -c1-200 gpurun_out/bench_n1_125f.json
+  timeout 600 python bench.py --height 576 --width 1024 --steps 1 --warmup 1 --no-cpu-baseline --also-batched 0 > gpurun_out/bench_n1_zeroscope_xl.json 2> gpurun_out/bench_n1_zeroscope_xl.err; echo "bench XL exit $?"; cut -c1-200 gpurun_out/bench_n1_zeroscope_xl.json
+  timeout 400 python bench.py --model lvdm --steps 2 --warmup 1 > gpurun_out/bench_n1_lvdm.json 2> gpurun_out/bench_n1_lvdm.err; echo "bench lvdm exit $?"; cut -c1-200 gpurun_out/bench_n1_lvdm.json
+  for g in "24 32 32 2 modelscope" "125 32 32 2 modelscope" "24 72 128 2 modelscope" "24 32 32 1 modelscope" "12 32 32 1 modelscope" "16 32 32 2 lvdm"; do
+    timeout 300 python tools/profile_unet.py $g > "gpurun_out/profile_$(echo $g | tr ' ' '_').log" 2>&1; sed -n 4,5p "gpurun_out/profile_$(echo $g | tr ' ' '_').log"
+  done
+  timeout 300 python tools/profile_aux.py > gpurun_out/aux_stages.txt 2>&1; tail -n 8 gpurun_out/aux_stages.txt
+  timeout 300 python tools/profile_vae.py 1 72 128 > gpurun_out/profile_vae_xl.txt 2>&1; tail -n 6 gpurun_out/profile_vae_xl.txt
+}
 for st in "$@"; do
   t0=$(date +%s); echo "######## stage $st"; stage_$st; echo "######## $st took $(( $(date +%s) - t0 )) s"
 done

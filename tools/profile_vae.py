@@ -1,5 +1,5 @@
 """Per-op HIP-event timings of the VAE decode of one clip (24 frames, 32x32 latents -> 256x256), the second stage of the
-bench workload.  Usage: python tools/profile_vae.py [frames]"""
+bench workload.  Usage: python tools/profile_vae.py [frames] [latent_h] [latent_w]   (1 72 128 = one 1024x576 ZeroScope-XL frame)"""
 import collections
 import os
 import sys
@@ -19,7 +19,9 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
     ae = V.AutoencoderKL(configs.VAE_DDCONFIG, 4, init_weights=False).half().to(dev).eval()
     random_weights_(ae, 3)
-    z = torch.randn(n, 4, 32, 32, device=dev)
+    lh = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+    lw = int(sys.argv[3]) if len(sys.argv) > 3 else 32
+    z = torch.randn(n, 4, lh, lw, device=dev)
     for _ in range(2):
         out = ae.decode(z)
     torch.cuda.synchronize()
@@ -35,7 +37,7 @@ def main():
     ms = comp.bound.run_timed(ext, st)
     prog = comp.prog
     tot, fl = sum(ms), prog.total_flops()
-    print(f"VAE decode {n} frames 32x32 -> 256x256: {len(ms)} ops, wall {wall:.2f} ms, sum(op events) {tot:.2f} ms, "
+    print(f"VAE decode {n} frames {lh}x{lw} -> {8 * lh}x{8 * lw}: {len(ms)} ops, wall {wall:.2f} ms, sum(op events) {tot:.2f} ms, "
           f"{fl / 1e12:.2f} TFLOP -> {fl / wall / 1e9:.1f} TF/s wall")
     names = {1: "gemm", 2: "groupnorm", 3: "layernorm", 4: "attention", 5: "softmax", 6: "to_cl", 7: "from_cl", 9: "copy2d"}
     rows = sorted(zip(ms, prog.ops), key=lambda r: -r[0])
