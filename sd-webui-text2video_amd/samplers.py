@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import ctypes
 import itertools
+import os
 import types
 from typing import Optional
 
@@ -199,6 +200,7 @@ class GaussianDiffusion(object):
         prev_auto = getattr(model, "auto_refresh", None)
         if prev_auto is not None:
             model.auto_refresh = False
+        prev_eps = _want_fp32_eps(model)
         stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
         pair_key = pair_ctx = pair_refs = None      # pair_refs keeps the tensors alive, so their ids stay unique
         run_nonce = next(_RUN_COUNTER)              # a new sampling run never reuses the previous run's cached context K/V
@@ -259,6 +261,7 @@ class GaussianDiffusion(object):
         finally:
             if prev_auto is not None:
                 model.auto_refresh = prev_auto
+            _restore_eps(model, prev_eps)
         return xt
 
 
@@ -306,6 +309,21 @@ def _ddim_update(out, xt, eps_pair, noise, coef, guided: int, mode: int):
 
 
 _RUN_COUNTER = itertools.count(1)
+
+
+def _want_fp32_eps(model):
+    """Inside a sampling loop the UNet hands eps over in fp32 (UNetSD.eps_out_dtype): the guided combination u + s (c - u) would
+    otherwise amplify the independent fp16 roundings of the two predictions ~12x at s = 9.  -> token for _restore_eps."""
+    if not hasattr(model, "eps_out_dtype") or os.environ.get("T2V_EPS_FP32", "1") == "0":
+        return "absent"
+    prev = model.eps_out_dtype
+    model.eps_out_dtype = torch.float32
+    return prev
+
+
+def _restore_eps(model, token):
+    if token != "absent":
+        model.eps_out_dtype = token
 
 
 class SharedNoise:
@@ -407,6 +425,7 @@ class DDIMSampler(object):
         prev_auto = getattr(model, "auto_refresh", None)
         if prev_auto is not None:
             model.auto_refresh = False
+        prev_eps = _want_fp32_eps(model)
         pair_cache = {}
         try:
             for i, step in enumerate(time_range):
@@ -422,6 +441,7 @@ class DDIMSampler(object):
         finally:
             if prev_auto is not None:
                 model.auto_refresh = prev_auto
+            _restore_eps(model, prev_eps)
         return img
 
     @torch.no_grad()
@@ -571,6 +591,7 @@ class UniPCSampler(object):
         prev_auto = getattr(model, "auto_refresh", None)
         if prev_auto is not None:
             model.auto_refresh = False
+        prev_eps = _want_fp32_eps(model)
 
         def conds():
             return reconstruct_conds(conditioning, unconditional_conditioning, state.sampling_step)
@@ -596,6 +617,7 @@ class UniPCSampler(object):
         finally:
             if prev_auto is not None:
                 model.auto_refresh = prev_auto
+            _restore_eps(model, prev_eps)
         return x
 
     @torch.no_grad()

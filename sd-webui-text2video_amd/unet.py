@@ -255,6 +255,12 @@ class UNetSD(nn.Module):
         # less than 144 of the tile's 192 rows (fewer than 12 frames) unless the option is "force".  Part of the program cache key.
         self.fused_temporal_attention = {"0": False, "force": "force"}.get(os.environ.get("T2V_FUSED_TATTN", "1"), True)
         self.t_shard = None           # parallel.TShard: this rank holds a contiguous slice of the clip's frames
+        # Output dtype override for the package's own samplers.  `forward` returns what the reference's autocast path returns (fp16
+        # for a `.half()` model) — but a guided step combines the two predictions as u + s (c - u): the INDEPENDENT fp16 roundings of
+        # c and u (2.8e-4 each) come out multiplied by sqrt(s^2 + (s - 1)^2) ~ 12 at s = 9, which made the eps rounding the largest
+        # single term of every sampled OUTPUT's error (round 4).  The samplers therefore set this to torch.float32 inside their loops
+        # (the last convolution's result is fp32 in the arena anyway; the exit op writes 0.4 MB instead of 0.2 MB) and restore it.
+        self.eps_out_dtype = None
         self.auto_refresh = True      # re-check parameter versions on every forward (~1 ms); the sampler
                                       # turns this off inside its loop after one explicit refresh
         self.device = torch.device("cpu")   # SamplerBase.register_buffers_to_model overwrites it (samplers_common.py:82)
@@ -427,6 +433,8 @@ class UNetSD(nn.Module):
             y = y.float()
         p0 = next(self.parameters())
         out_dtype = torch.float16 if p0.dtype == torch.float16 else torch.float32
+        if getattr(self, "eps_out_dtype", None) is not None:
+            out_dtype = self.eps_out_dtype              # the samplers of this package ask for fp32 (see `eps_out_dtype`)
         tf = t.to(device=x.device, dtype=torch.float32).contiguous()
         if tf.ndim == 0:
             tf = tf.expand(B).contiguous()

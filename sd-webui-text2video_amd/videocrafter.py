@@ -722,6 +722,7 @@ class DDIMSampler(object):
         unet = self.model.model.diffusion_model
         unet.refresh_weights(device)
         prev_auto, unet.auto_refresh = unet.auto_refresh, False
+        prev_eps = S._want_fp32_eps(unet)            # eps in fp32 inside the loop: the CFG combination amplifies fp16 output roundings
         nxt = torch.empty_like(img)
         nb, C = img.shape[0], img.shape[1]          # nb videos per batch (sample_text2video's batch_size)
         f32 = torch.float32
@@ -770,6 +771,7 @@ class DDIMSampler(object):
                     break
         finally:
             unet.auto_refresh = prev_auto
+            S._restore_eps(unet, prev_eps)
         return img, intermediates
 
 
