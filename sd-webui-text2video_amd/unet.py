@@ -243,10 +243,10 @@ class UNetSD(nn.Module):
         # linear that consumes them) — at the input-resolution level, where the probe puts their whole gain; "all" = at every level
         # (+0.7 ms per step for ~1 % less error), "r3" = the round-3 subset only (A/B).
         self.precise_operands = {"0": False, "r3": "r3", "all": "all"}.get(os.environ.get("T2V_PRECISE", "1"), True)
-        # Two more classes of the same ranking, OFF for ModelScope (its outputs are inside north_star's 1e-3 without them; +0.4 / +0.6 ms
-        # per step) and ON for videocrafter.UNetModel, whose 50-step output needs them (1.09e-3 -> below 1e-3; DESIGN.md "Precision"):
-        # the attention output in front of to_out (input-resolution level) and the fp32 -> fp16 cast in front of the Down / Upsample
-        # convolutions, both as rows [hi | lo] against [W | W].  Part of the program cache key.
+        # Two more classes of the same ranking, built and parity-tested but OFF by default (ModelScope's outputs are inside north_star's
+        # 1e-3 without them at +0.4 / +0.6 ms per step; on VideoCrafter they move the 10-step output 1.08e-3 -> 0.92e-3 but the 50-step
+        # output only 1.07e-3 -> 1.04e-3): the attention output in front of to_out (input-resolution level) and the fp32 -> fp16 cast in
+        # front of the Down / Upsample convolutions, both as rows [hi | lo] against [W | W].  Part of the program cache key.
         self.precise_attn_out = os.environ.get("T2V_PRECISE_ATTN", "0") != "0"
         self.precise_resample = os.environ.get("T2V_PRECISE_RESAMPLE", "0") != "0"
         # TemporalTransformer self-attention as ONE launch per attention (QKV projection + attention of every pixel's frame
