@@ -26,3 +26,8 @@ PY
 run n4 4 --frames 6 --also-frames 10
 run n2 2 --frames 6 --also-frames 10
 T2V_BENCH_INJECT_FAILURE=all run n4_fallback 4 --frames 6 --also-frames 10      # the frame-parallel job fails -> replicas headline + reason
+# the same N = 4 run with the exchanges INSIDE the library (csrc/comm.hip) over the shared-memory RCCL stand-in of tests/fake_rccl: the
+# self-check then really compares the library's collectives with the host executor (config.self_check.in_library == true)
+FAKE=tests/fake_rccl/libfakerccl.so
+[ -f $FAKE ] || /opt/rocm/bin/hipcc -O2 -std=c++17 -fPIC -shared tests/fake_rccl/fake_rccl.cpp -o $FAKE -lrt
+T2V_COLLECTIVES=library T2V_RCCL_SONAME=$PWD/$FAKE run n4_fake_rccl 4 --frames 6 --also-frames 0
