@@ -151,3 +151,30 @@ def test_every_rank_gets_the_frame_parallel_jobs_result():
     assert all(r == res[0] for r in res) and res[0]["ok"] and res[0]["line"]["value"] == 12.5
     import tempfile
     os.remove(os.path.join(tempfile.gettempdir(), f"t2v_bench_handoff_{os.getpid()}_29791.json"))
+
+
+def test_round4_bench_lines_and_rehearsals():
+    """Round 4: the committed N = 1 line of the final build, and the one-GPU rehearsals of the N > 1 flow — the frame-parallel layout is
+    the headline (strong scaling, self-check recorded, replicas beside it), an injected failure falls back to replicas with the reason."""
+    d = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_n1.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["config"]["layout"] == "single" and "configs[1]" in d["config"]["workload"]
+    assert abs(d["value"] - 24 * d["steps"] / (d["ms_per_step"] * d["steps"] / 1e3)) < 0.01 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["traffic"] > 0
+    assert 13.5 < r["flops_per_unet_step_T"] < 14.2          # algorithmic: the repeated K of the [hi | lo] GEMMs is not counted
+    t = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")))
+    assert t["hbm_bytes_per_launch"] > 5e7 and t["launches"] > 400
+    for name, layout in (("n4", "tshard"), ("n2", "pairs"), ("n4_fake_rccl", "tshard")):
+        rh = json.load(open(os.path.join(ROOT, "profiles", f"r04_rehearsal_{name}_one_gpu.json")))
+        assert rh["config"]["layout"] == layout and rh["scaling"] == "strong" and rh["value"] > 0 and "REHEARSAL" in rh["data"]
+        assert rh["steps"] == 3 and rh["warmup"] == 1 and rh["replicas"]["value"] > 0 and rh["collective_job"]["layout"] == layout
+        assert "layout_fallback" not in rh["config"]
+        if layout == "tshard":
+            assert rh["config"]["self_check"]["ok"] and rh["config"]["self_check"]["collective_ops_per_forward"] > 100
+    assert json.load(open(os.path.join(ROOT, "profiles", "r04_rehearsal_n4_fake_rccl_one_gpu.json")))["config"]["self_check"]["in_library"] is True
+    fb = json.load(open(os.path.join(ROOT, "profiles", "r04_rehearsal_n4_fallback_one_gpu.json")))
+    assert fb["config"]["layout"] == "replicas" and fb["scaling"] == "weak" and fb["value"] > 0
+    assert fb["config"]["layout_fallback"]["requested_layout"] == "tshard" and "injected failure" in fb["config"]["layout_fallback"]["reason"]
