@@ -129,6 +129,8 @@ enum t2v_gather {
  *         10 = 192x192 on 12 waves, T2V_EPI_TATTN only; 11 = 128x320 on 8 waves, 12 = 64x64 on 4 waves with a 4-deep ring),
  *      23 tconv halo (input rows are [clip][F+2][HW]: one halo frame either side, T-sharding);
  *         for CONV3X3: 1 = zero padding (0,1,0,1) instead of (1,1,1,1) (LDM encoder Downsample, taps at +0..+2)
+ *      PLAIN gather only: 12 = R > 0 -> the residual has R rows and row m >= R reads residual row m - R; 13 = R > 0 -> likewise for the A
+ *         operand (M <= 2R, no split-K): tensors shared by the cond | uncond pair of a guided step are computed once and wrapped;
  *      PLAIN gather only: 11 = 1 -> hi + lo fp16 output (fp16 out, plain epilogue, ldc >= 2N): out[m, N + n] = fp16(v - float(fp16(v)))
  *         beside out[m, n] = fp16(v) — a consumer GEMM over rows [hi | lo] with weights [W | W] (K = 2N) sees v with ~22 bits;
  *      PLAIN gather only: 8 = 1 -> fused LayerNorm second output (tile 8 or 11, N == 320, fp32 out, no split-K): p[7] fp16 [M, i[9]] =

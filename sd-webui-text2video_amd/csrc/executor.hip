@@ -82,6 +82,10 @@ int validate_op(const t2v_op& op, int idx) {
         if (op.i[5] < (N / 192) * 64 || op.i[5] % 4 != 0) return bad("fused temporal attention: ldc < heads * 64");
         return 0;
       }
+      if (g == T2V_GATHER_PLAIN && (op.i[12] != 0 || op.i[13] != 0)) {       // row wrap of the residual / the A operand
+        if (op.i[12] < 0 || op.i[13] < 0 || op.i[19] > 1 || op.i[16] == T2V_EPI_GEGLU) return bad("row wrap: non-negative, no split-K, plain epilogue");
+        if ((op.i[12] != 0 && (M > 2 * op.i[12] || op.p[4] == 0)) || (op.i[13] != 0 && M > 2 * op.i[13])) return bad("row wrap: M <= 2 * wrap (and a residual for the residual wrap)");
+      }
       if (g == T2V_GATHER_PLAIN && op.i[11] == 1) {       // hi + lo fp16 output
         if (op.i[17] != T2V_F16 || op.i[16] != T2V_EPI_NONE || op.i[8] == 1 || op.i[5] < 2 * N)
           return bad("hi + lo output: fp16 out, plain epilogue, no fused LayerNorm, ldc >= 2 N");
@@ -221,6 +225,7 @@ hipError_t launch_op(const t2v_op& op, hipStream_t s) {
       p.ws = reinterpret_cast<float*>(op.p[6]);
       p.halo = op.i[23];
       p.out_lo = (p.gather == T2V_GATHER_PLAIN && op.i[11] == 1) ? 1 : 0;
+      if (p.gather == T2V_GATHER_PLAIN && op.i[16] != T2V_EPI_TATTN) { p.res_wrap = op.i[12]; p.a_wrap = op.i[13]; }
       const int tile = op.i[22];
       if (p.epi == T2V_EPI_TATTN) {                              // fused QKV projection + temporal attention (tile 10)
         p.F = op.i[8]; p.HW = op.i[9]; p.tpix = op.i[10];

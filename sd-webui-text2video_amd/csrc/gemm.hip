@@ -136,7 +136,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmParams p) 
     xvalid[j] = m < p.M;
     xoff[j] = 0; xy[j] = 0; xx[j] = 0;
     if (GATHER == T2V_GATHER_PLAIN) {
-      xoff[j] = (long)m * p.lda;
+      xoff[j] = (long)((p.a_wrap && m >= p.a_wrap) ? m - p.a_wrap : m) * p.lda;
     } else if (GATHER == T2V_GATHER_CONV3X3 || GATHER == T2V_GATHER_CONV3X3_C8) {
       const int hw = p.Hout * p.Wout;
       const int img = m / hw, rem = m - img * hw;

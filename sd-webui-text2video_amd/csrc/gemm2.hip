@@ -167,7 +167,8 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm2_kernel(const GemmPar
           xstep[j] = STEP;
         }
       } else if (valid) {
-        xptr[j] = reinterpret_cast<const unsigned char*>(p.A + (long)m * p.lda + (long)kt_begin * BK + lc * 8);
+        const int ma = (p.a_wrap && m >= p.a_wrap) ? m - p.a_wrap : m;        // shared (one-sample) operand: rows wrap once
+        xptr[j] = reinterpret_cast<const unsigned char*>(p.A + (long)ma * p.lda + (long)kt_begin * BK + lc * 8);
         xstep[j] = STEP;
       }
     } else if (GATHER == T2V_GATHER_CONV3X3 || GATHER == G_CONV_UP) {

@@ -507,7 +507,11 @@ __global__ __launch_bounds__(GNC_THREADS) void gn_coop_kernel(const T* __restric
       t2v_wait_vm0();                                                                // complete before this workgroup arrives
     }
   }
-  gn_grid_barrier(bar, gridDim.x, gen0, fault);
+#ifndef T2V_GN_NO_BARRIER              // timing experiment only (tools/build_variant.py nobar -DT2V_GN_NO_BARRIER): the kernel WITHOUT its grid
+  gn_grid_barrier(bar, gridDim.x, gen0, fault);      // barrier = the floor of any scheme that gets the statistics from somewhere else
+#else
+  __syncthreads();
+#endif
   {
     double ds = 0.0, dq = 0.0;
     if (g < groups) {

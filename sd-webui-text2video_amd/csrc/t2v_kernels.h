@@ -53,6 +53,10 @@ struct GemmParams {
   // the 32-row strip of out[m, n], stats[m / 32][1][n] = sum of squares — fp32 [ceil(M / 32)][2][N].  The GroupNorm then needs no
   // statistics pass over the tensor (and no grid barrier): a small fold of the strips + one apply pass (norm.hip, phase 3).
   float* stats;
+  // Row wrap (PLAIN gather, M <= 2 * wrap, no split-K): operand row m >= a_wrap reads A row m - a_wrap; residual row m >= res_wrap reads
+  // residual row m - res_wrap.  The cond | uncond pair of a guided step shares every tensor up to the first text cross-attention
+  // (same x_t, same t): those are computed ONCE (one sample's rows) and the first per-sample GEMMs read them through the wrap.
+  int a_wrap, res_wrap;
 };
 
 
@@ -192,7 +196,8 @@ __device__ __forceinline__ void t2v_epilogue_rows(const GemmParams& p, const f32
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int m = mt + rrow + 8 * i;
-      const float* src = (m < p.M && n < p.N) ? p.res + (size_t)m * p.ldr + n : p.res;
+      const int mr = (p.res_wrap && m >= p.res_wrap) ? m - p.res_wrap : m;          // shared (one-sample) residual: rows wrap once
+      const float* src = (m < p.M && n < p.N) ? p.res + (size_t)mr * p.ldr + n : p.res;
       r[i] = *reinterpret_cast<const f32x4*>(src);
     }
   };
@@ -348,7 +353,8 @@ __device__ __forceinline__ void t2v_epilogue_rows_ln(const GemmParams& p, f32x16
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int m = m_wave + rrow + 8 * i;
-      const float* src = (m < p.M && n < p.N) ? p.res + (size_t)m * p.ldr + n : p.res;
+      const int mr = (p.res_wrap && m >= p.res_wrap) ? m - p.res_wrap : m;
+      const float* src = (m < p.M && n < p.N) ? p.res + (size_t)mr * p.ldr + n : p.res;
       r[i] = *reinterpret_cast<const f32x4*>(src);
     }
   };

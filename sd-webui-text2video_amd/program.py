@@ -332,9 +332,12 @@ class Program:
              rowbias: Optional[Buf] = None, rows_per_batch: int = 0, residual: Optional[Buf] = None,
              epi: int = L.EPI_NONE, act: int = 0, bias_along_m: bool = False, m: Optional[int] = None,
              allow_splitk: bool = True, halo: bool = False, ln: Optional[tuple] = None, step_invariant: bool = False,
-             a_lo: Optional[Buf] = None, out_lo: bool = False, k_alg: Optional[int] = None, stats: Optional[Buf] = None) -> Op:
+             a_lo: Optional[Buf] = None, out_lo: bool = False, k_alg: Optional[int] = None, stats: Optional[Buf] = None,
+             a_wrap: int = 0, res_wrap: int = 0) -> Op:
         """out[M, n_out] = epi(gather(a)[M, k] @ w[n, k]^T).  conv['pad_after_only'] (3x3, stride 2): zero padding
         (0,1,0,1) instead of 1 on every side.
+        a_wrap / res_wrap (plain gather, M <= 2 * wrap, no split-K): `a` / `residual` hold only `wrap` rows and row m >= wrap reads row
+        m - wrap — the operands the cond | uncond pair of a guided step shares are computed once (unet.py `share_cfg_prefix`).
         stats (fp32 [ceil(M / 32), 2 n]): the epilogue also writes per 32-row strip the column sums / sums of squares of the stored
         result (T2V_EPI_STATS) for a GroupNorm that consumes it (`groupnorm(..., stats=)`); honoured when the op runs without split-K
         (op.meta["stats"] says whether it was).
@@ -398,8 +401,13 @@ class Program:
         op.p[3] = rowbias.ref if rowbias is not None else NULL
         op.p[4] = residual.ref if residual is not None else NULL
         op.p[5] = out.ref
+        if a_wrap or res_wrap:
+            assert gather == L.GATHER_PLAIN and epi == L.EPI_NONE and a_lo is None
+            assert (not a_wrap or (M <= 2 * a_wrap and a.rows >= a_wrap)) and (not res_wrap or (M <= 2 * res_wrap and residual is not None))
+            I[12], I[13] = res_wrap, a_wrap
+            allow_splitk = False
         if residual is not None:
-            assert residual.dtype == "f32" and residual.rows >= M and residual.cols == n_out
+            assert residual.dtype == "f32" and residual.rows >= (res_wrap or M) and residual.cols == n_out
         tile, split = self.choose_tile(M, n, k, gather, allow_splitk)
         # (one CFG role per GPU, M = 24576: forcing the 320-wide tile on the LayerNorm-producing Linears so that the norm fuses was
         #  measured: LayerNorm -0.36 ms, GEMMs +0.34 ms per step — not taken; the 192x256 tile stays there)

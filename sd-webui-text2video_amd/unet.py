@@ -261,6 +261,13 @@ class UNetSD(nn.Module):
         # single term of every sampled OUTPUT's error (round 4).  The samplers therefore set this to torch.float32 inside their loops
         # (the last convolution's result is fp32 in the arena anyway; the exit op writes 0.4 MB instead of 0.2 MB) and restore it.
         self.eps_out_dtype = None
+        # Guided steps (forward_cfg_pair: one x_t, one t, [cond | uncond] contexts): everything up to the FIRST text cross-attention —
+        # the stem, input_blocks.0's TemporalTransformer, the first ResBlock with its temporal convolutions, the first
+        # SpatialTransformer's GroupNorm / proj_in / self-attention / to_q — is identical for the two samples.  With this option
+        # (default on) the lowering computes that prefix ONCE (one sample's rows) and the first per-sample GEMMs read it through a row
+        # wrap (T2V_OP_GEMM i[12]); the reference runs the two forwards separately and computes it twice (gaussian_sampler.py:161-162).
+        # Same arithmetic on the same values; 31 of 725 ops run at half their rows.  Part of the program cache key.
+        self.share_cfg_prefix = os.environ.get("T2V_SHARE_PREFIX", "1") != "0"
         self.auto_refresh = True      # re-check parameter versions on every forward (~1 ms); the sampler
                                       # turns this off inside its loop after one explicit refresh
         self.device = torch.device("cpu")   # SamplerBase.register_buffers_to_model overwrites it (samplers_common.py:82)
@@ -475,6 +482,7 @@ class UNetSD(nn.Module):
     def _lowering_options(self) -> tuple:
         """Lowering switches that change the program (part of the cache key)."""
         return ((("strips",),) if getattr(self, "gn_producer_stats", False) else ()) + \
+            ((("share",),) if getattr(self, "share_cfg_prefix", False) else ()) + \
             ((("pattn",),) if getattr(self, "precise_attn_out", False) else ()) + ((("presample",),) if getattr(self, "precise_resample", False) else ()) + \
             ((("precise", str(self.precise_operands)),) if getattr(self, "precise_operands", False) else ()) + \
             ((("tattn", str(self.fused_temporal_attention)),) if getattr(self, "fused_temporal_attention", False) else ())
@@ -569,6 +577,11 @@ class _Lowering:
             assert B == 1, "T-sharded forwards run one sample per rank (the CFG pair is split over ranks)"
             assert F == self.shard.frames
         self.net, self.B, self.F, self.H, self.W, self.Lctx = net, B, F, H, W, Lctx
+        # cond | uncond prefix sharing (UNetSD.share_cfg_prefix): while `sharing`, activations hold Bc = 1 sample; the first spatial
+        # transformer's text cross-attention is where the two samples part (transformer_block) and Bc becomes B
+        self.sharing = bool(getattr(net, "share_cfg_prefix", False)) and B == 2 and x_batch == 1 and self.shard is None and \
+            type(self) is _Lowering
+        self.Bc = 1 if self.sharing else B
         self.x_dt, self.out_dt, self.ctx_dt = x_dt, out_dt, ctx_dt
         self.x_batch = x_batch if 0 < x_batch < B else 0      # x holds fewer samples than the batch: sample b reads x[b % x_batch]
         self.precise = bool(getattr(net, "precise_operands", False))
@@ -665,7 +678,8 @@ class _Lowering:
 
     # -- geometry helpers ----------------------------------------------------------------------
     def M(self, h, w):
-        return self.B * self.F * h * w
+        """Token rows of an activation at h x w in the CURRENT batch (one sample while the cond | uncond prefix is shared)."""
+        return self.Bc * self.F * h * w
 
     # -- building blocks ------------------------------------------------------------------------
     def gn(self, name, x: Buf, key, *, per_frame: bool, eps, silu, out: Optional[Buf] = None, lo: bool = False,
@@ -678,7 +692,7 @@ class _Lowering:
             out = full.col_slice(0, x.cols)
         else:
             full = out = self.P.alloc(x.rows, x.cols, "f16") if out is None else out
-        n_inst = self.B * self.F if per_frame else self.B
+        n_inst = self.Bc * self.F if per_frame else self.Bc
         shard = None if per_frame else self.shard
         if stats is not None and (shard is not None or (x.rows // n_inst) % 32 != 0):
             stats = None                  # (a T-sharded cross-frame norm exchanges its own partials; strips are 32 rows)
@@ -702,7 +716,7 @@ class _Lowering:
         halves of a skip-connection concat write straight into the concat buffer (no copy ops)."""
         cin = a.cols if cin is None else cin
         ho, wo = (h * 2, w * 2) if up else ((h + 1) // 2 if stride == 2 else h, (w + 1) // 2 if stride == 2 else w)
-        Mo = self.B * self.F * ho * wo
+        Mo = self.Bc * self.F * ho * wo
         n = (cout + 3) // 4 * 4
         out = self._dest(dest, Mo, n, out_dtype)
         gather = L.GATHER_CONV3X3_C8 if cin == 8 else L.GATHER_CONV3X3
@@ -792,7 +806,7 @@ class _Lowering:
         K/V-gather lowering of a T-sharded temporal block, which normalises on its own).  Returns fp16 [M, inner] (feeds proj_out).
         geom = (frames, pixels per frame) of x1's rows when they are NOT this rank's frame slice: the pixel-sharded
         layout of a T-sharded TemporalTransformer — all frames of the clip, hw / R pixels — where the block is local."""
-        P, Mrows, hw, F, B = self.P, x1.rows, h * w, self.F, self.B
+        P, Mrows, hw, F, B = self.P, x1.rows, h * w, self.F, self.Bc
         local = geom is not None
         if local:
             F, hw = geom
@@ -892,16 +906,24 @@ class _Lowering:
                 k0, k1 = self.kv_slices[prefix + ".attn2"]
                 kv = self.kv_all
                 kbuf, vbuf = kv.col_slice(k0, k0 + inner), kv.col_slice(k0 + inner, k1)
-                a = P.alloc(Mrows, inner, "f16")
                 Lc = self.Lctx
+                # The text cross-attention is where cond and uncond part.  While the prefix is shared, q / x2 hold ONE sample's rows:
+                # the attention reads q with a zero sample stride against each sample's own K / V, and to_out adds x2 through the
+                # residual row wrap — from here on every tensor has B samples.
+                parting = self.sharing
+                Bq, q_b_stride, Mshared = (self.B, 0, Mrows) if parting else (B, F * hw * inner, 0)
+                if parting:
+                    self.sharing, self.Bc = False, self.B
+                    B, Mrows = self.B, self.B * Mrows
+                a = P.alloc(Mrows, inner, "f16")
                 P.attention(f"{prefix}.attn2", q.ref, kbuf.ref, vbuf.ref, a.ref, out_buf=a, nq=hw, nk=Lc, heads=heads,
-                            b_outer=B, b_inner=F, q_strides=(inner, F * hw * inner, hw * inner),
+                            b_outer=Bq, b_inner=F, q_strides=(inner, q_b_stride, hw * inner),
                             kv_strides=(kv.ld, Lc * kv.ld, 0), o_strides=(inner, F * hw * inner, hw * inner), scale=scale)
                 P.free(q)
                 x3 = P.alloc(Mrows, inner, "f32")
                 n3 = P.alloc(Mrows, inner, "f16")
                 P.gemm(f"{prefix}.attn2.to_out", a, self.w_linear(f"{prefix}.attn2.to_out.0"), inner, inner, x3,
-                       bias=self.vec(f"{prefix}.attn2.to_out.0.bias"), residual=x2, ln=self.ln_arg(f"{prefix}.norm3", n3))
+                       bias=self.vec(f"{prefix}.attn2.to_out.0.bias"), residual=x2, ln=self.ln_arg(f"{prefix}.norm3", n3), res_wrap=Mshared)
                 P.free(a, x2)
             else:
                 x3, n3 = self_attention(2, x2, n2, "norm3")
@@ -935,9 +957,9 @@ class _Lowering:
                ln=self.ln_arg(tb + ".norm1", n1), k_alg=c)
         P.free(n)
         x4 = self.transformer_block(tb, x1, n1, c, heads, "spatial", h, w)
-        out = self._dest(dest, x.rows, c, "f32")
+        out = self._dest(dest, x4.rows, c, "f32")          # (x4 has B samples even when the block's input x was the shared single sample)
         P.gemm(prefix + ".proj_out", x4, self.w_proj(prefix + ".proj_out", x4.cols // c), c, x4.cols, out,
-               bias=self.vec(prefix + ".proj_out.bias"), residual=x, k_alg=c)
+               bias=self.vec(prefix + ".proj_out.bias"), residual=x, k_alg=c, res_wrap=x.rows if x.rows != x4.rows else 0)
         P.free(x4)
         return out
 
@@ -1023,6 +1045,8 @@ class _Lowering:
         dim, emb = net.dim, net.embed_dim
         h, w = self.H, self.W
         P.begin()
+        if self.sharing and not any(kind == "st" for _, parts, _ in inputs for kind, _, _ in parts):
+            self.sharing, self.Bc = False, B           # no text cross-attention on the way down: nothing to share up to
 
         # ---- step-level prologue: time embedding, all ResBlock emb projections, all cross-attn K/V
         res_prefixes, st_prefixes = [], []
@@ -1083,13 +1107,18 @@ class _Lowering:
         # precise operands: the low-order fp16 images of the 4 latent channels ride in the 4 padding channels of the 8-channel
         # token rows, the stem's weights repeat W there — (x_hi + x_lo) . W in the one GEMM pass, no extra launch
         self.stem_dup = self.precise and self.x_dt == "f32" and net.in_dim == 4
-        P.ncthw_to_cl("x.to_tokens", Ref("ext", L.EXT_X), self.x_dt, xin, B=B, C=net.in_dim, F=F, HW=h * w, src_batch=self.x_batch,
-                      lo_in_pad=self.stem_dup)
+        P.ncthw_to_cl("x.to_tokens", Ref("ext", L.EXT_X), self.x_dt, xin, B=self.Bc, C=net.in_dim, F=F, HW=h * w,
+                      src_batch=self.x_batch if self.x_batch != self.Bc else 0, lo_in_pad=self.stem_dup)
 
         def run_parts(prefix, parts, bare, x, h, w, dest=None):
             for i, (kind, cin, cout) in enumerate(parts):
                 p = prefix if bare else f"{prefix}.{i}"
                 d = dest if i == len(parts) - 1 else None         # the block's result goes straight into a concat buffer
+                # shared cond | uncond prefix: this part's result has ONE sample's rows; a skip-connection window wants it for every
+                # sample -> the part writes its own buffer and two row-block copies fill the window (one site: input_blocks.0)
+                spread = d if (self.sharing and d is not None and kind != "st") else None
+                if spread is not None:
+                    d = None
                 if kind == "stem":
                     y = self.conv3(p, x, p, cout, h, w, cin=8, dest=d, dup_c8=self.stem_dup)
                 elif kind == "res":
@@ -1107,6 +1136,10 @@ class _Lowering:
                     h, w = h * 2, w * 2
                 else:
                     raise ValueError(kind)
+                if spread is not None:
+                    assert spread.rows == self.B * y.rows and spread.cols == y.cols
+                    for b in range(self.B):
+                        P.copy2d(f"{p}.to_skip.{b}", y, spread.row_slice(b * y.rows, (b + 1) * y.rows))
                 P.tap(p, y)
                 P.free(x)              # borrowed windows of a concat buffer are ignored by free()
                 x = y
@@ -1130,7 +1163,7 @@ class _Lowering:
             sc = parts[-1][2]
             cin_total = outputs[n_skip - 1 - k][1][0][1]            # input channels of the consuming decoder ResBlock
             ho, wo = out_hw(parts, h, w)
-            cat = P.alloc(self.M(ho, wo), cin_total, "f32")
+            cat = P.alloc(self.B * self.F * ho * wo, cin_total, "f32")        # (every sample, whatever the current batch of the prefix)
             cats.append(cat)
             x, h, w = run_parts(prefix, parts, bare, x, h, w, dest=cat.borrow_cols(cin_total - sc, cin_total))
         cat = cats.pop()
@@ -1141,6 +1174,7 @@ class _Lowering:
             x, h, w = run_parts(prefix, parts, bare, cat, h, w, dest=dest)
             cat = nxt
 
+        assert not self.sharing and self.Bc == B, "the shared cond | uncond prefix never reached a text cross-attention"
         # ---- head: GN + SiLU + conv 3x3 -> out_dim, then tokens -> b c f h w
         a = self.gn("out.0", x, "out.0", per_frame=True, eps=1e-5, silu=True)
         P.free(x)

@@ -88,7 +88,10 @@ class Interp:
         M, N, K, lda, ldw, ldc, ldr, gather = I[0:8]
         A16 = None
         if gather == L.GATHER_PLAIN:
-            A = self.mat(op.p[0], M, K, lda, torch.float16, ext).float()
+            aw = I[13]                                             # row wrap: only `aw` operand rows exist, row m >= aw reads row m - aw
+            A = self.mat(op.p[0], aw if aw else M, K, lda, torch.float16, ext).float()
+            if aw:
+                A = torch.cat([A, A[: M - aw]], dim=0)
         elif gather in (L.GATHER_CONV3X3, L.GATHER_CONV3X3_C8):
             Hin, Win, Cin, stride, up, Hout, Wout = I[8], I[9], I[10], I[11], I[12], I[13], I[14]
             nimg = M // (Hout * Wout)
@@ -143,7 +146,9 @@ class Interp:
             if I[18] == 1:
                 res = F.silu(res)
             if op.p[4].space != "null":
-                res = res + self.mat(op.p[4], M, N, ldr, torch.float32, ext)
+                rw = I[12] if gather == L.GATHER_PLAIN else 0
+                R = self.mat(op.p[4], rw if rw else M, N, ldr, torch.float32, ext)
+                res = res + (torch.cat([R, R[: M - rw]], dim=0) if rw else R)
         out = self.mat(op.p[5], M, n_out, ldc, _TD[I[17]], ext)
         self._st(out, res, _TD[I[17]])
         if want_stats:       # per 32-row strip: column sums / sums of squares of the STORED values -> fp32 [ceil(M / 32)][2][N]

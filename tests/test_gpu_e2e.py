@@ -19,7 +19,7 @@ import torch
 
 from harness import rel_l2
 from oracle import configs, synth, torch_port as tp
-from sd_webui_text2video_amd import samplers, unet as U, vae as V
+from sd_webui_text2video_amd import _lib as L, samplers, unet as U, vae as V
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -113,6 +113,7 @@ def test_cfg_pair_entry_and_cached_context_kv(tiny):
     context token the text K/V projections of the previous call are reused (bit-identical result); a changed context or a
     weight refresh (LoRA merge of a to_k weight) invalidates them."""
     net, sd, _ = tiny
+    net.share_cfg_prefix = False                        # (bit-equality with the explicit batch: the shared-prefix lowering is tested below)
     x, t, y, *_ = _tiny_inputs()
     x1 = x[:1].to(DEV)
     tt = torch.tensor([801.0, 801.0], device=DEV)
@@ -139,6 +140,33 @@ def test_cfg_pair_entry_and_cached_context_kv(tiny):
     assert not torch.equal(before, after)
     assert torch.isfinite(after).all()
     assert torch.equal(net.forward_cfg_pair(x1, tt, ctx, context_token=("run", 3)), want)
+    net.share_cfg_prefix = True
+
+
+def test_cfg_pair_shares_the_prefix_up_to_the_first_cross_attention(tiny):
+    """Round 4: in a guided step cond and uncond share x_t and t, so every op up to the first text cross-attention is computed ONCE
+    (one sample's rows; the first per-sample GEMMs read the shared tensors through the residual row wrap, the cross-attention reads q
+    with a zero sample stride).  Same values, fewer rows: as close to the oracle as the two-sample lowering, deterministic, and the
+    step-invariant K/V reuse still works."""
+    net, sd, _ = tiny
+    x, t, y, *_ = _tiny_inputs()
+    x1 = x[:1].to(DEV)
+    tt = torch.tensor([801.0, 801.0], device=DEV)
+    ctx = y.to(DEV)
+    ref = torch.cat([tp.unet_forward(sd, configs.TINY_UNET, x[:1], torch.tensor([801]), y[b:b + 1]) for b in range(2)])
+    net.share_cfg_prefix = False
+    plain = net.forward_cfg_pair(x1, tt, ctx).float().cpu()
+    net.share_cfg_prefix = True
+    a = net.forward_cfg_pair(x1, tt, ctx, context_token=("share", 1))
+    b = net.forward_cfg_pair(x1, tt, ctx, context_token=("share", 1))
+    assert torch.equal(a, b)
+    comp = next(c for k, c in net._programs.items() if ("xb", 1) in k and ("share",) in k)
+    wrapped = [op for op in comp.prog.ops if op.kind == L.OP_GEMM and op.i[7] == L.GATHER_PLAIN and op.i[16] != L.EPI_TATTN and op.i[12]]
+    assert len(wrapped) == 2 and comp.prog.ops[[o.name for o in comp.prog.ops].index("x.to_tokens")].i[0] == 1
+    shared = a.float().cpu()
+    e_plain, e_shared = rel_l2(plain, ref), rel_l2(shared, ref)
+    print(f"cfg pair, tiny config: rel-L2 vs the oracle {e_shared:.3e} with the shared prefix, {e_plain:.3e} without; between them {rel_l2(shared, plain):.3e}")
+    assert e_shared < 1.1 * e_plain + 1e-4 and rel_l2(shared, plain) < 2.0 * e_plain
 
 
 def test_weight_mutation_is_picked_up(tiny):

