@@ -778,7 +778,9 @@ def main():
             cal0 = {"error": f"{type(exc).__name__}: {exc}"}
         F_loc = runner.unet_frames
         net.t_shard = None
-        x = torch.randn(runner.unet_batch, 4, F_loc, args.height // 8, args.width // 8, device=dev)
+        # the program the sampler's guided step runs: ONE x_t for the cond | uncond pair (forward_cfg_pair: the prefix up to the first text
+        # cross-attention is computed once, UNetSD.share_cfg_prefix) — b = 2 * videos contexts, `videos` latents
+        x = torch.randn(max(1, runner.unet_batch // 2), 4, F_loc, args.height // 8, args.width // 8, device=dev)
         nv = max(1, runner.unet_batch // 2)
         y = torch.cat([cond.expand(nv, -1, -1), uncond.expand(nv, -1, -1)], 0)[: runner.unet_batch].contiguous()
         t = torch.full((runner.unet_batch,), 500, device=dev)
@@ -804,7 +806,9 @@ def main():
             "unet_step_ms_events": round(step_ms, 3),
             "unet_step_tflops_all_kernels": round(prog.total_flops() / (step_ms * 1e-3) / 1e12, 1),
             "unet_step_frac_of_peak": round(prog.total_flops() / (step_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
-            "geometry": f"one rank's UNet forward in this layout WITHOUT its exchanges: b={runner.unet_batch}, {F_loc} frames",
+            "geometry": f"one rank's UNet forward in this layout WITHOUT its exchanges: b={runner.unet_batch}, {F_loc} frames" +
+                        ("; cond | uncond share the ops up to the first text cross-attention (executed FLOPs are counted, not the reference's 2 full forwards)"
+                         if (runner.unet_batch == 2 and getattr(net, "share_cfg_prefix", False)) else ""),
             "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 --pmc, profiles/r0N_pmc_traffic.json)",
             # box calibration either side of the timed region: the same kernel family on an 8192^3 fp16 GEMM (random data)
             "calibration": {"gemm_8192_tflops_before": cal_before, **(cal0 or {}),

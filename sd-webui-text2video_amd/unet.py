@@ -579,8 +579,7 @@ class _Lowering:
         self.net, self.B, self.F, self.H, self.W, self.Lctx = net, B, F, H, W, Lctx
         # cond | uncond prefix sharing (UNetSD.share_cfg_prefix): while `sharing`, activations hold Bc = 1 sample; the first spatial
         # transformer's text cross-attention is where the two samples part (transformer_block) and Bc becomes B
-        self.sharing = bool(getattr(net, "share_cfg_prefix", False)) and B == 2 and x_batch == 1 and self.shard is None and \
-            type(self) is _Lowering
+        self.sharing = bool(getattr(net, "share_cfg_prefix", False)) and B == 2 and x_batch == 1 and self.shard is None
         self.Bc = 1 if self.sharing else B
         self.x_dt, self.out_dt, self.ctx_dt = x_dt, out_dt, ctx_dt
         self.x_batch = x_batch if 0 < x_batch < B else 0      # x holds fewer samples than the batch: sample b reads x[b % x_batch]

@@ -261,7 +261,7 @@ class _LvdmLowering(_Lowering):
         cin = a.cols if cin is None else cin
         ho, wo = (h * 2, w * 2) if up else ((h + 1) // 2 if stride == 2 else h, (w + 1) // 2 if stride == 2 else w)
         n = (cout + 3) // 4 * 4
-        out = self._dest(dest, self.B * self.F * ho * wo, n, out_dtype)
+        out = self._dest(dest, self.Bc * self.F * ho * wo, n, out_dtype)
         gather = L.GATHER_CONV3X3_C8 if cin == 8 else L.GATHER_CONV3X3
         wref = self.w_conv133_hilo(key) if hilo else (self.w_conv133_dup(key) if dup_c8 else self.w_conv133(key, 8 if cin == 8 else 0))
         op = self.P.gemm(name, a, wref, n, 9 * cin, out, bias=self.vec(key + ".bias"),
@@ -306,7 +306,7 @@ class _LvdmLowering(_Lowering):
     def st_transformer(self, prefix, x: Buf, c, h, w, dest: Optional[Buf] = None) -> Buf:
         """SpatialTemporalTransformer.forward + BasicTransformerBlockST._forward (attention_temporal.py:301-335,
         386-399): s-self, t-self (rel-pos), s-cross (text), t-self (rel-pos), GEGLU feed-forward."""
-        P, net, B, F, hw = self.P, self.net, self.B, self.F, h * w
+        P, net, B, F, hw = self.P, self.net, self.Bc, self.F, h * w
         heads, d = net.num_heads, c // net.num_heads
         scale = d ** -0.5
         M = x.rows
@@ -337,11 +337,11 @@ class _LvdmLowering(_Lowering):
         def attn_out() -> Buf:
             return P.alloc(M, 2 * c if attn_lo else c, "f16")
 
-        def out_proj(attn, a: Buf, res: Buf, next_norm: str):
+        def out_proj(attn, a: Buf, res: Buf, next_norm: str, res_wrap: int = 0):
             o = P.alloc(M, c, "f32")
             ln = ln_of(next_norm)
             P.gemm(f"{tb}.{attn}.to_out", a, self.w_proj(f"{tb}.{attn}.to_out.0", a.cols // c), c, a.cols, o,
-                   bias=self.vec(f"{tb}.{attn}.to_out.0.bias"), residual=res, ln=ln, k_alg=c)
+                   bias=self.vec(f"{tb}.{attn}.to_out.0.bias"), residual=res, ln=ln, k_alg=c, res_wrap=res_wrap)
             P.free(a, res)
             return o, (ln[3] if ln is not None else None)
 
@@ -403,13 +403,20 @@ class _LvdmLowering(_Lowering):
         P.free(nrm)
         k0, k1 = self.kv_slices[tb + ".attn2"]
         kv = self.kv_all
+        # cond and uncond part at the text cross-attention (unet.py transformer_block): q / cur hold ONE sample's rows while the prefix
+        # is shared — q is read with a zero sample stride, to_out adds `cur` through the residual row wrap, M becomes B samples' rows
+        parting = self.sharing
+        q_b_stride, shared_rows = (0, M) if parting else (F * hw * c, 0)
+        if parting:
+            self.sharing, self.Bc = False, self.B
+            B, M = self.B, self.B * M
         a = attn_out()
         Lc, lo = self.Lctx, a.ld
         P.attention(f"{tb}.attn2", q.ref, kv.col_slice(k0, k0 + c).ref, kv.col_slice(k0 + c, k1).ref, a.ref, out_buf=a, nq=hw,
-                    nk=Lc, heads=heads, b_outer=B, b_inner=F, q_strides=(c, F * hw * c, hw * c), kv_strides=(kv.ld, Lc * kv.ld, 0),
+                    nk=Lc, heads=heads, b_outer=B, b_inner=F, q_strides=(c, q_b_stride, hw * c), kv_strides=(kv.ld, Lc * kv.ld, 0),
                     o_strides=(lo, F * hw * lo, hw * lo), scale=scale, head_dim=d, lo_off=c if attn_lo else 0)
         P.free(q)
-        cur, nxt = out_proj("attn2", a, cur, "norm5")
+        cur, nxt = out_proj("attn2", a, cur, "norm5", res_wrap=shared_rows)
         cur, nxt = self_attn("attn2_tmp", "norm5", cur, nxt, temporal=True, next_norm="norm3")
         nrm = layer_norm("norm3", cur) if nxt is None else nxt
         wg, bg = self.w_geglu(f"{tb}.ff.net.0.proj")
@@ -426,7 +433,7 @@ class _LvdmLowering(_Lowering):
         P.free(g, cur)
         out = self._dest(dest, M, c, "f32")
         P.gemm(prefix + ".proj_out", x4, self.w_proj(prefix + ".proj_out", x4.cols // c), c, x4.cols, out, bias=self.vec(prefix + ".proj_out.bias"),
-               residual=x, k_alg=c)
+               residual=x, k_alg=c, res_wrap=x.rows if x.rows != M else 0)
         P.free(x4)
         return out
 
@@ -436,6 +443,8 @@ class _LvdmLowering(_Lowering):
         mc, emb = net.model_channels, net.time_embed_dim
         h, w = self.H, self.W
         P.begin()
+        if self.sharing and not any(kind == "st" for _, parts in inputs for kind, _, _ in parts):
+            self.sharing, self.Bc = False, B
         blocks = [(f"{pre}.{j}", part) for pre, parts in inputs + outputs for j, part in enumerate(parts)] + \
                  [(f"middle_block.{j}", part) for j, part in enumerate(middle)]
         res_prefixes = [(p, part[2]) for p, part in blocks if part[0] == "res"]
@@ -482,13 +491,16 @@ class _LvdmLowering(_Lowering):
 
         xin = P.alloc(self.M(h, w), 8, "f16")
         self.stem_dup = self.precise and self.x_dt == "f32" and net.in_dim == 4
-        P.ncthw_to_cl("x.to_tokens", Ref("ext", L.EXT_X), self.x_dt, xin, B=B, C=net.in_dim, F=F, HW=h * w, src_batch=self.x_batch,
-                      lo_in_pad=self.stem_dup)
+        P.ncthw_to_cl("x.to_tokens", Ref("ext", L.EXT_X), self.x_dt, xin, B=self.Bc, C=net.in_dim, F=F, HW=h * w,
+                      src_batch=self.x_batch if self.x_batch != self.Bc else 0, lo_in_pad=self.stem_dup)
 
         def run_parts(prefix, parts, x, h, w, dest=None):
             for j, (kind, cin, cout) in enumerate(parts):
                 p = f"{prefix}.{j}"
                 d = dest if j == len(parts) - 1 else None
+                spread = d if (self.sharing and d is not None and kind != "st") else None      # shared cond | uncond prefix: unet.py run_parts
+                if spread is not None:
+                    d = None
                 if kind == "stem":
                     y = self.conv133(p, x, p, cout, h, w, cin=8, dest=d, dup_c8=self.stem_dup)
                 elif kind == "res":
@@ -511,6 +523,10 @@ class _LvdmLowering(_Lowering):
                     h, w = ((h + 1) // 2, (w + 1) // 2) if kind == "down" else (h * 2, w * 2)
                 else:
                     raise ValueError(kind)
+                if spread is not None:
+                    assert spread.rows == self.B * y.rows and spread.cols == y.cols
+                    for b in range(self.B):
+                        P.copy2d(f"{p}.to_skip.{b}", y, spread.row_slice(b * y.rows, (b + 1) * y.rows))
                 P.tap(p, y)
                 P.free(x)              # borrowed windows of a concat buffer are ignored by free()
                 x = y
@@ -532,7 +548,7 @@ class _LvdmLowering(_Lowering):
             sc = parts[-1][2]
             cin_total = outputs[n_skip - 1 - k][1][0][1]
             ho, wo = out_hw(parts, h, w)
-            cat = P.alloc(self.M(ho, wo), cin_total, "f32")
+            cat = P.alloc(self.B * self.F * ho * wo, cin_total, "f32")
             cats.append(cat)
             x, h, w = run_parts(prefix, parts, x, h, w, dest=cat.borrow_cols(cin_total - sc, cin_total))
         cat = cats.pop()
@@ -543,6 +559,7 @@ class _LvdmLowering(_Lowering):
             x, h, w = run_parts(prefix, parts, cat, h, w, dest=dest)
             cat = nxt
 
+        assert not self.sharing and self.Bc == B, "the shared cond | uncond prefix never reached a text cross-attention"
         a = self.gn("out.0", x, "out.0", per_frame=False, eps=1e-5, silu=True)
         P.free(x)
         y = self.conv133("out.2", a, "out.2", net.out_dim, h, w)
@@ -737,7 +754,11 @@ class DDIMSampler(object):
                 index = total_steps - i - 1
                 ts = torch.full((nb,), int(step), device=device, dtype=torch.long)
                 if guided:
-                    eps = self.model.apply_model(torch.cat([img, img]), torch.cat([ts, ts]), torch.cat([c, uc])).contiguous()
+                    # ONE x_t for the [cond | uncond] pair (the reference builds torch.cat([x] * 2), lvdm/samplers/ddim.py:206-209): the
+                    # entry op reads it for both samples, and with UNetSD.share_cfg_prefix every op up to the first text
+                    # cross-attention is computed once
+                    xin = img if hasattr(unet, "share_cfg_prefix") else torch.cat([img, img])      # (a foreign model gets the reference's batch)
+                    eps = self.model.apply_model(xin, torch.cat([ts, ts]), torch.cat([c, uc])).contiguous()
                 else:
                     eps = self.model.apply_model(img, ts, c).contiguous()
                 a_t, a_prev = self.ddim_alphas[index].to(f32), self.ddim_alphas_prev[index].to(f32)
