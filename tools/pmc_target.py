@@ -14,7 +14,7 @@ from tools.profile_unet import random_weights_  # noqa: E402
 dev = torch.device("cuda:0")
 net = U.UNetSD(**configs.MODELSCOPE_UNET, init_weights=False).half().to(dev)
 random_weights_(net)
-x = torch.randn(2, 4, 24, 32, 32, device=dev)
+x = torch.randn(1, 4, 24, 32, 32, device=dev)      # ONE x_t for the cond | uncond pair: the samplers' guided step (shared prefix)
 y = torch.randn(2, 77, 1024, device=dev, dtype=torch.float16)
 t = torch.full((2,), 500, device=dev)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 3

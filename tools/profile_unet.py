@@ -43,7 +43,10 @@ def main():
         net = U.UNetSD(**configs.MODELSCOPE_UNET, init_weights=False).half().to(dev)
     random_weights_(net)
     print(f"{model} model on device in {time.time() - t0:.1f}s")
-    x = torch.randn(B, 4, F, H, W, device=dev)
+    # B = 2 is the guided step of the samplers: ONE x_t for the cond | uncond pair (forward_cfg_pair; the ops in front of the first text
+    # cross-attention run once, UNetSD.share_cfg_prefix); PROFILE_EXPLICIT_BATCH=1 profiles the explicit two-sample batch instead
+    Bx = 1 if (B == 2 and os.environ.get("PROFILE_EXPLICIT_BATCH") != "1") else B
+    x = torch.randn(Bx, 4, F, H, W, device=dev)
     y = torch.randn(B, 77, net.context_dim, device=dev, dtype=torch.float16)
     t = torch.full((B,), 500, device=dev)
     for _ in range(2):
@@ -66,7 +69,7 @@ def main():
     _, ms, prog = net.forward_timed(x, t, y)
     tot = sum(ms)
     flops = prog.total_flops()
-    print(f"geometry b{B} f{F} {H}x{W}: ops {len(ms)}  wall/forward {wall:.2f} ms (no auto-refresh {wall2:.2f} ms)  "
+    print(f"geometry b{B} (x batch {Bx}) f{F} {H}x{W}: ops {len(ms)}  wall/forward {wall:.2f} ms (no auto-refresh {wall2:.2f} ms)  "
           f"sum(op events) {tot:.2f} ms")
     print(f"algorithmic {flops / 1e12:.3f} TFLOP -> {flops / (wall2 * 1e-3) / 1e12:.1f} TF/s wall, "
           f"{flops / (tot * 1e-3) / 1e12:.1f} TF/s by events; arena {prog.arena.high / 2**30:.2f} GiB")
