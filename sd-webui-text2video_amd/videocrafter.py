@@ -630,6 +630,21 @@ class LatentDiffusion(nn.Module):
                           ("log_one_minus_alphas_cumprod", np.log(1.0 - ac)), ("sqrt_recip_alphas_cumprod", np.sqrt(1.0 / ac)),
                           ("sqrt_recipm1_alphas_cumprod", np.sqrt(1.0 / ac - 1))):
             self.register_buffer(name, t32(val))
+        self._schedule_names = ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod",
+                                "log_one_minus_alphas_cumprod", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod")
+
+    def _apply(self, fn, *args, **kwargs):
+        """`.half()` puts the NETWORKS in fp16; the schedule stays fp32 (the reference registers it as fp32 and never halves this
+        module: ddpm3d.py:125-165, sample_text2video.py).  A schedule rounded to fp16 is a 3e-4 error of every DDIM coefficient that
+        is the same for all pixels and does not average out over the steps — measured on configs[4]: 50-step output 1.06e-3 with the
+        rounded schedule, 4.96e-4 with this one (10 steps: 1.08e-3 -> 9.4e-4)."""
+        keep = {n: self._buffers[n] for n in getattr(self, "_schedule_names", ()) if self._buffers.get(n) is not None}
+        super()._apply(fn, *args, **kwargs)
+        for n, v in keep.items():
+            cur = self._buffers[n]
+            if cur.dtype != v.dtype:
+                self._buffers[n] = v.to(cur.device)
+        return self
 
     @property
     def device(self):

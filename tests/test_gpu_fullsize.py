@@ -29,8 +29,9 @@ DEV = "cuda:0"
 GATE_FWD_W16 = 1.2e-3          # measured round 4: 8.4e-4 (125 f) ... 9.6e-4 (ZeroScope-XL geometry)
 GATE_VIDEO_W16 = 1.0e-3        # configs[1] 50-step video: 6e-4 ... 7e-4
 GATE_FEWSTEP_W16 = 1.8e-3      # 5- / 10-step outputs: 1.55e-3 ... 1.68e-3 (each step's error x the CFG-9 amplification, not yet contracted)
-GATE_LVDM_VIDEO_W16 = 1.2e-3   # configs[4] 50-step output: 1.09e-3 — NOT inside north_star's 1e-3 (DESIGN.md "Precision": every cheap operand
-                               # class is split; all levels + fp32 GroupNorm-only tensors reach 1.077e-3, the floor of this design)
+GATE_LVDM_VIDEO_W16 = 8.0e-4   # configs[4] 50-step output: 4.96e-4 (10 steps: 9.4e-4) once the DDIM coefficients come from the fp32 schedule —
+                               # rounds 3-4 measured 1.06-1.13e-3 because `LatentDiffusion.half()` rounded alphas_cumprod to fp16
+GATE_LVDM_FEWSTEP_W16 = 1.2e-3
 
 
 def _gold(name):
@@ -207,12 +208,12 @@ def test_c4_lvdm_16f_ddim_and_decode():
                            x_T=x_T.to(DEV))
         r = rel_l2(x0.float().cpu(), torch.from_numpy(gold[f"ddim_x0_{steps}"]))
         print(f"configs[4] VideoCrafter 16f, {steps}-step lvdm DDIM CFG 7.5, fp16 weights: x0 rel-L2 {r:.3e}")
-        assert r < (2.7e-3 if steps == 10 else 2.3e-3)  # measured 1.77e-3 (10 steps), 1.49e-3 (50 steps)
+        assert r < (2.0e-3 if steps == 10 else 1.5e-3)  # measured 1.33e-3 (10 steps), 9.4e-4 (50 steps)
         g16 = _gold16("lvdm_16f_ddim.npz")
         if g16 is not None:
             ra = rel_l2(x0.float().cpu(), torch.from_numpy(g16[f"ddim_x0_{steps}"]))
             print(f"configs[4] VideoCrafter 16f, {steps}-step lvdm DDIM vs the reference on the DEPLOYED weights: x0 rel-L2 {ra:.3e}")
-            assert ra < (GATE_FEWSTEP_W16 if steps == 10 else GATE_LVDM_VIDEO_W16)
+            assert ra < (GATE_LVDM_FEWSTEP_W16 if steps == 10 else GATE_LVDM_VIDEO_W16)
     img = ld.decode_first_stage(torch.from_numpy(gold["ddim_x0_50"])[:, :, 0:1].to(DEV).half()).float().cpu()
     img = img.reshape(-1, 3, 256, 256)[0:1]
     rv = rel_l2(img[:, :, ::2, ::2], torch.from_numpy(gold["vae_img_frame0"]))

@@ -136,3 +136,19 @@ def test_entry_point_helpers():
     assert out[0, 0, 0, :, 0].tolist() == [0, 63, 127, 254, 255, 255]       # ((x+1)*127.5) clamped, truncated
     m = types.SimpleNamespace(image_size=[32, 32], model=types.SimpleNamespace(diffusion_model=types.SimpleNamespace(in_channels=4, temporal_length=16)))
     assert VC.make_model_input_shape(m, 1) == [1, 4, 16, 32, 32] and VC.make_model_input_shape(m, 2, T=24) == [2, 4, 24, 32, 32]
+
+
+def test_half_keeps_the_schedule_in_fp32():
+    """`.half()` is how the networks are put in fp16; the DDIM coefficients must keep coming from the reference's fp32 schedule
+    (ddpm3d.py:125-165 registers fp32 buffers and VideoCrafter never halves the module).  An fp16 alphas_cumprod is a per-step
+    coefficient error shared by every pixel: it was the part of configs[4]'s 50-step error that did not average out."""
+    ld = VC.LatentDiffusion(configs.TINY_LVDM_UNET, None, init_weights=False, **configs.LVDM_SCHEDULE)
+    ref = {n: getattr(ld, n).clone() for n in ld._schedule_names}
+    ld = ld.half()
+    assert next(ld.parameters()).dtype == torch.float16
+    for n, v in ref.items():
+        assert getattr(ld, n).dtype == torch.float32 and torch.equal(getattr(ld, n), v), n
+    smp = VC.DDIMSampler(ld)
+    smp.make_schedule(50, verbose=False)
+    assert smp.ddim_alphas.dtype == torch.float32
+    assert torch.equal(smp.ddim_alphas, ref["alphas_cumprod"][smp.ddim_timesteps])

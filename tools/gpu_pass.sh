@@ -58,6 +58,10 @@ for n in ("bench_lvdm", "bench_lvdm_notile11"):
         print(n, "no line:", e)
 PY
 }
+stage_lvdmp() {     # configs[4] parity only (10 / 50-step x0 against the reference on the deployed weights)
+  timeout 900 $PYT tests/test_gpu_fullsize.py -rP -k "c4" > gpurun_out/${TAG}_c4.log 2>&1; echo "c4 exit $?"
+  grep -E "rel-L2|passed|failed" gpurun_out/${TAG}_c4.log | cut -c1-200
+}
 stage_lvdmx() {     # configs[4] parity + bench under the heavier precision settings (every level split, fp32 GroupNorm-only tensors)
   for cfg in "T2V_PRECISE=all" "T2V_PRECISE=all T2V_NORM_INPUT=f32" "T2V_NORM_INPUT=f32"; do
     tag=$(echo $cfg | tr ' =' '__')
