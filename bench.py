@@ -823,6 +823,13 @@ def main():
             "whole_video": {"tflop": round(video_tflop, 1), "tflops_per_gpu": round(video_tflop / (ms_per_step * 1e-3) / world, 1),
                             "frac": round(video_tflop / (ms_per_step * 1e-3) / world / MFMA_PEAK_TFLOPS, 4)},
         }
+        if world == 1 and args.videos == 1:
+            # `tflop` is the WORKLOAD's count (two full forwards per guided step); the program executes fewer where cond | uncond share
+            # their prefix — both are printed so that neither rate is mistaken for the other
+            executed = args.ddim_steps * prog.total_flops() / 1e12 + VAE_TFLOP_PER_FRAME * px * frames
+            result["roofline"]["whole_video"].update(
+                tflop_executed=round(executed, 1), frac_executed=round(executed / (ms_per_step * 1e-3) / MFMA_PEAK_TFLOPS, 4),
+                note="tflop = SURVEY 8(d) count of the workload (2 UNet forwards per step + VAE); tflop_executed = what the program ran")
         if world == 1 and args.videos == 1 and args.also_batched > 1:
             # Reported beside the headline, never as `value`: the same workload with several videos per batch (the
             # reference's batch_count loop in one pass) — one warm-up pass, one timed pass.

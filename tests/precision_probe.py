@@ -25,6 +25,7 @@ from sd_webui_text2video_amd import _lib as L  # noqa: E402
 from sd_webui_text2video_amd import unet as U  # noqa: E402
 
 
+SPLIT_TEXT_KV = False  # "sample" mode: the text K / V are their own class
 BY_LEVEL = False       # "levels" on the command line: the round-4 classes are split by resolution level (rows of the tensor)
 
 
@@ -57,7 +58,9 @@ def _classify(op) -> str:
     if op.kind == L.OP_GEMM:
         if op.i[16] == L.EPI_GEGLU:
             return "geglu.out"
-        if n.endswith(".qkv") or n.endswith(".to_q") or n.endswith(".kv") or n == "attn2.kv.all":
+        if n.endswith(".kv") or n == "attn2.kv.all":
+            return "kv.text" if SPLIT_TEXT_KV else "qkv"     # K / V of the text: the SAME rounding at every step of a sampling run
+        if n.endswith(".qkv") or n.endswith(".to_q"):
             return "qkv"
         if n.startswith("time_embed") or n == "emb_layers.all":
             return "time"
@@ -120,6 +123,15 @@ def main():
     fast = "fast" in sys.argv           # only the "this class exact alone" column
     if fast:
         sys.argv.remove("fast")
+    steps, only = 0, None
+    for a in list(sys.argv):
+        if a.startswith("sample="):       # sample=N[:class,class]: N guided DDIM steps (eta 0, CFG 9) instead of one forward
+            global SPLIT_TEXT_KV
+            SPLIT_TEXT_KV = True
+            body = a.split("=", 1)[1]
+            steps = int(body.split(":")[0])
+            only = body.split(":")[1].split(",") if ":" in body else None
+            sys.argv.remove(a)
     which = sys.argv[1] if len(sys.argv) > 1 else "tiny"
     F = int(sys.argv[2]) if len(sys.argv) > 2 else 4
     cfg = dict(configs.TINY_UNET)
@@ -147,7 +159,7 @@ def main():
     t = torch.tensor([801.0])
     ref = tp.lvdm_unet_forward(sd, cfg, x, t.long(), y) if lvdm else tp.unet_forward(sd, cfg, x, t.long(), y)
     net16 = net.half()
-    comp = net16._compile(1, F, hw, hw, 7, "f32", "f16", "f16")
+    comp = net16._compile(1, F, hw, hw, 7, "f32", "f32" if steps else "f16", "f16")
     weights = comp.packer.materialise(net16.state_dict(), "cpu")
 
     def run(exact=()):
@@ -157,6 +169,8 @@ def main():
         e = out.float() - ref
         return float(e.norm() / ref.norm()), it.seen
 
+    if steps:
+        return sample_mode(which, cfg, sd, comp, weights, x, y, F, hw, steps, lvdm, only)
     base, seen = run()
     if "inner16" in sys.argv:
         Probe.round_inner = True
@@ -187,6 +201,57 @@ def main():
         chosen.add(c)
         order.append((c, run(chosen)[0]))
     print("cumulative, best single gains first: " + " -> ".join(f"{c} {r:.2e}" for c, r in order), flush=True)
+
+
+def sample_mode(which, cfg, sd, comp, weights, x_T, y, F, hw, steps, lvdm, only):
+    """Which classes carry the error of a SAMPLED latent?  Roundings that differ from step to step average out over the run, an error
+    that is the same at every step (the text K / V, anything derived from constants) adds up: a class whose share GROWS from the single
+    forward to the N-step output is of the second kind.  Deterministic DDIM (eta 0), CFG 9, linear-sd schedule, fp32 state; the
+    reference is the fp32 oracle port stepping the same recurrence."""
+    import numpy as np
+    from sd_webui_text2video_amd.pipeline import beta_schedule
+    betas = beta_schedule("linear_sd", 1000, init_beta=0.00085, last_beta=0.012).double()
+    ac = torch.cumprod(1.0 - betas, 0)
+    ts = list(range(999, -1, -(1000 // steps)))[:steps]
+    g = torch.Generator().manual_seed(7)
+    yu = torch.randn(y.shape, generator=g).half().float()
+    scale = 9.0
+
+    def loop(eps_fn):
+        x = x_T.clone().float()
+        for i, t in enumerate(ts):
+            a_t = float(ac[t]); a_p = float(ac[ts[i + 1]]) if i + 1 < len(ts) else 1.0
+            ec, eu = eps_fn(x, t, y), eps_fn(x, t, yu)
+            eps = eu + scale * (ec - eu)
+            x0 = (x - np.sqrt(1 - a_t) * eps) / np.sqrt(a_t)
+            x = np.sqrt(a_p) * x0 + np.sqrt(1 - a_p) * eps
+        return x
+
+    fwd = tp.lvdm_unet_forward if lvdm else tp.unet_forward
+    ref = loop(lambda x, t, c: fwd(sd, cfg, x, torch.tensor([t]), c))
+
+    def run(exact=()):
+        seen = {}
+
+        def eps_fn(x, t, c):
+            it = Probe(comp.prog, weights, exact)
+            out = torch.empty(1, 4, F, hw, hw, dtype=torch.float32)
+            it.run({L.EXT_X: x, L.EXT_T: torch.tensor([float(t)]), L.EXT_CTX: c.half(), L.EXT_OUT: out})
+            seen.update(it.seen)
+            return out.float()
+        got = loop(eps_fn)
+        return float((got - ref).norm() / ref.norm()), seen
+
+    base, seen = run()
+    classes = [c for c in sorted(seen) if only is None or any(c.startswith(o) for o in only)]
+    print(f"{which} UNet, {F} frames @{hw}x{hw}: {steps}-step guided DDIM (CFG 9, eta 0), fp32 eps; rel-L2 of the sampled latent vs the fp32 oracle")
+    print(f"baseline (all fp16 operands, as on the device): {base:.3e}", flush=True)
+    print(f"{'class':16s} {'stores':>6s} {'exact alone':>12s} {'gain':>8s}")
+    for c in classes:
+        r1, _ = run({c})
+        print(f"{c:16s} {seen[c]:6d} {r1:12.3e} {100 * (1 - r1 / base):7.1f}%", flush=True)
+    rall, _ = run(set(seen))
+    print(f"every class exact: {rall:.3e}", flush=True)
 
 
 if __name__ == "__main__":
