@@ -3,6 +3,7 @@
     python tests/golden/make_golden_full.py [c1] [c2] [c3] [c4]      # default: all (~45 min on 8 cores)
     python tests/golden/make_golden_full.py w16 [c1] [c2] [c3] [c4]  # "deployed-weights" goldens  -> *_w16.npz
     python tests/golden/make_golden_full.py w16 c3x12                # 12-frame ZeroScope-XL forward -> zeroscope_xl_12f_w16.npz
+    python tests/golden/make_golden_full.py w16 c1s50                # round 4: 50-step "DDIM" / "UniPC" latents at the full size
     python tests/golden/make_golden_full.py w16 c1s c3s c2s          # round 4: OUTPUT-level goldens (sampled latents) for the other
                                                                      # two samplers at configs[1] and for configs[3] / configs[2]
 
@@ -248,6 +249,23 @@ def c1s():
     print("c1s done", flush=True)
 
 
+def c1s50():
+    """The other two samplers at the DEPLOYED step count: 50-step "DDIM" and 50-step "UniPC" latents of the full model (the 10-step
+    goldens above sit in the few-step regime where the trajectory has not contracted yet)."""
+    ref = rb.bootstrap()
+    unet, betas = _unet()
+    _, cond, uncond = _inputs(24, 256, 256)
+    out = {}
+    for name in ("DDIM", "UniPC"):
+        t0 = time.time()
+        x0 = _sample_named(ref, unet, betas, 24, 50, cond, uncond, name)
+        out[f"{name.lower()}_x0_50"] = x0.numpy()
+        out[f"{name.lower()}_timing"] = np.array([time.time() - t0, torch.get_num_threads()], dtype=np.float64)
+        print(f"c1s50 {name} 50 steps {time.time() - t0:.0f}s std {x0.std():.4f}", flush=True)
+        np.savez_compressed(os.path.join(OUT, f"modelscope_24f_samplers50{SUFFIX}.npz"), **out)
+    print("c1s50 done", flush=True)
+
+
 def c3s():
     """configs[3] OUTPUT-level golden (VERDICT r03 missing #2): 5-step DDIM_Gaussian CFG 9 latent of a 4-frame clip at the
     ZeroScope-XL geometry (latent 72x128, 9216-token spatial attention)."""
@@ -281,6 +299,6 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     if "w16" in sys.argv[1:]:
         W16, SUFFIX = True, "_w16"
-    which = [a for a in sys.argv[1:] if a in ("c1", "c2", "c3", "c4", "c3x12", "c1s", "c3s", "c2s")] or ["c2", "c3", "c4", "c1"]
+    which = [a for a in sys.argv[1:] if a in ("c1", "c2", "c3", "c4", "c3x12", "c1s", "c3s", "c2s", "c1s50")] or ["c2", "c3", "c4", "c1"]
     for name in which:
         globals()[name]()
