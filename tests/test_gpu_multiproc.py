@@ -42,7 +42,10 @@ def _pipe(dev):
 FRAMES, STEPS, SEED = 7, 3, 99
 
 
-def _worker(rank, world, port, mode, ret, eta=0.0):
+ETAS = (0.0, 0.6)
+
+
+def _worker(rank, world, port, mode, ret):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ["T2V_GN_COOP"] = "0"      # 2-4 processes share ONE GPU here: no co-residency guarantee for a grid barrier (csrc/norm.hip)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -51,53 +54,56 @@ def _worker(rank, world, port, mode, ret, eta=0.0):
         torch.cuda.set_device(0)
         dev = torch.device("cuda", 0)
         pipe, c, uc = _pipe(dev)
-        runner = parallel.make_runner(pipe, world, rank, frames=FRAMES, height=64, width=64, ddim_steps=STEPS, guidance=9.0,
-                                      mode=mode, eta=eta)
-        out = runner(c.to(dev), uc.to(dev), SEED)
-        out2 = runner(c.to(dev), uc.to(dev), SEED)          # programs / weights / communicator state are reusable
-        assert torch.equal(out, out2)
-        if mode == "tshard":
-            # the advisor's scenario: an UNSHARDED forward after the sharded ones (and back) on the same module
-            x = torch.randn(1, 4, 2, 8, 8, device=dev)
-            pipe.sd_model(x, torch.tensor([10.0], device=dev), c.to(dev))
-            out3 = runner(c.to(dev), uc.to(dev), SEED)
-            assert torch.equal(out, out3)
-        ret[rank] = out.cpu().numpy()
+        for eta in ETAS:                 # both in ONE set of processes: spawning ranks is what this test's time goes into
+            runner = parallel.make_runner(pipe, world, rank, frames=FRAMES, height=64, width=64, ddim_steps=STEPS, guidance=9.0,
+                                          mode=mode, eta=eta)
+            out = runner(c.to(dev), uc.to(dev), SEED)
+            out2 = runner(c.to(dev), uc.to(dev), SEED)          # programs / weights / communicator state are reusable
+            assert torch.equal(out, out2)
+            if mode == "tshard" and eta == 0.0:
+                # the advisor's scenario: an UNSHARDED forward after the sharded ones (and back) on the same module
+                x = torch.randn(1, 4, 2, 8, 8, device=dev)
+                pipe.sd_model(x, torch.tensor([10.0], device=dev), c.to(dev))
+                out3 = runner(c.to(dev), uc.to(dev), SEED)
+                assert torch.equal(out, out3)
+            ret[(rank, eta)] = out.cpu().numpy()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,mode,eta", [(4, "tshard", 0.0), (2, "pairs", 0.0), (4, "tshard", 0.6), (2, "pairs", 0.6)])
-def test_runner_layouts_multi_process_on_one_gpu(world, mode, eta):
+@pytest.mark.parametrize("world,mode", [(4, "tshard"), (2, "pairs")])
+def test_runner_layouts_multi_process_on_one_gpu(world, mode):
     """eta > 0 (round 4, VERDICT r03 missing #3): every rank draws the per-step noise of the WHOLE clip from an identically
     seeded generator (samplers.SharedNoise) and keeps the frames it holds — the split run reproduces a single-GPU run that is
     given the same noise stream."""
     port = _free_port()
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, port, mode, ret, eta), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, mode, ret), nprocs=world, join=True)
     dev = torch.device("cuda", 0)
-    pipe, c, uc = _pipe(dev)
-    seed = SEED + (0 if mode == "tshard" else 0)      # pair 0 / the single T-sharded video use the seed as given
-    keep = False
-    if eta:
-        from sd_webui_text2video_amd.samplers import SharedNoise
-        pipe.diffusion.get_sampler("DDIM_Gaussian", return_sampler=False)
-        pipe.diffusion.sampler.shared_noise = SharedNoise(seed, FRAMES, 0, dev)
-        keep = True
-    want, _ = pipe.infer_conditioned(c, uc, STEPS, FRAMES, seed, 9.0, 64, 64, eta, to_host=False, _keep_sampler=keep)
-    want = want.cpu().numpy()
-    for r in range(world):
-        got = ret[r]
-        assert got.shape == want.shape == (FRAMES, 64, 64, 3)
-        assert np.array_equal(got, ret[0])                   # every rank ends with the same gathered video
-    d = np.abs(ret[0].astype(int) - want.astype(int))
-    per_frame = [(d[f] > 1).mean() for f in range(FRAMES)]
-    print(f"{mode} x{world}: {100 * (d == 0).mean():.2f}% identical to the single-GPU video, max |diff| {d.max()}, "
-          f"worst frame {100 * max(per_frame):.3f}% off by > 1")
-    # b = 1 per-role programs (other tiles / split-K than the b = 2 single-GPU forward): rounding-level differences only;
-    # a wrong slice / halo / frame order is an O(100 %) error on the affected frames
-    assert (d == 0).mean() > 0.85 and max(per_frame) < 0.02
+    for eta in ETAS:
+        pipe, c, uc = _pipe(dev)
+        seed = SEED                                           # pair 0 / the single T-sharded video use the seed as given
+        keep = False
+        if eta:
+            from sd_webui_text2video_amd.samplers import SharedNoise
+            pipe.diffusion.get_sampler("DDIM_Gaussian", return_sampler=False)
+            pipe.diffusion.sampler.shared_noise = SharedNoise(seed, FRAMES, 0, dev)
+            keep = True
+        want, _ = pipe.infer_conditioned(c, uc, STEPS, FRAMES, seed, 9.0, 64, 64, eta, to_host=False, _keep_sampler=keep)
+        want = want.cpu().numpy()
+        for r in range(world):
+            got = ret[(r, eta)]
+            assert got.shape == want.shape == (FRAMES, 64, 64, 3)
+            assert np.array_equal(got, ret[(0, eta)])            # every rank ends with the same gathered video
+        d = np.abs(ret[(0, eta)].astype(int) - want.astype(int))
+        per_frame = [(d[f] > 1).mean() for f in range(FRAMES)]
+        print(f"{mode} x{world}, eta {eta}: {100 * (d == 0).mean():.2f}% identical to the single-GPU video, max |diff| {d.max()}, "
+              f"worst frame {100 * max(per_frame):.3f}% off by > 1")
+        # b = 1 per-role programs (other tiles / split-K than the b = 2 single-GPU forward): rounding-level differences only;
+        # a wrong slice / halo / frame order is an O(100 %) error on the affected frames
+        assert (d == 0).mean() > 0.85 and max(per_frame) < 0.02
+    assert not np.array_equal(ret[(0, 0.0)], ret[(0, 0.6)])      # eta really changed the run
 
 
 def test_bench_self_launch_one_device_rehearsal():
