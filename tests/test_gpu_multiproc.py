@@ -58,14 +58,15 @@ def _worker(rank, world, port, mode, ret):
             runner = parallel.make_runner(pipe, world, rank, frames=FRAMES, height=64, width=64, ddim_steps=STEPS, guidance=9.0,
                                           mode=mode, eta=eta)
             out = runner(c.to(dev), uc.to(dev), SEED)
-            out2 = runner(c.to(dev), uc.to(dev), SEED)          # programs / weights / communicator state are reusable
-            assert torch.equal(out, out2)
-            if mode == "tshard" and eta == 0.0:
-                # the advisor's scenario: an UNSHARDED forward after the sharded ones (and back) on the same module
-                x = torch.randn(1, 4, 2, 8, 8, device=dev)
-                pipe.sd_model(x, torch.tensor([10.0], device=dev), c.to(dev))
-                out3 = runner(c.to(dev), uc.to(dev), SEED)
-                assert torch.equal(out, out3)
+            # (four processes time-slicing one GPU with every exchange staged through the host: a T-sharded run costs ~70 s here,
+            #  so the repeat runs only where they test something new)
+            if eta == 0.0 or mode == "pairs":
+                if mode == "tshard":
+                    # the advisor's scenario: an UNSHARDED forward between two sharded runs on the same module
+                    x = torch.randn(1, 4, 2, 8, 8, device=dev)
+                    pipe.sd_model(x, torch.tensor([10.0], device=dev), c.to(dev))
+                out2 = runner(c.to(dev), uc.to(dev), SEED)      # programs / weights / communicator state / noise stream are reusable
+                assert torch.equal(out, out2)
             ret[(rank, eta)] = out.cpu().numpy()
     finally:
         dist.destroy_process_group()
