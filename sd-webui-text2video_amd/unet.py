@@ -21,7 +21,6 @@ Every `rearrange(...).contiguous()` of the reference (t2v_model.py:429,458,648,6
 """
 from __future__ import annotations
 
-import math
 import os
 from functools import partial
 from typing import Dict, List, Optional, Tuple
@@ -32,7 +31,7 @@ import torch.nn as nn
 
 from . import _lib as L
 from . import packing as pk
-from .program import COLLECTIVE_KINDS, NULL, BoundProgram, Buf, Program, Ref, TShardSpec
+from .program import COLLECTIVE_KINDS, BoundProgram, Buf, Program, Ref, TShardSpec
 
 
 # ------------------------------------------------------------------------------------------

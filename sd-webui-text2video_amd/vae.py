@@ -17,14 +17,14 @@ Downsample pads (0,1,0,1) and convolves with stride 2 — and returns the Diagon
 """
 from __future__ import annotations
 
-from typing import Dict, Optional
+from typing import Dict
 
 import torch
 import torch.nn as nn
 
 from . import _lib as L
 from . import packing as pk
-from .program import NULL, Buf, Program, Ref
+from .program import Buf, Program, Ref
 from .unet import _Compiled, _dt
 
 

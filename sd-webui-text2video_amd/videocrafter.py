@@ -17,9 +17,8 @@ the MFMA flash-attention kernel, TemporalCrossAttention with relative-position t
 from __future__ import annotations
 
 import math
-import os
 from functools import partial
-from typing import Dict, List, Optional, Tuple
+from typing import List, Optional
 
 import numpy as np
 import torch
