@@ -80,10 +80,11 @@ def _usable_cores():
 
 def cpu_baseline_worker(frames, ddim_steps):
     """Runs in a child process (bounded by a timeout in the parent): the oracle port
-    (oracle/torch_port.py, fp32) on the host cores — ONE UNet forward (b=1, 8 frames @256x256 = the C1 geometry,
-    2.44 TFLOP: long enough that streaming the 5.6 GB of fp32 weights no longer dominates) and ONE VAE frame decode
-    (0.62 TFLOP).  frames/s for the whole workload is extrapolated as 1 / (2*steps*t_unet_per_frame + t_vae_frame): UNet
-    cost is linear in F.  Weights are seeded synthetic (timing does not depend on their values)."""
+    (oracle/torch_port.py, fp32) on the host cores — ONE UNet forward of the workload's own clip (b=1, up to 24 frames
+    @256x256: 7.3 TFLOP, the unit the sampling loop repeats 2 x steps times; rounds 1-3 timed 8 frames and scaled) and ONE VAE
+    frame decode (0.62 TFLOP): ~10-15 s of CPU work on 16 cores.  frames/s for the whole workload is
+    1 / (2*steps*t_unet_per_frame + t_vae_frame); for clips longer than 24 frames the UNet cost is linear in F.
+    Weights are seeded synthetic (timing does not depend on their values)."""
     from oracle import configs, synth, torch_port as tp
     from sd_webui_text2video_amd import unet as U, vae as V
     cores = _usable_cores()
@@ -103,7 +104,7 @@ def cpu_baseline_worker(frames, ddim_steps):
         else:
             sd[n] = torch.ones(shp) if n.endswith("weight") else torch.zeros(shp)
     t_w = time.time() - t0
-    fs = 8
+    fs = max(1, min(int(frames), 24))
     x = torch.randn(1, 4, fs, 32, 32, generator=g)
     y = torch.randn(1, 77, 1024, generator=g)
     with torch.no_grad():
@@ -122,7 +123,7 @@ def cpu_baseline_worker(frames, ddim_steps):
     print(json.dumps({"value": round(1.0 / per_frame, 5), "unit": "frames/s", "cores": threads, "kind": "port",
                       "sample": f"oracle/torch_port.py fp32, {threads} torch threads ({cores} usable host cores): 1 UNet forward "
                                 f"b=1 {fs}f@256x256 = {t_unet:.2f}s + 1 VAE frame decode = {t_vae:.2f}s (weights built in "
-                                f"{t_w:.0f}s, untimed); extrapolated to {frames}f x {ddim_steps} steps x 2 (CFG) + decode"}))
+                                f"{t_w:.0f}s, untimed); x {ddim_steps} steps x 2 (CFG) + decode of {frames} frames"}))
 
 
 def reference_cpu_timing():
