@@ -707,7 +707,8 @@ class DDIMSampler(object):
         assert ac.shape[0] == T, "alphas have to be defined for each timestep"
         alphas = ac[self.ddim_timesteps]
         alphas_prev = torch.cat([ac[0:1], ac[self.ddim_timesteps[:-1]]])
-        self.ddim_sigmas = ddim_eta * torch.sqrt((1 - alphas_prev) / (1 - alphas) * (1 - alphas / alphas_prev))
+        a64, p64 = alphas.double(), alphas_prev.double()        # (util.py:52-63 does this in numpy float64 on the fp32 values)
+        self.ddim_sigmas = ddim_eta * torch.sqrt((1 - p64) / (1 - a64) * (1 - a64 / p64))
         self.ddim_alphas, self.ddim_alphas_prev = alphas, alphas_prev
         self.ddim_sqrt_one_minus_alphas = torch.sqrt(1.0 - alphas)
 

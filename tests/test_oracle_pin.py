@@ -164,3 +164,27 @@ def test_tensor2vid_port_matches_live_reference_function():
         want = np.stack(pl.tensor2vid(v.clone()))
         got = np.stack([np.asarray(f) for f in tp.tensor2vid_uint8(v.clone())])
         assert np.array_equal(got, want)
+
+
+@pytest.mark.skipif(not rb.reference_available(), reason="/root/reference not mounted (GPU box)")
+def test_lvdm_schedule_of_a_halved_model_matches_the_live_reference():
+    """The DDIM coefficients of the VideoCrafter path against the reference's own helpers (lvdm/models/modules/util.py:13-63), with the
+    product's LatentDiffusion put in fp16 the way bench.py / the tests do it: the schedule must be the reference's fp32 one, bit for bit
+    (round 4: `.half()` used to round it to fp16 — 5e-4 of the 50-step output's parity)."""
+    import importlib
+    from sd_webui_text2video_amd import videocrafter as VC
+    rb.bootstrap()
+    vu = importlib.import_module("videocrafter.lvdm.models.modules.util")
+    betas = vu.make_beta_schedule("linear", 1000, linear_start=configs.LVDM_SCHEDULE["linear_start"],
+                                  linear_end=configs.LVDM_SCHEDULE["linear_end"])
+    ac = torch.tensor(np.cumprod(1.0 - betas, axis=0), dtype=torch.float32)          # ddpm3d.py:141-150 (to_torch = float32)
+    ld = VC.LatentDiffusion(configs.TINY_LVDM_UNET, None, init_weights=False, **configs.LVDM_SCHEDULE).half()
+    assert ld.alphas_cumprod.dtype == torch.float32 and torch.equal(ld.alphas_cumprod, ac)
+    for steps, eta in ((50, 0.0), (10, 1.0)):
+        ts = vu.make_ddim_timesteps("uniform", steps, 1000, verbose=False)
+        sig, a, a_prev = vu.make_ddim_sampling_parameters(ac.cpu(), ts, eta, verbose=False)
+        smp = VC.DDIMSampler(ld)
+        smp.make_schedule(steps, ddim_eta=eta, verbose=False)
+        assert np.array_equal(smp.ddim_timesteps, ts)
+        assert torch.equal(smp.ddim_alphas, torch.as_tensor(a)) and torch.equal(smp.ddim_alphas_prev, torch.as_tensor(a_prev, dtype=torch.float32))
+        assert torch.allclose(smp.ddim_sigmas.double(), torch.as_tensor(sig, dtype=torch.float64), rtol=1e-7, atol=0)   # (util.py:58 mixes fp32 tensors and float64 arrays)
