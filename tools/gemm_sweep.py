@@ -27,13 +27,15 @@ for (C, hw, lvl) in [(320, 32, "L0"), (640, 16, "L1"), (1280, 8, "L2"), (1280, 4
 SHAPES.append(("L1 conv cat", L.GATHER_CONV3X3, B * F * 256, 640, 9 * 1920, dict(Hin=16, Win=16, Cin=1920, stride=1, up=0, Hout=16, Wout=16), 0))
 SHAPES.append(("L2 conv cat", L.GATHER_CONV3X3, B * F * 64, 1280, 9 * 2560, dict(Hin=8, Win=8, Cin=2560, stride=1, up=0, Hout=8, Wout=8), 0))
 
+SHAPES.append(("L0 lin hi|lo", L.GATHER_PLAIN, B * F * 1024, 320, 640, None, 0))
+TILES = tuple(int(t) for t in os.environ["SWEEP_TILES"].split(",")) if os.environ.get("SWEEP_TILES") else (0, 1, 2, 3, 4, 5, 8, 9, 11, 12)
 only = sys.argv[1] if len(sys.argv) > 1 else None
 print(f"{'shape':14s} {'M':>6s} {'N':>6s} {'K':>6s} | tile:split -> TF/s")
 for label, gather, M, N, K, conv, epi in SHAPES:
     if only and only not in label:
         continue
     res = []
-    for tile in (0, 1, 2, 3, 4, 5, 8, 9, 11, 12):
+    for tile in TILES:
         if tile in (2, 7, 8, 11) and N % 320 != 0:
             continue
         splits = [1]

@@ -27,6 +27,65 @@ def random_weights_(module, seed=0):
                 p.normal_(0.0, 0.05, generator=g)
 
 
+HBM_TBS, MFMA_TFS = 8.0, 2500.0      # MI355X_MICROARCH.md: HBM3E ~8 TB/s, dense fp16 MFMA ~2.5 PFLOP/s
+
+
+def op_bytes(op):
+    """Algorithmic HBM bytes of one op in THIS design (what bench.py's `algorithmic_bytes_per_launch` sums for the GEMM family):
+    every operand once, every result once."""
+    import bench
+    i = op.i
+    if op.kind == 1:
+        return bench.gemm_algorithmic_bytes(op)
+    if op.kind == 2:                                   # GroupNorm: input (fp32 / fp16) once, fp16 output (+ its lo image)
+        m = op.meta
+        return m["n_inst"] * m["rows"] * m["C"] * ((4 if m["dt"] == "f32" else 2) + 2 + (2 if i[16] else 0))
+    if op.kind == 3:                                   # LayerNorm: fp32 rows in, fp16 out
+        return i[0] * i[1] * 6
+    if op.kind in (4, 13):                             # attention: q and o once, k and v once per (batch, head) — fp16
+        nq, nk, heads, bo, bi, d = i[0], i[1], i[2], i[3], i[4], i[14]
+        kv_shared = (i[8] == 0)                        # text K / V: broadcast over the batch by a zero stride
+        return heads * d * 2 * (2 * nq * bo * bi + 2 * nk * (1 if kv_shared else bo * bi))
+    if op.kind == 9:                                   # casts / copies
+        return i[0] * i[1] * ((4 if i[4] == 1 else 2) + (4 if i[5] == 1 else 2))
+    return 0
+
+
+def roofline_by_class(prog, ms, tot):
+    """Every op against ITS roof: t_roof = max(bytes / 8 TB/s, flops / 2.5 PF/s); an op class is 'hbm' or 'mfma' by which term is the
+    larger one.  sum(t_roof) is the step's own speed of light in this design (fp32 residual stream, fp16 operands)."""
+    names = {1: "gemm", 2: "groupnorm", 3: "layernorm", 4: "attention", 9: "copy2d", 13: "relpos_attn"}
+    agg = collections.defaultdict(lambda: [0.0, 0, 0.0, 0.0, 0.0])      # ms, count, roof ms, bytes, flops
+    for op, m in zip(prog.ops, ms):
+        if op.kind not in names:
+            continue
+        b, fl = op_bytes(op), op.flops
+        t_h, t_m = b / (HBM_TBS * 1e12) * 1e3, fl / (MFMA_TFS * 1e12) * 1e3
+        k = names[op.kind]
+        if op.kind == 1:
+            k = "gemm/" + {0: "plain", 1: "conv3x3", 2: "tconv", 3: "conv_c8"}[op.meta["gather"]]
+            lvl = op.meta["M"]
+        elif op.kind == 2:
+            lvl = op.meta["n_inst"] * op.meta["rows"]
+        else:
+            lvl = op.i[0] if op.kind in (3, 9) else op.i[0] * op.i[3] * op.i[4]
+        key = (k, "hbm" if t_h >= t_m else "mfma", lvl)
+        a = agg[key]
+        a[0] += m; a[1] += 1; a[2] += max(t_h, t_m); a[3] += b; a[4] += fl
+    print("every op against its own roof (bytes / 8 TB/s vs flops / 2.5 PF/s; rows = token rows of the op's level):")
+    print(f"{'class':16s} {'bound':5s} {'rows':>7s} {'count':>5s} {'ms':>8s} {'roof ms':>8s} {'of roof':>8s} {'TB/s':>6s} {'TF/s':>7s}")
+    sums = collections.defaultdict(lambda: [0.0, 0.0])
+    for (k, bound, lvl), (m, c, r, b, fl) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+        sums[bound][0] += m; sums[bound][1] += r
+        if m >= 0.15:
+            print(f"{k:16s} {bound:5s} {lvl:7d} {c:5d} {m:8.3f} {r:8.3f} {100 * r / m:7.1f}% {b / m / 1e9:6.2f} {fl / m / 1e9:7.1f}")
+    for bound, (m, r) in sums.items():
+        print(f"all {bound}-bound ops: {m:7.3f} ms measured, {r:7.3f} ms at the roof = {100 * r / m:.1f} % of it")
+    m_all, r_all = sum(v[0] for v in sums.values()), sum(v[1] for v in sums.values())
+    print(f"step: {m_all:.3f} of {tot:.3f} ms classified; its own roofline {r_all:.3f} ms = {100 * r_all / m_all:.1f} % achieved "
+          f"(HIP-event timings: +2-3 us per op over back-to-back execution)")
+
+
 def main():
     F = int(sys.argv[1]) if len(sys.argv) > 1 else 24
     H = int(sys.argv[2]) if len(sys.argv) > 2 else 32
@@ -100,6 +159,7 @@ def main():
     print("attention (nq, nk, heads, batch): ms total, count, TF/s")
     for key, (m, c, fl) in sorted(att.items(), key=lambda kv: -kv[1][0]):
         print(f"  {str(key):32s} {m:8.3f} {c:4d} {fl / max(m, 1e-9) / 1e9:8.1f}")
+    roofline_by_class(prog, ms, tot)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", f"unet_ops_b{B}_f{F}_{H}x{W}.json" if model == "modelscope" else f"lvdm_ops_b{B}_f{F}_{H}x{W}.json"), "w") as f:
         json.dump([dict(name=op.name, kind=op.kind, ms=m, flops=op.flops, meta={k: v for k, v in op.meta.items() if k != "conv"})
