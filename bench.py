@@ -190,6 +190,8 @@ def gemm_algorithmic_bytes(op) -> int:
         a = (M * max(i[11], 1) ** 2 // (4 if i[12] else 1)) * i[10] * 2
     n_out = N // 2 if epi == 1 else N
     out = M * n_out * (4 if i[17] == 1 else 2)
+    if epi == 4:           # T2V_EPI_GN: the normalised fp16 tensor (+ its low-order image); the result itself only if someone else reads it
+        out = (0 if i[29] else out) + M * N * 2 * (2 if i[27] else 1)
     res = M * n_out * 4 if op.p[4].space != "null" else 0
     slabs = 2 * split * M * N * 4 if split > 1 else 0
     return a + N * K * 2 + out + res + slabs

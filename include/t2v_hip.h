@@ -26,7 +26,8 @@
 extern "C" {
 #endif
 
-#define T2V_ABI_VERSION 4   /* 4 (round 4): t2v_async_status, t2v_sync_reset, T2V_ERR_ASYNC (bounded grid barrier of the single-pass GroupNorm);
+#define T2V_ABI_VERSION 5   /* 5 (round 5): T2V_OP_NI 32 / T2V_OP_NP 12 (record grew), T2V_EPI_GN — GroupNorm (+SiLU) of a GEMM's result fused into its epilogue;
+                               4 (round 4): t2v_async_status, t2v_sync_reset, T2V_ERR_ASYNC (bounded grid barrier of the single-pass GroupNorm);
                                3 (round 3): T2V_EPI_TATTN + tile 10, GROUPNORM i[15] / p[5], GEMM p[7] tickets, RELPOS i[17], low-order outputs of the cast ops, T2V_SYNC_* */
 
 /* error codes */
@@ -86,6 +87,20 @@ enum t2v_gather {
                              STORED result (after bias / row bias / activation / residual; fp16 outputs: of the rounded values) — the input of a
                              GROUPNORM phase 3, which then needs no pass over the tensor for its statistics.  No split-K, no fused LayerNorm. */
 
+#define T2V_EPI_GN 4      /* = T2V_EPI_NONE, and the GroupNorm (+SiLU) that consumes the result runs INSIDE the epilogue (round 5): every workgroup keeps
+                             its bias / row-bias / residual-added fp32 tile in registers, publishes {sum, sum of squares} per (statistics instance, group
+                             piece), all workgroups of the launch meet at a bounded grid barrier (p[11]: T2V_SYNC_BARRIER_INTS words, as GROUPNORM p[5]),
+                             fold the partials of their instances in a fixed order (bit-identical statistics everywhere) and write
+                             p[9] = fp16 [M, i[25]] = (silu)((v - mean) * rstd * gamma + beta) — no statistics pass, no second launch, and for a
+                             result that only the norm consumes (i[29] = 1) no fp16 / fp32 round trip of the tensor at all.
+                             i[24] rows per statistics instance (a frame: H*W; all frames of a sample: F*H*W; multiple of 32, >= the tile's rows),
+                             i[25] ld of the normalised output, i[26] SiLU, i[27] = 1: low-order fp16 image at column N + n (ld >= 2N, as GROUPNORM i[16]),
+                             i[28] groups (N % groups == 0), i[29] = 1: `out` (p[5]) is NOT written; f[2] eps;
+                             p[8] gamma | beta fp32 [2N], p[9] normalised output fp16, p[10] scratch fp64 [tiles_m][2][tiles_n][T2V_GN_PIECES][2],
+                             p[11] grid-barrier words.  No split-K / GEGLU / fused LayerNorm; tiles 8 / 11 (whole rows, N == 320), 0, 3, 5 — the
+                             grid must be co-resident on the device (the library checks with the occupancy API and refuses otherwise). */
+#define T2V_GN_PIECES 36  /* group pieces (group x column tile intersections) per column tile in the T2V_EPI_GN scratch */
+
 /* dtype tags */
 #define T2V_F16 0
 #define T2V_F32 1
@@ -114,9 +129,9 @@ enum t2v_gather {
 #define T2V_SYNC_INTS 4096
 #define T2V_SYNC_BARRIER_INTS 512
 
-#define T2V_OP_NI 24
+#define T2V_OP_NI 32
 #define T2V_OP_NF 8
-#define T2V_OP_NP 8
+#define T2V_OP_NP 12
 
 /* One program record.  Field meaning per kind:
  *
@@ -138,7 +153,8 @@ enum t2v_gather {
  *   p: 0 A fp16, 1 W fp16 [N,K], 2 bias fp32 [N] (or [M] if bias_along_m), 3 rowbias fp32
  *      [M/rows_per_batch, ldrb], 4 residual fp32 [M,ldr], 5 out, 6 split-K workspace fp32 [split_k, M, N],
  *      7 split-K (epilogue NONE): T2V_SYNC_INTS zeroed int32 tile tickets -> the last workgroup of a tile to arrive folds the
- *        slabs in split order and applies the epilogue (no reduction launch); 0 -> a reduction kernel follows
+ *        slabs in split order and applies the epilogue (no reduction launch); 0 -> a reduction kernel follows;
+ *      8 .. 11 and i[24 .. 29], f[2]: T2V_EPI_GN (above)
  * GROUPNORM: i: 0 n_inst, 1 rows_per_inst, 2 C, 3 ld_in, 4 groups, 5 in dtype, 6 silu,
  *      7 ld_out, 8 phase (0 whole op | 1 statistics only | 2 fold gathered parts + normalise | 3 statistics from the producing GEMM:
  *         p[6] = its T2V_EPI_STATS strips fp32 [n_inst * rows / 32][2][i[17]], rows % 32 == 0 — a fold of the strips + ONE apply pass),

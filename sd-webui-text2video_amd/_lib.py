@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("T2V_LIB_PATH") or os.path.join(_HERE, "libt2v_hip.so")   # T2V_LIB_PATH: A/B builds of the same ABI (tools/build_variant.py)
 
 # ---- mirrors of include/t2v_hip.h (checked against the header by tests/test_abi.py) -------
-ABI_VERSION = 4
+ABI_VERSION = 5
 OP_GEMM, OP_GROUPNORM, OP_LAYERNORM, OP_ATTENTION, OP_SOFTMAX = 1, 2, 3, 4, 5
 OP_NCTHW_TO_CL, OP_CL_TO_NCTHW, OP_TIME_EMBED, OP_COPY2D, OP_DDIM_STEP, OP_MEMSET = 6, 7, 8, 9, 10, 11
 OP_LINCOMB = 12
@@ -19,11 +19,12 @@ OP_EMBED_ROWS = 14
 OP_TO_UINT8, OP_ALLGATHER, OP_HALO_EXCHANGE = 15, 16, 17
 OP_RESHARD_ROWS, OP_ALLTOALL = 18, 19
 GATHER_PLAIN, GATHER_CONV3X3, GATHER_TCONV3, GATHER_CONV3X3_C8 = 0, 1, 2, 3
-EPI_NONE, EPI_GEGLU, EPI_TATTN, EPI_STATS = 0, 1, 2, 3
+EPI_NONE, EPI_GEGLU, EPI_TATTN, EPI_STATS, EPI_GN = 0, 1, 2, 3, 4
+GN_PIECES = 36                  # T2V_GN_PIECES
 F16, F32 = 0, 1
 EXT_SLOTS = 16
 EXT_X, EXT_T, EXT_CTX, EXT_OUT, EXT_XT, EXT_XT_OUT, EXT_NOISE, EXT_EPS = 1, 2, 3, 4, 5, 6, 7, 8
-OP_NI, OP_NF, OP_NP = 24, 8, 8
+OP_NI, OP_NF, OP_NP = 32, 8, 12
 GN_ROWS_PER_BLOCK = 64           # T2V_GN_ROWS_PER_BLOCK
 SYNC_INTS = 4096                 # T2V_SYNC_INTS
 SYNC_BARRIER_INTS = 512          # T2V_SYNC_BARRIER_INTS

@@ -65,9 +65,32 @@ int validate_op(const t2v_op& op, int idx) {
       if (op.i[16] == T2V_EPI_GEGLU && (N % 32 != 0 || op.i[17] != T2V_F16)) return bad("GEGLU needs N % 32 == 0, fp16 out");
       if (op.i[16] == T2V_EPI_STATS && (op.p[7] == 0 || op.i[19] > 1 || (g == T2V_GATHER_PLAIN && op.i[8] == 1)))
         return bad("column statistics (T2V_EPI_STATS): strips pointer p[7], no split-K, no fused LayerNorm");
-      if (op.i[16] < 0 || op.i[16] > T2V_EPI_STATS) return bad("unknown epilogue");
+      if (op.i[16] < 0 || op.i[16] > T2V_EPI_GN) return bad("unknown epilogue");
+      if (op.i[16] == T2V_EPI_GN) {
+        // GroupNorm (+SiLU) of the result inside the epilogue: the tiles with an instantiation, whole 32-row strips per statistics
+        // instance, at most two instances per row tile, whole groups, every pointer of the exchange
+        const int tile = op.i[22], rows = op.i[24], groups = op.i[28];
+        const int bm = tile == 8 ? 192 : 128, bn = (tile == 8 || tile == 11) ? 320 : (tile == 3 ? 256 : 128);
+        if (g == T2V_GATHER_CONV3X3_C8 || (g == T2V_GATHER_CONV3X3 && op.i[12] != 0)) return bad("fused GroupNorm: not for the C8 stem / the upsampling gather");
+        if (op.i[20] != 0 || K % 64 != 0 || op.i[18] != 0) return bad("fused GroupNorm: no bias along M, no activation, K % 64 == 0");
+        if (g == T2V_GATHER_PLAIN && (op.i[8] != 0 || op.i[11] == 1)) return bad("fused GroupNorm: no fused LayerNorm / hi + lo output on the same op");
+        if (groups <= 0 || N % groups != 0 || rows <= 0 || M % rows != 0) return bad("fused GroupNorm: N % groups == 0, rows per instance must divide M");
+        if (op.i[19] > 1) {
+          // split-K: the norm runs in the reduction's launch (one thread per row x 8 channels, any tile)
+          if (groups > 32 || N % 8 != 0 || N / 8 > 512 || op.p[6] == 0) return bad("fused GroupNorm on a split-K GEMM: groups <= 32, N % 8 == 0, N <= 4096, a slab workspace");
+        } else {
+          if (tile != 8 && tile != 11 && tile != 3 && tile != 5 && tile != 0) return bad("fused GroupNorm: tile must be 8, 11, 3, 5 or 0");
+          if (tile == 0 && N % 128 != 0) return bad("fused GroupNorm on the 128x128-class kernel: N % 128 == 0");
+          if (N / groups > bn || (bn + N / groups - 1) / (N / groups) + 1 > T2V_GN_PIECES) return bad("fused GroupNorm: a group no wider than the tile");
+          if (rows % 32 != 0 || rows < bm) return bad("fused GroupNorm: rows per instance must be a multiple of 32 and >= the tile's rows");
+        }
+        if (op.p[8] == 0 || op.p[9] == 0 || op.p[10] == 0 || op.p[11] == 0) return bad("fused GroupNorm: gamma|beta, output, scratch and barrier words are required");
+        if (op.i[25] < N * (op.i[27] ? 2 : 1) || op.i[25] % 4 != 0) return bad("fused GroupNorm: leading dimension of the normalised output");
+        if (op.i[29] == 0 && op.p[5] == 0) return bad("fused GroupNorm: `out` is null but i[29] asks for it");
+        if (op.i[5] < N || (op.p[4] != 0 && (op.i[6] < N || op.i[6] % 4 != 0))) return bad("fused GroupNorm: ldc / ldr must be >= N and multiples of 4");
+      }
       if (op.i[19] > 1 && op.p[6] == 0) return bad("split-K without workspace");
-      if (op.p[3] != 0 && op.i[15] <= 0 && !(g == T2V_GATHER_PLAIN && op.i[8] == 1)) return bad("rowbias without rows_per_batch");
+      if (op.p[3] != 0 && op.i[15] <= 0 && !(g == T2V_GATHER_PLAIN && (op.i[8] == 1 || op.i[8] == 2))) return bad("rowbias without rows_per_batch");
       if (op.i[22] < 0 || op.i[22] > 12) return bad("unknown tile id");
       if ((op.i[16] == T2V_EPI_TATTN) != (op.i[22] == 10)) return bad("tile 10 is the fused QKV + temporal attention tile (T2V_EPI_TATTN), and only that");
       if (op.i[16] == T2V_EPI_TATTN) {
@@ -89,6 +112,15 @@ int validate_op(const t2v_op& op, int idx) {
       if (g == T2V_GATHER_PLAIN && op.i[11] == 1) {       // hi + lo fp16 output
         if (op.i[17] != T2V_F16 || op.i[16] != T2V_EPI_NONE || op.i[8] == 1 || op.i[5] < 2 * N)
           return bad("hi + lo output: fp16 out, plain epilogue, no fused LayerNorm, ldc >= 2 N");
+      }
+      if (g == T2V_GATHER_PLAIN && op.i[8] == 2) {         // LayerNorm second output across the column tiles (grid barrier)
+        const int tile = op.i[22];
+        if ((tile != 0 && tile != 5 && tile != 12 && tile != 9 && tile != 3) || (tile == 0 && N % 128 != 0) || op.i[19] > 1 || op.i[16] != T2V_EPI_NONE ||
+            op.i[17] != T2V_F32 || op.i[18] != 0 || op.i[20] != 0 || K % 64 != 0 || op.i[11] == 1)
+          return bad("cross-tile LayerNorm output: tile 0 (N % 128 == 0), 3, 5, 9 or 12, fp32 out, plain epilogue, no split-K / activation");
+        if (op.p[3] == 0 || op.p[7] == 0 || op.p[10] == 0 || op.p[11] == 0 || op.i[9] < N || op.i[9] % 4 != 0)
+          return bad("cross-tile LayerNorm output: gamma|beta, output, scratch, barrier words or leading dimension");
+        if (op.i[5] < N || (op.p[4] != 0 && (op.i[6] < N || op.i[6] % 4 != 0))) return bad("cross-tile LayerNorm output: ldc / ldr must be >= N and multiples of 4");
       }
       if (g == T2V_GATHER_PLAIN && op.i[8] == 1) {
         if ((op.i[22] != 8 && op.i[22] != 11) || N != 320 || op.i[19] > 1 || op.i[16] != T2V_EPI_NONE || op.i[17] != T2V_F32 || op.i[18] != 0 || op.i[20] != 0 ||
@@ -214,6 +246,17 @@ hipError_t launch_op(const t2v_op& op, hipStream_t s) {
       p.rows_per_batch = op.i[15] > 0 ? op.i[15] : 1;
       p.epi = op.i[16]; p.out_f32 = op.i[17] == T2V_F32; p.act = op.i[18];
       if (p.epi == T2V_EPI_STATS) { p.epi = T2V_EPI_NONE; p.stats = reinterpret_cast<float*>(op.p[7]); }   // (validated: no split-K -> p[7] is not a ticket buffer)
+      if (p.epi == T2V_EPI_GN) {                                  // GroupNorm (+SiLU) of the result inside the epilogue (validated above)
+        p.epi = T2V_EPI_NONE;
+        p.gn_gb = reinterpret_cast<const float*>(op.p[8]);
+        p.gn_out = reinterpret_cast<f16*>(op.p[9]);
+        p.gn_part = reinterpret_cast<double*>(op.p[10]);
+        p.gn_bar = reinterpret_cast<unsigned*>(op.p[11]);
+        p.gn_fault = t2v_coop_fault_word();
+        p.gn_rows = op.i[24]; p.ld_gn = op.i[25]; p.gn_silu = op.i[26]; p.gn_lo = op.i[27] ? op.i[1] : 0;
+        p.gn_cpg = op.i[1] / op.i[28]; p.gn_store_out = op.i[29] ? 0 : 1;
+        p.gn_eps = op.f[2];
+      }
       p.splitk = op.i[19] > 1 ? op.i[19] : 1;
       p.bias_m = op.i[20]; p.ldrb = op.i[21];
       p.A = reinterpret_cast<const f16*>(op.p[0]);
@@ -235,13 +278,21 @@ hipError_t launch_op(const t2v_op& op, hipStream_t s) {
         return t2v_launch_gemm2(p, tile, s);
       }
       // split-K: p[7] = T2V_SYNC_INTS zeroed ints -> the fold runs in the GEMM's last-arriving workgroups; 0 -> reduction kernel
-      if (p.splitk > 1 && !(p.gather == T2V_GATHER_PLAIN && op.i[8] == 1)) p.tickets = reinterpret_cast<int*>(op.p[7]);
-      if (p.gather == T2V_GATHER_PLAIN && op.i[8] == 1) {       // fused LayerNorm second output (validated: tile 8, N == 320; TATTN returned above)
+      const bool ln_any = p.gather == T2V_GATHER_PLAIN && (op.i[8] == 1 || op.i[8] == 2);
+      if (p.splitk > 1 && !ln_any) p.tickets = reinterpret_cast<int*>(op.p[7]);
+      if (ln_any) {       // fused LayerNorm second output (validated: tile 8 / 11, N == 320 — or, i[8] == 2, across column tiles; TATTN returned above)
         p.ln_gb = reinterpret_cast<const float*>(op.p[3]);
         p.rowbias = nullptr;
         p.ln_out = reinterpret_cast<f16*>(op.p[7]);
         p.ld_ln = op.i[9];
         p.ln_eps = op.f[0];
+        if (op.i[8] == 2) {
+          p.ln_x = 1;
+          p.ln_out = reinterpret_cast<f16*>(op.p[7]);
+          p.gn_part = reinterpret_cast<double*>(op.p[10]);
+          p.gn_bar = reinterpret_cast<unsigned*>(op.p[11]);
+          p.gn_fault = t2v_coop_fault_word();
+        }
       }
       // the large-tile kernel advances its source pointers by whole k-tiles: needs K % BK == 0
       if (tile >= 1 && tile <= 12 && tile != 10 && p.gather != T2V_GATHER_CONV3X3_C8 && p.K % 64 == 0) return t2v_launch_gemm2(p, tile, s);

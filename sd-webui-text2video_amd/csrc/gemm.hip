@@ -90,7 +90,10 @@ __device__ __forceinline__ void epilogue_store_geglu(const GemmParams& p, int m,
   *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(p.out) + (size_t)m * p.ldc + n_out) = o;
 }
 
-template <int BM, int BN, int WM, int WN, int GATHER>
+// XE = 2: the plain epilogue is t2v_epilogue_rows_gn — GroupNorm (+SiLU) of the result inside the epilogue, statistics across the launch's
+// workgroups at a grid barrier (T2V_EPI_GN; its own instantiations, launched only on a co-resident grid); XE = 3: t2v_epilogue_rows_lnx, the
+// LayerNorm second output across the launch's column tiles (same exchange along the rows)
+template <int BM, int BN, int WM, int WN, int GATHER, int XE = 0>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmParams p) {
   constexpr int NW = WM * WN;
   constexpr int TM = BM / WM / 32;       // 32-row token tiles per wave
@@ -107,9 +110,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmParams p) 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
 
-  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
   int tile_m, tile_n;
-  t2v_tile_of_block(blockIdx.x, (p.M + BM - 1) / BM, tiles_n, p.panel, tile_m, tile_n);   // XCD-aware order
+  t2v_tile_of_block(blockIdx.x, tiles_m, tiles_n, p.panel, tile_m, tile_n);   // XCD-aware order
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const int KT = (p.K + BK - 1) / BK;
@@ -263,6 +266,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmParams p) 
   // ---- epilogue: lane holds token (lane & 31), channels 8q + 4*(lane>>5) + {0..3} -------
   if (p.epi == T2V_EPI_NONE) {      // row-coalesced through a per-wave LDS buffer (t2v_kernels.h); also the split-K slabs
     __syncthreads();                // every wave is done reading the operand stages
+    if constexpr (XE == 2) {
+      t2v_epilogue_rows_gn<WM, WN, TM, TN>(p, acc, smem, lane, wave, m0, n0, tile_m, tile_n, tiles_m, tiles_n);
+      return;
+    }
+    if constexpr (XE == 3) {
+      t2v_epilogue_rows_lnx<WM, WN, TM, TN>(p, acc, smem, lane, wave, m0, n0, tile_m, tile_n, tiles_n);
+      return;
+    }
     t2v_epilogue_rows<TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wave * (32 * T2V_EPI_SP), lane, m0 + wm * TM * 32,
                               n0 + wn * TN * 32, blockIdx.y, tile_m * tiles_n + tile_n);
     return;
@@ -345,6 +356,29 @@ hipError_t launch_tile(const GemmParams& pin, hipStream_t s) {
   const dim3 grid(tiles, p.splitk > 1 ? p.splitk : 1);
   const dim3 block(WM * WN * 64);
   constexpr int lds = 2 * (BM + BN) * BK * 2;
+  if ((p.gn_out != nullptr && p.splitk == 1) || p.ln_x) {
+    // GroupNorm inside the epilogue: the 128x128 tile only; the grid barrier needs the whole launch resident (no split-K, the grid
+    // within what the occupancy API grants this instantiation on the stream's device)
+    if constexpr (BM == 128 && BN == 128) {
+      static_assert(t2v_gn_epilogue_lds(WM * WN, BM / 32, BN) <= lds && t2v_lnx_epilogue_lds(WM * WN, WN, BM) <= lds, "the norm epilogues re-use the operand stages");
+      if (p.splitk != 1 || !t2v_coop_allowed() || p.gather == T2V_GATHER_CONV3X3_C8) return hipErrorInvalidValue;
+      auto launch = [&](auto k, int* occ, t2v_device_flags& once) {
+        (void)t2v_set_dynamic_lds(reinterpret_cast<const void*>(k), lds, once, s);
+        if (!t2v_grid_fits(reinterpret_cast<const void*>(k), WM * WN * 64, lds, tiles, s, occ)) return hipErrorCooperativeLaunchTooLarge;
+        hipLaunchKernelGGL(k, grid, block, lds, s, p);
+        return hipGetLastError();
+      };
+      static int occ0[T2V_MAX_DEVICES] = {}, occ1[T2V_MAX_DEVICES] = {}, occ2[T2V_MAX_DEVICES] = {};
+      static t2v_device_flags g0, g1, g2;
+      static int occ3[T2V_MAX_DEVICES] = {};
+      static t2v_device_flags g3;
+      if (p.ln_x) return p.gather == T2V_GATHER_PLAIN ? launch(gemm_kernel<BM, BN, WM, WN, T2V_GATHER_PLAIN, 3>, occ3, g3) : hipErrorInvalidValue;
+      if (p.gather == T2V_GATHER_PLAIN) return launch(gemm_kernel<BM, BN, WM, WN, T2V_GATHER_PLAIN, 2>, occ0, g0);
+      if (p.gather == T2V_GATHER_CONV3X3) return launch(gemm_kernel<BM, BN, WM, WN, T2V_GATHER_CONV3X3, 2>, occ1, g1);
+      if (p.gather == T2V_GATHER_TCONV3) return launch(gemm_kernel<BM, BN, WM, WN, T2V_GATHER_TCONV3, 2>, occ2, g2);
+    }
+    return hipErrorInvalidValue;
+  }
   switch (p.gather) {
     case T2V_GATHER_PLAIN: {
       auto k = gemm_kernel<BM, BN, WM, WN, T2V_GATHER_PLAIN>;
@@ -406,13 +440,14 @@ hipError_t t2v_launch_gemm(const GemmParams& pin, hipStream_t s) {
     const int bn = narrow ? 64 : 128;
     const long tiles = (long)((p.M + 127) / 128) * ((p.N + bn - 1) / bn);
     // in-kernel fold by the last-arriving workgroup of a tile (t2v_epilogue_rows) where a ticket buffer is given; else the reduction kernel
-    if (p.splitk <= 1 || p.epi != T2V_EPI_NONE || tiles > T2V_SYNC_INTS) p.tickets = nullptr;
+    if (p.splitk <= 1 || p.epi != T2V_EPI_NONE || tiles > T2V_SYNC_INTS || p.gn_out != nullptr) p.tickets = nullptr;
   }
   if (narrow)
     e = launch_tile<128, 64, 4, 1>(p, s);
   else
     e = launch_tile<128, 128, 2, 2>(p, s);
   if (e != hipSuccess) return e;
-  if (p.splitk > 1 && p.tickets == nullptr) e = t2v_launch_splitk_reduce(p, s);
+  // (split-K whose result feeds a fused GroupNorm: the reduction is the loader of a cooperative GroupNorm launch, norm.hip)
+  if (p.splitk > 1 && p.tickets == nullptr) e = p.gn_out != nullptr ? t2v_launch_splitk_reduce_gn(p, s) : t2v_launch_splitk_reduce(p, s);
   return e;
 }

@@ -93,7 +93,9 @@ __device__ __forceinline__ void epi_store_geglu(const GemmParams& p, int m, int 
 }
 
 // WM x WN waves; each wave owns TM x TN MFMA tiles (32 tokens x 32 channels each).
-template <int WM, int WN, int TM, int TN, int BK, int STAGES, int MINW, int GATHER, bool PP, bool LN = false, bool TAT = false>
+// XE: extra epilogue of the plain (T2V_EPI_NONE) path — 0 none, 1 fused LayerNorm second output (whole-row tiles), 2 fused GroupNorm
+// (+SiLU) of the result with a grid barrier (T2V_EPI_GN); separate instantiations, so the plain kernels keep their register budgets.
+template <int WM, int WN, int TM, int TN, int BK, int STAGES, int MINW, int GATHER, bool PP, int XE = 0, bool TAT = false>
 __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm2_kernel(const GemmParams p) {
   constexpr int NW = WM * WN;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -525,7 +527,15 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm2_kernel(const GemmPar
   }
   if (p.epi == T2V_EPI_NONE) {      // row-coalesced through a per-wave LDS buffer (t2v_kernels.h); also the split-K slabs
     __builtin_amdgcn_s_barrier();   // every wave is done reading the operand stages
-    if constexpr (LN) {             // whole rows in this tile (192x320, N == 320, validated by the executor): fused LayerNorm output
+    if constexpr (XE == 2) {        // GroupNorm (+SiLU) of the result inside the epilogue: statistics meet at a grid barrier (t2v_kernels.h)
+      t2v_epilogue_rows_gn<WM, WN, TM, TN>(p, acc, smem, lane, wave, m0, n0, tile_m, tile_n, tiles_m, tiles_n);
+      return;
+    }
+    if constexpr (XE == 3) {        // LayerNorm second output across the column tiles of the launch (partial row sums meet at the grid barrier)
+      t2v_epilogue_rows_lnx<WM, WN, TM, TN>(p, acc, smem, lane, wave, m0, n0, tile_m, tile_n, tiles_n);
+      return;
+    }
+    if constexpr (XE == 1) {        // whole rows in this tile (192x320, N == 320, validated by the executor): fused LayerNorm output
       float* fs = reinterpret_cast<float*>(smem);
       t2v_epilogue_rows_ln<TN>(p, acc, fs + wave * (32 * T2V_EPI_SP), fs + NW * (32 * T2V_EPI_SP), lane, wave, m0 + wm * 32,
                                n0 + wn * TN * 32);
@@ -626,18 +636,28 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm2_kernel(const GemmPar
   }
 }
 
-template <int WM, int WN, int TM, int TN, int BK, int STAGES, int MINW, int GATHER, bool PP, bool LN = false, bool TAT = false>
+template <int WM, int WN, int TM, int TN, int BK, int STAGES, int MINW, int GATHER, bool PP, int XE = 0, bool TAT = false>
 hipError_t launch_cfg_gather(const GemmParams& p, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   // TAT: the attention epilogue re-uses the operand ring for q | k (BM x 272 B) and V^T (<= 12 pixels x 64 x 72 B)
-  constexpr int lds = TAT ? (BM * 272 + 12 * 64 * 72 > STAGES * (BM + BN) * BK * 2 + 1024 ? BM * 272 + 12 * 64 * 72 : STAGES * (BM + BN) * BK * 2 + 1024)
-                          : STAGES * (BM + BN) * BK * 2 + 1024;
+  constexpr int ring = STAGES * (BM + BN) * BK * 2 + 1024;
+  constexpr int gn_lds = t2v_gn_epilogue_lds(WM * WN, WM * TM, BN);
+  constexpr int lnx_lds = t2v_lnx_epilogue_lds(WM * WN, WN, BM);
+  constexpr int lds = TAT ? (BM * 272 + 12 * 64 * 72 > ring ? BM * 272 + 12 * 64 * 72 : ring)
+                          : (XE == 2 && gn_lds > ring ? gn_lds : (XE == 3 && lnx_lds > ring ? lnx_lds : ring));
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  auto k = gemm2_kernel<WM, WN, TM, TN, BK, STAGES, MINW, GATHER, PP, LN, TAT>;
+  auto k = gemm2_kernel<WM, WN, TM, TN, BK, STAGES, MINW, GATHER, PP, XE, TAT>;
   static t2v_device_flags attr_set;     // once per (instantiation, device): the call costs microseconds on the host
   {
     const hipError_t e = t2v_set_dynamic_lds(reinterpret_cast<const void*>(k), lds, attr_set, s);
     if (e != hipSuccess) return e;
+  }
+  if constexpr (XE == 2 || XE == 3) {
+    // the epilogue's grid barrier needs every workgroup of the launch resident: no split-K, and the grid within what the occupancy
+    // API grants this instantiation on the stream's device (cached); a process in which a barrier already timed out stays off it
+    static int occ[T2V_MAX_DEVICES] = {};
+    if (p.splitk != 1 || !t2v_coop_allowed() || !t2v_grid_fits(reinterpret_cast<const void*>(k), WM * WN * 64, lds, tiles, s, occ))
+      return hipErrorCooperativeLaunchTooLarge;
   }
   hipLaunchKernelGGL(k, dim3(tiles, p.splitk > 1 ? p.splitk : 1), dim3(WM * WN * 64), lds, s, p);
   return hipGetLastError();
@@ -656,34 +676,58 @@ hipError_t launch_cfg(const GemmParams& pin, hipStream_t s) {
     p.panel = t2v_choose_panel(p, (p.M + BM - 1) / BM, (p.N + BN - 1) / BN);
     const long tiles = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     // in-kernel fold by the last-arriving workgroup of a tile (t2v_epilogue_rows) where a ticket buffer is given; else the reduction kernel
-    if (p.splitk <= 1 || p.epi != T2V_EPI_NONE || tiles > T2V_SYNC_INTS) p.tickets = nullptr;
+    if (p.splitk <= 1 || p.epi != T2V_EPI_NONE || tiles > T2V_SYNC_INTS || p.gn_out != nullptr) p.tickets = nullptr;
   }
+  // tiles with a T2V_EPI_GN instantiation (validated by the executor): the whole-row tiles 8 / 11, and the 128-row tiles 3 / 5
+  constexpr bool GN_TILE = !PP && (((WM == 6 || WM == 4) && WN == 2 && TM == 1 && TN == 5) || (WM == 2 && WN == 4 && TM == 2 && (TN == 1 || TN == 2)));
+  // (with split-K the norm runs in the reduction's launch instead: any tile, t2v_launch_splitk_reduce_gn below)
+  const bool gn_here = p.gn_out != nullptr && p.splitk == 1;
+  if (gn_here && (!GN_TILE || (p.gather == T2V_GATHER_CONV3X3 && p.up))) return hipErrorInvalidValue;
+  // ... and with a cross-tile LayerNorm instantiation: 5 (128x128), 12 (64x64), 9 (192x256), 3 (128x256); plain gather only
+  constexpr bool LNX_TILE = !PP && ((WM == 2 && WN == 4 && TM == 2 && (TN == 1 || TN == 2)) || (WM == 2 && WN == 2 && TM == 1 && TN == 1) ||
+                                    (WM == 6 && WN == 2 && TM == 1 && TN == 4));
+  if (p.ln_x && (!LNX_TILE || p.gather != T2V_GATHER_PLAIN)) return hipErrorInvalidValue;
   hipError_t e;
   switch (p.gather) {
     case T2V_GATHER_PLAIN:
       if constexpr (WM == 6 && WN == 2 && TM == 1 && TN == 3 && !PP) {
         if (p.epi != T2V_EPI_TATTN || p.splitk != 1 || p.tpix < 1 || p.tpix > 12 || p.tpix * p.F > BM_OF(WM, TM) || p.F > 32) return hipErrorInvalidValue;
-        e = launch_cfg_gather<WM, WN, TM, TN, BK, STAGES, MINW, T2V_GATHER_PLAIN, PP, false, true>(p, s);
+        e = launch_cfg_gather<WM, WN, TM, TN, BK, STAGES, MINW, T2V_GATHER_PLAIN, PP, 0, true>(p, s);
         break;
       }
       if (p.epi == T2V_EPI_TATTN) return hipErrorInvalidValue;
       if constexpr ((WM == 6 || WM == 4) && WN == 2 && TM == 1 && TN == 5 && !PP) {      // whole-row tiles: 192x320 / 128x320
         if (p.ln_out != nullptr) {
-          e = launch_cfg_gather<WM, WN, TM, TN, BK, STAGES, MINW, T2V_GATHER_PLAIN, PP, true>(p, s);
+          e = launch_cfg_gather<WM, WN, TM, TN, BK, STAGES, MINW, T2V_GATHER_PLAIN, PP, 1>(p, s);
           break;
         }
+      }
+      if constexpr (GN_TILE) {
+        if (gn_here) { e = launch_cfg_gather<WM, WN, TM, TN, BK, STAGES, MINW, T2V_GATHER_PLAIN, PP, 2>(p, s); break; }
+      }
+      if constexpr (LNX_TILE) {
+        if (p.ln_x) { e = launch_cfg_gather<WM, WN, TM, TN, BK, STAGES, MINW, T2V_GATHER_PLAIN, PP, 3>(p, s); break; }
       }
       e = launch_cfg_gather<WM, WN, TM, TN, BK, STAGES, MINW, T2V_GATHER_PLAIN, PP>(p, s);
       break;
     case T2V_GATHER_CONV3X3:
+      if constexpr (GN_TILE) {
+        if (gn_here && !p.up) { e = launch_cfg_gather<WM, WN, TM, TN, BK, STAGES, MINW, T2V_GATHER_CONV3X3, PP, 2>(p, s); break; }
+      }
       if (p.up) e = launch_cfg_gather<WM, WN, TM, TN, BK, STAGES, MINW, G_CONV_UP, PP>(p, s);
       else e = launch_cfg_gather<WM, WN, TM, TN, BK, STAGES, MINW, T2V_GATHER_CONV3X3, PP>(p, s);
       break;
-    case T2V_GATHER_TCONV3: e = launch_cfg_gather<WM, WN, TM, TN, BK, STAGES, MINW, T2V_GATHER_TCONV3, PP>(p, s); break;
+    case T2V_GATHER_TCONV3:
+      if constexpr (GN_TILE) {
+        if (gn_here) { e = launch_cfg_gather<WM, WN, TM, TN, BK, STAGES, MINW, T2V_GATHER_TCONV3, PP, 2>(p, s); break; }
+      }
+      e = launch_cfg_gather<WM, WN, TM, TN, BK, STAGES, MINW, T2V_GATHER_TCONV3, PP>(p, s);
+      break;
     default: return hipErrorInvalidValue;
   }
   if (e != hipSuccess) return e;
-  if (p.splitk > 1 && p.tickets == nullptr) e = t2v_launch_splitk_reduce(p, s);
+  // (split-K whose result feeds a fused GroupNorm: the reduction is the loader of a cooperative GroupNorm launch, norm.hip)
+  if (p.splitk > 1 && p.tickets == nullptr) e = p.gn_out != nullptr ? t2v_launch_splitk_reduce_gn(p, s) : t2v_launch_splitk_reduce(p, s);
   return e;
 }
 

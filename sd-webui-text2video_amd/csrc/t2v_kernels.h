@@ -57,6 +57,18 @@ struct GemmParams {
   // residual row m - res_wrap.  The cond | uncond pair of a guided step shares every tensor up to the first text cross-attention
   // (same x_t, same t): those are computed ONCE (one sample's rows) and the first per-sample GEMMs read them through the wrap.
   int a_wrap, res_wrap;
+  // GroupNorm (+SiLU) of the result inside the epilogue (T2V_EPI_GN, round 5; t2v_epilogue_rows_gn below): the tile stays in registers,
+  // the statistics meet at a grid barrier — the launch must be co-resident (checked by the launcher)
+  const float* gn_gb;                          // fp32 [2 N]: gamma | beta
+  f16* gn_out;                                 // fp16 [M, ld_gn] (+ low-order image at column gn_lo)
+  double* gn_part;                             // fp64 [tiles_m][2][tiles_n][T2V_GN_PIECES][2]
+  unsigned* gn_bar;                            // T2V_SYNC_BARRIER_INTS grid-barrier words
+  unsigned* gn_fault;                          // host-mapped fault word of the bounded barrier
+  int ld_gn, gn_rows, gn_cpg, gn_silu, gn_lo, gn_store_out;
+  float gn_eps;
+  // LayerNorm second output ACROSS column tiles (t2v_epilogue_rows_lnx: ln_gb / ln_out / ld_ln / ln_eps as above, partial row sums
+  // through gn_part, the grid barrier on gn_bar): any N, the launch must be co-resident
+  int ln_x;
 };
 
 
@@ -139,11 +151,35 @@ inline hipError_t t2v_set_dynamic_lds(const void* kernel, int lds_bytes, t2v_dev
   return e;
 }
 int t2v_num_cus(hipStream_t s);                         // compute units of the stream's device (norm.hip, cached per device)
+// makes the stream's device current for the lifetime of the object (occupancy queries answer for the CURRENT device)
+struct t2v_device_guard {
+  int prev = -1;
+  explicit t2v_device_guard(hipStream_t s) {
+    const int d = t2v_device_of(s);
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur != d && hipSetDevice(d) == hipSuccess) prev = cur;
+  }
+  ~t2v_device_guard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+// A kernel whose workgroups meet at a grid barrier must be wholly resident: `nwg` workgroups of `threads` threads and `lds` dynamic
+// bytes against what the occupancy API grants `kernel` per CU on the stream's device (cache[device]: 0 = not asked yet, -1 = failed).
+inline bool t2v_grid_fits(const void* kernel, int threads, size_t lds, long nwg, hipStream_t s, int* cache) {
+  const int d = t2v_device_of(s);
+  if (cache[d] == 0) {
+    t2v_device_guard guard(s);
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, threads, lds) != hipSuccess) { (void)hipGetLastError(); nb = 0; }
+    cache[d] = nb > 0 ? nb : -1;
+  }
+  return cache[d] > 0 && nwg <= (long)cache[d] * t2v_num_cus(s);
+}
 
 // Asynchronous faults (norm.hip): a kernel that gives up waiting for a co-resident workgroup (bounded grid barrier of the
 // single-pass GroupNorm) raises a flag in host-mapped memory instead of hanging the device.  The executor reads it at the entry
 // of every run: the run that raised it produced invalid results, the NEXT call reports it (t2v_async_status() reports it at once)
 // and the cooperative path stays off for the rest of the process.
+unsigned* t2v_coop_fault_word();                        // the host-mapped fault word of the bounded grid barriers (null: unavailable)
+bool t2v_coop_allowed();                                // false once a barrier timed out in this process (or the word could not be mapped)
 int t2v_async_fault_pending();                          // 1 = a fault was raised and not yet reported
 int t2v_async_fault_consume(std::string* msg);          // returns 1 (and clears "pending", keeps the path disabled) if a fault was raised
 
@@ -151,6 +187,7 @@ int t2v_async_fault_consume(std::string* msg);          // returns 1 (and clears
 hipError_t t2v_launch_gemm(const GemmParams& p, hipStream_t s);             // 128x128 / 128x64 tiles (any N, C8 stem)
 hipError_t t2v_launch_gemm2(const GemmParams& p, int tile, hipStream_t s);  // 256/128 x 256/320 tiles, deep DMA ring
 hipError_t t2v_launch_splitk_reduce(const GemmParams& p, hipStream_t s);
+hipError_t t2v_launch_splitk_reduce_gn(const GemmParams& p, hipStream_t s);   // split-K reduction + the GroupNorm (+SiLU) that consumes the result, one cooperative launch (norm.hip)
 hipError_t t2v_launch_groupnorm(const t2v_op& op, hipStream_t s);
 hipError_t t2v_launch_layernorm(const t2v_op& op, hipStream_t s);
 hipError_t t2v_launch_attention(const t2v_op& op, hipStream_t s);
@@ -437,6 +474,473 @@ __device__ __forceinline__ void t2v_epilogue_rows_ln(const GemmParams& p, f32x16
     }
   }
 }
+
+// ---- bounded grid barrier (shared by the single-pass GroupNorm of norm.hip and the fused-norm GEMM epilogues) ---------------------
+// Eight monotonic 64-bit counters on words of the program's zero-initialised sync buffer, one 128-byte line each; workgroup b belongs to
+// counter b % 8 (atomics on ONE address serialise at ~25 ns each: 256 arrivals would be 6 us).  Every barrier adds EXACTLY 2^32 to EVERY
+// counter: a member adds floor(2^32 / members), the first member of a group the remainder as well, and block 0 the whole 2^32 of a group
+// that has no members (grids of fewer than 8 workgroups).  So between launches every counter reads k * 2^32, and inside a launch a
+// workgroup's OWN counter stays below (k + 1) * 2^32 until that workgroup has arrived — its high word, read any time before arriving
+// (`epoch` below, read at kernel start), is the same k for every workgroup of the launch, and "all eight counters >= (k + 1) * 2^32"
+// means everybody has arrived.  One fire-and-forget atomic per workgroup and one polling round trip: no returning atomic, no second
+// level, no generation word (round 4's two-level sense-reversing form had four dependent device-scope round trips), nothing to reset
+// between launches, wrap-safe (signed differences).  All flag accesses are relaxed device-scope atomics (no cache-wide write-back /
+// invalidate); the data exchanged around it moves with device-scope (sc1) stores that their writers waited for (s_waitcnt vmcnt(0))
+// before arriving, and device-scope loads after it.
+// The wait is BOUNDED: a waiter that sees no release within GNB_TIMEOUT_TICKS of the constant 100 MHz clock (0.25 s; a healthy
+// barrier takes microseconds) raises the fault word in host-mapped memory and falls through — this launch's output is invalid, the
+// device is not hung, the host reports the fault at its next call.
+constexpr int GNB_STRIDE = 32;                       // ints between counters (one 128-byte line each)
+constexpr unsigned long long GNB_TIMEOUT_TICKS = 25000000ull;
+// thread 0 of every workgroup, any time before t2v_grid_barrier: the barrier epoch k of this launch
+__device__ __forceinline__ unsigned t2v_grid_epoch(unsigned* bar) {
+  const unsigned long long* ctr = reinterpret_cast<const unsigned long long*>(bar + (blockIdx.x & 7u) * GNB_STRIDE);
+  return (unsigned)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32);
+}
+// arrive: every thread's published (sc1) stores are complete once thread 0 has passed its s_waitcnt — each WAVE waits for its own
+// stores before the __syncthreads (callers: t2v_wait_vm0() right after publishing)
+__device__ __forceinline__ void t2v_grid_arrive(unsigned* bar, unsigned nwg) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned grp = blockIdx.x & 7u;
+    const unsigned ngrp = nwg < 8u ? nwg : 8u;
+    const unsigned in_grp = (nwg - grp + 7u) >> 3;                                   // workgroups b with b % 8 == grp
+    const unsigned long long one = 1ull << 32, w = one / in_grp;
+    t2v_wait_vm0();
+    (void)__hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(bar + grp * GNB_STRIDE), (blockIdx.x >> 3) == 0 ? one - w * (in_grp - 1) : w,
+                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (blockIdx.x == 0)
+      for (unsigned e = ngrp; e < 8u; ++e)                                           // groups without members keep step
+        (void)__hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(bar + e * GNB_STRIDE), one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+// wait: work that does not depend on the other workgroups may be issued between arrive and wait (it overlaps the barrier's latency)
+__device__ __forceinline__ void t2v_grid_wait(unsigned* bar, unsigned epoch, unsigned* fault) {
+  if (threadIdx.x == 0) {
+    const unsigned long long target = (unsigned long long)(epoch + 1u) << 32;
+    const unsigned long long t0 = wall_clock64();
+    unsigned polls = 0;
+    for (;;) {
+      unsigned long long v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        v[e] = __hip_atomic_load(reinterpret_cast<unsigned long long*>(bar + e * GNB_STRIDE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      bool all = true;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) all = all && (long long)(v[e] - target) >= 0;
+      if (all) break;
+      __builtin_amdgcn_s_sleep(4);
+      if ((++polls & 63u) == 0u && wall_clock64() - t0 > GNB_TIMEOUT_TICKS) {        // give up: flag it, never hang the device
+        __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ void t2v_grid_barrier(unsigned* bar, unsigned nwg, unsigned epoch, unsigned* fault) {
+  t2v_grid_arrive(bar, nwg);
+  t2v_grid_wait(bar, epoch, fault);
+}
+
+// ---- GroupNorm (+SiLU) of a GEMM's result inside its epilogue (T2V_EPI_GN, round 5) -----------------------------------------------
+// Replaces nn.GroupNorm(32, C) [+ SiLU] where its input is the result of ONE convolution / linear of this library (reference:
+// ResBlock in_layers conv -> out_layers norm t2v_model.py:929-957, TemporalConvBlock_v2 conv_i -> conv_{i+1} norm :1201-1212, block
+// output -> next block's norm): the stand-alone kernel re-reads the tensor the GEMM just wrote (and, for a tensor only the norm
+// consumes, the GEMM wrote it only for that) and pays a launch boundary; here the workgroup's fp32 tile never leaves its registers.
+//   A  every 32x32 accumulator block is turned through the per-wave LDS buffer (as t2v_epilogue_rows), bias / row bias / residual
+//      added, the fp32 (fp16) stream stored if anyone else needs it, the value kept in the accumulator registers (now row-major),
+//      its 32-row column sums and sums of squares folded over the 8 lanes that share a column quad -> LDS [strip][2][BN];
+//   B  per (instance slot, group piece) — a tile of BM <= rows-per-instance rows touches at most 2 statistics instances, a column
+//      tile cuts a group into at most 2 pieces — 4 lanes fold strips x channels in fp64 in a fixed order and publish ONE
+//      {sum, sum of squares} pair with a device-scope store: [tile_m][slot][tile_n][piece];
+//   C  bounded grid barrier (every workgroup of the launch is resident: checked by the launcher);
+//   D  8 lanes per (slot, group) fold the published pairs of every tile of the instance (and of both column tiles of a cut group)
+//      in a fixed order — every workgroup the same values in the same order: bit-identical statistics, no atomics on data;
+//   E  scale / shift per (slot, column) in LDS, normalise (+SiLU) from registers, fp16 out (+ low-order image).
+// Rows >= M / columns >= N contribute zeros to the sums and are not stored.
+template <int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void t2v_epilogue_rows_gn(const GemmParams& p, f32x16 (&acc)[TM][TN], unsigned char* smem, int lane, int wave,
+                                                     int m0, int n0, int tile_m, int tile_n, int tiles_m, int tiles_n) {
+  constexpr int NW = WM * WN, NT = NW * 64, S = WM * TM, BM = S * 32, BN = WN * TN * 32;
+  const int tid = threadIdx.x;
+  const int wm = wave / WN, wn = wave % WN;
+  float* stg = reinterpret_cast<float*>(smem) + wave * (32 * T2V_EPI_SP);
+  float* colsum = reinterpret_cast<float*>(smem) + NW * (32 * T2V_EPI_SP);       // [S][2][BN]
+  float* scsf = colsum + S * 2 * BN;                                             // [2 slots][scale | shift][BN]
+  float* stat = scsf + 4 * BN;                                                   // [2 slots][T2V_GN_PIECES][mean | rstd]
+  const int wrow = lane & 31, wcol = (lane >> 5) * 4;
+  const int rrow = lane >> 3, rcol = (lane & 7) * 4;
+  unsigned gen0 = 0;
+  if (tid == 0) gen0 = t2v_grid_epoch(p.gn_bar);
+  const bool has_res = p.res != nullptr;
+  // ---- A
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+    const int mt = m0 + (wm * TM + a) * 32;
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const int n = n0 + (wn * TN + b) * 32 + rcol;
+      const bool ncol = n < p.N;
+      f32x4 r[4];
+      if (has_res) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int m = mt + rrow + 8 * i;
+          const int mr = (p.res_wrap && m >= p.res_wrap) ? m - p.res_wrap : m;
+          const float* src = (m < p.M && ncol) ? p.res + (size_t)mr * p.ldr + n : p.res;
+          r[i] = *reinterpret_cast<const f32x4*>(src);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 v = {acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
+        *reinterpret_cast<f32x4*>(stg + wrow * T2V_EPI_SP + 8 * q + wcol) = v;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      f32x4 cb = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias && !p.bias_m && ncol) cb = *reinterpret_cast<const f32x4*>(p.bias + n);
+      f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, q4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = rrow + 8 * i;
+        f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * T2V_EPI_SP + rcol);
+        const int m = mt + row;
+        if (m < p.M && ncol) {
+          v += cb;
+          if (p.bias && p.bias_m) { const float bm = p.bias[m]; v[0] += bm; v[1] += bm; v[2] += bm; v[3] += bm; }
+          if (p.rowbias) v += *reinterpret_cast<const f32x4*>(p.rowbias + (size_t)(m / p.rows_per_batch) * p.ldrb + n);
+          if (p.act == 1) { v[0] = t2v_silu(v[0]); v[1] = t2v_silu(v[1]); v[2] = t2v_silu(v[2]); v[3] = t2v_silu(v[3]); }
+          if (has_res) v += r[i];
+        } else {
+          v = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        acc[a][b][4 * i] = v[0]; acc[a][b][4 * i + 1] = v[1]; acc[a][b][4 * i + 2] = v[2]; acc[a][b][4 * i + 3] = v[3];   // row-major now
+        s4 += v;
+        q4 += v * v;
+      }
+      // the 8 lanes with the same (lane & 7) hold the other rows of these 4 columns: fixed butterfly over lane bits 3, 4, 5
+#pragma unroll
+      for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s4[e] += __shfl_xor(s4[e], o); q4[e] += __shfl_xor(q4[e], o); }
+      if (lane < 8) {
+        float* cs = colsum + (size_t)(wm * TM + a) * 2 * BN + (wn * TN + b) * 32 + rcol;
+        *reinterpret_cast<f32x4*>(cs) = s4;
+        *reinterpret_cast<f32x4*>(cs + BN) = q4;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    }
+  }
+  __syncthreads();
+  // ---- B
+  const int R = p.gn_rows, cpg = p.gn_cpg;
+  const int n_hi = min(n0 + BN, p.N);
+  const int g_lo = n0 / cpg, npc = (n_hi - 1) / cpg - g_lo + 1;                    // groups (pieces) this column tile touches
+  const int inst0 = m0 / R;
+  for (int base = 0; base < 2 * npc; base += NT / 4) {
+    const int item = base + (tid >> 2), sub = tid & 3;
+    const bool active = item < 2 * npc;
+    const int slot = active ? item / npc : 0, pc = active ? item - slot * npc : 0;
+    const int g = g_lo + pc;
+    const int c_lo = max(g * cpg, n0) - n0, c_hi = min((g + 1) * cpg, n_hi) - n0;
+    double ds = 0.0, dq = 0.0;
+    if (active) {
+      for (int st = 0; st < S; ++st) {
+        if ((m0 + st * 32) / R - inst0 != slot) continue;
+        const float* cs = colsum + (size_t)st * 2 * BN;
+        for (int c = c_lo + sub; c < c_hi; c += 4) { ds += (double)cs[c]; dq += (double)cs[BN + c]; }
+      }
+    }
+    ds += __shfl_xor(ds, 1); dq += __shfl_xor(dq, 1);
+    ds += __shfl_xor(ds, 2); dq += __shfl_xor(dq, 2);
+    if (active && sub == 0) {
+      double* dst = p.gn_part + ((((size_t)tile_m * 2 + slot) * tiles_n + tile_n) * T2V_GN_PIECES + pc) * 2;
+      union { double d[2]; f32x4 v; } pk;
+      pk.d[0] = ds;
+      pk.d[1] = dq;
+      t2v_st_dev(reinterpret_cast<float*>(dst), pk.v);             // one 16-byte device-scope (write-through) store
+    }
+  }
+  t2v_wait_vm0();                                                  // ... complete before this workgroup arrives
+  // ---- C: arrive, then — under the barrier's latency — the result itself goes out if anyone else reads it (from the registers, row-major)
+  t2v_grid_arrive(p.gn_bar, gridDim.x);
+  if (p.gn_store_out) {
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+      const int mt = m0 + (wm * TM + a) * 32;
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        const int n = n0 + (wn * TN + b) * 32 + rcol;
+        if (n >= p.N) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int m = mt + rrow + 8 * i;
+          if (m >= p.M) continue;
+          const f32x4 v = {acc[a][b][4 * i], acc[a][b][4 * i + 1], acc[a][b][4 * i + 2], acc[a][b][4 * i + 3]};
+          if (p.out_f32) {
+            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n) = v;
+          } else {
+            const f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+            *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(p.out) + (size_t)m * p.ldc + n) = o;
+          }
+        }
+      }
+    }
+  }
+  t2v_grid_wait(p.gn_bar, gen0, p.gn_fault);
+  // ---- D: as many lanes per (slot, group) as the workgroup has (a power of two, 8 .. 64): one round of loads in flight where possible
+  const int last_inst = (min(m0 + BM, p.M) - 1) / R;               // instance of the tile's last real row (>= inst0, <= inst0 + 1)
+  const double inv_n = 1.0 / ((double)R * cpg);
+  const int nitems = (last_inst - inst0 + 1) * npc;
+  int lpi = 8;
+  while (lpi < 64 && nitems * (lpi * 2) <= NT) lpi *= 2;
+  for (int base = 0; base < nitems; base += NT / lpi) {
+    const int item = base + tid / lpi, sub = tid % lpi;
+    const int slot = item < nitems ? item / npc : 2, pc = item < nitems ? item - slot * npc : 0;
+    const bool active = slot < 2;
+    double ds = 0.0, dq = 0.0;
+    if (active) {
+      const int g = g_lo + pc, inst = inst0 + slot;
+      const int t_lo = (int)(((long)inst * R) / BM), t_hi = min((int)((((long)inst + 1) * R - 1) / BM), tiles_m - 1);
+      const int tn_a = (g * cpg) / BN, ntn = ((g + 1) * cpg - 1) / BN - tn_a + 1;
+      const int count = (t_hi - t_lo + 1) * ntn;
+      auto src = [&](int u) {
+        const int t = t_lo + u / ntn, tn = tn_a + u % ntn;
+        const int sl = inst - (int)(((long)t * BM) / R);            // slot of this instance in tile t
+        const int pp = g - (tn * BN) / cpg;                         // piece of this group in column tile tn
+        return reinterpret_cast<const float*>(p.gn_part + ((((size_t)t * 2 + sl) * tiles_n + tn) * T2V_GN_PIECES + pp) * 2);
+      };
+      for (int u = sub; u < count; u += 8 * lpi) {                  // EIGHT 16-byte device-scope loads in flight per round
+        f32x4 t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = t2v_ld_dev(src(u + lpi * j < count ? u + lpi * j : u));
+        t2v_wait_dev(t[0], t[1], t[2], t[3]);
+        t2v_wait_dev(t[4], t[5], t[6], t[7]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          union { f32x4 v; double d[2]; } uu;
+          uu.v = t[j];
+          if (u + lpi * j < count) { ds += uu.d[0]; dq += uu.d[1]; }
+        }
+      }
+    }
+    for (int o = 1; o < lpi; o <<= 1) { ds += __shfl_xor(ds, o); dq += __shfl_xor(dq, o); }      // (lpi is workgroup-uniform)
+    if (active && sub == 0) {
+      const double m = ds * inv_n;
+      double var = dq * inv_n - m * m;
+      var = var < 0.0 ? 0.0 : var;
+      stat[(slot * T2V_GN_PIECES + pc) * 2] = (float)m;
+      stat[(slot * T2V_GN_PIECES + pc) * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.gn_eps));
+    }
+  }
+  __syncthreads();
+  // ---- E
+  const int bnv = n_hi - n0;
+  for (int idx = tid; idx < 2 * bnv; idx += NT) {
+    const int slot = idx / bnv, c = idx - slot * bnv, n = n0 + c;
+    if (inst0 + slot > last_inst) continue;
+    const int pc = n / cpg - g_lo;
+    const float a = stat[(slot * T2V_GN_PIECES + pc) * 2 + 1] * p.gn_gb[n];
+    scsf[(slot * 2) * BN + c] = a;
+    scsf[(slot * 2 + 1) * BN + c] = p.gn_gb[p.N + n] - stat[(slot * T2V_GN_PIECES + pc) * 2] * a;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+    const int mt = m0 + (wm * TM + a) * 32;
+    if (mt >= p.M) continue;                                       // wave-uniform
+    const int slot = mt / R - inst0;
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const int cl = (wn * TN + b) * 32 + rcol, n = n0 + cl;
+      if (n >= p.N) continue;
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(scsf + (slot * 2) * BN + cl);
+      const f32x4 sf = *reinterpret_cast<const f32x4*>(scsf + (slot * 2 + 1) * BN + cl);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = mt + rrow + 8 * i;
+        if (m < p.M) {
+          f16x4 o, l;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float y = acc[a][b][4 * i + e] * sc[e] + sf[e];
+            if (p.gn_silu) y = t2v_silu(y);
+            o[e] = (f16)y;
+            l[e] = (f16)(y - (float)o[e]);
+          }
+          f16* dst = p.gn_out + (size_t)m * p.ld_gn + n;
+          *reinterpret_cast<f16x4*>(dst) = o;
+          if (p.gn_lo) *reinterpret_cast<f16x4*>(dst + p.gn_lo) = l;
+        }
+      }
+    }
+  }
+}
+// ---- LayerNorm of a GEMM's result rows ACROSS the column tiles of the launch (round 5) ------------------------------------------------
+// The fused LayerNorm second output of t2v_epilogue_rows_ln needs a tile that holds whole rows (N == 320).  At the 16x16 / 8x8 / 4x4
+// levels (C = 640 / 1280) a row is cut into 5 - 20 column tiles and the norm was its own launch (read fp32, write fp16, ~10-12 us for
+// <= 31 MB).  Same exchange as the GroupNorm epilogue above, along the other axis: every workgroup keeps its tile in registers, stores
+// the fp32 stream, publishes {sum, sum of squares} per ROW of its column range, the launch meets at the grid barrier, every workgroup
+// sums the tiles_n pairs of its rows in fp64 in tile order (bit-identical for every column tile of a row) and writes
+// LayerNorm(row) * gamma + beta for its columns.  Scratch: fp32 [tiles_m][tiles_n][BM][2] (p.gn_part).
+template <int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void t2v_epilogue_rows_lnx(const GemmParams& p, f32x16 (&acc)[TM][TN], unsigned char* smem, int lane, int wave,
+                                                      int m0, int n0, int tile_m, int tile_n, int tiles_n) {
+  constexpr int NW = WM * WN, NT = NW * 64, S = WM * TM, BM = S * 32;
+  static_assert(BM / 2 <= NT, "one thread per row pair");
+  const int tid = threadIdx.x;
+  const int wm = wave / WN, wn = wave % WN;
+  float* stg = reinterpret_cast<float*>(smem) + wave * (32 * T2V_EPI_SP);
+  float* rowsum = reinterpret_cast<float*>(smem) + NW * (32 * T2V_EPI_SP);       // [WN][BM][2]
+  float* rowstat = rowsum + WN * BM * 2;                                         // [BM][mean | rstd]
+  const int wrow = lane & 31, wcol = (lane >> 5) * 4;
+  const int rrow = lane >> 3, rcol = (lane & 7) * 4;
+  unsigned gen0 = 0;
+  if (tid == 0) gen0 = t2v_grid_epoch(p.gn_bar);
+  const bool has_res = p.res != nullptr;
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+    const int mt = m0 + (wm * TM + a) * 32;
+    float rs[4] = {0.f, 0.f, 0.f, 0.f}, rq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const int n = n0 + (wn * TN + b) * 32 + rcol;
+      const bool ncol = n < p.N;
+      f32x4 r[4];
+      if (has_res) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int m = mt + rrow + 8 * i;
+          const int mr = (p.res_wrap && m >= p.res_wrap) ? m - p.res_wrap : m;
+          const float* src = (m < p.M && ncol) ? p.res + (size_t)mr * p.ldr + n : p.res;
+          r[i] = *reinterpret_cast<const f32x4*>(src);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 v = {acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
+        *reinterpret_cast<f32x4*>(stg + wrow * T2V_EPI_SP + 8 * q + wcol) = v;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      f32x4 cb = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias && ncol) cb = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = rrow + 8 * i;
+        f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * T2V_EPI_SP + rcol);
+        const int m = mt + row;
+        if (m < p.M && ncol) {
+          v += cb;
+          if (has_res) v += r[i];
+        } else {
+          v = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        acc[a][b][4 * i] = v[0]; acc[a][b][4 * i + 1] = v[1]; acc[a][b][4 * i + 2] = v[2]; acc[a][b][4 * i + 3] = v[3];   // row-major now
+        rs[i] += (v[0] + v[1]) + (v[2] + v[3]);
+        rq[i] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    }
+    // 8 lanes share a row (xor 1, 2, 4); the WN column waves of the strip meet in LDS
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float s1 = rs[i], s2 = rq[i];
+      s1 += __shfl_xor(s1, 1); s2 += __shfl_xor(s2, 1);
+      s1 += __shfl_xor(s1, 2); s2 += __shfl_xor(s2, 2);
+      s1 += __shfl_xor(s1, 4); s2 += __shfl_xor(s2, 4);
+      if ((lane & 7) == 0) {
+        float* dst = rowsum + ((size_t)wn * BM + (wm * TM + a) * 32 + rrow + 8 * i) * 2;
+        dst[0] = s1;
+        dst[1] = s2;
+      }
+    }
+  }
+  __syncthreads();
+  float* part = reinterpret_cast<float*>(p.gn_part);
+  if (tid < BM / 2) {                                              // rows 2 tid, 2 tid + 1 of the tile: one 16-byte device-scope store
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < WN; ++w) v += *reinterpret_cast<const f32x4*>(rowsum + ((size_t)w * BM + 2 * tid) * 2);
+    t2v_st_dev(part + (((size_t)tile_m * tiles_n + tile_n) * BM + 2 * tid) * 2, v);
+  }
+  t2v_wait_vm0();
+  // arrive, then — under the barrier's latency — the fp32 stream goes out (from the registers, row-major)
+  t2v_grid_arrive(p.gn_bar, gridDim.x);
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+    const int mt = m0 + (wm * TM + a) * 32;
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const int n = n0 + (wn * TN + b) * 32 + rcol;
+      if (n >= p.N) continue;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = mt + rrow + 8 * i;
+        if (m < p.M)
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n) =
+              f32x4{acc[a][b][4 * i], acc[a][b][4 * i + 1], acc[a][b][4 * i + 2], acc[a][b][4 * i + 3]};
+      }
+    }
+  }
+  t2v_grid_wait(p.gn_bar, gen0, p.gn_fault);
+  if (tid < BM / 2) {
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    const float* base = part + ((size_t)tile_m * tiles_n * BM + 2 * tid) * 2;
+    for (int tn = 0; tn < tiles_n; tn += 8) {                      // EIGHT 16-byte device-scope loads in flight per round, summed in tile order
+      f32x4 t[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t[j] = t2v_ld_dev(base + (size_t)(tn + j < tiles_n ? tn + j : tn) * BM * 2);
+      t2v_wait_dev(t[0], t[1], t[2], t[3]);
+      t2v_wait_dev(t[4], t[5], t[6], t[7]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (tn + j < tiles_n) { s[0] += (double)t[j][0]; s[1] += (double)t[j][1]; s[2] += (double)t[j][2]; s[3] += (double)t[j][3]; }
+    }
+    const double inv_n = 1.0 / (double)p.N;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const double m = s[2 * k] * inv_n;
+      double var = s[2 * k + 1] * inv_n - m * m;
+      var = var < 0.0 ? 0.0 : var;
+      rowstat[(2 * tid + k) * 2] = (float)m;
+      rowstat[(2 * tid + k) * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.ln_eps));
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+    const int mt = m0 + (wm * TM + a) * 32;
+    if (mt >= p.M) continue;                                       // wave-uniform
+    float mean[4], rstd[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      mean[i] = rowstat[((wm * TM + a) * 32 + rrow + 8 * i) * 2];
+      rstd[i] = rowstat[((wm * TM + a) * 32 + rrow + 8 * i) * 2 + 1];
+    }
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const int n = n0 + (wn * TN + b) * 32 + rcol;
+      if (n >= p.N) continue;
+      const f32x4 g = *reinterpret_cast<const f32x4*>(p.ln_gb + n);
+      const f32x4 be = *reinterpret_cast<const f32x4*>(p.ln_gb + p.N + n);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = mt + rrow + 8 * i;
+        if (m < p.M) {
+          f16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (f16)((acc[a][b][4 * i + e] - mean[i]) * rstd[i] * g[e] + be[e]);
+          *reinterpret_cast<f16x4*>(p.ln_out + (size_t)m * p.ld_ln + n) = o;
+        }
+      }
+    }
+  }
+}
+constexpr int t2v_lnx_epilogue_lds(int nw, int wn, int bm) { return nw * 32 * T2V_EPI_SP * 4 + (wn * bm * 2 + bm * 2) * 4; }
+
+// bytes of LDS the T2V_EPI_GN epilogue needs for a tile of NW waves, S 32-row strips, BN columns
+constexpr int t2v_gn_epilogue_lds(int nw, int s, int bn) { return nw * 32 * T2V_EPI_SP * 4 + (s * 2 * bn + 4 * bn + 2 * T2V_GN_PIECES * 2) * 4; }
 
 // exact-erf GELU (nn.GELU default, reference GEGLU t2v_model.py:817-821).  erfc(|z|) by Abramowitz-Stegun
 // 7.1.26 (|abs err| < 1.5e-7, far below the fp16 output rounding); the negative side uses erfc directly, so

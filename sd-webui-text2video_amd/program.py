@@ -152,6 +152,7 @@ class Op:
     flops: float = 0.0            # algorithmic 2*MAC (matmul/conv only), for the roofline
     meta: dict = field(default_factory=dict)
     out: Optional["Buf"] = None   # arena buffer this op writes (debug / determinism tooling)
+    out2: Optional["Buf"] = None  # second output (the normalised tensor of a T2V_EPI_GN op)
 
 
 class Program:
@@ -181,6 +182,15 @@ class Program:
         # of device-scope load latencies, where the reduction kernel uses the whole chip -> off by default
         self.splitk_tickets = os.environ.get("T2V_SPLITK_TICKETS", "0") != "0"
         self.gn_coop = os.environ.get("T2V_GN_COOP", "1") != "0"
+        # GroupNorm inside the epilogue of the GEMM that produces its input (T2V_EPI_GN, round 5): a peephole of groupnorm() below.
+        # It relies on the same co-residency as the single-pass kernel (one grid barrier per launch), so T2V_GN_COOP=0 turns it off too.
+        self.gn_epilogue = self.gn_coop and os.environ.get("T2V_GN_EPI", "1") != "0"
+        # its exchange scratch ([tiles_m][2][tiles_n][GN_PIECES] fp64 pairs, <= 512 tiles): ONE region for every fused op of the program
+        # (launches are stream-ordered and each rewrites every word it reads), allocated here for the reason given above for the sync words
+        self._gn_part: Optional[Buf] = self.alloc(1 << 20, 1, "u8") if self.gn_epilogue else None
+        # Buffers whose free() is postponed: operands of the GEMM emitted last.  If the next groupnorm() makes itself that GEMM's
+        # epilogue, its output is written by the SAME launch that still reads these — it must not be allocated over them.
+        self._deferred: List[Buf] = []
 
     # ---- memory ---------------------------------------------------------------------------
     def alloc(self, rows: int, cols: int, dtype: str, ld: Optional[int] = None) -> Buf:
@@ -194,7 +204,25 @@ class Program:
                 continue
             if self.keep_taps and any(t.alloc_off == b.alloc_off for t in self.taps.values()):
                 continue
+            if self._is_operand_of_last_gemm(b):
+                self._deferred.append(b)          # until the next op is emitted (or groupnorm() has decided)
+                continue
             self.arena.free(b.alloc_off)
+
+    def _is_operand_of_last_gemm(self, b: Buf) -> bool:
+        if not getattr(self, "gn_epilogue", False) or not self.ops:
+            return False
+        op = self.ops[-1]
+        if op.kind != L.OP_GEMM or op.i[16] != L.EPI_NONE or op.meta.get("tile") not in self._GN_EPI_TILES or op.meta.get("split", 1) != 1:
+            return False
+        lo, hi = b.alloc_off, b.alloc_off + self.arena.live.get(b.alloc_off, 0)
+        return any(r.space == "arena" and lo <= r.off < hi for r in (op.p[0], op.p[4]))
+
+    def _flush_deferred(self):
+        pending, self._deferred = self._deferred, []
+        for b in pending:
+            if b.alloc_off in self.arena.live:
+                self.arena.free(b.alloc_off)
 
     def sync_ref(self, which: str) -> Ref:
         return self._sync.ref if which == "tickets" else self._sync.ref.shifted(4 * L.SYNC_INTS)
@@ -205,6 +233,7 @@ class Program:
 
     def _emit(self, op: Op) -> Op:
         self.ops.append(op)
+        self._flush_deferred()       # (operands of the PREVIOUS op: it can no longer grow an epilogue)
         return op
 
     # ---- GEMM tiling policy ----------------------------------------------------------------
@@ -325,7 +354,7 @@ class Program:
         """Program prologue (kept for symmetry; nothing to initialise)."""
 
     def finish(self):
-        pass
+        self._flush_deferred()
 
     def gemm(self, name: str, a: Buf, w: Ref, n: int, k: int, out: Buf, *, bias: Ref = NULL,
              ldw: Optional[int] = None, gather: int = L.GATHER_PLAIN, conv: Optional[dict] = None,
@@ -418,10 +447,22 @@ class Program:
             assert out.dtype == "f32" and ln_out.dtype == "f16" and ln_out.cols == n and ln_out.rows >= M
             ln_fused = (tile in (8, 11) and split == 1 and n == 320 and gather == L.GATHER_PLAIN and epi == L.EPI_NONE and act == 0
                         and rowbias is None and not bias_along_m and k % 64 == 0 and os.environ.get("T2V_LN_FUSE", "1") != "0")
-            if ln_fused:
-                I[8], I[9] = 1, ln_out.ld
+            # ... or ACROSS the column tiles of the launch (round 5, t2v_epilogue_rows_lnx): the partial row sums meet at a grid barrier, so
+            # the whole grid must be resident at once (the 16x16 / 8x8 / 4x4-level C -> C linears: 480 / 240 / 240 workgroups)
+            ln_x = False
+            if not ln_fused and self.gn_epilogue and tile in self._LNX_TILES and os.environ.get("T2V_LN_X", "1") != "0":
+                bm, bn, per_cu = self._LNX_TILES[tile]
+                tiles_m, tiles_n = -(-M // bm), -(-n // bn)
+                ln_x = (split == 1 and gather == L.GATHER_PLAIN and epi == L.EPI_NONE and act == 0 and rowbias is None and not bias_along_m
+                        and k % 64 == 0 and not out_lo and (tile != 0 or n % 128 == 0) and tiles_m * tiles_n <= per_cu * self.device_cus()
+                        and tiles_m * tiles_n * bm * 8 <= self._gn_part.rows and ln_out.ld % 4 == 0)
+            if ln_fused or ln_x:
+                I[8], I[9] = (2 if ln_x else 1), ln_out.ld
                 op.f[0] = ln_eps
                 op.p[3], op.p[7] = gb, ln_out.ref
+                if ln_x:
+                    op.p[10], op.p[11] = self._gn_part.ref, self.sync_ref("barrier")
+                    ln_fused = True
         with_stats = stats is not None and split == 1 and epi == L.EPI_NONE and not ln_fused and ln is None
         if with_stats:
             assert stats.dtype == "f32" and stats.rows >= -(-M // 32) and stats.ld == 2 * n
@@ -437,6 +478,8 @@ class Program:
         op.out = out
         op.meta = dict(M=M, N=n, K=k, gather=gather, conv=dict(conv), epi=epi, split=split, tile=tile, halo=halo, ln=int(ln_fused),
                        stats=int(with_stats))
+        if ln_fused:
+            op.out2 = ln[3]
         if step_invariant:
             op.meta["step_invariant"] = True      # (also set on the .w_lo pass above: both halves of a split weight are skipped together)
         self._emit(op)
@@ -478,9 +521,94 @@ class Program:
                        frames=frames, hw=hw, heads=heads)
         return self._emit(op)
 
+    # (rows, columns) of the tiles that have a T2V_EPI_GN instantiation, workgroups per CU they are resident with
+    _GN_EPI_TILES = {8: (192, 320, 1), 11: (128, 320, 1), 3: (128, 256, 1), 5: (128, 128, 1), 0: (128, 128, 2)}
+    # ... with a cross-tile LayerNorm instantiation (t2v_epilogue_rows_lnx)
+    _LNX_TILES = {0: (128, 128, 2), 5: (128, 128, 1), 12: (64, 64, 2), 9: (192, 256, 1), 3: (128, 256, 1)}
+
+    _DEVICE_CUS = None
+
+    @classmethod
+    def device_cus(cls) -> int:
+        """Compute units of the current device (the co-residency bound of the T2V_EPI_GN launches); 256 (MI355X) when there is no
+        device to ask (lowering tests on the CPU).  T2V_DEVICE_CUS overrides."""
+        if cls._DEVICE_CUS is None:
+            n = int(os.environ.get("T2V_DEVICE_CUS", "0"))
+            if n <= 0:
+                try:
+                    import torch
+                    n = L.device_info()[1] if torch.cuda.is_available() else 256
+                except Exception:
+                    n = 256
+            Program._DEVICE_CUS = n
+        return cls._DEVICE_CUS
+
+    def _fuse_groupnorm(self, name: str, x: Buf, gb: Optional[Ref], out: Buf, *, n_inst: int, eps: float, silu: bool, groups: int, lo: bool,
+                        x_dead: bool) -> Optional[Op]:
+        """The peephole: if the LAST emitted op is the GEMM that produced `x` and it runs on a tile with a T2V_EPI_GN instantiation,
+        without split-K, on a grid that is resident at once, the norm becomes that GEMM's epilogue (the op record is patched) and no
+        GROUPNORM op is emitted.  x_dead: nothing but this norm reads `x` — the GEMM then does not store it at all."""
+        if not self.gn_epilogue or gb is None or not self.ops:
+            return None
+        op = self.ops[-1]
+        if op.kind != L.OP_GEMM or op.out is not x or op.i[16] != L.EPI_NONE or op.meta.get("ln"):
+            return None
+        tile, I, split = op.meta.get("tile"), op.i, op.meta.get("split", 1)
+        M, N, K, gather = I[0], I[1], I[2], I[7]
+        rows = x.rows // n_inst
+        if gather == L.GATHER_CONV3X3_C8 or (gather == L.GATHER_CONV3X3 and I[12]) or K % 64 or I[20] or I[18] or (gather == L.GATHER_PLAIN and (I[8] or I[11] == 1)):
+            return None
+        if x.rows != M or x.cols != N or N % groups or M % rows:
+            return None
+        if x.dtype == "f16" and not x_dead:
+            return None                                   # (an fp16 stream that someone else reads: keep the rounding where it was)
+        if split > 1:
+            # split-K: the norm runs in the REDUCTION's launch (norm.hip splitk_gn_kernel: 512 threads, a thread = rows x 8 channels in
+            # registers) — a co-resident grid of n_inst x chunks workgroups must exist for some rows-per-thread count
+            if os.environ.get("T2V_GN_EPI_SPLITK", "1") == "0" or op.p[7].space != "null" or N % 8 or N // 8 > 512 or groups > 32:
+                return None
+            rpass = 512 // (N // 8)
+            chunks = [n_inst * -(-rows // (rpass * kr)) for kr in (4, 8, 12, 16, 20)]
+            fit = [c for c in chunks if c <= self.device_cus()]
+            if not fit or fit[0] * groups * 16 > self._gn_part.rows:
+                return None
+        else:
+            if tile not in self._GN_EPI_TILES or os.environ.get(f"T2V_GN_EPI_TILE{tile}", "1") == "0":
+                return None
+            bm, bn, per_cu = self._GN_EPI_TILES[tile]
+            if tile == 0 and N % 128 != 0:
+                return None                               # (the narrow 128x64 form of the 128x128-class kernel has no instantiation)
+            if N // groups > bn or rows % 32 or rows < bm:
+                return None
+            tiles_m, tiles_n = -(-M // bm), -(-N // bn)
+            if tiles_m * tiles_n > per_cu * self.device_cus():
+                return None                               # the grid barrier needs every workgroup resident
+            if tiles_m * 2 * tiles_n * L.GN_PIECES * 16 > self._gn_part.rows:
+                return None
+            # the normalised tensor is written by the launch that reads the GEMM's operands: never over them (free() defers those)
+            o_lo = out.ref.off
+            o_hi = o_lo + ((out.rows - 1) * out.ld + out.cols * (2 if lo else 1)) * 2
+            for r in (op.p[0], op.p[4]):
+                if r.space == "arena":
+                    a_lo = max((off for off in self.arena.live if off <= r.off), default=None)
+                    a_hi = a_lo + self.arena.live[a_lo] if a_lo is not None else None
+                    if a_lo is None or not (o_hi <= a_lo or o_lo >= a_hi):
+                        return None
+        part = self._gn_part
+        I[16] = L.EPI_GN
+        I[24], I[25], I[26], I[27], I[28], I[29] = rows, out.ld, int(silu), int(lo), groups, int(x_dead)
+        op.f[2] = eps
+        op.p[8], op.p[9], op.p[10], op.p[11] = gb, out.ref, part.ref, self.sync_ref("barrier")
+        op.meta["gn"] = dict(name=name, n_inst=n_inst, rows=rows, silu=int(silu), lo=int(lo), dead=int(x_dead))
+        op.meta["epi"] = L.EPI_GN
+        op.out2 = out
+        return op
+
     def groupnorm(self, name: str, x: Buf, gamma: Ref, beta: Ref, out: Buf, *, n_inst: int, eps: float,
-                  silu: bool, groups: int = 32, shard: Optional[TShardSpec] = None, lo: bool = False, stats: Optional[Buf] = None) -> Op:
-        """GroupNorm(+SiLU).  With `shard` (cross-frame statistics of a T-sharded clip; n_inst = 1) the op is split
+                  silu: bool, groups: int = 32, shard: Optional[TShardSpec] = None, lo: bool = False, stats: Optional[Buf] = None,
+                  gb: Optional[Ref] = None, x_dead: bool = False) -> Op:
+        """GroupNorm(+SiLU).  gb (fp32 [2C] gamma | beta) + x produced by the op emitted last: the norm may become that GEMM's
+        epilogue (`_fuse_groupnorm`; x_dead = nothing else reads x).  With `shard` (cross-frame statistics of a T-sharded clip; n_inst = 1) the op is split
         into: statistics (this rank's partials) -> all-gather of the fp64 partials over the T group ->
         ordered fold of all parts + normalise; every rank ends up with bit-identical statistics.  Each rank folds its own
         block partials first, so a part is one {sum, sum of squares} pair per group: 512 bytes per instance, whatever the
@@ -492,6 +620,11 @@ class Program:
         rows = x.rows // n_inst
         assert not lo or out.ld >= 2 * x.cols
         assert rows * n_inst == x.rows and out.dtype == "f16" and x.cols % 4 == 0
+        if shard is None and stats is None:
+            fused = self._fuse_groupnorm(name, x, gb, out, n_inst=n_inst, eps=eps, silu=silu, groups=groups, lo=lo, x_dead=x_dead)
+            self._flush_deferred()
+            if fused is not None:
+                return fused
         nparts, part = (shard.size, shard.index) if shard is not None else (1, 0)
         rows_total = rows * nparts
         if shard is not None:

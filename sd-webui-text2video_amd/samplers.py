@@ -234,7 +234,7 @@ class GaussianDiffusion(object):
                         ident = (run_nonce, id(c0), c0._version, id(uc0), uc0._version, Bx)
                         if pair_key != ident:
                             pair_key, pair_ctx, pair_refs = ident, torch.cat([c, uc], dim=0), (c0, uc0)
-                        eps = model.forward_cfg_pair(xt, tt_all[step], pair_ctx, context_token=pair_key)
+                        eps = model.forward_cfg_pair(xt, tt_all[step], pair_ctx, context_token=pair_key, single_t=True)   # (one timestep per step)
                     elif getattr(model, "supports_cfg_batch", False):
                         eps = model(torch.cat([xt, xt], dim=0), torch.cat([tt, tt]), torch.cat([c, uc], dim=0))
                     else:
@@ -376,7 +376,7 @@ def _eval_eps_pair(model, x, t_value, c, uc, guide, cfg_parallel=None, cache: Op
         ident = (cache.setdefault("nonce", next(_RUN_COUNTER)), id(c), c._version, id(uc), uc._version)
         if cache.get("key") != ident:
             cache.update(key=ident, ctx=torch.cat([c, uc], dim=0), refs=(c, uc))
-        return model.forward_cfg_pair(x, tt, cache["ctx"], context_token=ident).contiguous(), True
+        return model.forward_cfg_pair(x, tt, cache["ctx"], context_token=ident, single_t=True).contiguous(), True
     if getattr(model, "supports_cfg_batch", False):
         return model(torch.cat([x, x], dim=0), torch.cat([tt, tt]), torch.cat([c, uc], dim=0)).contiguous(), True
     return torch.cat([model(x, tt, c), model(x, tt, uc)], dim=0).contiguous(), True

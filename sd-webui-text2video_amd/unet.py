@@ -229,6 +229,11 @@ class UNetSD(nn.Module):
         # 8x8, GroupNorm 3.40 vs 3.21 ms per step) — two launches cost what one grid barrier costs — so it is OFF by default.
         self.gn_producer_stats = os.environ.get("T2V_GN_STRIPS", "0") != "0"
         self.context_token = None     # one-shot hint consumed by the next forward (see forward_cfg_pair)
+        # one-shot hint consumed by the next forward: every sample of the batch has the SAME timestep (forward_cfg_pair and the samplers
+        # of this package set it).  Only then may the cond | uncond pair share its prefix — the shared ops use sample 0's time embedding,
+        # and forward(x[1], t = [t0, t1], ctx[2]) with t0 != t1 must keep each sample's own t
+        self.single_timestep = False
+        self._share_now = False
         # Precision option (off by default): weights whose packed-image name starts with one of these prefixes are applied as
         # hi + lo fp16 images in two MFMA passes (fp32 weights only; e.g. ("input_blocks.0", "input_blocks.1") — the blocks
         # that produce 46 % of the weight-rounding error).  Set before the first forward.
@@ -449,6 +454,10 @@ class UNetSD(nn.Module):
             shard = self.t_shard.spec                             # x holds only this rank's frames
             if shard.frames != F:
                 raise L.T2VError(f"T-sharded forward: this rank holds {shard.frames} of {shard.total} frames, got {F}")
+        single, self.single_timestep = self.single_timestep or tf.numel() == 1 or t.ndim == 0, False
+        if not single and not tf.is_cuda:
+            single = bool((tf == tf.reshape(-1)[0]).all())
+        self._share_now = bool(getattr(self, "share_cfg_prefix", False)) and single
         key = self._program_key(B, F, H, W, y.shape[1], x.dtype, y.dtype, out_dtype, shard, Bx)
         comp = self._programs.get(key)
         if comp is None:
@@ -481,19 +490,22 @@ class UNetSD(nn.Module):
     def _lowering_options(self) -> tuple:
         """Lowering switches that change the program (part of the cache key)."""
         return ((("strips",),) if getattr(self, "gn_producer_stats", False) else ()) + \
-            ((("share",),) if getattr(self, "share_cfg_prefix", False) else ()) + \
+            ((("share",),) if getattr(self, "_share_now", False) else ()) + \
             ((("pattn",),) if getattr(self, "precise_attn_out", False) else ()) + ((("presample",),) if getattr(self, "precise_resample", False) else ()) + \
             ((("precise", str(self.precise_operands)),) if getattr(self, "precise_operands", False) else ()) + \
             ((("tattn", str(self.fused_temporal_attention)),) if getattr(self, "fused_temporal_attention", False) else ())
 
-    def forward_cfg_pair(self, x, t, ctx_pair, context_token=None):
+    def forward_cfg_pair(self, x, t, ctx_pair, context_token=None, single_t=None):
         """One guided step's two evaluations (gaussian_sampler.py:161-162) as ONE forward: x [V,4,F,h,w] is read twice by
         the entry op (no torch.cat([x, x])), ctx_pair = [cond (V) | uncond (V)]; -> eps [2V,...].  `context_token`: any
         hashable the caller changes whenever ctx_pair's CONTENT changes — equal to the previous call's token, the
         text-context K/V projections of that call are reused (they do not depend on x or t)."""
         tt = t.to(device=x.device, dtype=torch.float32).reshape(-1)
+        if single_t is None:          # one t for every sample?  (a [1] tensor: yes; per-sample values: compared — the samplers say it outright)
+            single_t = tt.shape[0] == 1 or bool((tt == tt[0]).all())
         tt = tt.repeat(ctx_pair.shape[0] // tt.shape[0]) if tt.shape[0] != ctx_pair.shape[0] else tt
         self.context_token = context_token
+        self.single_timestep = bool(single_t)
         return UNetSD.forward(self, x, tt, ctx_pair)
 
     max_programs = 4      # compiled geometries kept (each owns a device arena: 0.4 GiB per 24-frame sample, GiBs for long clips)
@@ -508,6 +520,8 @@ class UNetSD(nn.Module):
     def forward_timed(self, x, t, y):
         """Like forward, but returns (eps, per-op milliseconds) using HIP events around every op
         on the launch stream (bench.py roofline measurement)."""
+        single = bool((t.reshape(-1) == t.reshape(-1)[0]).all())      # (a profiling entry point: the comparison may synchronise)
+        self.single_timestep = single
         out = UNetSD.forward(self, x, t, y)
         comp = self._programs[self._program_key(y.shape[0], x.shape[2], x.shape[3], x.shape[4], y.shape[1], x.dtype, y.dtype, out.dtype,
                                                 Bx=x.shape[0])]
@@ -578,7 +592,8 @@ class _Lowering:
         self.net, self.B, self.F, self.H, self.W, self.Lctx = net, B, F, H, W, Lctx
         # cond | uncond prefix sharing (UNetSD.share_cfg_prefix): while `sharing`, activations hold Bc = 1 sample; the first spatial
         # transformer's text cross-attention is where the two samples part (transformer_block) and Bc becomes B
-        self.sharing = bool(getattr(net, "share_cfg_prefix", False)) and B == 2 and x_batch == 1 and self.shard is None
+        # (`_share_now`: forward() sets it from `share_cfg_prefix` AND the single-timestep hint; a direct _compile keeps the attribute's value)
+        self.sharing = bool(getattr(net, "_share_now", False)) and B == 2 and x_batch == 1 and self.shard is None
         self.Bc = 1 if self.sharing else B
         self.x_dt, self.out_dt, self.ctx_dt = x_dt, out_dt, ctx_dt
         self.x_batch = x_batch if 0 < x_batch < B else 0      # x holds fewer samples than the batch: sample b reads x[b % x_batch]
@@ -680,8 +695,12 @@ class _Lowering:
         return self.Bc * self.F * h * w
 
     # -- building blocks ------------------------------------------------------------------------
+    def gn_gb(self, key) -> Ref:
+        """gamma | beta of the GroupNorm `key` as ONE fp32 [2C] vector (the T2V_EPI_GN epilogue reads both from one pointer)."""
+        return Ref("weight", 0, self.packer.add(key + ":gn_gb", "f32", lambda sd, k=key: torch.cat([sd[k + ".weight"], sd[k + ".bias"]])))
+
     def gn(self, name, x: Buf, key, *, per_frame: bool, eps, silu, out: Optional[Buf] = None, lo: bool = False,
-           stats: Optional[Buf] = None) -> Buf:
+           stats: Optional[Buf] = None, x_dead: bool = False) -> Buf:
         """lo (precise_operands): the result is a [rows, 2C] buffer of rows [hi | lo] — fp16(y) and the low-order image of that
         rounding — for a consumer GEMM with weights [W | W] (K = 2C)."""
         if lo:
@@ -694,8 +713,10 @@ class _Lowering:
         shard = None if per_frame else self.shard
         if stats is not None and (shard is not None or (x.rows // n_inst) % 32 != 0):
             stats = None                  # (a T-sharded cross-frame norm exchanges its own partials; strips are 32 rows)
+        # (x produced by the op emitted last, on a tile with the instantiation: the norm becomes that GEMM's epilogue — Program._fuse_groupnorm;
+        #  x_dead: only this norm reads x)
         self.P.groupnorm(name, x, self.vec(key + ".weight"), self.vec(key + ".bias"), out, n_inst=n_inst, eps=eps, silu=silu,
-                         shard=shard, lo=lo, stats=stats)
+                         shard=shard, lo=lo, stats=stats, gb=self.gn_gb(key) if self.shard is None and x.cols % 4 == 0 else None, x_dead=x_dead)
         return full
 
     def strips_for(self, rows: int, n: int, inst_rows: int) -> Optional[Buf]:
@@ -740,7 +761,7 @@ class _Lowering:
         h1 = self.conv3(prefix + ".in_layers.2", a, prefix + ".in_layers.2", cout, h, w,
                         rowbias=self.emb_out.col_slice(e0, e1), out_dtype=self.net.norm_input_dtype, stats=st)
         P.free(a)
-        b = self.gn(prefix + ".out_layers.0", h1, prefix + ".out_layers.0", per_frame=True, eps=1e-5, silu=True, stats=self.last_stats)
+        b = self.gn(prefix + ".out_layers.0", h1, prefix + ".out_layers.0", per_frame=True, eps=1e-5, silu=True, stats=self.last_stats, x_dead=True)
         P.free(h1, st)
         if cin != cout:
             skip = P.alloc(x.rows, cout, "f32")
@@ -769,7 +790,7 @@ class _Lowering:
         tp = prefix + ".temopral_conv"
         for name, idx in (("conv1", 2), ("conv2", 3), ("conv3", 3), ("conv4", 3)):
             if self.shard is None:
-                nrm = self.gn(f"{tp}.{name}.0", t, f"{tp}.{name}.0", per_frame=False, eps=1e-5, silu=True, stats=st_live)
+                nrm = self.gn(f"{tp}.{name}.0", t, f"{tp}.{name}.0", per_frame=False, eps=1e-5, silu=True, stats=st_live, x_dead=t is not h2)
                 P.free(st)
                 st = st_live = None
             else:

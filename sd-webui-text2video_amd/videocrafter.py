@@ -279,7 +279,7 @@ class _LvdmLowering(_Lowering):
         h1 = self.conv133(prefix + ".in_layers.2", a, prefix + ".in_layers.2", cout, h, w,
                           rowbias=self.emb_out.col_slice(e0, e1), out_dtype=self.net.norm_input_dtype, stats=st)
         P.free(a)
-        b = self.gn(prefix + ".out_layers.0", h1, prefix + ".out_layers.0", per_frame=False, eps=1e-5, silu=True, stats=self.last_stats)
+        b = self.gn(prefix + ".out_layers.0", h1, prefix + ".out_layers.0", per_frame=False, eps=1e-5, silu=True, stats=self.last_stats, x_dead=True)
         P.free(h1, st)
         if cin != cout:
             skip = P.alloc(x.rows, cout, "f32")
@@ -773,6 +773,8 @@ class DDIMSampler(object):
                     # entry op reads it for both samples, and with UNetSD.share_cfg_prefix every op up to the first text
                     # cross-attention is computed once
                     xin = img if hasattr(unet, "share_cfg_prefix") else torch.cat([img, img])      # (a foreign model gets the reference's batch)
+                    if hasattr(unet, "single_timestep"):
+                        unet.single_timestep = True        # [ts | ts]: one timestep for the pair -> the prefix may be shared
                     eps = self.model.apply_model(xin, torch.cat([ts, ts]), torch.cat([c, uc])).contiguous()
                 else:
                     eps = self.model.apply_model(img, ts, c).contiguous()

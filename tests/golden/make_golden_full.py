@@ -6,6 +6,8 @@
     python tests/golden/make_golden_full.py w16 c1s50                # round 4: 50-step "DDIM" / "UniPC" latents at the full size
     python tests/golden/make_golden_full.py w16 c1s c3s c2s          # round 4: OUTPUT-level goldens (sampled latents) for the other
                                                                      # two samplers at configs[1] and for configs[3] / configs[2]
+    python tests/golden/make_golden_full.py w16 c0 c2s20             # round 5: configs[0] (8 f, 5 steps) on the deployed weights;
+                                                                     # a 20-step configs[2] output (125 frames)
 
 "w16" (round 3): the SAME reference classes, the SAME fp32 CPU arithmetic, but every parameter and the
 text conditioning are first rounded to fp16 and back (`w.half().float()`).  The reference pipeline always deploys `.half()`
@@ -295,10 +297,50 @@ def c2s():
     print(f"c2s done 10 steps {t10:.0f}s std {x0.std():.4f}", flush=True)
 
 
+def c0():
+    """configs[0] on the DEPLOYED weights: 8 frames @256x256, one forward, 5-step DDIM_Gaussian CFG 9, one VAE
+    frame — the recipe of make_golden.modelscope() with fp16-representable parameters / conditioning (modelscope_8f_w16.npz)."""
+    ref = rb.bootstrap()
+    unet, betas = _unet()
+    noise, cond, uncond = _inputs(8, 256, 256)
+    with torch.no_grad():
+        t0 = time.time()
+        eps = unet(noise, torch.tensor([801]), cond)
+        t_fwd = time.time() - t0
+    t0 = time.time()
+    x0 = _sample(ref, unet, betas, 8, 5, cond, uncond)
+    t_loop = time.time() - t0
+    del unet
+    vae = rb.build_reference_vae(configs.VAE_DDCONFIG)
+    synth.load_synth(vae, seed=3)
+    _deploy(vae)
+    with torch.no_grad():
+        img = vae.decode(x0[:, :, 0] / configs.SCALE_FACTOR)
+    np.savez_compressed(os.path.join(OUT, f"modelscope_8f{SUFFIX}.npz"), unet_eps=eps.numpy(), sampler_x0=x0.numpy(),
+                        vae_img_frame0=img.numpy().astype(np.float32),
+                        timing=np.array([t_fwd, t_loop, torch.get_num_threads()], dtype=np.float64))
+    print(f"c0 done fwd {t_fwd:.1f}s loop {t_loop:.0f}s std {eps.std():.4f} {x0.std():.4f}", flush=True)
+
+
+def c2s20():
+    """configs[2] OUTPUT-level golden at 20 steps: DDIM_Gaussian CFG 9 latent of the 125-frame clip, frames
+    FRAMES_125 — twice the step count of c2s, past the few-step regime (the 50 steps of the config are ~4.5 h of reference CPU time)."""
+    ref = rb.bootstrap()
+    unet, betas = _unet()
+    _, cond, uncond = _inputs(125, 256, 256)
+    t0 = time.time()
+    x0 = _sample(ref, unet, betas, 125, 20, cond, uncond)
+    t20 = time.time() - t0
+    np.savez_compressed(os.path.join(OUT, f"modelscope_125f_s20{SUFFIX}.npz"), sampler_x0_20_frames=x0[:, :, FRAMES_125].numpy(),
+                        frames=np.array(FRAMES_125), x0_std=np.float64(x0.std()),
+                        timing=np.array([t20, torch.get_num_threads()], dtype=np.float64))
+    print(f"c2s20 done 20 steps {t20:.0f}s std {x0.std():.4f}", flush=True)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     if "w16" in sys.argv[1:]:
         W16, SUFFIX = True, "_w16"
-    which = [a for a in sys.argv[1:] if a in ("c1", "c2", "c3", "c4", "c3x12", "c1s", "c3s", "c2s", "c1s50")] or ["c2", "c3", "c4", "c1"]
+    which = [a for a in sys.argv[1:] if a in ("c1", "c2", "c3", "c4", "c3x12", "c1s", "c3s", "c2s", "c1s50", "c0", "c2s20")] or ["c2", "c3", "c4", "c1"]
     for name in which:
         globals()[name]()

@@ -129,7 +129,8 @@ class Interp:
                 acc = acc + self.view(op.p[2], (N,), (1,), torch.float32, ext)[None, :]
         epi = I[16]
         want_stats = epi == L.EPI_STATS
-        if want_stats:
+        want_gn = epi == L.EPI_GN
+        if want_stats or want_gn:
             epi = L.EPI_NONE
         if epi == L.EPI_GEGLU:
             a = acc.view(M, N // 16, 2, 8)
@@ -138,7 +139,7 @@ class Interp:
             n_out = N // 2
         else:
             res, n_out = acc, N
-            ln_fused = gather == L.GATHER_PLAIN and I[8] == 1     # fused LayerNorm second output: p[3] = gamma | beta, p[7] = fp16 out
+            ln_fused = gather == L.GATHER_PLAIN and I[8] in (1, 2)     # fused LayerNorm second output (2: across column tiles): p[3] = gamma | beta, p[7] = fp16 out
             if op.p[3].space != "null" and not ln_fused:
                 rpb, ldrb = I[15], I[21]
                 rb = self.mat(op.p[3], M // rpb, N, ldrb, torch.float32, ext)
@@ -149,6 +150,25 @@ class Interp:
                 rw = I[12] if gather == L.GATHER_PLAIN else 0
                 R = self.mat(op.p[4], rw if rw else M, N, ldr, torch.float32, ext)
                 res = res + (torch.cat([R, R[: M - rw]], dim=0) if rw else R)
+        if want_gn:
+            # T2V_EPI_GN: GroupNorm (+SiLU) of the fp32 result inside the epilogue — statistics and normalisation on the UNROUNDED values;
+            # `out` itself is stored only if someone else reads it (i[29] == 0)
+            rows, ld_gn, silu, lo, groups, dead = I[24], I[25], I[26], I[27], I[28], I[29]
+            if not dead:
+                self._st(self.mat(op.p[5], M, N, ldc, _TD[I[17]], ext), res, _TD[I[17]])
+            cpg = N // groups
+            x = res.double().view(M // rows, rows, groups, cpg)
+            mean = x.mean(dim=(1, 3), keepdim=True)
+            var = (x * x).mean(dim=(1, 3), keepdim=True) - mean * mean
+            y = ((x - mean) / torch.sqrt(var.clamp_min(0) + op.f[2])).view(M, N).float()
+            gb = self.view(op.p[8], (2 * N,), (1,), torch.float32, ext)
+            y = y * gb[:N] + gb[N:]
+            if silu:
+                y = F.silu(y)
+            self._st(self.mat(op.p[9], M, N, ld_gn, torch.float16, ext), y, torch.float16)
+            if lo:
+                self._st(self.view(op.p[9].shifted(2 * N), (M, N), (ld_gn, 1), torch.float16, ext), y.float() - y.half().float(), torch.float16)
+            return
         out = self.mat(op.p[5], M, n_out, ldc, _TD[I[17]], ext)
         self._st(out, res, _TD[I[17]])
         if want_stats:       # per 32-row strip: column sums / sums of squares of the STORED values -> fp32 [ceil(M / 32)][2][N]
@@ -163,7 +183,7 @@ class Interp:
         if gather == L.GATHER_PLAIN and I[11] == 1:          # hi + lo fp16 output: the rounding's low-order image beside the row
             lo_view = self.view(op.p[5].shifted(2 * N), (M, N), (ldc, 1), torch.float16, ext)
             self._st(lo_view, res.float() - res.half().float(), torch.float16)
-        if epi != L.EPI_GEGLU and gather == L.GATHER_PLAIN and I[8] == 1:
+        if epi != L.EPI_GEGLU and gather == L.GATHER_PLAIN and I[8] in (1, 2):
             gb = self.view(op.p[3], (2 * N,), (1,), torch.float32, ext)
             y = F.layer_norm(res.float(), (N,), gb[:N], gb[N:], op.f[0])
             self._st(self.mat(op.p[7], M, N, I[9], torch.float16, ext), y, torch.float16)

@@ -170,6 +170,13 @@ def test_cfg_pair_shares_the_prefix_up_to_the_first_cross_attention(tiny):
     e_plain, e_shared = rel_l2(plain, ref), rel_l2(shared, ref)
     print(f"cfg pair, tiny config: rel-L2 vs the oracle {e_shared:.3e} with the shared prefix, {e_plain:.3e} without; between them {rel_l2(shared, plain):.3e}")
     assert e_shared < 1.1 * e_plain + 1e-4 and rel_l2(shared, plain) < 2.0 * e_plain
+    # the prefix is shared only when the caller says (or shows) that the samples have ONE timestep — a direct forward with
+    # one x and two DIFFERENT timesteps keeps each sample's own t (the shared ops would use sample 0's time embedding)
+    t2 = torch.tensor([801.0, 333.0], device=DEV)
+    two_t = net(x1, t2, ctx)
+    assert torch.equal(two_t, net(torch.cat([x1, x1]), t2, ctx)), "per-sample timesteps were lost to the shared prefix"
+    assert torch.equal(net.forward_cfg_pair(x1, t2, ctx), two_t)              # (forward_cfg_pair compares the values itself)
+    assert not torch.equal(two_t[1], a[1])
 
 
 def test_weight_mutation_is_picked_up(tiny):

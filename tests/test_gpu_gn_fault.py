@@ -37,7 +37,9 @@ bp.run({}, st); torch.cuda.synchronize(); L.async_status()                      
 got = Interp(P, w, poison=False); got.arena = arena.cpu()
 assert rel_l2(read(got, out).float(), read(it, out).float()) < 1e-3
 bar = P.sync_ref("barrier").off
-arena[bar: bar + 4].copy_(torch.tensor([1 << 30], dtype=torch.int32).view(torch.uint8).to(dev))   # level-1 counter 0 can never reach its count
+# counter 0 (64-bit, counters advance by 2^32 per barrier): a high word far ahead of the other seven — the workgroups of group 0 read their
+# epoch from it and wait for the others to reach a count they never will
+arena[bar + 4: bar + 8].copy_(torch.tensor([1 << 30], dtype=torch.int32).view(torch.uint8).to(dev))
 t0 = time.time(); bp.run({}, st); torch.cuda.synchronize(); dt = time.time() - t0
 assert dt < 5.0, f"the poisoned barrier took {dt:.1f}s: the wait is not bounded"
 try:

@@ -9,7 +9,7 @@ import torch
 from harness import TD, fill, read, rel_l2, run_both
 from sd_webui_text2video_amd import _lib as L
 from sd_webui_text2video_amd import packing as pk
-from sd_webui_text2video_amd.program import Buf, Program, Ref
+from sd_webui_text2video_amd.program import BoundProgram, Buf, Program, Ref
 
 pytestmark = pytest.mark.gpu
 
@@ -1197,3 +1197,188 @@ def test_conv3x3_on_hi_lo_channel_blocks_against_torch():
     ref = torch.nn.functional.conv2d(xin, w4.float(), w["b"], stride=2, padding=1).permute(0, 2, 3, 1).reshape(M // 4, Cout)
     r = rel_l2(read(got, out), ref)
     assert r < 2e-5, r
+
+
+# ---- round 5: GroupNorm (+SiLU) inside the epilogue of the GEMM that produces its input (T2V_EPI_GN) -----------------------------------
+@pytest.mark.parametrize("kind,tile,C", [("conv", 8, 320), ("tconv", 8, 320), ("plain", 8, 320), ("tconv", 11, 320), ("plain", 11, 320),
+                                         ("tconv", 0, 640), ("conv", 0, 640), ("plain", 0, 640), ("tconv", 5, 640), ("plain", 5, 1280),
+                                         ("conv", 3, 640), ("plain", 3, 640)])
+@pytest.mark.parametrize("per_frame,dead,lo", [(True, True, False), (False, False, True), (False, True, False), (True, False, False)])
+def test_groupnorm_in_producer_epilogue_against_torch(kind, tile, C, per_frame, dead, lo):
+    """Round 5: the norm that consumes a convolution / linear result runs in that GEMM's epilogue — the tile stays
+    in registers, {sum, sum of squares} per (instance, group piece) meet at a grid barrier, no GROUPNORM op, and a result only the norm
+    reads (`dead`) is never stored.  Tiles of 192 / 128 rows against instances of 256 rows (a tile straddles two instances), groups cut
+    by the 128- / 256-wide column tiles (C = 640: 20 channels per group), hi + lo output, residual + row bias.  Checked against the CPU
+    interpreter and against torch: conv / linear -> group_norm -> SiLU on the fp32 result."""
+    B, F, H, W = 2, 3, 16, 16
+    M = B * F * H * W                                       # 1536 rows: 8 x 192, 12 x 128; a frame = 256 rows
+    P = Program()
+    P.force_tile = tile
+    g = _g(500 + tile)
+    y = P.alloc(M, C, "f16" if dead else "f32")
+    res = P.alloc(M, C, "f32") if not dead else None
+    rb = P.alloc(B, C, "f32") if kind == "conv" else None
+    w = {"b": torch.randn(C, generator=g), "g": 1 + 0.1 * torch.randn(C, generator=g), "be": 0.1 * torch.randn(C, generator=g)}
+    w["gb"] = torch.cat([w["g"], w["be"]])
+    if kind == "conv":
+        cin = 64
+        a = P.alloc(M, cin, "f16")
+        w4 = (torch.randn(C, cin, 3, 3, generator=g) / math.sqrt(9 * cin)).half()
+        w["w"] = pk.conv3x3(w4.float()).half()
+        op = P.gemm("c", a, Ref("weight", 0, "w"), C, 9 * cin, y, bias=Ref("weight", 0, "b"), gather=L.GATHER_CONV3X3,
+                    conv=dict(Hin=H, Win=W, Cin=cin, stride=1, up=0, Hout=H, Wout=W), residual=res, rowbias=rb, rows_per_batch=F * H * W,
+                    allow_splitk=False)
+    elif kind == "tconv":
+        cin = 64
+        a = P.alloc(M, cin, "f16")
+        w5 = (torch.randn(C, cin, 3, 1, 1, generator=g) / math.sqrt(3 * cin)).half()
+        w["w"] = pk.tconv3(w5.float()).half()
+        op = P.gemm("t", a, Ref("weight", 0, "w"), C, 3 * cin, y, bias=Ref("weight", 0, "b"), gather=L.GATHER_TCONV3, conv=dict(F=F, HW=H * W, Cin=cin),
+                    residual=res, allow_splitk=False)
+    else:
+        a = P.alloc(M, 128, "f16")
+        w["w"] = (torch.randn(C, 128, generator=g) / math.sqrt(128)).half()
+        op = P.gemm("l", a, Ref("weight", 0, "w"), C, 128, y, bias=Ref("weight", 0, "b"), residual=res, allow_splitk=False)
+    assert op.meta["tile"] == tile and op.meta["split"] == 1
+    full = P.alloc(M, 2 * C if lo else C, "f16")
+    out = full.col_slice(0, C)
+    n_inst = B * F if per_frame else B
+    fused = P.groupnorm("gn", y, Ref("weight", 0, "g"), Ref("weight", 0, "be"), out, n_inst=n_inst, eps=1e-5, silu=True, lo=lo,
+                        gb=Ref("weight", 0, "gb"), x_dead=dead)
+    assert fused is op and op.i[16] == L.EPI_GN and len(P.ops) == 1, "the norm did not become the GEMM's epilogue"
+
+    def init(it):
+        fill(it, a, g)
+        if res is not None:
+            fill(it, res, g, 2.0)
+        if rb is not None:
+            fill(it, rb, g)
+        if dead:                                            # the GEMM must not touch a result nobody reads
+            it.mat(y.ref, M, C, C, torch.float16, {}).fill_(7.0)
+    it, got = _gpu_run(P, w, init)
+    _check(it, got, full, 1e-3, "GroupNorm in the producer's epilogue vs the interpreter")
+    if dead:
+        assert bool((read(got, y) == 7.0).all()), "the dead result was stored"
+    else:
+        _check(it, got, y, 2e-5, "the fp32 stream beside the fused norm")
+        v = read(got, y).float()
+        ref = torch.nn.functional.silu(torch.nn.functional.group_norm(v.view(n_inst, M // n_inst, C).permute(0, 2, 1), 32, w["g"], w["be"], 1e-5))
+        ref = ref.permute(0, 2, 1).reshape(M, C)
+        hi = read(got, out).float()
+        assert rel_l2(hi, ref) < 1e-3
+        if lo:                                              # hi + lo reproduces the normalised value far below fp16 resolution
+            assert rel_l2(hi + read(got, full.col_slice(C, 2 * C)).float(), ref) < 2e-5
+
+
+def test_groupnorm_in_producer_epilogue_bench_shape_is_deterministic():
+    """The 32x32-level shape of the bench workload (M = 49152 rows = 256 workgroups of 192 x 320, one per CU; cross-frame statistics over
+    24576 rows = 128 tiles): two runs are bitwise equal (fixed fold order, no atomics on data) and match torch."""
+    B, F, HW, C = 2, 24, 1024, 320
+    M = B * F * HW
+    P = Program()
+    g = _g(77)
+    a, y, out = P.alloc(M, C, "f16"), P.alloc(M, C, "f16"), P.alloc(M, C, "f16")
+    w5 = (torch.randn(C, C, 3, 1, 1, generator=g) / math.sqrt(3 * C)).half()
+    w = {"w": pk.tconv3(w5.float()).half(), "b": torch.randn(C, generator=g), "g": 1 + 0.1 * torch.randn(C, generator=g), "be": 0.1 * torch.randn(C, generator=g)}
+    w["gb"] = torch.cat([w["g"], w["be"]])
+    op = P.gemm("t", a, Ref("weight", 0, "w"), C, 3 * C, y, bias=Ref("weight", 0, "b"), gather=L.GATHER_TCONV3, conv=dict(F=F, HW=HW, Cin=C))
+    fused = P.groupnorm("gn", y, Ref("weight", 0, "g"), Ref("weight", 0, "be"), out, n_inst=B, eps=1e-5, silu=True, gb=Ref("weight", 0, "gb"), x_dead=True)
+    assert fused is op and op.meta["tile"] == 8
+    dev = torch.device("cuda:0")
+    arena = torch.zeros(P.arena.high + 256, dtype=torch.uint8, device=dev)
+    av = arena[a.ref.off: a.ref.off + M * C * 2].view(torch.float16).view(M, C)
+    av.copy_(torch.randn(M, C, generator=g).half())
+    wg = {k: v.to(dev).contiguous() for k, v in w.items()}
+    bp = BoundProgram(P, arena.data_ptr(), {k: v.data_ptr() for k, v in wg.items()})
+    st = torch.cuda.current_stream(dev).cuda_stream
+    ov = arena[out.ref.off: out.ref.off + M * C * 2].view(torch.float16).view(M, C)
+    bp.run({}, st); torch.cuda.synchronize()
+    first = ov.clone()
+    bp.run({}, st); torch.cuda.synchronize()
+    assert torch.equal(first, ov)
+    L.async_status()
+    x = av.float().view(B, F, HW, C)
+    xp = torch.nn.functional.pad(x, (0, 0, 0, 0, 1, 1))
+    conv = sum(xp[:, kt:kt + F] @ w5[:, :, kt, 0, 0].to(dev).float().t() for kt in range(3)) + wg["b"]
+    ref = torch.nn.functional.silu(torch.nn.functional.group_norm(conv.view(B, F * HW, C).permute(0, 2, 1), 32, wg["g"], wg["be"], 1e-5))
+    assert rel_l2(first.float().cpu(), ref.permute(0, 2, 1).reshape(M, C).cpu()) < 1e-3
+
+
+@pytest.mark.parametrize("tile,N,K,M", [(0, 640, 640, 1536), (5, 1280, 1280, 1152), (12, 1280, 1280, 768), (9, 512, 512, 1152), (3, 768, 256, 1000)])
+def test_layernorm_across_column_tiles_against_torch(tile, N, K, M):
+    """Round 5: the LayerNorm that follows a C -> C linear whose rows are cut into several column tiles (C = 640 / 1280: the 16x16 / 8x8 /
+    4x4 levels) runs in that GEMM's epilogue — per-row {sum, sum of squares} of every column tile meet at the grid barrier — instead of
+    as its own launch.  Checked against the interpreter and torch.nn.functional.layer_norm; ragged M (1000 rows: a partial last tile)."""
+    P = Program()
+    P.force_tile = tile
+    g = _g(600 + tile)
+    a, res, out, ln_out = P.alloc(M, K, "f16"), P.alloc(M, N, "f32"), P.alloc(M, N, "f32"), P.alloc(M, N, "f16")
+    w = {"w": (torch.randn(N, K, generator=g) / math.sqrt(K)).half(), "b": torch.randn(N, generator=g),
+         "g": 1 + 0.1 * torch.randn(N, generator=g), "be": 0.1 * torch.randn(N, generator=g)}
+    w["gb"] = torch.cat([w["g"], w["be"]])
+    op = P.gemm("l", a, Ref("weight", 0, "w"), N, K, out, bias=Ref("weight", 0, "b"), residual=res, allow_splitk=False,
+                ln=(Ref("weight", 0, "gb"), Ref("weight", 0, "g"), Ref("weight", 0, "be"), ln_out, 1e-5))
+    assert op.meta["tile"] == tile and op.i[8] == 2 and len(P.ops) == 1, "the LayerNorm did not become the GEMM's epilogue"
+    it, got = _gpu_run(P, w, lambda it: (fill(it, a, g), fill(it, res, g, 3.0)))
+    _check(it, got, out, 2e-5, "fp32 stream")
+    _check(it, got, ln_out, 1e-3, "cross-tile LayerNorm vs the interpreter")
+    ref = torch.nn.functional.layer_norm(read(got, out).float() + 0.0, (N,), w["g"], w["be"], 1e-5)
+    assert rel_l2(read(got, ln_out).float(), ref) < 1e-3
+    # rows with a large common offset: the single-pass variance (fp32 sums, fp64 combination) must survive mean^2 >> var
+    it2, got2 = _gpu_run(P, w, lambda it: (fill(it, a, g), it.mat(res.ref, M, N, N, torch.float32, {}).copy_(torch.randn(M, N, generator=g) + 40.0)))
+    ref2 = torch.nn.functional.layer_norm(read(got2, out).double(), (N,), w["g"].double(), w["be"].double(), 1e-5).float()
+    assert rel_l2(read(got2, ln_out).float(), ref2) < 2e-3
+
+
+@pytest.mark.parametrize("kind,C,per_frame,dead,lo", [("conv", 640, True, True, False), ("conv", 1280, False, False, True), ("plain", 640, False, True, False),
+                                                       ("plain", 320, True, False, False)])
+def test_groupnorm_in_splitk_reduction_against_torch(kind, C, per_frame, dead, lo):
+    """Round 5: a split-K GEMM whose result feeds a GroupNorm — the reduction over the slabs IS the loader of a single-pass cooperative
+    GroupNorm launch (norm.hip splitk_gn_kernel): no splitk_reduce_kernel launch, no GROUPNORM op, the result stored only if someone else
+    reads it.  The long-K convolutions of the 8x8 / 4x4 levels."""
+    B, F, H, W = 2, 3, 8, 8
+    M = B * F * H * W                                       # 384 rows: 3 row tiles of 128
+    P = Program()
+    P.force_tile = 5
+    g = _g(700 + C)
+    y = P.alloc(M, C, "f16" if dead else "f32")
+    res = P.alloc(M, C, "f32") if not dead else None
+    rb = P.alloc(B, C, "f32") if kind == "conv" else None
+    w = {"b": torch.randn(C, generator=g), "g": 1 + 0.1 * torch.randn(C, generator=g), "be": 0.1 * torch.randn(C, generator=g)}
+    w["gb"] = torch.cat([w["g"], w["be"]])
+    if kind == "conv":
+        cin = 256
+        a = P.alloc(M, cin, "f16")
+        w4 = (torch.randn(C, cin, 3, 3, generator=g) / math.sqrt(9 * cin)).half()
+        w["w"] = pk.conv3x3(w4.float()).half()
+        op = P.gemm("c", a, Ref("weight", 0, "w"), C, 9 * cin, y, bias=Ref("weight", 0, "b"), gather=L.GATHER_CONV3X3,
+                    conv=dict(Hin=H, Win=W, Cin=cin, stride=1, up=0, Hout=H, Wout=W), residual=res, rowbias=rb, rows_per_batch=F * H * W)
+    else:
+        a = P.alloc(M, 2048, "f16")
+        w["w"] = (torch.randn(C, 2048, generator=g) / math.sqrt(2048)).half()
+        op = P.gemm("l", a, Ref("weight", 0, "w"), C, 2048, y, bias=Ref("weight", 0, "b"), residual=res)
+    assert op.meta["split"] > 1, op.meta
+    full = P.alloc(M, 2 * C if lo else C, "f16")
+    out = full.col_slice(0, C)
+    n_inst = B * F if per_frame else B
+    fused = P.groupnorm("gn", y, Ref("weight", 0, "g"), Ref("weight", 0, "be"), out, n_inst=n_inst, eps=1e-5, silu=True, lo=lo,
+                        gb=Ref("weight", 0, "gb"), x_dead=dead)
+    assert fused is op and op.i[16] == L.EPI_GN and len(P.ops) == 1
+
+    def init(it):
+        fill(it, a, g)
+        if res is not None:
+            fill(it, res, g, 2.0)
+        if rb is not None:
+            fill(it, rb, g)
+        if dead:
+            it.mat(y.ref, M, C, C, torch.float16, {}).fill_(7.0)
+    it, got = _gpu_run(P, w, init)
+    _check(it, got, full, 1e-3, "GroupNorm in the split-K reduction vs the interpreter")
+    if dead:
+        assert bool((read(got, y) == 7.0).all()), "the dead result was stored"
+    else:
+        _check(it, got, y, 2e-5, "the fp32 stream beside the fused norm")
+        v = read(got, y).float()
+        ref = torch.nn.functional.silu(torch.nn.functional.group_norm(v.view(n_inst, M // n_inst, C).permute(0, 2, 1), 32, w["g"], w["be"], 1e-5))
+        assert rel_l2(read(got, out).float(), ref.permute(0, 2, 1).reshape(M, C)) < 1e-3

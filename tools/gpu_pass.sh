@@ -45,6 +45,18 @@ stage_abgn() {      # same-box A/B: GroupNorm statistics from the producing GEMM
   prof strips2 T2V_X=0
   prof nostrips2 T2V_GN_STRIPS=0
 }
+stage_gnepi() {     # round 5: GroupNorm inside the producing GEMM's epilogue (T2V_EPI_GN) — op tests, the bounded-barrier fault test
+  timeout 900 $PYT tests/test_gpu_ops.py -x -k "producer_epilogue or groupnorm or layernorm" > gpurun_out/${TAG}_gnepi.log 2>&1
+  echo "gnepi exit $?"; digest gpurun_out/${TAG}_gnepi.log
+}
+stage_abgnepi() {   # same-box A/B of the per-op UNet step: fused GroupNorm epilogues (default) vs T2V_GN_EPI=0, twice; then per level
+  prof epi T2V_X=0
+  prof noepi T2V_GN_EPI=0
+  prof epi2 T2V_X=0
+  prof noepi2 T2V_GN_EPI=0
+  prof epi_only32 T2V_GN_EPI_TILE0=0 T2V_GN_EPI_TILE5=0 T2V_GN_EPI_TILE3=0
+  prof nolnx T2V_LN_X=0
+}
 stage_lvdm() {      # configs[4]: bench line + step profile with the 128x320 tile (default) and without
   timeout 400 python bench.py --model lvdm --steps 2 --warmup 1 > gpurun_out/${TAG}_bench_lvdm.json 2> gpurun_out/${TAG}_bench_lvdm.err; echo "bench lvdm exit $?"; cut -c1-200 gpurun_out/${TAG}_bench_lvdm.json
   T2V_TILE11=0 timeout 400 python bench.py --model lvdm --steps 2 --warmup 1 > gpurun_out/${TAG}_bench_lvdm_notile11.json 2> gpurun_out/${TAG}_bench_lvdm_notile11.err; echo "bench lvdm (no tile 11) exit $?"; cut -c1-200 gpurun_out/${TAG}_bench_lvdm_notile11.json

@@ -108,20 +108,24 @@ def main():
     x = torch.randn(Bx, 4, F, H, W, device=dev)
     y = torch.randn(B, 77, net.context_dim, device=dev, dtype=torch.float16)
     t = torch.full((B,), 500, device=dev)
+    def fwd():
+        net.single_timestep = True           # one t for the cond | uncond pair (what the samplers tell the UNet): the prefix is shared
+        return net(x, t, context=y) if model == "lvdm" else net(x, t, y)
+
     for _ in range(2):
-        out = net(x, t, context=y) if model == "lvdm" else net(x, t, y)
+        out = fwd()
     torch.cuda.synchronize()
     assert os.environ.get("T2V_PROFILE_NOCHECK") == "1" or torch.isfinite(out.float()).all()
     n = 5
     t0 = time.time()
     for _ in range(n):
-        out = net(x, t, context=y) if model == "lvdm" else net(x, t, y)
+        out = fwd()
     torch.cuda.synchronize()
     wall = (time.time() - t0) / n * 1e3
     net.auto_refresh = False
     t0 = time.time()
     for _ in range(n):
-        out = net(x, t, context=y) if model == "lvdm" else net(x, t, y)
+        out = fwd()
     torch.cuda.synchronize()
     wall2 = (time.time() - t0) / n * 1e3
     _, ms, prog = net.forward_timed(x, t, y)
