@@ -169,7 +169,9 @@ enum t2v_gather {
  *      scratch, phase 0: block partials [n_inst][nblk][groups][2] fp64, then {mean, rstd} fp32;  phases 1 / 2: gathered parts
  *      [nparts][n_inst][groups][2] fp64 (phase 1 folds this rank's block partials into its part; ALLGATHER of
  *      n_inst*groups*16 bytes per part), then this rank's block partials, then {mean, rstd};
- *      f: 0 eps;  p: 0 x, 1 gamma, 2 beta, 3 out fp16, 4 scratch, 5 grid-barrier words (i[15]), 6 producer strips (phase 3)
+ *      f: 0 eps;  p: 0 x, 1 gamma, 2 beta, 3 out fp16, 4 scratch, 5 grid-barrier words (i[15]), 6 producer strips (phase 3),
+ *      7 (i[15], optional) exchange-record region of i[18] bytes that nothing but fused-norm launches ever writes (zero at bind time): the
+ *        single-pass kernel then exchanges TAGGED records (no grid barrier) — the same region GEMM p[10] names
  * LAYERNORM: i: 0 M, 1 C, 2 ld_in, 3 ld_out, 4 workgroup cap (0 = 2048; rows beyond 4 x cap are walked grid-stride); f: 0 eps;
  *      p: 0 x fp32, 1 gamma, 2 beta, 3 out fp16
  * ATTENTION: i: 0 nq, 1 nk, 2 heads, 3 batch_outer, 4 batch_inner, 5..7 q strides (seq,
@@ -248,6 +250,9 @@ int t2v_device_info(char* name, int len, int* compute_units, uint64_t* hbm_bytes
  * and the three-launch GroupNorm is used for the rest of the process.  t2v_async_status() reports the same condition without running
  * anything (call it after synchronising the stream at the end of a job): T2V_OK or T2V_ERR_ASYNC. */
 int t2v_async_status(void);
+/* test hook: the next `n` fused-norm launches (single-pass GroupNorm, T2V_EPI_GN, cross-tile LayerNorm) wait for exchange records that
+ * nobody publishes — every waiter gives up after 0.25 s and the asynchronous fault is reported as above.  Never call it in production. */
+void t2v_debug_poison_exchange(int n);
 /* zero the T2V_SYNC_INTS + T2V_SYNC_BARRIER_INTS int32 words at `sync_words` on `stream` */
 int t2v_sync_reset(void* sync_words, void* stream);
 

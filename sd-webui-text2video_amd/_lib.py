@@ -34,7 +34,7 @@ EXPORTS = [
     "t2v_plan_num_ops", "t2v_plan_run", "t2v_plan_run_timed", "t2v_plan_destroy",
     "t2v_unet_forward", "t2v_vae_decode", "t2v_ddim_step",
     "t2v_comm_unique_id", "t2v_comm_create", "t2v_comm_size", "t2v_comm_destroy", "t2v_plan_set_comm",
-    "t2v_async_status", "t2v_sync_reset",
+    "t2v_async_status", "t2v_sync_reset", "t2v_debug_poison_exchange",
 ]
 
 
@@ -86,6 +86,8 @@ def load():
     lib.t2v_plan_set_comm.argtypes = [vp, vp]
     lib.t2v_async_status.restype = ctypes.c_int
     lib.t2v_sync_reset.argtypes = [vp, vp]
+    lib.t2v_debug_poison_exchange.argtypes = [ctypes.c_int]
+    lib.t2v_debug_poison_exchange.restype = None
     if lib.t2v_abi_version() != ABI_VERSION:
         raise T2VError(f"libt2v_hip.so ABI {lib.t2v_abi_version()} != binding {ABI_VERSION}; rebuild")
     _lib = lib

@@ -256,6 +256,7 @@ hipError_t launch_op(const t2v_op& op, hipStream_t s) {
         p.gn_rows = op.i[24]; p.ld_gn = op.i[25]; p.gn_silu = op.i[26]; p.gn_lo = op.i[27] ? op.i[1] : 0;
         p.gn_cpg = op.i[1] / op.i[28]; p.gn_store_out = op.i[29] ? 0 : 1;
         p.gn_eps = op.f[2];
+        t2v_exchange_ids(&p.gn_seq, &p.gn_want);
       }
       p.splitk = op.i[19] > 1 ? op.i[19] : 1;
       p.bias_m = op.i[20]; p.ldrb = op.i[21];
@@ -292,6 +293,7 @@ hipError_t launch_op(const t2v_op& op, hipStream_t s) {
           p.gn_part = reinterpret_cast<double*>(op.p[10]);
           p.gn_bar = reinterpret_cast<unsigned*>(op.p[11]);
           p.gn_fault = t2v_coop_fault_word();
+          t2v_exchange_ids(&p.gn_seq, &p.gn_want);
         }
       }
       // the large-tile kernel advances its source pointers by whole k-tiles: needs K % BK == 0

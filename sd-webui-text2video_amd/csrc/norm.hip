@@ -20,6 +20,8 @@
 // Bitwise reproducible run to run.
 // (T-sharded clips: statistics / all-gather of the partials / fold + normalise, see phase below.)
 // HBM-bound: 4 B + 4 B read, 2 B written per element.
+#include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 #include "t2v_kernels.h"
@@ -393,13 +395,13 @@ __global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(const T* __restri
 // select the three-launch path with T2V_GN_COOP=0.
 constexpr int GNC_THREADS = 512;
 
-// The grid barrier (eight monotonic counters, one fire-and-forget arrival, bounded wait) is t2v_grid_barrier of t2v_kernels.h, shared with the
-// fused-norm GEMM epilogues.
+// The grid barrier (sense-reversing, two levels, bounded wait) is t2v_grid_barrier of t2v_kernels.h, shared with the fused-norm GEMM epilogues.
 template <typename T, bool SILU, int KR>
 __global__ __launch_bounds__(GNC_THREADS) void gn_coop_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, f16* __restrict__ out, double* partials,
                                                               unsigned* bar, unsigned* fault, int rows, int C, int ld_in, int ld_out,
-                                                              int groups, int nchunk, int rc, double inv_n, float eps, int lo_off) {
+                                                              int groups, int nchunk, int rc, double inv_n, float eps, int lo_off,
+                                                              unsigned seq, unsigned want) {
   extern __shared__ float sh[];            // phase 1: parked sums [2][R][C]; phase 2: scale[C] | shift[C]
   __shared__ float stat[2 * 32];           // {mean, rstd} per group (groups <= 32)
   const int tid = threadIdx.x;
@@ -411,8 +413,9 @@ __global__ __launch_bounds__(GNC_THREADS) void gn_coop_kernel(const T* __restric
   const int r0 = chunk * rc, r1 = min(rows, r0 + rc);
   const int c8 = cs * 8;
   const T* xb = x + (size_t)inst * rows * ld_in + c8;
+  const bool tags = seq != 0u;            // tagged records instead of the grid barrier (t2v_kernels.h)
   unsigned gen0 = 0;
-  if (tid == 0) gen0 = t2v_grid_epoch(bar);
+  if (!tags && tid == 0) gen0 = t2v_grid_epoch(bar);
   f32x8 v[KR];
   f32x8 s, q;
 #pragma unroll
@@ -448,18 +451,11 @@ __global__ __launch_bounds__(GNC_THREADS) void gn_coop_kernel(const T* __restric
     for (int o = 1; o < 16; o <<= 1) { ds += __shfl_xor(ds, o); dq += __shfl_xor(dq, o); }
     if (g < groups && sub == 0) {
       double* st = partials + (((size_t)inst * nchunk + chunk) * groups + g) * 2;
-      union { double d[2]; f32x4 v; } pk;
-      pk.d[0] = ds;
-      pk.d[1] = dq;
-      t2v_st_dev(reinterpret_cast<float*>(st), pk.v);                                // one 16-byte device-scope (write-through) store,
-      t2v_wait_vm0();                                                                // complete before this workgroup arrives
+      t2v_st_dev(reinterpret_cast<float*>(st), t2v_rec_pack(ds, dq, seq));           // one 16-byte device-scope (write-through) store,
+      if (!tags) t2v_wait_vm0();                                                     // (barrier mode) complete before this workgroup arrives
     }
   }
-#ifndef T2V_GN_NO_BARRIER              // timing experiment only (tools/build_variant.py nobar -DT2V_GN_NO_BARRIER): the kernel WITHOUT its grid
-  t2v_grid_barrier(bar, gridDim.x, gen0, fault);     // barrier = the floor of any scheme that gets the statistics from somewhere else
-#else
-  __syncthreads();
-#endif
+  if (!tags) t2v_grid_barrier(bar, gridDim.x, gen0, fault);
   {
     double ds = 0.0, dq = 0.0;
     if (g < groups) {
@@ -469,18 +465,12 @@ __global__ __launch_bounds__(GNC_THREADS) void gn_coop_kernel(const T* __restric
       for (int c = sub; c < nchunk; c += 128) {
         f32x4 t[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int cj = c + 16 * j;
-          t[j] = t2v_ld_dev(reinterpret_cast<const float*>(base + (size_t)(cj < nchunk ? cj : c) * groups * 2));
-        }
-        t2v_wait_dev(t[0], t[1], t[2], t[3]);      // vmcnt(0): all eight have landed; the second call only ties the operands
-        t2v_wait_dev(t[4], t[5], t[6], t[7]);
+        for (int j = 0; j < 8; ++j) t[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int nrec = min(8, (nchunk - c + 15) / 16);
+        t2v_rec_fetch8([&](int j) { return reinterpret_cast<const float*>(base + (size_t)(c + 16 * j) * groups * 2); }, nrec, want, fault, t);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          union { f32x4 v; double d[2]; } u;
-          u.v = t[j];
-          if (c + 16 * j < nchunk) { ds += u.d[0]; dq += u.d[1]; }
-        }
+        for (int j = 0; j < 8; ++j)
+          if (j < nrec) t2v_rec_add(t[j], ds, dq);
       }
     }
     for (int o = 1; o < 16; o <<= 1) { ds += __shfl_xor(ds, o); dq += __shfl_xor(dq, o); }
@@ -556,14 +546,18 @@ bool coop_fits(K kernel, int nwg, size_t lds, hipStream_t s, int* cache) {
 template <typename T, bool SILU>
 bool gn_coop_launch(int kr, dim3 grid, size_t lds, hipStream_t s, const T* x, const float* gamma, const float* beta, f16* out,
                     double* partials, unsigned* bar, int rows, int C, int ld_in, int ld_out, int groups, int nchunk, int rc, double inv_n,
-                    float eps, int lo_off) {
+                    float eps, int lo_off, double* records) {
+  // tagged records need a region that only ever holds records (a recycled arena block could hold a matching bit pattern by chance):
+  // op.p[7], the program's exchange scratch; without it the grid barrier synchronises and the per-op scratch carries the partials
+  unsigned seq = 0, want = 0;
 #define GNC_CASE(K)                                                                                                              \
   case K: {                                                                                                                      \
     static int occ[T2V_MAX_DEVICES] = {};                                                                                        \
     auto kern = gn_coop_kernel<T, SILU, K>;                                                                                      \
     if (!coop_fits(kern, (int)grid.x, lds, s, occ)) return false;                                                                \
-    hipLaunchKernelGGL(kern, grid, dim3(GNC_THREADS), lds, s, x, gamma, beta, out, partials, bar, g_coop.fault, rows, C, ld_in,   \
-                       ld_out, groups, nchunk, rc, inv_n, eps, lo_off);                                                          \
+    if (records != nullptr) t2v_exchange_ids(&seq, &want);                                                                       \
+    hipLaunchKernelGGL(kern, grid, dim3(GNC_THREADS), lds, s, x, gamma, beta, out, seq != 0u ? records : partials, bar,           \
+                       g_coop.fault, rows, C, ld_in, ld_out, groups, nchunk, rc, inv_n, eps, lo_off, seq, want);                 \
     return true;                                                                                                                 \
   }
   switch (kr) {
@@ -592,8 +586,9 @@ __global__ __launch_bounds__(GNC_THREADS) void splitk_gn_kernel(const GemmParams
   const bool live = rr < R;
   const int r0 = chunk * rc, r1 = min(rows, r0 + rc);
   const int c8 = cs * 8;
+  const bool tags = p.gn_seq != 0u;
   unsigned gen0 = 0;
-  if (tid == 0) gen0 = t2v_grid_epoch(p.gn_bar);
+  if (!tags && tid == 0) gen0 = t2v_grid_epoch(p.gn_bar);
   f32x8 v[KR];
   f32x8 s, q;
 #pragma unroll
@@ -655,14 +650,11 @@ __global__ __launch_bounds__(GNC_THREADS) void splitk_gn_kernel(const GemmParams
     for (int o = 1; o < 16; o <<= 1) { ds += __shfl_xor(ds, o); dq += __shfl_xor(dq, o); }
     if (g < groups && sub == 0) {
       double* st = partials + (((size_t)inst * nchunk + chunk) * groups + g) * 2;
-      union { double d[2]; f32x4 v; } pk;
-      pk.d[0] = ds;
-      pk.d[1] = dq;
-      t2v_st_dev(reinterpret_cast<float*>(st), pk.v);
-      t2v_wait_vm0();
+      t2v_st_dev(reinterpret_cast<float*>(st), t2v_rec_pack(ds, dq, p.gn_seq));
+      if (!tags) t2v_wait_vm0();
     }
   }
-  t2v_grid_barrier(p.gn_bar, gridDim.x, gen0, p.gn_fault);
+  if (!tags) t2v_grid_barrier(p.gn_bar, gridDim.x, gen0, p.gn_fault);
   {
     double ds = 0.0, dq = 0.0;
     if (g < groups) {
@@ -670,18 +662,12 @@ __global__ __launch_bounds__(GNC_THREADS) void splitk_gn_kernel(const GemmParams
       for (int c = sub; c < nchunk; c += 128) {
         f32x4 t[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int cj = c + 16 * j;
-          t[j] = t2v_ld_dev(reinterpret_cast<const float*>(base + (size_t)(cj < nchunk ? cj : c) * groups * 2));
-        }
-        t2v_wait_dev(t[0], t[1], t[2], t[3]);
-        t2v_wait_dev(t[4], t[5], t[6], t[7]);
+        for (int j = 0; j < 8; ++j) t[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int nrec = min(8, (nchunk - c + 15) / 16);
+        t2v_rec_fetch8([&](int j) { return reinterpret_cast<const float*>(base + (size_t)(c + 16 * j) * groups * 2); }, nrec, p.gn_want, p.gn_fault, t);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          union { f32x4 v; double d[2]; } u;
-          u.v = t[j];
-          if (c + 16 * j < nchunk) { ds += u.d[0]; dq += u.d[1]; }
-        }
+        for (int j = 0; j < 8; ++j)
+          if (j < nrec) t2v_rec_add(t[j], ds, dq);
       }
     }
     for (int o = 1; o < 16; o <<= 1) { ds += __shfl_xor(ds, o); dq += __shfl_xor(dq, o); }
@@ -849,7 +835,9 @@ static int splitk_gn_kr(const GemmParams& p, hipStream_t s, int* rc_out, int* nc
   const int cv = p.N / 8;
   if (p.N % 8 != 0 || cv > GNC_THREADS || p.gn_cpg <= 0 || p.N / p.gn_cpg > 32 || p.gn_rows <= 0 || p.M % p.gn_rows != 0) return 0;
   const int Rc = GNC_THREADS / cv, ncu = t2v_num_cus(s), n_inst = p.M / p.gn_rows;
-  for (int kr : {4, 8, 12, 16, 20}) {
+  // the FEWEST rows per thread whose grid is still resident at once: the loader sums `splitk` slabs per element, and at the 4x4 level
+  // (768 rows) 4 rows per thread left 64 workgroups to read 8 slabs — measured slower than the reduction kernel + the norm it replaces
+  for (int kr : {1, 2, 4, 8, 12, 16, 20}) {
     const int rc = Rc * kr, nchunk = (p.gn_rows + rc - 1) / rc;
     if ((long)n_inst * nchunk <= ncu) { *rc_out = rc; *nchunk_out = nchunk; return kr; }
   }
@@ -878,12 +866,35 @@ hipError_t t2v_launch_splitk_reduce_gn(const GemmParams& p, hipStream_t s) {
     return hipGetLastError();                                                                                               \
   }
   switch (kr) {
-    SKG_CASE(4) SKG_CASE(8) SKG_CASE(12) SKG_CASE(16) SKG_CASE(20)
+    SKG_CASE(1) SKG_CASE(2) SKG_CASE(4) SKG_CASE(8) SKG_CASE(12) SKG_CASE(16) SKG_CASE(20)
     default: break;
   }
 #undef SKG_CASE
   return hipErrorInvalidValue;
 }
+
+// Sequence numbers of the tagged-record exchange: process-wide, never 0, never repeated within 2^32 fused-norm launches (a record slot
+// is rewritten by every launch that uses it, long before the numbers wrap).  T2V_EXCHANGE=barrier selects the grid barrier instead
+// (seq = want = 0).  t2v_debug_poison_exchange(n): the next n launches expect a number nobody publishes — the bounded wait's test.
+static unsigned g_seq = 0;
+static int g_poison = 0;
+static int g_exchange_mode = -1;      // 1 = tagged records, 0 = grid barrier
+void t2v_exchange_ids(unsigned* seq, unsigned* want) {
+  if (g_exchange_mode < 0) {
+    const char* e = getenv("T2V_EXCHANGE");
+    g_exchange_mode = (e != nullptr && strcmp(e, "barrier") == 0) ? 0 : 1;
+  }
+  if (g_exchange_mode == 0) { *seq = *want = 0u; return; }
+  unsigned v = __atomic_add_fetch(&g_seq, 1u, __ATOMIC_RELAXED);
+  if (v == 0u) v = __atomic_add_fetch(&g_seq, 1u, __ATOMIC_RELAXED);
+  *seq = v;
+  *want = v;
+  if (__atomic_load_n(&g_poison, __ATOMIC_RELAXED) > 0) {
+    __atomic_sub_fetch(&g_poison, 1, __ATOMIC_RELAXED);
+    *want = v ^ 0x80008000u;
+  }
+}
+extern "C" void t2v_debug_poison_exchange(int n) { __atomic_store_n(&g_poison, n, __ATOMIC_RELAXED); }
 
 unsigned* t2v_coop_fault_word() { return coop_fault_word(); }
 
@@ -901,9 +912,10 @@ int t2v_async_fault_consume(std::string* msg) {
   if (!t2v_async_fault_pending()) return 0;
   g_coop.reported = true;
   g_coop.disabled = true;
-  if (msg) *msg = "single-pass GroupNorm: a workgroup gave up waiting at the grid barrier (the device is shared with another client that "
-                  "holds compute units); the results of the run that was in flight are invalid.  The three-launch GroupNorm is used from "
-                  "now on (T2V_GN_COOP=0 selects it from the start)";
+  if (msg) *msg = "fused normalisation: a workgroup gave up waiting for the statistics of the other workgroups of its launch (the device is "
+                  "shared with another client that holds compute units); the results of the run that was in flight are invalid.  The "
+                  "three-launch GroupNorm is used from now on; programs with norms fused into GEMM epilogues must be lowered again with "
+                  "T2V_GN_COOP=0 (which selects the unfused forms from the start)";
   return 1;
 }
 
@@ -958,10 +970,11 @@ hipError_t t2v_launch_groupnorm(const t2v_op& op, hipStream_t s) {
       const size_t ldsc = (size_t)2 * (GNC_THREADS / cv) * C * sizeof(float);
       unsigned* bar = reinterpret_cast<unsigned*>(op.p[5]);
       const dim3 grid(n_inst * coop_nchunk);
+      double* records = ((size_t)n_inst * coop_nchunk * groups * 16 <= (size_t)op.i[18]) ? reinterpret_cast<double*>(op.p[7]) : nullptr;
       const bool done = silu ? gn_coop_launch<T, true>(coop_kr, grid, ldsc, s, x, gamma, beta, out, partials, bar, rows, C, ld_in, ld_out, groups,
-                                                       coop_nchunk, coop_rc, inv_n, op.f[0], lo_off)
+                                                       coop_nchunk, coop_rc, inv_n, op.f[0], lo_off, records)
                              : gn_coop_launch<T, false>(coop_kr, grid, ldsc, s, x, gamma, beta, out, partials, bar, rows, C, ld_in, ld_out, groups,
-                                                        coop_nchunk, coop_rc, inv_n, op.f[0], lo_off);
+                                                        coop_nchunk, coop_rc, inv_n, op.f[0], lo_off, records);
       if (done) return;             // else: not provably co-resident (or a fault was raised earlier) -> the three launches below
     }
     if (fused) {

@@ -69,6 +69,10 @@ struct GemmParams {
   // LayerNorm second output ACROSS column tiles (t2v_epilogue_rows_lnx: ln_gb / ln_out / ld_ln / ln_eps as above, partial row sums
   // through gn_part, the grid barrier on gn_bar): any N, the launch must be co-resident
   int ln_x;
+  // Exchange mode of the fused-norm kernels: gn_seq != 0 -> TAGGED RECORDS (every published {sum, sum of squares} pair carries the
+  // launch's 32-bit sequence number in the low mantissa bits; consumers poll the records they need until the tags match: no barrier);
+  // gn_seq == 0 -> the grid barrier on gn_bar.  gn_want = the number consumers expect (== gn_seq except in the fault-injection test).
+  unsigned gn_seq, gn_want;
 };
 
 
@@ -178,6 +182,7 @@ inline bool t2v_grid_fits(const void* kernel, int threads, size_t lds, long nwg,
 // single-pass GroupNorm) raises a flag in host-mapped memory instead of hanging the device.  The executor reads it at the entry
 // of every run: the run that raised it produced invalid results, the NEXT call reports it (t2v_async_status() reports it at once)
 // and the cooperative path stays off for the rest of the process.
+void t2v_exchange_ids(unsigned* seq, unsigned* want);     // sequence number of the next fused-norm launch (0, 0: barrier mode — T2V_EXCHANGE=barrier)
 unsigned* t2v_coop_fault_word();                        // the host-mapped fault word of the bounded grid barriers (null: unavailable)
 bool t2v_coop_allowed();                                // false once a barrier timed out in this process (or the word could not be mapped)
 int t2v_async_fault_pending();                          // 1 = a fault was raised and not yet reported
@@ -475,61 +480,56 @@ __device__ __forceinline__ void t2v_epilogue_rows_ln(const GemmParams& p, f32x16
   }
 }
 
-// ---- bounded grid barrier (shared by the single-pass GroupNorm of norm.hip and the fused-norm GEMM epilogues) ---------------------
-// Eight monotonic 64-bit counters on words of the program's zero-initialised sync buffer, one 128-byte line each; workgroup b belongs to
-// counter b % 8 (atomics on ONE address serialise at ~25 ns each: 256 arrivals would be 6 us).  Every barrier adds EXACTLY 2^32 to EVERY
-// counter: a member adds floor(2^32 / members), the first member of a group the remainder as well, and block 0 the whole 2^32 of a group
-// that has no members (grids of fewer than 8 workgroups).  So between launches every counter reads k * 2^32, and inside a launch a
-// workgroup's OWN counter stays below (k + 1) * 2^32 until that workgroup has arrived — its high word, read any time before arriving
-// (`epoch` below, read at kernel start), is the same k for every workgroup of the launch, and "all eight counters >= (k + 1) * 2^32"
-// means everybody has arrived.  One fire-and-forget atomic per workgroup and one polling round trip: no returning atomic, no second
-// level, no generation word (round 4's two-level sense-reversing form had four dependent device-scope round trips), nothing to reset
-// between launches, wrap-safe (signed differences).  All flag accesses are relaxed device-scope atomics (no cache-wide write-back /
-// invalidate); the data exchanged around it moves with device-scope (sc1) stores that their writers waited for (s_waitcnt vmcnt(0))
-// before arriving, and device-scope loads after it.
+// ---- bounded two-level grid barrier (shared by the single-pass GroupNorm of norm.hip and the fused-norm GEMM epilogues) -----------
+// Sense-reversing on words of the program's zero-initialised sync buffer.  Two levels, because atomics on ONE address serialise at
+// ~25 ns each (256 arrivals = 6 us): workgroup b arrives at counter b % 8 (its own 128-byte line), the last arrival of each counter
+// re-arms it and arrives at the top counter, the last of those re-arms that and bumps the generation word every waiter polls.
+// Counters return to 0 and the generation only grows, so nothing needs a reset between launches.  All flag accesses are relaxed
+// device-scope atomics (no cache-wide write-back / invalidate); the data exchanged around it moves with device-scope (sc1) stores
+// that their writers waited for (s_waitcnt vmcnt(0)) before arriving, and device-scope loads after it.
+// Split in two so that work which does not depend on the other workgroups (the fp32 stream store of the fused-norm epilogues) can be
+// issued between arriving and waiting.
+// (Round 5 measured a single-round variant — eight monotonic 64-bit counters, a fire-and-forget arrival, every waiter polling all
+// eight — and it was SLOWER: +8 us on the 240 / 480-workgroup launches of the 8x8 / 16x16 levels, equal at 256 workgroups: hundreds of
+// pollers on the lines the arrivals go to delay the arrivals.  Here the waiters poll ONE word that nobody writes until the release.)
 // The wait is BOUNDED: a waiter that sees no release within GNB_TIMEOUT_TICKS of the constant 100 MHz clock (0.25 s; a healthy
 // barrier takes microseconds) raises the fault word in host-mapped memory and falls through — this launch's output is invalid, the
 // device is not hung, the host reports the fault at its next call.
-constexpr int GNB_STRIDE = 32;                       // ints between counters (one 128-byte line each)
+constexpr int GNB_STRIDE = 32;                       // ints between level-1 counters (one 128-byte line each)
+constexpr int GNB_TOP = 8 * GNB_STRIDE, GNB_GEN = 9 * GNB_STRIDE;
 constexpr unsigned long long GNB_TIMEOUT_TICKS = 25000000ull;
-// thread 0 of every workgroup, any time before t2v_grid_barrier: the barrier epoch k of this launch
-__device__ __forceinline__ unsigned t2v_grid_epoch(unsigned* bar) {
-  const unsigned long long* ctr = reinterpret_cast<const unsigned long long*>(bar + (blockIdx.x & 7u) * GNB_STRIDE);
-  return (unsigned)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32);
-}
-// arrive: every thread's published (sc1) stores are complete once thread 0 has passed its s_waitcnt — each WAVE waits for its own
-// stores before the __syncthreads (callers: t2v_wait_vm0() right after publishing)
-__device__ __forceinline__ void t2v_grid_arrive(unsigned* bar, unsigned nwg) {
+// thread 0 of every workgroup, any time before it arrives: the generation word (it cannot change before this workgroup has arrived)
+__device__ __forceinline__ unsigned t2v_grid_epoch(unsigned* bar) { return __hip_atomic_load(bar + GNB_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// arrive (callers: every wave has waited for its own published stores, t2v_wait_vm0(), before).  Returns, in thread 0, whether this
+// workgroup was the last to arrive — hand it to t2v_grid_wait.
+__device__ __forceinline__ bool t2v_grid_arrive(unsigned* bar, unsigned nwg) {
   __syncthreads();
+  bool release = false;
   if (threadIdx.x == 0) {
     const unsigned grp = blockIdx.x & 7u;
     const unsigned ngrp = nwg < 8u ? nwg : 8u;
     const unsigned in_grp = (nwg - grp + 7u) >> 3;                                   // workgroups b with b % 8 == grp
-    const unsigned long long one = 1ull << 32, w = one / in_grp;
     t2v_wait_vm0();
-    (void)__hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(bar + grp * GNB_STRIDE), (blockIdx.x >> 3) == 0 ? one - w * (in_grp - 1) : w,
-                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (blockIdx.x == 0)
-      for (unsigned e = ngrp; e < 8u; ++e)                                           // groups without members keep step
-        (void)__hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(bar + e * GNB_STRIDE), one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (__hip_atomic_fetch_add(bar + grp * GNB_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_grp - 1) {
+      __hip_atomic_store(bar + grp * GNB_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__hip_atomic_fetch_add(bar + GNB_TOP, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngrp - 1) {
+        __hip_atomic_store(bar + GNB_TOP, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        release = true;
+      }
+    }
+    if (release) {
+      t2v_wait_vm0();                                                                // every counter re-armed before anyone leaves
+      __hip_atomic_fetch_add(bar + GNB_GEN, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
+  return release;
 }
-// wait: work that does not depend on the other workgroups may be issued between arrive and wait (it overlaps the barrier's latency)
-__device__ __forceinline__ void t2v_grid_wait(unsigned* bar, unsigned epoch, unsigned* fault) {
-  if (threadIdx.x == 0) {
-    const unsigned long long target = (unsigned long long)(epoch + 1u) << 32;
+__device__ __forceinline__ void t2v_grid_wait(unsigned* bar, unsigned gen, bool released, unsigned* fault) {
+  if (threadIdx.x == 0 && !released) {
     const unsigned long long t0 = wall_clock64();
     unsigned polls = 0;
-    for (;;) {
-      unsigned long long v[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e)
-        v[e] = __hip_atomic_load(reinterpret_cast<unsigned long long*>(bar + e * GNB_STRIDE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      bool all = true;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) all = all && (long long)(v[e] - target) >= 0;
-      if (all) break;
-      __builtin_amdgcn_s_sleep(4);
+    while (__hip_atomic_load(bar + GNB_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+      __builtin_amdgcn_s_sleep(8);
       if ((++polls & 63u) == 0u && wall_clock64() - t0 > GNB_TIMEOUT_TICKS) {        // give up: flag it, never hang the device
         __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         break;
@@ -538,10 +538,86 @@ __device__ __forceinline__ void t2v_grid_wait(unsigned* bar, unsigned epoch, uns
   }
   __syncthreads();
 }
-__device__ __forceinline__ void t2v_grid_barrier(unsigned* bar, unsigned nwg, unsigned epoch, unsigned* fault) {
-  t2v_grid_arrive(bar, nwg);
-  t2v_grid_wait(bar, epoch, fault);
+__device__ __forceinline__ void t2v_grid_barrier(unsigned* bar, unsigned nwg, unsigned gen, unsigned* fault) {
+  const bool released = t2v_grid_arrive(bar, nwg);
+  t2v_grid_wait(bar, gen, released, fault);
 }
+
+// ---- tagged records: the exchange without a barrier (round 5) ------------------------------------------------------------------------
+// What the workgroups of a fused-norm launch exchange is small: one {sum, sum of squares} fp64 pair per (tile, group) or per row.  With
+// the barrier the chain publish -> s_waitcnt -> returning atomic -> second-level atomic -> generation bump -> poll -> fold loads is
+// ~7 dependent device-scope round trips (measured: +9 .. 12 us on the producing GEMM).  A record that says by itself whether it is the
+// one of THIS launch needs none of that: the 16-byte record carries the launch's 32-bit sequence number (handed out by the library,
+// never 0, never repeated within 2^32 launches) in the 16 low mantissa bits of each double — 2^-36 relative, far below the fp32
+// inputs of the sums — and a consumer simply loads the records it needs (device-scope loads) and re-loads the ones whose tag is not
+// this launch's yet: publish -> (flight) -> load.  A torn 16-byte record shows two different tag halves and is just re-polled.  Every
+// consumer strips the tags the same way and adds the records in index order only once ALL of a round are fresh: bit-identical
+// statistics in every workgroup, run to run.  The wait is bounded exactly as the barrier's (fault word, 0.25 s).
+__device__ __forceinline__ f32x4 t2v_rec_pack(double a, double b, unsigned seq) {
+  union { double d[2]; unsigned long long u[2]; f32x4 v; } r;
+  r.d[0] = a;
+  r.d[1] = b;
+  r.u[0] = (r.u[0] & ~0xFFFFull) | (unsigned long long)(seq & 0xFFFFu);
+  r.u[1] = (r.u[1] & ~0xFFFFull) | (unsigned long long)(seq >> 16);
+  return r.v;
+}
+__device__ __forceinline__ bool t2v_rec_fresh(const f32x4& v, unsigned want) {
+  union { f32x4 v; unsigned long long u[2]; } r;
+  r.v = v;
+  return (unsigned)(r.u[0] & 0xFFFFull) == (want & 0xFFFFu) && (unsigned)(r.u[1] & 0xFFFFull) == (want >> 16);
+}
+__device__ __forceinline__ void t2v_rec_add(const f32x4& v, double& a, double& b) {
+  union { f32x4 v; unsigned long long u[2]; double d[2]; } r;
+  r.v = v;
+  r.u[0] &= ~0xFFFFull;
+  r.u[1] &= ~0xFFFFull;
+  a += r.d[0];
+  b += r.d[1];
+}
+// Fetch the first `n` (<= NR) of the records addr(0 .. NR-1) into t[]: all loads in flight together; want != 0: re-load those whose tag is
+// not `want` yet (bounded); want == 0: the caller has synchronised otherwise (barrier mode), one round.
+// Four device-scope 16-byte loads AND their completion in ONE asm statement: the values are valid when it ends.  (A load in its own
+// asm statement is only safe while nothing touches its destination before the separate s_waitcnt — under register pressure the compiler
+// spills or copies the destination in between and reads it before the data has landed: measured, tile 8 of the first tagged build.)
+__device__ __forceinline__ void t2v_ld_dev4(const float* p0, const float* p1, const float* p2, const float* p3, f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
+  asm volatile(
+      "global_load_dwordx4 %0, %4, off sc1\n\t"
+      "global_load_dwordx4 %1, %5, off sc1\n\t"
+      "global_load_dwordx4 %2, %6, off sc1\n\t"
+      "global_load_dwordx4 %3, %7, off sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d)
+      : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
+      : "memory");
+}
+// Fetch the first `n` (1 .. NR) of the records addr(0 .. NR-1) into t[] (slots >= n hold a copy of record 0); want != 0: poll until
+// every one of them carries this launch's tag (bounded); want == 0: the caller has synchronised otherwise (barrier mode), one round.
+template <int NR, typename F>
+__device__ __forceinline__ void t2v_rec_fetch(F addr, int n, unsigned want, unsigned* fault, f32x4 (&t)[NR]) {
+  static_assert(NR == 4 || NR == 8, "4 or 8 records in flight");
+  const float* a[NR];
+#pragma unroll
+  for (int j = 0; j < NR; ++j) a[j] = addr(j < n ? j : 0);
+  unsigned long long t0 = 0;
+  unsigned polls = 0;
+  for (;;) {
+    t2v_ld_dev4(a[0], a[1], a[2], a[3], t[0], t[1], t[2], t[3]);
+    if constexpr (NR == 8) t2v_ld_dev4(a[4], a[5], a[6], a[7], t[4], t[5], t[6], t[7]);
+    if (want == 0u) break;
+    bool fresh = true;
+#pragma unroll
+    for (int j = 0; j < NR; ++j) fresh = fresh && t2v_rec_fresh(t[j], want);
+    if (fresh) break;
+    if (polls == 0) t0 = wall_clock64();
+    __builtin_amdgcn_s_sleep(2);
+    if ((++polls & 63u) == 0u && wall_clock64() - t0 > GNB_TIMEOUT_TICKS) {         // give up: flag it, never hang the device
+      __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      break;
+    }
+  }
+}
+template <typename F>
+__device__ __forceinline__ void t2v_rec_fetch8(F addr, int n, unsigned want, unsigned* fault, f32x4 (&t)[8]) { t2v_rec_fetch<8>(addr, n, want, fault, t); }
 
 // ---- GroupNorm (+SiLU) of a GEMM's result inside its epilogue (T2V_EPI_GN, round 5) -----------------------------------------------
 // Replaces nn.GroupNorm(32, C) [+ SiLU] where its input is the result of ONE convolution / linear of this library (reference:
@@ -571,8 +647,9 @@ __device__ __forceinline__ void t2v_epilogue_rows_gn(const GemmParams& p, f32x16
   float* stat = scsf + 4 * BN;                                                   // [2 slots][T2V_GN_PIECES][mean | rstd]
   const int wrow = lane & 31, wcol = (lane >> 5) * 4;
   const int rrow = lane >> 3, rcol = (lane & 7) * 4;
+  const bool tags = p.gn_seq != 0u;
   unsigned gen0 = 0;
-  if (tid == 0) gen0 = t2v_grid_epoch(p.gn_bar);
+  if (!tags && tid == 0) gen0 = t2v_grid_epoch(p.gn_bar);
   const bool has_res = p.res != nullptr;
   // ---- A
 #pragma unroll
@@ -656,15 +733,16 @@ __device__ __forceinline__ void t2v_epilogue_rows_gn(const GemmParams& p, f32x16
     ds += __shfl_xor(ds, 2); dq += __shfl_xor(dq, 2);
     if (active && sub == 0) {
       double* dst = p.gn_part + ((((size_t)tile_m * 2 + slot) * tiles_n + tile_n) * T2V_GN_PIECES + pc) * 2;
-      union { double d[2]; f32x4 v; } pk;
-      pk.d[0] = ds;
-      pk.d[1] = dq;
-      t2v_st_dev(reinterpret_cast<float*>(dst), pk.v);             // one 16-byte device-scope (write-through) store
+      t2v_st_dev(reinterpret_cast<float*>(dst), t2v_rec_pack(ds, dq, p.gn_seq));      // one 16-byte device-scope (write-through) store
     }
   }
-  t2v_wait_vm0();                                                  // ... complete before this workgroup arrives
-  // ---- C: arrive, then — under the barrier's latency — the result itself goes out if anyone else reads it (from the registers, row-major)
-  t2v_grid_arrive(p.gn_bar, gridDim.x);
+  // ---- C: (barrier mode: arrive;) then — under the exchange's latency — the result itself goes out if anyone else reads it (from the
+  // registers, row-major)
+  bool released = false;
+  if (!tags) {
+    t2v_wait_vm0();                                                // ... complete before this workgroup arrives
+    released = t2v_grid_arrive(p.gn_bar, gridDim.x);
+  }
   if (p.gn_store_out) {
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
@@ -688,7 +766,7 @@ __device__ __forceinline__ void t2v_epilogue_rows_gn(const GemmParams& p, f32x16
       }
     }
   }
-  t2v_grid_wait(p.gn_bar, gen0, p.gn_fault);
+  if (!tags) t2v_grid_wait(p.gn_bar, gen0, released, p.gn_fault);
   // ---- D: as many lanes per (slot, group) as the workgroup has (a power of two, 8 .. 64): one round of loads in flight where possible
   const int last_inst = (min(m0 + BM, p.M) - 1) / R;               // instance of the tile's last real row (>= inst0, <= inst0 + 1)
   const double inv_n = 1.0 / ((double)R * cpg);
@@ -711,18 +789,16 @@ __device__ __forceinline__ void t2v_epilogue_rows_gn(const GemmParams& p, f32x16
         const int pp = g - (tn * BN) / cpg;                         // piece of this group in column tile tn
         return reinterpret_cast<const float*>(p.gn_part + ((((size_t)t * 2 + sl) * tiles_n + tn) * T2V_GN_PIECES + pp) * 2);
       };
-      for (int u = sub; u < count; u += 8 * lpi) {                  // EIGHT 16-byte device-scope loads in flight per round
-        f32x4 t[8];
+      constexpr int NREC = 4;                                       // records in flight per lane and round (register room: the tile is live)
+      for (int u = sub; u < count; u += NREC * lpi) {
+        f32x4 t[NREC];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) t[j] = t2v_ld_dev(src(u + lpi * j < count ? u + lpi * j : u));
-        t2v_wait_dev(t[0], t[1], t[2], t[3]);
-        t2v_wait_dev(t[4], t[5], t[6], t[7]);
+        for (int j = 0; j < NREC; ++j) t[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int nrec = min(NREC, (count - u + lpi - 1) / lpi);
+        t2v_rec_fetch<NREC>([&](int j) { return src(u + lpi * j); }, nrec, p.gn_want, p.gn_fault, t);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          union { f32x4 v; double d[2]; } uu;
-          uu.v = t[j];
-          if (u + lpi * j < count) { ds += uu.d[0]; dq += uu.d[1]; }
-        }
+        for (int j = 0; j < NREC; ++j)
+          if (j < nrec) t2v_rec_add(t[j], ds, dq);
       }
     }
     for (int o = 1; o < lpi; o <<= 1) { ds += __shfl_xor(ds, o); dq += __shfl_xor(dq, o); }      // (lpi is workgroup-uniform)
@@ -783,12 +859,12 @@ __device__ __forceinline__ void t2v_epilogue_rows_gn(const GemmParams& p, f32x16
 // <= 31 MB).  Same exchange as the GroupNorm epilogue above, along the other axis: every workgroup keeps its tile in registers, stores
 // the fp32 stream, publishes {sum, sum of squares} per ROW of its column range, the launch meets at the grid barrier, every workgroup
 // sums the tiles_n pairs of its rows in fp64 in tile order (bit-identical for every column tile of a row) and writes
-// LayerNorm(row) * gamma + beta for its columns.  Scratch: fp32 [tiles_m][tiles_n][BM][2] (p.gn_part).
+// LayerNorm(row) * gamma + beta for its columns.  Scratch: fp64 records [tiles_m][tiles_n][BM][2] (p.gn_part).
 template <int WM, int WN, int TM, int TN>
 __device__ __forceinline__ void t2v_epilogue_rows_lnx(const GemmParams& p, f32x16 (&acc)[TM][TN], unsigned char* smem, int lane, int wave,
                                                       int m0, int n0, int tile_m, int tile_n, int tiles_n) {
   constexpr int NW = WM * WN, NT = NW * 64, S = WM * TM, BM = S * 32;
-  static_assert(BM / 2 <= NT, "one thread per row pair");
+  static_assert(BM <= NT, "one thread per row");
   const int tid = threadIdx.x;
   const int wm = wave / WN, wn = wave % WN;
   float* stg = reinterpret_cast<float*>(smem) + wave * (32 * T2V_EPI_SP);
@@ -796,8 +872,9 @@ __device__ __forceinline__ void t2v_epilogue_rows_lnx(const GemmParams& p, f32x1
   float* rowstat = rowsum + WN * BM * 2;                                         // [BM][mean | rstd]
   const int wrow = lane & 31, wcol = (lane >> 5) * 4;
   const int rrow = lane >> 3, rcol = (lane & 7) * 4;
+  const bool tags = p.gn_seq != 0u;
   unsigned gen0 = 0;
-  if (tid == 0) gen0 = t2v_grid_epoch(p.gn_bar);
+  if (!tags && tid == 0) gen0 = t2v_grid_epoch(p.gn_bar);
   const bool has_res = p.res != nullptr;
 #pragma unroll
   for (int a = 0; a < TM; ++a) {
@@ -857,16 +934,18 @@ __device__ __forceinline__ void t2v_epilogue_rows_lnx(const GemmParams& p, f32x1
     }
   }
   __syncthreads();
-  float* part = reinterpret_cast<float*>(p.gn_part);
-  if (tid < BM / 2) {                                              // rows 2 tid, 2 tid + 1 of the tile: one 16-byte device-scope store
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (tid < BM) {                                                  // row tid of the tile: one 16-byte device-scope record {sum, sum of squares}
+    double ds = 0.0, dq = 0.0;
 #pragma unroll
-    for (int w = 0; w < WN; ++w) v += *reinterpret_cast<const f32x4*>(rowsum + ((size_t)w * BM + 2 * tid) * 2);
-    t2v_st_dev(part + (((size_t)tile_m * tiles_n + tile_n) * BM + 2 * tid) * 2, v);
+    for (int w = 0; w < WN; ++w) { ds += (double)rowsum[((size_t)w * BM + tid) * 2]; dq += (double)rowsum[((size_t)w * BM + tid) * 2 + 1]; }
+    t2v_st_dev(reinterpret_cast<float*>(p.gn_part + (((size_t)tile_m * tiles_n + tile_n) * BM + tid) * 2), t2v_rec_pack(ds, dq, p.gn_seq));
   }
-  t2v_wait_vm0();
-  // arrive, then — under the barrier's latency — the fp32 stream goes out (from the registers, row-major)
-  t2v_grid_arrive(p.gn_bar, gridDim.x);
+  // (barrier mode: arrive;) then — under the exchange's latency — the fp32 stream goes out (from the registers, row-major)
+  bool released = false;
+  if (!tags) {
+    t2v_wait_vm0();
+    released = t2v_grid_arrive(p.gn_bar, gridDim.x);
+  }
 #pragma unroll
   for (int a = 0; a < TM; ++a) {
     const int mt = m0 + (wm * TM + a) * 32;
@@ -883,29 +962,26 @@ __device__ __forceinline__ void t2v_epilogue_rows_lnx(const GemmParams& p, f32x1
       }
     }
   }
-  t2v_grid_wait(p.gn_bar, gen0, p.gn_fault);
-  if (tid < BM / 2) {
-    double s[4] = {0.0, 0.0, 0.0, 0.0};
-    const float* base = part + ((size_t)tile_m * tiles_n * BM + 2 * tid) * 2;
-    for (int tn = 0; tn < tiles_n; tn += 8) {                      // EIGHT 16-byte device-scope loads in flight per round, summed in tile order
+  if (!tags) t2v_grid_wait(p.gn_bar, gen0, released, p.gn_fault);
+  if (tid < BM) {
+    double ds = 0.0, dq = 0.0;
+    const double* base = p.gn_part + ((size_t)tile_m * tiles_n * BM + tid) * 2;
+    for (int tn = 0; tn < tiles_n; tn += 8) {                      // EIGHT records in flight per round, summed in tile order
       f32x4 t[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) t[j] = t2v_ld_dev(base + (size_t)(tn + j < tiles_n ? tn + j : tn) * BM * 2);
-      t2v_wait_dev(t[0], t[1], t[2], t[3]);
-      t2v_wait_dev(t[4], t[5], t[6], t[7]);
+      for (int j = 0; j < 8; ++j) t[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int nrec = min(8, tiles_n - tn);
+      t2v_rec_fetch8([&](int j) { return reinterpret_cast<const float*>(base + (size_t)(tn + j) * BM * 2); }, nrec, p.gn_want, p.gn_fault, t);
 #pragma unroll
       for (int j = 0; j < 8; ++j)
-        if (tn + j < tiles_n) { s[0] += (double)t[j][0]; s[1] += (double)t[j][1]; s[2] += (double)t[j][2]; s[3] += (double)t[j][3]; }
+        if (j < nrec) t2v_rec_add(t[j], ds, dq);
     }
     const double inv_n = 1.0 / (double)p.N;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const double m = s[2 * k] * inv_n;
-      double var = s[2 * k + 1] * inv_n - m * m;
-      var = var < 0.0 ? 0.0 : var;
-      rowstat[(2 * tid + k) * 2] = (float)m;
-      rowstat[(2 * tid + k) * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.ln_eps));
-    }
+    const double m = ds * inv_n;
+    double var = dq * inv_n - m * m;
+    var = var < 0.0 ? 0.0 : var;
+    rowstat[tid * 2] = (float)m;
+    rowstat[tid * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.ln_eps));
   }
   __syncthreads();
 #pragma unroll

@@ -187,7 +187,7 @@ class Program:
         self.gn_epilogue = self.gn_coop and os.environ.get("T2V_GN_EPI", "1") != "0"
         # its exchange scratch ([tiles_m][2][tiles_n][GN_PIECES] fp64 pairs, <= 512 tiles): ONE region for every fused op of the program
         # (launches are stream-ordered and each rewrites every word it reads), allocated here for the reason given above for the sync words
-        self._gn_part: Optional[Buf] = self.alloc(1 << 20, 1, "u8") if self.gn_epilogue else None
+        self._gn_part: Optional[Buf] = self.alloc(2 << 20, 1, "u8") if self.gn_epilogue else None
         # Buffers whose free() is postponed: operands of the GEMM emitted last.  If the next groupnorm() makes itself that GEMM's
         # epilogue, its output is written by the SAME launch that still reads these — it must not be allocated over them.
         self._deferred: List[Buf] = []
@@ -455,7 +455,7 @@ class Program:
                 tiles_m, tiles_n = -(-M // bm), -(-n // bn)
                 ln_x = (split == 1 and gather == L.GATHER_PLAIN and epi == L.EPI_NONE and act == 0 and rowbias is None and not bias_along_m
                         and k % 64 == 0 and not out_lo and (tile != 0 or n % 128 == 0) and tiles_m * tiles_n <= per_cu * self.device_cus()
-                        and tiles_m * tiles_n * bm * 8 <= self._gn_part.rows and ln_out.ld % 4 == 0)
+                        and tiles_m * tiles_n * bm * 16 <= self._gn_part.rows and ln_out.ld % 4 == 0)
             if ln_fused or ln_x:
                 I[8], I[9] = (2 if ln_x else 1), ln_out.ld
                 op.f[0] = ln_eps
@@ -568,7 +568,7 @@ class Program:
             if os.environ.get("T2V_GN_EPI_SPLITK", "1") == "0" or op.p[7].space != "null" or N % 8 or N // 8 > 512 or groups > 32:
                 return None
             rpass = 512 // (N // 8)
-            chunks = [n_inst * -(-rows // (rpass * kr)) for kr in (4, 8, 12, 16, 20)]
+            chunks = [n_inst * -(-rows // (rpass * kr)) for kr in (1, 2, 4, 8, 12, 16, 20)]
             fit = [c for c in chunks if c <= self.device_cus()]
             if not fit or fit[0] * groups * 16 > self._gn_part.rows:
                 return None
@@ -676,6 +676,8 @@ class Program:
                 # by the library from the device's CU count; otherwise it runs the three launches on the same scratch)
                 op.i[15] = 1
                 op.p[5] = self.sync_ref("barrier")
+                if self._gn_part is not None:        # tagged-record exchange instead of the barrier: the program's record-only region
+                    op.p[7], op.i[18] = self._gn_part.ref, self._gn_part.rows
             op.meta = dict(n_inst=n_inst, rows=rows, C=x.cols, dt=x.dtype, fused=int(op.i[12]), coop=int(op.i[15]))
             op.out = out
             self._emit(op)

@@ -1,7 +1,8 @@
 """GPU (-m gpu): the single-pass GroupNorm's grid barrier is BOUNDED (VERDICT r03 weak #6 / ADVICE r03).
 
-A barrier that can never complete — here: its arrival counter is corrupted after binding, which is what a launch aborted
-mid-barrier or a co-tenant holding compute units looks like to the waiters — must not hang the device: every waiter gives up
+An exchange that can never complete — here: the launch is told to wait for records nobody publishes (round 5: tagged records; with
+T2V_EXCHANGE=barrier the barrier's arrival counter is corrupted after binding), which is what a launch aborted mid-way or a co-tenant
+holding compute units looks like to the waiters — must not hang the device: every waiter gives up
 after 0.25 s, the fault is raised in host-mapped memory, the NEXT library call reports T2V_ERR_ASYNC once, and from then on the
 three-launch GroupNorm runs (and is correct).  Runs in its own process: the fault switches the cooperative path off for the rest
 of the process that saw it."""
@@ -14,7 +15,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 WORKER = r'''
-import sys, time, torch
+import os, sys, time, torch
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
 from harness import fill, read, rel_l2
 from interp import Interp
@@ -36,16 +37,17 @@ st = torch.cuda.current_stream(dev).cuda_stream
 bp.run({}, st); torch.cuda.synchronize(); L.async_status()                      # healthy run first
 got = Interp(P, w, poison=False); got.arena = arena.cpu()
 assert rel_l2(read(got, out).float(), read(it, out).float()) < 1e-3
-bar = P.sync_ref("barrier").off
-# counter 0 (64-bit, counters advance by 2^32 per barrier): a high word far ahead of the other seven — the workgroups of group 0 read their
-# epoch from it and wait for the others to reach a count they never will
-arena[bar + 4: bar + 8].copy_(torch.tensor([1 << 30], dtype=torch.int32).view(torch.uint8).to(dev))
+if os.environ.get("T2V_EXCHANGE") == "barrier":
+    bar = P.sync_ref("barrier").off
+    arena[bar: bar + 4].copy_(torch.tensor([1 << 30], dtype=torch.int32).view(torch.uint8).to(dev))   # level-1 counter 0 can never reach its count
+else:
+    L.load().t2v_debug_poison_exchange(1)       # tagged-record exchange: the next launch waits for records that nobody publishes
 t0 = time.time(); bp.run({}, st); torch.cuda.synchronize(); dt = time.time() - t0
 assert dt < 5.0, f"the poisoned barrier took {dt:.1f}s: the wait is not bounded"
 try:
     L.async_status(); raise SystemExit("no fault was reported")
 except L.T2VError as e:
-    assert "grid barrier" in str(e), str(e)
+    assert "gave up waiting" in str(e), str(e)
 L.async_status()                                                                 # reported once
 arena.copy_(arena0.to(dev))                                                      # (the poisoned counter is gone with the refill)
 bp.run({}, st); torch.cuda.synchronize(); L.async_status()                       # three-launch path from now on

@@ -56,6 +56,18 @@ stage_abgnepi() {   # same-box A/B of the per-op UNet step: fused GroupNorm epil
   prof noepi2 T2V_GN_EPI=0
   prof epi_only32 T2V_GN_EPI_TILE0=0 T2V_GN_EPI_TILE5=0 T2V_GN_EPI_TILE3=0
   prof nolnx T2V_LN_X=0
+  prof barrier T2V_EXCHANGE=barrier
+  prof epi3 T2V_X=0
+  prof barrier2 T2V_EXCHANGE=barrier
+}
+stage_ab2() {       # short same-box A/B: fused norms on / off, ModelScope and VideoCrafter steps
+  prof epi T2V_X=0
+  prof noepi T2V_GN_EPI=0
+  prof nosplitk T2V_GN_EPI_SPLITK=0
+  for v in "T2V_X=0" "T2V_GN_EPI=0"; do
+    env $v timeout 300 python tools/profile_unet.py 16 32 32 2 lvdm > gpurun_out/${TAG}_prof_lvdm_$(echo $v | tr '=' '_').log 2>&1
+    echo "== lvdm $v"; sed -n 4,5p gpurun_out/${TAG}_prof_lvdm_$(echo $v | tr '=' '_').log
+  done
 }
 stage_lvdm() {      # configs[4]: bench line + step profile with the 128x320 tile (default) and without
   timeout 400 python bench.py --model lvdm --steps 2 --warmup 1 > gpurun_out/${TAG}_bench_lvdm.json 2> gpurun_out/${TAG}_bench_lvdm.err; echo "bench lvdm exit $?"; cut -c1-200 gpurun_out/${TAG}_bench_lvdm.json
