@@ -95,7 +95,7 @@ __device__ __forceinline__ void epi_store_geglu(const GemmParams& p, int m, int 
 // WM x WN waves; each wave owns TM x TN MFMA tiles (32 tokens x 32 channels each).
 // XE: extra epilogue of the plain (T2V_EPI_NONE) path — 0 none, 1 fused LayerNorm second output (whole-row tiles), 2 fused GroupNorm
 // (+SiLU) of the result with a grid barrier (T2V_EPI_GN); separate instantiations, so the plain kernels keep their register budgets.
-template <int WM, int WN, int TM, int TN, int BK, int STAGES, int MINW, int GATHER, bool PP, int XE = 0, bool TAT = false>
+template <int WM, int WN, int TM, int TN, int BK, int STAGES, int MINW, int GATHER, int PP, int XE = 0, bool TAT = false>
 __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm2_kernel(const GemmParams p) {
   constexpr int NW = WM * WN;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -243,10 +243,10 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm2_kernel(const GemmPar
       boff = (delta + (long)chunk * BK) * 2;
     }
   };
-  auto stage_piece = [&](int slot, int j) {        // j in [0, LPS): token pieces first, then weights
-    unsigned char* base = smem + slot * STAGE_BYTES;
+  // source of piece j of the k-tile being staged (per-lane pointer; advances the running pointers) and its 1-KiB LDS destination
+  auto piece_src = [&](int j) -> const void* {     // j in [0, LPS): token pieces first, then weights
+    const void* src = zero;
     if (j < XPW) {
-      const void* src = zero;
       if (GATHER == T2V_GATHER_PLAIN) {
         if (live) { src = xptr[j]; xptr[j] += xstep[j]; }
       } else if (!general) {
@@ -259,13 +259,24 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm2_kernel(const GemmPar
         const long row = xoff[j] + (long)(yv >> 1) * p.Win + (xv >> 1);
         if (live && ((xmask[j] >> ktap) & 1u)) src = p.A + row * p.lda + (long)chunk * BK + lc * 8;
       }
-      glds16(src, base + (wave + j * NW) * 1024);
     } else {
       const int jw = j - XPW;
-      const void* src = zero;
       if (live) { src = wptr[jw]; wptr[jw] += wstep[jw]; }
-      glds16(src, wdummy[jw] ? (smem + DUMMY_OFF) : (base + (XSLABS + wave + jw * NW) * 1024));
     }
+    return src;
+  };
+  auto piece_dst = [&](int slot, int j) -> unsigned char* {
+    unsigned char* base = smem + slot * STAGE_BYTES;
+    if (j < XPW) return base + (wave + j * NW) * 1024;
+    const int jw = j - XPW;
+    return wdummy[jw] ? (smem + DUMMY_OFF) : (base + (XSLABS + wave + jw * NW) * 1024);
+  };
+  auto stage_piece = [&](int slot, int j) {
+#ifdef T2V_G2_NODMA      // timing experiment only (wrong results): the main loop WITHOUT its operand DMA — what do the LDS-DMA instructions cost?
+    if (staged >= STAGES - 1) return;
+#endif
+    const void* src = piece_src(j);
+    glds16(src, piece_dst(slot, j));
   };
   auto stage_end = [&]() {
     if (GATHER != T2V_GATHER_PLAIN && live) {
@@ -282,13 +293,15 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm2_kernel(const GemmPar
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  // prologue: STAGES-1 k-tiles in flight
+  // prologue: STAGES-1 k-tiles in flight (the register-staged schedule, PP == 3, has its own)
+  if constexpr (PP != 3) {
 #pragma unroll
-  for (int g = 0; g < STAGES - 1; ++g) {
-    stage_begin();
+    for (int g = 0; g < STAGES - 1; ++g) {
+      stage_begin();
 #pragma unroll
-    for (int j = 0; j < LPS; ++j) stage_piece(g, j);
-    stage_end();
+      for (int j = 0; j < LPS; ++j) stage_piece(g, j);
+      stage_end();
+    }
   }
 
   // fragment read addressing: lane reads row (tile_row0 + lane&31), logical chunk kk*2 + (lane>>5);
@@ -309,12 +322,157 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm2_kernel(const GemmPar
   }
 
   constexpr int KSTEPS = BK / 16;
-  if constexpr (!PP) {
+  if constexpr (PP == 3) {
+    // ---- operands staged through REGISTERS (global_load_dwordx4 -> ds_write_b128) instead of LDS-DMA (round 5) -------------------
+    // Finding of round 5 (tools/gemm_pf_probe.py on a build whose main loop issues no DMA): the LDS-DMA instructions cost 27 % of the
+    // loop (256x256 tile 1041 -> 1422 TF/s on 8192^3 without them) — not the barrier (the two waves of a SIMD run their k-tiles one
+    // after the other: the leader's barrier wait is the follower's MFMA time), not the fragment latency (prefetching it across the
+    // barrier: +-0).  A `global_load_lds_dwordx4` moves 1 KiB per instruction and holds the issuing wave's port ~60-185 cycles while
+    // the address unit walks its 64 lanes: 64 KiB per k-tile = 64 such instructions per CU against 2048 MFMA cycles per SIMD.  The
+    // plain vector load is four times cheaper to issue per KiB and ds_write_b128 costs ~13 LDS cycles; the price is LPS * 4 staging
+    // registers per lane and one more pipeline level: tile t+2 is in flight to registers while tile t+1 goes from registers to the
+    // other LDS slot and tile t is being multiplied.  Two LDS slots (the slot written in iteration t held tile t-1: everyone finished
+    // reading it before the barrier that ended iteration t-1), one barrier per k-tile, as before.
+    static_assert(STAGES == 2, "register staging: two LDS slots");
+    f32x4 rg[LPS];
+    stage_begin();
+#pragma unroll
+    for (int j = 0; j < LPS; ++j) rg[j] = *reinterpret_cast<const f32x4*>(piece_src(j));
+    stage_end();
+#pragma unroll
+    for (int j = 0; j < LPS; ++j) *reinterpret_cast<f32x4*>(piece_dst(0, j) + lane * 16) = rg[j];
+    stage_begin();
+#pragma unroll
+    for (int j = 0; j < LPS; ++j) rg[j] = *reinterpret_cast<const f32x4*>(piece_src(j));
+    stage_end();
+    __syncthreads();
     int slot = 0;
     for (int t = 0; t < nkt; ++t) {
+      const unsigned char* st = smem + slot * STAGE_BYTES;
+      const int nslot = slot ^ 1;
+      stage_begin();                                   // (tile t+2: the zero page past the end)
+#pragma unroll
+      for (int kk = 0; kk < KSTEPS; ++kk) {
+        const int lc4 = (kk * 2 + fhalf) << 4;
+        f16x8 xf[TM], wf[TN];
+#pragma unroll
+        for (int a = 0; a < TM; ++a) xf[a] = *reinterpret_cast<const f16x8*>(st + xbase[a] + (lc4 ^ xsw[a]));
+#pragma unroll
+        for (int b = 0; b < TN; ++b) wf[b] = *reinterpret_cast<const f16x8*>(st + wbase[b] + (lc4 ^ wsw[b]));
+        // this k-step's share of the pieces: tile t+1 from the registers into the other slot, then tile t+2 on its way into them
+#pragma unroll
+        for (int j = (LPS * kk) / KSTEPS; j < (LPS * (kk + 1)) / KSTEPS; ++j) {
+          *reinterpret_cast<f32x4*>(piece_dst(nslot, j) + lane * 16) = rg[j];
+          rg[j] = *reinterpret_cast<const f32x4*>(piece_src(j));
+        }
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[b], xf[a], acc[a][b], 0, 0, 0);
+      }
+      stage_end();
+      __syncthreads();                                 // (waits for this wave's ds_writes, then everyone's)
+      slot = nslot;
+    }
+  } else if constexpr (PP == 2) {
+    // ---- lock-step schedule with the fragments of the NEXT k-tile prefetched across the barrier (round 5) ------------------------
+    // Phase stamps of the plain schedule below (tools/gemm_phase_probe.py, 256x256 tile, 8192^3): of ~3060 cycles per k-tile a wave
+    // spends ~40 waiting for its DMA, ~550 at the barrier (the two waves of a SIMD run their MFMAs one after the other — the leader
+    // waits for the follower, the matrix pipe is busy meanwhile) and ~340 between the barrier and its first MFMA, waiting for the
+    // first fragment reads: THAT is when the pipe idles.  Here the barrier sits before the LAST k-step's MFMAs: a wave that has its
+    // fragments for that step (lgkmcnt(0)) and its DMA pieces of the next tile (vmcnt) meets the others, issues the ds_reads of the
+    // next tile's first k-step and only then runs the last step's MFMAs — the LDS latency hides under them.  Same number of
+    // barriers; every DMA piece of an iteration is issued in k-steps 0 .. KSTEPS-2, so that the vmcnt count at the barrier is exact;
+    // the slot a DMA overwrites was last read before the previous barrier (reads complete: lgkmcnt(0) precedes it).
+    static_assert(KSTEPS >= 2, "needs a k-step to hide the prefetch under");
+    wait_vmcnt<LPS*(STAGES - 2)>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    f16x8 xc[TM], wc[TN];
+    {
+      const int lc4 = fhalf << 4;
+#pragma unroll
+      for (int a = 0; a < TM; ++a) xc[a] = *reinterpret_cast<const f16x8*>(smem + xbase[a] + (lc4 ^ xsw[a]));
+#pragma unroll
+      for (int b = 0; b < TN; ++b) wc[b] = *reinterpret_cast<const f16x8*>(smem + wbase[b] + (lc4 ^ wsw[b]));
+    }
+    int slot = 0;
+    for (int t = 0; t < nkt; ++t) {
+      int fs = slot + STAGES - 1;
+      if (fs >= STAGES) fs -= STAGES;
+      const int nslot = slot + 1 == STAGES ? 0 : slot + 1;
+      stage_begin();
+      const unsigned char* st = smem + slot * STAGE_BYTES;
+      const unsigned char* stn = smem + nslot * STAGE_BYTES;
+#pragma unroll
+      for (int kk = 0; kk < KSTEPS; ++kk) {
+        f16x8 xn[TM], wn[TN];
+        if (kk + 1 < KSTEPS) {
+          const int lc4 = ((kk + 1) * 2 + fhalf) << 4;
+#pragma unroll
+          for (int a = 0; a < TM; ++a) xn[a] = *reinterpret_cast<const f16x8*>(st + xbase[a] + (lc4 ^ xsw[a]));
+#pragma unroll
+          for (int b = 0; b < TN; ++b) wn[b] = *reinterpret_cast<const f16x8*>(st + wbase[b] + (lc4 ^ wsw[b]));
+        } else {
+#pragma unroll
+          for (int a = 0; a < TM; ++a) xn[a] = xc[a];
+#pragma unroll
+          for (int b = 0; b < TN; ++b) wn[b] = wc[b];
+          if (t + 1 < nkt) {                                           // wave-uniform
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // this step's fragments are in; every read of the current slot is done
+            wait_vmcnt<LPS*(STAGES - 2)>();                            // my pieces of the next tile have landed
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const int lc4 = fhalf << 4;
+#pragma unroll
+            for (int a = 0; a < TM; ++a) xn[a] = *reinterpret_cast<const f16x8*>(stn + xbase[a] + (lc4 ^ xsw[a]));
+#pragma unroll
+            for (int b = 0; b < TN; ++b) wn[b] = *reinterpret_cast<const f16x8*>(stn + wbase[b] + (lc4 ^ wsw[b]));
+          }
+        }
+        constexpr int SPREAD = STAGES == 2 ? (KSTEPS / 2 > 0 ? KSTEPS / 2 : 1) : KSTEPS - 1;
+        if (kk < SPREAD) {
+#pragma unroll
+          for (int j = (LPS * kk) / SPREAD; j < (LPS * (kk + 1)) / SPREAD; ++j) stage_piece(fs, j);
+        }
+        if (kk + 1 == KSTEPS && t + 1 < nkt) {
+          // the MFMAs of the last step read fragments fetched BEFORE the barrier; keep the compiler from sinking the prefetch below them
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wc[b], xc[a], acc[a][b], 0, 0, 0);
+#pragma unroll
+        for (int a = 0; a < TM; ++a) xc[a] = xn[a];
+#pragma unroll
+        for (int b = 0; b < TN; ++b) wc[b] = wn[b];
+      }
+      stage_end();
+      slot = nslot;
+    }
+  } else if constexpr (PP == 0) {
+    int slot = 0;
+#ifdef T2V_G2_TIMING     // experiment build (tools/build_variant.py): where does a wave park in a k-tile?  cycles -> p.ws[wave slot][4]
+    unsigned long long tm_vm = 0, tm_bar = 0, tm_lds = 0;
+    const unsigned long long tm_begin = clock64();
+#endif
+    for (int t = 0; t < nkt; ++t) {
+#ifdef T2V_G2_TIMING
+      const unsigned long long tm0 = clock64();
+#endif
       wait_vmcnt<LPS*(STAGES - 2)>();
+#ifdef T2V_G2_TIMING
+      const unsigned long long tm1 = clock64();
+#endif
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+#ifdef T2V_G2_TIMING
+      const unsigned long long tm2 = clock64();
+      tm_vm += tm1 - tm0; tm_bar += tm2 - tm1;
+#endif
       int fs = slot + STAGES - 1;
       if (fs >= STAGES) fs -= STAGES;
       stage_begin();
@@ -327,6 +485,9 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm2_kernel(const GemmPar
         for (int a = 0; a < TM; ++a) xf[a] = *reinterpret_cast<const f16x8*>(st + xbase[a] + (lc4 ^ xsw[a]));
   #pragma unroll
         for (int b = 0; b < TN; ++b) wf[b] = *reinterpret_cast<const f16x8*>(st + wbase[b] + (lc4 ^ wsw[b]));
+#ifdef T2V_G2_TIMING
+        if (kk == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tm_lds += clock64() - tm2; }
+#endif
         // this k-step's share of the next tile's DMA, issued between the fragment reads and the MFMAs.
         // With a 2-deep ring the pieces must land before the next barrier, so they go out in the first
         // half of the k-tile; with 3 stages they have a whole extra k-tile and are spread over all steps.
@@ -344,6 +505,12 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm2_kernel(const GemmPar
       stage_end();
       slot = slot + 1 == STAGES ? 0 : slot + 1;
     }
+#ifdef T2V_G2_TIMING
+    if (lane == 0 && p.ws != nullptr && p.splitk == 1) {
+      float* dst = p.ws + ((size_t)blockIdx.x * NW + wave) * 4;
+      dst[0] = (float)tm_vm; dst[1] = (float)tm_bar; dst[2] = (float)tm_lds; dst[3] = (float)(clock64() - tm_begin);
+    }
+#endif
   } else {
     // ---- ping-pong schedule ---------------------------------------------------------------------
     // The 8 waves form two groups (waves 0-3 / 4-7: one wave of each group per SIMD).  A k-tile is
@@ -636,7 +803,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm2_kernel(const GemmPar
   }
 }
 
-template <int WM, int WN, int TM, int TN, int BK, int STAGES, int MINW, int GATHER, bool PP, int XE = 0, bool TAT = false>
+template <int WM, int WN, int TM, int TN, int BK, int STAGES, int MINW, int GATHER, int PP, int XE = 0, bool TAT = false>
 hipError_t launch_cfg_gather(const GemmParams& p, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   // TAT: the attention epilogue re-uses the operand ring for q | k (BM x 272 B) and V^T (<= 12 pixels x 64 x 72 B)
@@ -663,7 +830,7 @@ hipError_t launch_cfg_gather(const GemmParams& p, hipStream_t s) {
   return hipGetLastError();
 }
 
-template <int WM, int WN, int TM, int TN, int BK, int STAGES, int MINW, bool PP = false>
+template <int WM, int WN, int TM, int TN, int BK, int STAGES, int MINW, int PP = 0>
 hipError_t launch_cfg(const GemmParams& pin, hipStream_t s) {
   GemmParams p = pin;
   const int KT = (p.K + BK - 1) / BK;
@@ -679,24 +846,24 @@ hipError_t launch_cfg(const GemmParams& pin, hipStream_t s) {
     if (p.splitk <= 1 || p.epi != T2V_EPI_NONE || tiles > T2V_SYNC_INTS || p.gn_out != nullptr) p.tickets = nullptr;
   }
   // tiles with a T2V_EPI_GN instantiation (validated by the executor): the whole-row tiles 8 / 11, and the 128-row tiles 3 / 5
-  constexpr bool GN_TILE = !PP && (((WM == 6 || WM == 4) && WN == 2 && TM == 1 && TN == 5) || (WM == 2 && WN == 4 && TM == 2 && (TN == 1 || TN == 2)));
+  constexpr bool GN_TILE = PP != 1 && (((WM == 6 || WM == 4) && WN == 2 && TM == 1 && TN == 5) || (WM == 2 && WN == 4 && TM == 2 && (TN == 1 || TN == 2)));
   // (with split-K the norm runs in the reduction's launch instead: any tile, t2v_launch_splitk_reduce_gn below)
   const bool gn_here = p.gn_out != nullptr && p.splitk == 1;
   if (gn_here && (!GN_TILE || (p.gather == T2V_GATHER_CONV3X3 && p.up))) return hipErrorInvalidValue;
   // ... and with a cross-tile LayerNorm instantiation: 5 (128x128), 12 (64x64), 9 (192x256), 3 (128x256); plain gather only
-  constexpr bool LNX_TILE = !PP && ((WM == 2 && WN == 4 && TM == 2 && (TN == 1 || TN == 2)) || (WM == 2 && WN == 2 && TM == 1 && TN == 1) ||
+  constexpr bool LNX_TILE = PP != 1 && ((WM == 2 && WN == 4 && TM == 2 && (TN == 1 || TN == 2)) || (WM == 2 && WN == 2 && TM == 1 && TN == 1) ||
                                     (WM == 6 && WN == 2 && TM == 1 && TN == 4));
   if (p.ln_x && (!LNX_TILE || p.gather != T2V_GATHER_PLAIN)) return hipErrorInvalidValue;
   hipError_t e;
   switch (p.gather) {
     case T2V_GATHER_PLAIN:
-      if constexpr (WM == 6 && WN == 2 && TM == 1 && TN == 3 && !PP) {
+      if constexpr (WM == 6 && WN == 2 && TM == 1 && TN == 3 && PP == 0) {
         if (p.epi != T2V_EPI_TATTN || p.splitk != 1 || p.tpix < 1 || p.tpix > 12 || p.tpix * p.F > BM_OF(WM, TM) || p.F > 32) return hipErrorInvalidValue;
         e = launch_cfg_gather<WM, WN, TM, TN, BK, STAGES, MINW, T2V_GATHER_PLAIN, PP, 0, true>(p, s);
         break;
       }
       if (p.epi == T2V_EPI_TATTN) return hipErrorInvalidValue;
-      if constexpr ((WM == 6 || WM == 4) && WN == 2 && TM == 1 && TN == 5 && !PP) {      // whole-row tiles: 192x320 / 128x320
+      if constexpr ((WM == 6 || WM == 4) && WN == 2 && TM == 1 && TN == 5 && PP != 1) {      // whole-row tiles: 192x320 / 128x320
         if (p.ln_out != nullptr) {
           e = launch_cfg_gather<WM, WN, TM, TN, BK, STAGES, MINW, T2V_GATHER_PLAIN, PP, 1>(p, s);
           break;
@@ -737,6 +904,23 @@ hipError_t launch_cfg(const GemmParams& pin, hipStream_t s) {
 // (few-row levels: latency-bound, keep 96 KiB per CU in flight) — 64-wide k-tiles
 // (full 128-byte lines per row = one conv reduction chunk), 2-3 stage ring, one workgroup per CU.
 hipError_t t2v_launch_gemm2(const GemmParams& p, int tile, hipStream_t s) {
+#ifdef T2V_G2_FEW        // experiment build (with -DT2V_G2_EXPERIMENTS): only the tiles under study (compile time)
+  switch (tile) {
+    case 1: return launch_cfg<2, 4, 4, 2, 64, 2, 2>(p, s);
+    case 2: return launch_cfg<4, 2, 2, 5, 64, 2, 2>(p, s);
+    case 3: return launch_cfg<2, 4, 2, 2, 64, 3, 2>(p, s);
+    case 8: return launch_cfg<6, 2, 1, 5, 64, 2, 3>(p, s);
+    case 13: return launch_cfg<2, 4, 4, 2, 64, 2, 2, 2>(p, s);
+    case 14: return launch_cfg<4, 2, 2, 5, 64, 2, 2, 2>(p, s);
+    case 15: return launch_cfg<2, 4, 2, 2, 64, 3, 2, 2>(p, s);
+    case 17: return launch_cfg<6, 2, 1, 5, 64, 2, 3, 2>(p, s);
+    case 18: return launch_cfg<2, 4, 4, 2, 64, 2, 2, 3>(p, s);
+    case 19: return launch_cfg<4, 2, 2, 5, 64, 2, 2, 3>(p, s);
+    case 20: return launch_cfg<6, 2, 1, 5, 64, 2, 3, 3>(p, s);
+    case 21: return launch_cfg<2, 4, 2, 2, 64, 2, 2, 3>(p, s);
+    default: return hipErrorInvalidValue;
+  }
+#endif
   switch (tile) {
     case 1: return launch_cfg<2, 4, 4, 2, 64, 2, 2>(p, s);   // 2 x 64 KiB
     case 2: return launch_cfg<4, 2, 2, 5, 64, 2, 2>(p, s);   // 2 x 72 KiB
@@ -750,10 +934,23 @@ hipError_t t2v_launch_gemm2(const GemmParams& p, int tile, hipStream_t s) {
                                                              // FULL reduction each — no split-K slabs, no reduction launch (experiment, round 4)
     case 11: return launch_cfg<4, 2, 1, 5, 64, 2, 2>(p, s);  // 128x320, 8 waves (2 per SIMD), 2 x 56 KiB: M = 32768 (VideoCrafter, 16 frames) -> exactly
                                                              // 256 workgroups where 192-row tiles make 171; also the b = 1 per-GPU shapes (M = 24576 -> 192)
-    case 6: return launch_cfg<2, 4, 4, 2, 64, 2, 2, true>(p, s);   // 256x256 ping-pong (two staggered wave groups)
+#ifdef T2V_G2_EXPERIMENTS   // round-5 schedule experiments, measured and NOT selected (tools/gemm_pf_probe.py): instantiated on request only
+    // 13 .. 17 = 1, 2, 3, 5, 8 with the next k-tile's first fragments prefetched across the barrier: +-0 (-1.5 % .. +3.7 %)
+    case 13: return launch_cfg<2, 4, 4, 2, 64, 2, 2, 2>(p, s);
+    case 14: return launch_cfg<4, 2, 2, 5, 64, 2, 2, 2>(p, s);
+    case 15: return launch_cfg<2, 4, 2, 2, 64, 3, 2, 2>(p, s);
+    case 16: return launch_cfg<2, 4, 2, 1, 64, 4, 2, 2>(p, s);
+    case 17: return launch_cfg<6, 2, 1, 5, 64, 2, 3, 2>(p, s);
+    // 18 .. 21 = 1, 2, 8 and the 128x256 tile with the operands staged through registers instead of LDS-DMA: +4 % on 8192^3, -1 .. -8 % on the UNet's shapes
+    case 18: return launch_cfg<2, 4, 4, 2, 64, 2, 2, 3>(p, s);
+    case 19: return launch_cfg<4, 2, 2, 5, 64, 2, 2, 3>(p, s);
+    case 20: return launch_cfg<6, 2, 1, 5, 64, 2, 3, 3>(p, s);
+    case 21: return launch_cfg<2, 4, 2, 2, 64, 2, 2, 3>(p, s);
+#endif
+    case 6: return launch_cfg<2, 4, 4, 2, 64, 2, 2, 1>(p, s);   // 256x256 ping-pong (two staggered wave groups)
     case 7:                                                         // 256x320 ping-pong
       if (p.gather == T2V_GATHER_CONV3X3 && p.up) return launch_cfg<4, 2, 2, 5, 64, 2, 2>(p, s);   // (upsample gather: register budget)
-      return launch_cfg<4, 2, 2, 5, 64, 2, 2, true>(p, s);
+      return launch_cfg<4, 2, 2, 5, 64, 2, 2, 1>(p, s);
     default: return hipErrorInvalidValue;
   }
 }

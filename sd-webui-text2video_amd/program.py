@@ -312,7 +312,9 @@ class Program:
             bm, bn, bk = 128, (64 if (n % 128 != 0 and n % 128 <= 64) else 128), 64
         else:
             bm, bn, bk = {1: (256, 256, 64), 2: (256, 320, 64), 3: (128, 256, 64), 4: (128, 128, 64), 5: (128, 128, 64),
-                          6: (256, 256, 64), 7: (256, 320, 64), 8: (192, 320, 64), 9: (192, 256, 64), 11: (128, 320, 64), 12: (64, 64, 64)}[tile]
+                          6: (256, 256, 64), 7: (256, 320, 64), 8: (192, 320, 64), 9: (192, 256, 64), 11: (128, 320, 64), 12: (64, 64, 64),
+                          13: (256, 256, 64), 14: (256, 320, 64), 15: (128, 256, 64), 16: (128, 128, 64), 17: (192, 320, 64),
+                          18: (256, 256, 64), 19: (256, 320, 64), 20: (192, 320, 64), 21: (128, 256, 64)}[tile]
         tiles = math.ceil(M / bm) * math.ceil(n / bn)
         kt = math.ceil(k / bk)
         split = 1

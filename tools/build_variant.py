@@ -1,5 +1,5 @@
 """Build an A/B variant of libt2v_hip.so with extra -D flags:  python tools/build_variant.py <tag> -DFOO=0 ...
--> sd-webui-text2video_amd/build/variants/libt2v_hip_<tag>.so (select with T2V_LIB_PATH; under build/: git-ignored, and never beside the
+-> tools/variants/libt2v_hip_<tag>.so (select with T2V_LIB_PATH; git-ignored, and never beside the
 product library — a timing-only variant may compute wrong results)."""
 import os
 import subprocess
@@ -20,7 +20,7 @@ for src in ge.SOURCES:
     procs.append((obj, subprocess.Popen(cmd, cwd=ROOT)))
 for obj, pr in procs:
     assert pr.wait() == 0, obj
-os.makedirs(os.path.join(ge.PKG, "build", "variants"), exist_ok=True)
-out = os.path.join(ge.PKG, "build", "variants", f"libt2v_hip_{tag}.so")
+os.makedirs(os.path.join(ROOT, "tools", "variants"), exist_ok=True)
+out = os.path.join(ROOT, "tools", "variants", f"libt2v_hip_{tag}.so")
 subprocess.run([ge._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + [o for o, _ in procs] + ["-ldl"], check=True)
 print(out)

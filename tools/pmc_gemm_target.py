@@ -10,7 +10,11 @@ sys.path.insert(0, ROOT)
 from sd_webui_text2video_amd.program import BoundProgram, Program, Ref  # noqa: E402
 
 dev = torch.device("cuda:0")
-for (M, N, K, tile) in [(8192, 8192, 8192, 1), (49152, 320, 2880, 2), (8192, 8192, 8192, 3)]:
+# round 5: tiles 1 / 2 / 8 on the square shape (N = 8320 for the 320-wide tiles) and on the 32x32-level convolution shape
+SHAPES = [(8192, 8192, 8192, 1), (8192, 8320, 8192, 2), (8192, 8320, 8192, 8), (49152, 320, 2880, 2), (49152, 320, 2880, 8), (8192, 8192, 8192, 3)]
+if len(sys.argv) > 1:
+    SHAPES = [SHAPES[int(i)] for i in sys.argv[1].split(",")]
+for (M, N, K, tile) in SHAPES:
     P = Program()
     P.force_tile = tile
     a, out = P.alloc(M, K, "f16"), P.alloc(M, N, "f16")
