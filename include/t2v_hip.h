@@ -170,6 +170,8 @@ enum t2v_gather {
  *      [nparts][n_inst][groups][2] fp64 (phase 1 folds this rank's block partials into its part; ALLGATHER of
  *      n_inst*groups*16 bytes per part), then this rank's block partials, then {mean, rstd};
  *      f: 0 eps;  p: 0 x, 1 gamma, 2 beta, 3 out fp16, 4 scratch, 5 grid-barrier words (i[15]), 6 producer strips (phase 3),
+ *      8 (optional; phases 0 / 2 / 3) second output: the RAW input as fp16 [n_inst * rows, i[19]] (+ its low-order image at column i[20] > 0) — the
+ *        operand of a 1x1 convolution that reads the same tensor (ResBlock skip_connection beside in_layers, t2v_model.py:965)
  *      7 (i[15], optional) exchange-record region of i[18] bytes that nothing but fused-norm launches ever writes (zero at bind time): the
  *        single-pass kernel then exchanges TAGGED records (no grid barrier) — the same region GEMM p[10] names
  * LAYERNORM: i: 0 M, 1 C, 2 ld_in, 3 ld_out, 4 workgroup cap (0 = 2048; rows beyond 4 x cap are walked grid-stride); f: 0 eps;

@@ -82,7 +82,8 @@ int validate_op(const t2v_op& op, int idx) {
           if (tile != 8 && tile != 11 && tile != 3 && tile != 5 && tile != 0) return bad("fused GroupNorm: tile must be 8, 11, 3, 5 or 0");
           if (tile == 0 && N % 128 != 0) return bad("fused GroupNorm on the 128x128-class kernel: N % 128 == 0");
           if (N / groups > bn || (bn + N / groups - 1) / (N / groups) + 1 > T2V_GN_PIECES) return bad("fused GroupNorm: a group no wider than the tile");
-          if (rows % 32 != 0 || rows < bm) return bad("fused GroupNorm: rows per instance must be a multiple of 32 and >= the tile's rows");
+          if (rows % 32 != 0 || !(rows >= bm || 2 * rows == bm))
+            return bad("fused GroupNorm: rows per instance must be a multiple of 32 and >= the tile's rows (or exactly half of them): at most two instances per row tile");
         }
         if (op.p[8] == 0 || op.p[9] == 0 || op.p[10] == 0 || op.p[11] == 0) return bad("fused GroupNorm: gamma|beta, output, scratch and barrier words are required");
         if (op.i[25] < N * (op.i[27] ? 2 : 1) || op.i[25] % 4 != 0) return bad("fused GroupNorm: leading dimension of the normalised output");
@@ -141,6 +142,8 @@ int validate_op(const t2v_op& op, int idx) {
       if (op.i[13] != 0 && op.i[13] < op.i[1]) return bad("rows of the largest part < rows");
       if (op.i[12] != 0 && (phase != 0 || (C / groups) % 4 != 0)) return bad("single-launch GroupNorm: phase 0, (C/groups) % 4 == 0");
       if (op.i[16] != 0 && (phase == 1 || op.i[7] < 2 * C)) return bad("GroupNorm low-order output: not for the statistics-only phase, ld_out >= 2 C");
+      if (op.p[8] != 0 && (phase == 1 || op.i[19] % 8 != 0 || op.i[20] % 8 != 0 || op.i[19] < C + (op.i[20] ? C : 0) || (op.i[20] != 0 && op.i[20] < C)))
+        return bad("GroupNorm cast output: not for the statistics-only phase; leading dimension >= C (+ C for the low-order image), multiples of 8");
       if (op.p[0] == 0 || op.p[1] == 0 || op.p[2] == 0 || op.p[4] == 0 || (phase != 1 && op.p[3] == 0)) return bad("null GroupNorm pointer");
       return 0;
     }

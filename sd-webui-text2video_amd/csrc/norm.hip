@@ -47,6 +47,23 @@ template <> struct Load8<f16> {
   }
 };
 
+// Optional second output of a GroupNorm op (round 5): the RAW input cast to fp16 (+ its low-order image at column `lo`) — the operand of the
+// 1x1 skip convolution of a ResBlock whose input the norm reads anyway (t2v_model.py:965: skip_connection(x) beside in_layers(x)); the
+// separate cast pass (read 4 B + write 2-4 B per element of the concat tensor) disappears.
+struct GnCast {
+  f16* out;      // null: none
+  int ld, lo;    // leading dimension; column offset of the low-order image (0: none)
+};
+template <typename V>
+__device__ __forceinline__ void gn_cast_store8(const GnCast& c, size_t row, int col, const V& v) {
+  f16x8 o, l;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { o[e] = (f16)v[e]; l[e] = (f16)(v[e] - (float)o[e]); }
+  f16* dst = c.out + row * c.ld + col;
+  *reinterpret_cast<f16x8*>(dst) = o;
+  if (c.lo) *reinterpret_cast<f16x8*>(dst + c.lo) = l;
+}
+
 constexpr int GN_UNROLL = 8;   // token rows a thread keeps in flight (HBM-bound: ~48 KiB per CU must be outstanding)
 
 // Launch 1 — grid (nblk, n_inst), nblk = ceil(rows / rpb).  Threads form R row-replicas x TPR column slots of
@@ -226,7 +243,7 @@ template <typename T, bool SILU>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ finals,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        f16* __restrict__ out, int rows, int C, int ld_in, int ld_out,
-                                                       int groups, int lo_off) {
+                                                       int groups, int lo_off, GnCast cast) {
   extern __shared__ float sh[];   // scale[C], shift[C]
   float* sc = sh;
   float* sf = sh + C;
@@ -274,6 +291,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
         }
         *reinterpret_cast<f16x8*>(ob + (size_t)rk * ld_out + c8) = o;
         if (lo_off) *reinterpret_cast<f16x8*>(ob + (size_t)rk * ld_out + lo_off + c8) = l;     // hi + lo operand split (op.i[16])
+        if (cast.out) gn_cast_store8(cast, (size_t)inst * rows + rk, c8, v[k]);
       }
     }
   }
@@ -302,7 +320,7 @@ template <> struct Load4<f16> {
 template <typename T, bool SILU>
 __global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, f16* __restrict__ out, int rows,
-                                                               int C, int ld_in, int ld_out, int groups, float eps, int lo_off) {
+                                                               int C, int ld_in, int ld_out, int groups, float eps, int lo_off, GnCast cast) {
   __shared__ double red[2 * (GNF_THREADS / 64)];
   __shared__ float stat[2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -376,6 +394,14 @@ __global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(const T* __restri
         }
         *reinterpret_cast<f16x4*>(ob + (size_t)rk * ld_out) = o;
         if (lo_off) *reinterpret_cast<f16x4*>(ob + (size_t)rk * ld_out + lo_off) = l;
+        if (cast.out) {
+          f16x4 co, cl;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { co[e] = (f16)v[k][e]; cl[e] = (f16)(v[k][e] - (float)co[e]); }
+          f16* cd = cast.out + ((size_t)inst * rows + rk) * cast.ld + c0;
+          *reinterpret_cast<f16x4*>(cd) = co;
+          if (cast.lo) *reinterpret_cast<f16x4*>(cd + cast.lo) = cl;
+        }
       }
     }
   }
@@ -401,7 +427,7 @@ __global__ __launch_bounds__(GNC_THREADS) void gn_coop_kernel(const T* __restric
                                                               const float* __restrict__ beta, f16* __restrict__ out, double* partials,
                                                               unsigned* bar, unsigned* fault, int rows, int C, int ld_in, int ld_out,
                                                               int groups, int nchunk, int rc, double inv_n, float eps, int lo_off,
-                                                              unsigned seq, unsigned want) {
+                                                              unsigned seq, unsigned want, GnCast cast) {
   extern __shared__ float sh[];            // phase 1: parked sums [2][R][C]; phase 2: scale[C] | shift[C]
   __shared__ float stat[2 * 32];           // {mean, rstd} per group (groups <= 32)
   const int tid = threadIdx.x;
@@ -507,6 +533,7 @@ __global__ __launch_bounds__(GNC_THREADS) void gn_coop_kernel(const T* __restric
       }
       *reinterpret_cast<f16x8*>(ob + (size_t)r * ld_out) = o;
       if (lo_off) *reinterpret_cast<f16x8*>(ob + (size_t)r * ld_out + lo_off) = l;
+      if (cast.out) gn_cast_store8(cast, (size_t)inst * rows + r, c8, v[k]);
     }
   }
 }
@@ -546,7 +573,7 @@ bool coop_fits(K kernel, int nwg, size_t lds, hipStream_t s, int* cache) {
 template <typename T, bool SILU>
 bool gn_coop_launch(int kr, dim3 grid, size_t lds, hipStream_t s, const T* x, const float* gamma, const float* beta, f16* out,
                     double* partials, unsigned* bar, int rows, int C, int ld_in, int ld_out, int groups, int nchunk, int rc, double inv_n,
-                    float eps, int lo_off, double* records) {
+                    float eps, int lo_off, double* records, GnCast cast) {
   // tagged records need a region that only ever holds records (a recycled arena block could hold a matching bit pattern by chance):
   // op.p[7], the program's exchange scratch; without it the grid barrier synchronises and the per-op scratch carries the partials
   unsigned seq = 0, want = 0;
@@ -557,7 +584,7 @@ bool gn_coop_launch(int kr, dim3 grid, size_t lds, hipStream_t s, const T* x, co
     if (!coop_fits(kern, (int)grid.x, lds, s, occ)) return false;                                                                \
     if (records != nullptr) t2v_exchange_ids(&seq, &want);                                                                       \
     hipLaunchKernelGGL(kern, grid, dim3(GNC_THREADS), lds, s, x, gamma, beta, out, seq != 0u ? records : partials, bar,           \
-                       g_coop.fault, rows, C, ld_in, ld_out, groups, nchunk, rc, inv_n, eps, lo_off, seq, want);                 \
+                       g_coop.fault, rows, C, ld_in, ld_out, groups, nchunk, rc, inv_n, eps, lo_off, seq, want, cast);           \
     return true;                                                                                                                 \
   }
   switch (kr) {
@@ -953,6 +980,9 @@ hipError_t t2v_launch_groupnorm(const t2v_op& op, hipStream_t s) {
   f16* out = reinterpret_cast<f16*>(op.p[3]);
   const bool fused = op.i[12] != 0;
   const int lo_off = op.i[16] != 0 ? C : 0;        // hi + lo operand split: low-order images at columns C .. 2C-1 of the output rows
+  // second output: the raw input as fp16 (+ low-order image), p[8] [n_inst * rows, i[19]], i[20] = column of the low-order image (0: none)
+  const GnCast cast = {reinterpret_cast<f16*>(op.p[8]), op.i[19], op.i[20]};
+  if (cast.out != nullptr && (phase == 1 || cast.ld < C + (cast.lo ? C : 0) || cast.ld % 8 != 0 || cast.lo % 8 != 0)) return hipErrorInvalidValue;
   if (lo_off && (phase == 1 || ld_out < 2 * C)) return hipErrorInvalidValue;
   if (fused && (phase != 0 || (C / groups) % 4 != 0 || (C / groups) / 4 > GNF_THREADS)) return hipErrorInvalidValue;
   // single-pass cooperative variant: the smallest rows-per-thread count whose grid still fits one workgroup per CU
@@ -972,16 +1002,16 @@ hipError_t t2v_launch_groupnorm(const t2v_op& op, hipStream_t s) {
       const dim3 grid(n_inst * coop_nchunk);
       double* records = ((size_t)n_inst * coop_nchunk * groups * 16 <= (size_t)op.i[18]) ? reinterpret_cast<double*>(op.p[7]) : nullptr;
       const bool done = silu ? gn_coop_launch<T, true>(coop_kr, grid, ldsc, s, x, gamma, beta, out, partials, bar, rows, C, ld_in, ld_out, groups,
-                                                       coop_nchunk, coop_rc, inv_n, op.f[0], lo_off, records)
+                                                       coop_nchunk, coop_rc, inv_n, op.f[0], lo_off, records, cast)
                              : gn_coop_launch<T, false>(coop_kr, grid, ldsc, s, x, gamma, beta, out, partials, bar, rows, C, ld_in, ld_out, groups,
-                                                        coop_nchunk, coop_rc, inv_n, op.f[0], lo_off, records);
+                                                        coop_nchunk, coop_rc, inv_n, op.f[0], lo_off, records, cast);
       if (done) return;             // else: not provably co-resident (or a fault was raised earlier) -> the three launches below
     }
     if (fused) {
       if (silu) hipLaunchKernelGGL((gn_fused_kernel<T, true>), dim3(groups * n_inst), dim3(GNF_THREADS), 0, s, x, gamma, beta, out, rows,
-                                   C, ld_in, ld_out, groups, op.f[0], lo_off);
+                                   C, ld_in, ld_out, groups, op.f[0], lo_off, cast);
       else hipLaunchKernelGGL((gn_fused_kernel<T, false>), dim3(groups * n_inst), dim3(GNF_THREADS), 0, s, x, gamma, beta, out, rows, C,
-                              ld_in, ld_out, groups, op.f[0], lo_off);
+                              ld_in, ld_out, groups, op.f[0], lo_off, cast);
       return;
     }
     if (phase == 3 && (long)(rows / 32) * (C / groups) > 1024)
@@ -1002,8 +1032,8 @@ hipError_t t2v_launch_groupnorm(const t2v_op& op, hipStream_t s) {
       const int rpa = R * GN_UNROLL;    // rows per normalise workgroup
       const dim3 g3((rows + rpa - 1) / rpa, n_inst);
       const size_t lds3 = 2 * (size_t)C * sizeof(float);
-      if (silu) hipLaunchKernelGGL((gn_apply_kernel<T, true>), g3, dim3(256), lds3, s, x, finals, gamma, beta, out, rows, C, ld_in, ld_out, groups, lo_off);
-      else hipLaunchKernelGGL((gn_apply_kernel<T, false>), g3, dim3(256), lds3, s, x, finals, gamma, beta, out, rows, C, ld_in, ld_out, groups, lo_off);
+      if (silu) hipLaunchKernelGGL((gn_apply_kernel<T, true>), g3, dim3(256), lds3, s, x, finals, gamma, beta, out, rows, C, ld_in, ld_out, groups, lo_off, cast);
+      else hipLaunchKernelGGL((gn_apply_kernel<T, false>), g3, dim3(256), lds3, s, x, finals, gamma, beta, out, rows, C, ld_in, ld_out, groups, lo_off, cast);
     }
   };
   if (in_dt == T2V_F32) run(reinterpret_cast<const float*>(op.p[0]));

@@ -580,8 +580,8 @@ class Program:
             bm, bn, per_cu = self._GN_EPI_TILES[tile]
             if tile == 0 and N % 128 != 0:
                 return None                               # (the narrow 128x64 form of the 128x128-class kernel has no instantiation)
-            if N // groups > bn or rows % 32 or rows < bm:
-                return None
+            if N // groups > bn or rows % 32 or not (rows >= bm or 2 * rows == bm):
+                return None                               # (a row tile may touch at most two statistics instances)
             tiles_m, tiles_n = -(-M // bm), -(-N // bn)
             if tiles_m * tiles_n > per_cu * self.device_cus():
                 return None                               # the grid barrier needs every workgroup resident
@@ -608,9 +608,11 @@ class Program:
 
     def groupnorm(self, name: str, x: Buf, gamma: Ref, beta: Ref, out: Buf, *, n_inst: int, eps: float,
                   silu: bool, groups: int = 32, shard: Optional[TShardSpec] = None, lo: bool = False, stats: Optional[Buf] = None,
-                  gb: Optional[Ref] = None, x_dead: bool = False) -> Op:
+                  gb: Optional[Ref] = None, x_dead: bool = False, cast: Optional[Buf] = None, cast_lo: bool = False) -> Op:
         """GroupNorm(+SiLU).  gb (fp32 [2C] gamma | beta) + x produced by the op emitted last: the norm may become that GEMM's
-        epilogue (`_fuse_groupnorm`; x_dead = nothing else reads x).  With `shard` (cross-frame statistics of a T-sharded clip; n_inst = 1) the op is split
+        epilogue (`_fuse_groupnorm`; x_dead = nothing else reads x).
+        cast (fp16 [x.rows, >= C (2C with cast_lo)]): second output — the RAW input as fp16 (+ its low-order image at column C): the operand
+        of a 1x1 skip convolution that reads the same tensor (no separate cast pass); the norm then stays its own op.  With `shard` (cross-frame statistics of a T-sharded clip; n_inst = 1) the op is split
         into: statistics (this rank's partials) -> all-gather of the fp64 partials over the T group ->
         ordered fold of all parts + normalise; every rank ends up with bit-identical statistics.  Each rank folds its own
         block partials first, so a part is one {sum, sum of squares} pair per group: 512 bytes per instance, whatever the
@@ -622,7 +624,7 @@ class Program:
         rows = x.rows // n_inst
         assert not lo or out.ld >= 2 * x.cols
         assert rows * n_inst == x.rows and out.dtype == "f16" and x.cols % 4 == 0
-        if shard is None and stats is None:
+        if shard is None and stats is None and cast is None:
             fused = self._fuse_groupnorm(name, x, gb, out, n_inst=n_inst, eps=eps, silu=silu, groups=groups, lo=lo, x_dead=x_dead)
             self._flush_deferred()
             if fused is not None:
@@ -653,6 +655,9 @@ class Program:
                 op.i[14] = rows_total
             if lo and phase != 1:
                 op.i[16] = 1
+            if cast is not None and phase != 1:
+                assert cast.dtype == "f16" and cast.rows == x.rows and cast.ld % 8 == 0 and cast.ld >= x.cols * (2 if cast_lo else 1) and x.cols % 8 == 0
+                op.p[8], op.i[19], op.i[20] = cast.ref, cast.ld, (x.cols if cast_lo else 0)
             op.f[0] = eps
             op.p[0:5] = [x.ref, gamma, beta, out.ref, scratch.ref]
             return op

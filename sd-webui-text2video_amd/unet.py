@@ -700,7 +700,7 @@ class _Lowering:
         return Ref("weight", 0, self.packer.add(key + ":gn_gb", "f32", lambda sd, k=key: torch.cat([sd[k + ".weight"], sd[k + ".bias"]])))
 
     def gn(self, name, x: Buf, key, *, per_frame: bool, eps, silu, out: Optional[Buf] = None, lo: bool = False,
-           stats: Optional[Buf] = None, x_dead: bool = False) -> Buf:
+           stats: Optional[Buf] = None, x_dead: bool = False, cast: Optional[Buf] = None, cast_lo: bool = False) -> Buf:
         """lo (precise_operands): the result is a [rows, 2C] buffer of rows [hi | lo] — fp16(y) and the low-order image of that
         rounding — for a consumer GEMM with weights [W | W] (K = 2C)."""
         if lo:
@@ -716,7 +716,8 @@ class _Lowering:
         # (x produced by the op emitted last, on a tile with the instantiation: the norm becomes that GEMM's epilogue — Program._fuse_groupnorm;
         #  x_dead: only this norm reads x)
         self.P.groupnorm(name, x, self.vec(key + ".weight"), self.vec(key + ".bias"), out, n_inst=n_inst, eps=eps, silu=silu,
-                         shard=shard, lo=lo, stats=stats, gb=self.gn_gb(key) if self.shard is None and x.cols % 4 == 0 else None, x_dead=x_dead)
+                         shard=shard, lo=lo, stats=stats, gb=self.gn_gb(key) if self.shard is None and x.cols % 4 == 0 else None, x_dead=x_dead,
+                         cast=cast, cast_lo=cast_lo)
         return full
 
     def strips_for(self, rows: int, n: int, inst_rows: int) -> Optional[Buf]:
@@ -755,7 +756,15 @@ class _Lowering:
 
     def res_block(self, prefix, x: Buf, cin, cout, h, w, dest: Optional[Buf] = None) -> Buf:
         P = self.P
-        a = self.gn(prefix + ".in_layers.0", x, prefix + ".in_layers.0", per_frame=True, eps=1e-5, silu=True)
+        # The 1x1 skip convolution (cin != cout) reads the block input as an fp16 operand.  Where the in_layers norm is its own op anyway
+        # (its input is a skip-connection concat: two producers), that norm writes the cast as a second output — no separate pass over the
+        # concat tensor (round 5).  Elsewhere (the norm is fused into its producer's epilogue) the cast op stays.
+        x16 = None
+        cast_in_norm = (cin != cout and self.shard is None and x.cols % 8 == 0 and os.environ.get("T2V_GN_CAST", "1") != "0"
+                        and not (P.ops and P.ops[-1].kind == L.OP_GEMM and P.ops[-1].out is x))
+        if cast_in_norm:
+            x16 = P.alloc(x.rows, 2 * cin if self.precise else cin, "f16")
+        a = self.gn(prefix + ".in_layers.0", x, prefix + ".in_layers.0", per_frame=True, eps=1e-5, silu=True, cast=x16, cast_lo=self.precise and cast_in_norm)
         e0, e1 = self.emb_slices[prefix]
         st = self.strips_for(x.rows, cout, h * w)
         h1 = self.conv3(prefix + ".in_layers.2", a, prefix + ".in_layers.2", cout, h, w,
@@ -767,13 +776,15 @@ class _Lowering:
             skip = P.alloc(x.rows, cout, "f32")
             if self.precise:
                 # hi + lo operand split in ONE pass: rows [hi (cin) | lo (cin)], weights [W | W], K = 2 cin
-                x16 = P.alloc(x.rows, 2 * cin, "f16")
-                P.copy2d(prefix + ".skip.cast", x, x16.col_slice(0, cin), lo=x16.col_slice(cin, 2 * cin))
+                if x16 is None:
+                    x16 = P.alloc(x.rows, 2 * cin, "f16")
+                    P.copy2d(prefix + ".skip.cast", x, x16.col_slice(0, cin), lo=x16.col_slice(cin, 2 * cin))
                 P.gemm(prefix + ".skip_connection", x16, self.w_linear_dup(prefix + ".skip_connection"), cout, 2 * cin, skip,
                        bias=self.vec(prefix + ".skip_connection.bias"), k_alg=cin)
             else:
-                x16 = P.alloc(x.rows, cin, "f16")
-                P.copy2d(prefix + ".skip.cast", x, x16)
+                if x16 is None:
+                    x16 = P.alloc(x.rows, cin, "f16")
+                    P.copy2d(prefix + ".skip.cast", x, x16)
                 P.gemm(prefix + ".skip_connection", x16, self.w_linear(prefix + ".skip_connection"), cout, cin, skip,
                        bias=self.vec(prefix + ".skip_connection.bias"))
             P.free(x16)

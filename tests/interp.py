@@ -210,6 +210,11 @@ class Interp:
                 pv[part, :, :, 1] = (x * x).sum(dim=(1, 3))
                 return
             s1, s2, n = pv[..., 0].sum(dim=0), pv[..., 1].sum(dim=0), rows_total * cpg
+        if len(op.p) > 8 and op.p[8].space != "null" and phase != 1:      # second output: the raw input as fp16 (+ low-order image at column i[20])
+            raw = self.mat(op.p[0], n_inst * rows, C, ld_in, _TD[in_dt], ext).float()
+            self._st(self.mat(op.p[8], n_inst * rows, C, op.i[19], torch.float16, ext), raw, torch.float16)
+            if op.i[20]:
+                self._st(self.view(op.p[8].shifted(2 * op.i[20]), (n_inst * rows, C), (op.i[19], 1), torch.float16, ext), raw - raw.half().float(), torch.float16)
         mean = (s1 / n).view(n_inst, 1, groups, 1)
         var = (s2 / n).view(n_inst, 1, groups, 1) - mean * mean
         y = ((x - mean) / torch.sqrt(var.clamp_min(0) + op.f[0])).view(n_inst * rows, C).float()

@@ -323,3 +323,24 @@ def test_c0_8f_forward_and_5_steps_on_the_deployed_weights(modelscope_full_fp16)
     rs = rel_l2(x0.float().cpu(), torch.from_numpy(g16["sampler_x0"]))
     print(f"configs[0] 8f forward / 5-step DDIM_Gaussian CFG 9 vs the reference on the DEPLOYED weights: rel-L2 {r:.3e} / {rs:.3e}")
     assert r < GATE_FWD_W16 and rs < GATE_FEWSTEP_W16
+
+
+def test_c2_125f_sampled_output_20_steps(modelscope_full_fp16):
+    """configs[2] OUTPUT-level golden past the few-step regime (round 5): 20-step DDIM_Gaussian CFG 9 latent of the
+    125-frame clip (2.7 h of reference CPU time), frames at the slice edges of the 4-way T split and both clip ends."""
+    net, betas = modelscope_full_fp16
+    gold = _need("modelscope_125f_s20_w16.npz")
+    frames = [int(f) for f in gold["frames"]]
+    _, cond, uncond = synth.synth_inputs(125, 256, 256)
+    smp = samplers.Txt2VideoSampler(net, torch.device(DEV), betas=betas, sampler_name="DDIM_Gaussian")
+    smp.progress = False
+    _, nz, shape = smp.get_noise(1, 4, 125, 256, 256, seed=1234)
+    x0 = smp.sample_loop(steps=20, strength=None, conditioning=cond.to(DEV).half(), unconditional_conditioning=uncond.to(DEV).half(),
+                         batch_size=1, shape=shape, noise=nz, guidance_scale=9.0, eta=0.0, sampler_name="DDIM_Gaussian").float().cpu()
+    want = torch.from_numpy(gold["sampler_x0_20_frames"])
+    r = rel_l2(x0[:, :, frames], want)
+    worst = max(rel_l2(x0[:, :, f], want[:, :, k]) for k, f in enumerate(frames))
+    print(f"configs[2] 125f, 20-step DDIM_Gaussian CFG 9 vs the reference on the DEPLOYED weights: x0 rel-L2 {r:.3e} over frames {frames}, "
+          f"worst single frame {worst:.3e}")
+    assert abs(float(x0.std()) - float(gold["x0_std"])) < 3e-3 * float(gold["x0_std"])
+    assert r < 1.2e-3 and worst < 1.3e-3

@@ -1382,3 +1382,23 @@ def test_groupnorm_in_splitk_reduction_against_torch(kind, C, per_frame, dead, l
         v = read(got, y).float()
         ref = torch.nn.functional.silu(torch.nn.functional.group_norm(v.view(n_inst, M // n_inst, C).permute(0, 2, 1), 32, w["g"], w["be"], 1e-5))
         assert rel_l2(read(got, out).float(), ref.permute(0, 2, 1).reshape(M, C)) < 1e-3
+
+
+@pytest.mark.parametrize("n_inst,rows,C,dt,lo", [(2, 1536, 640, "f32", True), (6, 64, 1280, "f32", True), (2, 24576, 640, "f32", False), (4, 256, 320, "f32", True)])
+def test_groupnorm_cast_second_output(n_inst, rows, C, dt, lo):
+    """Round 5: a GroupNorm whose input also feeds a 1x1 skip convolution writes the raw input's fp16 cast (+ low-order image) as a second
+    output (single-pass cooperative kernel / one-workgroup-per-group kernel / the three-launch path)."""
+    M = n_inst * rows
+    P = Program()
+    g = _g(800 + C)
+    x, out, cast = P.alloc(M, C, dt), P.alloc(M, C, "f16"), P.alloc(M, 2 * C if lo else C, "f16")
+    w = {"g": 1 + 0.1 * torch.randn(C, generator=g), "be": 0.1 * torch.randn(C, generator=g)}
+    op = P.groupnorm("gn", x, Ref("weight", 0, "g"), Ref("weight", 0, "be"), out, n_inst=n_inst, eps=1e-5, silu=True, cast=cast, cast_lo=lo)
+    assert op.kind == L.OP_GROUPNORM and len(P.ops) == 1
+    it, got = _gpu_run(P, w, lambda it: fill(it, x, g, 3.0))
+    _check(it, got, out, 1e-3, "normalised output")
+    xv = read(got, x).float()
+    hi = read(got, cast.col_slice(0, C)).float()
+    assert torch.equal(hi, xv.half().float()), "the cast output is not the rounded input"
+    if lo:
+        assert rel_l2(hi + read(got, cast.col_slice(C, 2 * C)).float(), xv) < 1e-6
