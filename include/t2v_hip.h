@@ -99,6 +99,11 @@ enum t2v_gather {
                              p[8] gamma | beta fp32 [2N], p[9] normalised output fp16, p[10] scratch fp64 [tiles_m][2][tiles_n][T2V_GN_PIECES][2],
                              p[11] grid-barrier words.  No split-K / GEGLU / fused LayerNorm; tiles 8 / 11 (whole rows, N == 320), 0, 3, 5 — the
                              grid must be co-resident on the device (the library checks with the occupancy API and refuses otherwise). */
+#define T2V_EPI_XATTN 5   /* fused to_q projection + text cross-attention (round 5): out fp16 [M, ldc] = softmax(q k^T f[1]) v per (sample, head of 64
+                             channels), q = A W^T (no bias), keys = the i[25] (<= 96) text tokens.  p[8] = K fp16 [samples][i[25]][i[24]] (this
+                             site's N columns; i[27] elements between samples), p[9] = V^T fp16 [samples][N][i[26]] (keys contiguous, finite
+                             beyond i[25]; i[28] elements between samples), both written by step-invariant ops; the sample of row m is
+                             m / i[15].  N % 64 == 0; tiles 8 / 11 (N == 320) and 0 (N % 128 == 0); plain gather, no split-K, fp16 out. */
 #define T2V_GN_PIECES 36  /* group pieces (group x column tile intersections) per column tile in the T2V_EPI_GN scratch */
 
 /* dtype tags */

@@ -19,7 +19,7 @@ OP_EMBED_ROWS = 14
 OP_TO_UINT8, OP_ALLGATHER, OP_HALO_EXCHANGE = 15, 16, 17
 OP_RESHARD_ROWS, OP_ALLTOALL = 18, 19
 GATHER_PLAIN, GATHER_CONV3X3, GATHER_TCONV3, GATHER_CONV3X3_C8 = 0, 1, 2, 3
-EPI_NONE, EPI_GEGLU, EPI_TATTN, EPI_STATS, EPI_GN = 0, 1, 2, 3, 4
+EPI_NONE, EPI_GEGLU, EPI_TATTN, EPI_STATS, EPI_GN, EPI_XATTN = 0, 1, 2, 3, 4, 5
 GN_PIECES = 36                  # T2V_GN_PIECES
 F16, F32 = 0, 1
 EXT_SLOTS = 16
@@ -94,8 +94,22 @@ def load():
     return lib
 
 
+_exchange_disabled = False
+
+
+def exchange_disabled() -> bool:
+    """True once the library has reported an asynchronous fault (T2V_ERR_ASYNC: a workgroup of a fused-norm launch gave up waiting for the
+    others — the device is shared with a client that holds compute units).  The library then refuses the launches that rely on a
+    co-resident grid; programs are lowered WITHOUT norms fused into GEMM epilogues from then on (program.Program.gn_epilogue), and cached
+    programs that have them are lowered again (unet.UNetSD.forward)."""
+    return _exchange_disabled
+
+
 def check(rc: int):
+    global _exchange_disabled
     if rc != 0:
+        if rc == -6:                     # T2V_ERR_ASYNC
+            _exchange_disabled = True
         msg = load().t2v_last_error()
         raise T2VError(f"libt2v_hip error {rc}: {msg.decode() if msg else '?'}")
 

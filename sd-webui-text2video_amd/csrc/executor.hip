@@ -65,7 +65,19 @@ int validate_op(const t2v_op& op, int idx) {
       if (op.i[16] == T2V_EPI_GEGLU && (N % 32 != 0 || op.i[17] != T2V_F16)) return bad("GEGLU needs N % 32 == 0, fp16 out");
       if (op.i[16] == T2V_EPI_STATS && (op.p[7] == 0 || op.i[19] > 1 || (g == T2V_GATHER_PLAIN && op.i[8] == 1)))
         return bad("column statistics (T2V_EPI_STATS): strips pointer p[7], no split-K, no fused LayerNorm");
-      if (op.i[16] < 0 || op.i[16] > T2V_EPI_GN) return bad("unknown epilogue");
+      if (op.i[16] < 0 || op.i[16] > T2V_EPI_XATTN) return bad("unknown epilogue");
+      if (op.i[16] == T2V_EPI_XATTN) {
+        const int tile = op.i[22];
+        if (g != T2V_GATHER_PLAIN || N % 64 != 0 || K % 64 != 0 || op.i[17] != T2V_F16 || op.i[19] > 1 || op.i[18] != 0 || op.i[8] != 0 || op.i[11] == 1)
+          return bad("fused cross-attention: plain gather, N = 64 * heads, K % 64 == 0, fp16 out, no split-K / activation / LayerNorm / hi + lo output");
+        if (!(((tile == 8 || tile == 11) && N == 320) || (tile == 0 && N % 128 == 0))) return bad("fused cross-attention: tile 8 / 11 with N == 320, or tile 0 with N % 128 == 0");
+        if (op.p[2] != 0 || op.p[3] != 0 || op.p[4] != 0 || op.p[8] == 0 || op.p[9] == 0 || !(op.f[1] > 0.f)) return bad("fused cross-attention: no bias / row bias / residual; K, V^T and a positive scale are required");
+        if (op.i[25] < 1 || op.i[25] > 96 || op.i[24] < N || op.i[24] % 8 != 0 || op.i[26] < ((op.i[25] + 31) / 32) * 32 || op.i[26] % 8 != 0 || op.i[15] <= 0 || op.i[15] % 32 != 0 || op.i[27] < 0 || op.i[28] < 0)
+          return bad("fused cross-attention: 1 .. 96 keys, ld(K) >= N, V^T rows of >= ceil32(keys) halfs, rows per sample a multiple of 32");
+        if (op.i[5] < N || op.i[5] % 4 != 0) return bad("fused cross-attention: ldc");
+        if (op.i[12] != 0) return bad("fused cross-attention: no residual wrap");
+        return 0;
+      }
       if (op.i[16] == T2V_EPI_GN) {
         // GroupNorm (+SiLU) of the result inside the epilogue: the tiles with an instantiation, whole 32-row strips per statistics
         // instance, at most two instances per row tile, whole groups, every pointer of the exchange
@@ -282,6 +294,13 @@ hipError_t launch_op(const t2v_op& op, hipStream_t s) {
         return t2v_launch_gemm2(p, tile, s);
       }
       // split-K: p[7] = T2V_SYNC_INTS zeroed ints -> the fold runs in the GEMM's last-arriving workgroups; 0 -> reduction kernel
+      if (p.epi == T2V_EPI_XATTN) {                              // fused to_q + text cross-attention (validated above)
+        p.epi = T2V_EPI_NONE;
+        p.xa_k = reinterpret_cast<const f16*>(op.p[8]);
+        p.xa_vt = reinterpret_cast<const f16*>(op.p[9]);
+        p.xa_ldk = op.i[24]; p.xa_lc = op.i[25]; p.xa_lcp = op.i[26]; p.xa_k_sample = op.i[27]; p.xa_vt_sample = op.i[28];
+        p.attn_scale_log2 = op.f[1] * 1.44269504088896340736f;
+      }
       const bool ln_any = p.gather == T2V_GATHER_PLAIN && (op.i[8] == 1 || op.i[8] == 2);
       if (p.splitk > 1 && !ln_any) p.tickets = reinterpret_cast<int*>(op.p[7]);
       if (ln_any) {       // fused LayerNorm second output (validated: tile 8 / 11, N == 320 — or, i[8] == 2, across column tiles; TATTN returned above)

@@ -274,6 +274,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmParams p) 
       t2v_epilogue_rows_lnx<WM, WN, TM, TN>(p, acc, smem, lane, wave, m0, n0, tile_m, tile_n, tiles_n);
       return;
     }
+    if constexpr (XE == 4) {
+      t2v_epilogue_xattn<WM, WN, TM, TN>(p, acc, smem, lane, wave, m0, n0);
+      return;
+    }
     t2v_epilogue_rows<TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wave * (32 * T2V_EPI_SP), lane, m0 + wm * TM * 32,
                               n0 + wn * TN * 32, blockIdx.y, tile_m * tiles_n + tile_n);
     return;
@@ -356,6 +360,18 @@ hipError_t launch_tile(const GemmParams& pin, hipStream_t s) {
   const dim3 grid(tiles, p.splitk > 1 ? p.splitk : 1);
   const dim3 block(WM * WN * 64);
   constexpr int lds = 2 * (BM + BN) * BK * 2;
+  if (p.xa_k != nullptr) {         // fused to_q + text cross-attention (T2V_EPI_XATTN): the 128x128 tile = two heads per column tile, plain gather
+    if constexpr (BM == 128 && BN == 128) {
+      static_assert(t2v_xattn_epilogue_lds(BM, BN) <= lds, "Q [BM][BN] fp16 re-uses the operand stages");
+      if (p.splitk != 1 || p.gather != T2V_GATHER_PLAIN) return hipErrorInvalidValue;
+      auto k = gemm_kernel<BM, BN, WM, WN, T2V_GATHER_PLAIN, 4>;
+      static t2v_device_flags once_xa;
+      (void)t2v_set_dynamic_lds(reinterpret_cast<const void*>(k), lds, once_xa, s);
+      hipLaunchKernelGGL(k, grid, block, lds, s, p);
+      return hipGetLastError();
+    }
+    return hipErrorInvalidValue;
+  }
   if ((p.gn_out != nullptr && p.splitk == 1) || p.ln_x) {
     // GroupNorm inside the epilogue: the 128x128 tile only; the grid barrier needs the whole launch resident (no split-K, the grid
     // within what the occupancy API grants this instantiation on the stream's device)

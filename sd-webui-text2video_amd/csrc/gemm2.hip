@@ -698,6 +698,10 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm2_kernel(const GemmPar
       t2v_epilogue_rows_gn<WM, WN, TM, TN>(p, acc, smem, lane, wave, m0, n0, tile_m, tile_n, tiles_m, tiles_n);
       return;
     }
+    if constexpr (XE == 4) {        // to_q projection + text cross-attention: the accumulators are Q (T2V_EPI_XATTN, t2v_kernels.h)
+      t2v_epilogue_xattn<WM, WN, TM, TN>(p, acc, smem, lane, wave, m0, n0);
+      return;
+    }
     if constexpr (XE == 3) {        // LayerNorm second output across the column tiles of the launch (partial row sums meet at the grid barrier)
       t2v_epilogue_rows_lnx<WM, WN, TM, TN>(p, acc, smem, lane, wave, m0, n0, tile_m, tile_n, tiles_n);
       return;
@@ -810,8 +814,9 @@ hipError_t launch_cfg_gather(const GemmParams& p, hipStream_t s) {
   constexpr int ring = STAGES * (BM + BN) * BK * 2 + 1024;
   constexpr int gn_lds = t2v_gn_epilogue_lds(WM * WN, WM * TM, BN);
   constexpr int lnx_lds = t2v_lnx_epilogue_lds(WM * WN, WN, BM);
+  constexpr int xa_lds = t2v_xattn_epilogue_lds(BM, BN);
   constexpr int lds = TAT ? (BM * 272 + 12 * 64 * 72 > ring ? BM * 272 + 12 * 64 * 72 : ring)
-                          : (XE == 2 && gn_lds > ring ? gn_lds : (XE == 3 && lnx_lds > ring ? lnx_lds : ring));
+                          : (XE == 2 && gn_lds > ring ? gn_lds : (XE == 3 && lnx_lds > ring ? lnx_lds : (XE == 4 && xa_lds > ring ? xa_lds : ring)));
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   auto k = gemm2_kernel<WM, WN, TM, TN, BK, STAGES, MINW, GATHER, PP, XE, TAT>;
   static t2v_device_flags attr_set;     // once per (instantiation, device): the call costs microseconds on the host
@@ -863,6 +868,13 @@ hipError_t launch_cfg(const GemmParams& pin, hipStream_t s) {
         break;
       }
       if (p.epi == T2V_EPI_TATTN) return hipErrorInvalidValue;
+      if constexpr ((WM == 6 || WM == 4) && WN == 2 && TM == 1 && TN == 5 && PP == 0) {      // whole-row tiles: 192x320 / 128x320
+        if (p.xa_k != nullptr) {      // fused to_q + text cross-attention (validated: N == 320 = 5 heads, fp16 out, no split-K)
+          e = launch_cfg_gather<WM, WN, TM, TN, BK, STAGES, MINW, T2V_GATHER_PLAIN, PP, 4>(p, s);
+          break;
+        }
+      }
+      if (p.xa_k != nullptr) return hipErrorInvalidValue;
       if constexpr ((WM == 6 || WM == 4) && WN == 2 && TM == 1 && TN == 5 && PP != 1) {      // whole-row tiles: 192x320 / 128x320
         if (p.ln_out != nullptr) {
           e = launch_cfg_gather<WM, WN, TM, TN, BK, STAGES, MINW, T2V_GATHER_PLAIN, PP, 1>(p, s);

@@ -73,6 +73,11 @@ struct GemmParams {
   // launch's 32-bit sequence number in the low mantissa bits; consumers poll the records they need until the tags match: no barrier);
   // gn_seq == 0 -> the grid barrier on gn_bar.  gn_want = the number consumers expect (== gn_seq except in the fault-injection test).
   unsigned gn_seq, gn_want;
+  // fused to_q projection + text cross-attention (T2V_EPI_XATTN, t2v_epilogue_xattn): K [samples][Lc][ldk] (this site's columns), V^T
+  // [samples][N][lcp] (keys contiguous, zero beyond Lc), both step-invariant; the sample of a row = m / rows_per_batch
+  const f16* xa_k;
+  const f16* xa_vt;
+  int xa_ldk, xa_lc, xa_lcp, xa_k_sample, xa_vt_sample;
 };
 
 
@@ -1014,6 +1019,109 @@ __device__ __forceinline__ void t2v_epilogue_rows_lnx(const GemmParams& p, f32x1
   }
 }
 constexpr int t2v_lnx_epilogue_lds(int nw, int wn, int bm) { return nw * 32 * T2V_EPI_SP * 4 + (wn * bm * 2 + bm * 2) * 4; }
+
+// ---- to_q projection + text cross-attention in ONE launch (T2V_EPI_XATTN, round 5; VERDICT r04 next #1b) --------------------------------
+// Reference: CrossAttention of a BasicTransformerBlock's attn2 (t2v_model.py:540-584 called from :807): q = to_q(LayerNorm(x)), 77 text
+// keys.  The text K / V projections are step-invariant (one GEMM per sampling run, the program's prologue), so after the to_q main loop a
+// workgroup holds everything an attention over its rows needs: the accumulators go to LDS as fp16 Q [BM][BN] (BN = 64 * heads of the
+// tile; re-using the operand ring), and every wave takes (32-row strip, head) items: S^T = K Q^T with the key on the MFMA row axis (<= 96
+// keys = 3 blocks; K fragments straight from global memory — 10 KB per head, L2-resident), in-lane softmax, P from the accumulator
+// registers, O^T = V^T P^T with V^T fragments from the transposed copy the prologue keeps ([N][lcp], keys contiguous).  Q never reaches
+// HBM (one [M, C] fp16 round trip and one launch less per site).  Same fragment conventions as the fused temporal attention (gemm2.hip).
+template <int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void t2v_epilogue_xattn(const GemmParams& p, const f32x16 (&acc)[TM][TN], unsigned char* smem, int lane, int wave,
+                                                   int m0, int n0) {
+  constexpr int NW = WM * WN, S = WM * TM, BN = WN * TN * 32, HEADS = BN / 64, PITCH = BN * 2 + 16;
+  static_assert(BN % 64 == 0, "whole heads per column tile");
+  const int wm = wave / WN, wn = wave % WN;
+  const int frow = lane & 31, fhalf = lane >> 5;
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = (wm * TM + a) * 32 + frow, col = (wn * TN + b) * 32 + 8 * q + 4 * fhalf;
+        const f16x4 v = {(f16)acc[a][b][4 * q], (f16)acc[a][b][4 * q + 1], (f16)acc[a][b][4 * q + 2], (f16)acc[a][b][4 * q + 3]};
+        *reinterpret_cast<f16x4*>(smem + row * PITCH + col * 2) = v;
+      }
+  __syncthreads();
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int Lc = p.xa_lc;
+  for (int item = wave; item < S * HEADS; item += NW) {
+    const int st = item / HEADS, hh = item - st * HEADS;
+    const int mt = m0 + st * 32, h = n0 / 64 + hh;
+    if (mt >= p.M || h * 64 >= p.N) continue;                      // wave-uniform
+    const int smp = mt / p.rows_per_batch;
+    const f16* K = p.xa_k + (size_t)smp * p.xa_k_sample + h * 64;
+    const f16* VT = p.xa_vt + (size_t)smp * p.xa_vt_sample + (size_t)h * 64 * p.xa_lcp;
+    const unsigned char* qrow = smem + (st * 32 + frow) * PITCH + hh * 128;
+    f32x16 sc[3] = {zero16, zero16, zero16};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const f16x8 qf = *reinterpret_cast<const f16x8*>(qrow + ((kk * 2 + fhalf) << 4));
+#pragma unroll
+      for (int kb = 0; kb < 3; ++kb) {
+        const int key = min(kb * 32 + frow, Lc - 1);               // rows past the last key: a finite copy, masked below
+        const f16x8 kf = *reinterpret_cast<const f16x8*>(K + (size_t)key * p.xa_ldk + (kk * 2 + fhalf) * 8);
+        sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf, sc[kb], 0, 0, 0);
+      }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 3; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+        if (key >= Lc) sc[kb][r] = -INFINITY;
+        mx = fmaxf(mx, sc[kb][r]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float neg_m = -mx * p.attn_scale_log2;
+    float psum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 3; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kb][r], p.attn_scale_log2, neg_m));
+        sc[kb][r] = pv;
+        psum += pv;
+      }
+    psum += __shfl_xor(psum, 32);
+    f32x16 oacc[2] = {zero16, zero16};
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+      const int kb = t >> 1, tt = t & 1;
+      f16x8 pf;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pf[e] = (f16)sc[kb][8 * tt + e];
+      const int kofs = kb * 32 + tt * 16 + 4 * fhalf;
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        const f16* vrow = VT + (size_t)(d * 32 + frow) * p.xa_lcp + kofs;
+        const f16x4 lo = *reinterpret_cast<const f16x4*>(vrow);
+        const f16x4 hi = *reinterpret_cast<const f16x4*>(vrow + 8);
+        const f16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, oacc[d], 0, 0, 0);
+      }
+    }
+    const int m = mt + frow;
+    if (m < p.M) {
+      const float inv = 1.0f / psum;
+      f16* orow = reinterpret_cast<f16*>(p.out) + (size_t)m * p.ldc + h * 64;
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          f16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (f16)(oacc[d][4 * qd + r] * inv);
+          *reinterpret_cast<f16x4*>(orow + d * 32 + 8 * qd + 4 * fhalf) = o;
+        }
+    }
+  }
+}
+constexpr int t2v_xattn_epilogue_lds(int bm, int bn) { return bm * (bn * 2 + 16); }
 
 // bytes of LDS the T2V_EPI_GN epilogue needs for a tile of NW waves, S 32-row strips, BN columns
 constexpr int t2v_gn_epilogue_lds(int nw, int s, int bn) { return nw * 32 * T2V_EPI_SP * 4 + (s * 2 * bn + 4 * bn + 2 * T2V_GN_PIECES * 2) * 4; }

@@ -184,7 +184,7 @@ class Program:
         self.gn_coop = os.environ.get("T2V_GN_COOP", "1") != "0"
         # GroupNorm inside the epilogue of the GEMM that produces its input (T2V_EPI_GN, round 5): a peephole of groupnorm() below.
         # It relies on the same co-residency as the single-pass kernel (one grid barrier per launch), so T2V_GN_COOP=0 turns it off too.
-        self.gn_epilogue = self.gn_coop and os.environ.get("T2V_GN_EPI", "1") != "0"
+        self.gn_epilogue = self.gn_coop and os.environ.get("T2V_GN_EPI", "1") != "0" and not L.exchange_disabled()
         # its exchange scratch ([tiles_m][2][tiles_n][GN_PIECES] fp64 pairs, <= 512 tiles): ONE region for every fused op of the program
         # (launches are stream-ordered and each rewrites every word it reads), allocated here for the reason given above for the sync words
         self._gn_part: Optional[Buf] = self.alloc(2 << 20, 1, "u8") if self.gn_epilogue else None
@@ -493,6 +493,33 @@ class Program:
         if lo_tmp is not None:
             self.free(lo_tmp)
         return op
+
+    def to_q_cross_attention(self, name: str, a: Buf, w: Ref, out: Buf, *, k: int, heads: int, kbuf: Buf, vt: Buf, n_keys: int,
+                             rows_per_sample: int, samples: int, scale: float, a_wrap: int = 0) -> Optional[Op]:
+        """out[M, heads*64] = text cross-attention of q = a @ w^T — ONE launch (T2V_EPI_XATTN): the to_q accumulators become Q in LDS and
+        the attention against the step-invariant K (`kbuf`: [samples * n_keys, heads*64] window, row stride kbuf.ld) / V^T (`vt`:
+        [samples * N_total_rows..., lcp] with this site's heads*64 rows first, keys contiguous) runs in the epilogue.  Returns None where
+        the tile policy picks a tile without the instantiation (the caller then emits the projection + attention pair)."""
+        n = heads * 64
+        M = out.rows
+        assert a.dtype == "f16" and out.dtype == "f16" and out.cols == n and k % 64 == 0 and n_keys <= 96 and rows_per_sample % 32 == 0
+        tile, split = self.choose_tile(M, n, k, L.GATHER_PLAIN, allow_splitk=False)
+        if not (((tile in (8, 11)) and n == 320) or (tile == 0 and n % 128 == 0)) or split != 1:
+            return None
+        op = Op(L.OP_GEMM, name)
+        I = op.i
+        I[0], I[1], I[2] = M, n, k
+        I[3], I[4], I[5] = a.ld, k, out.ld
+        I[7], I[13], I[15] = L.GATHER_PLAIN, a_wrap, rows_per_sample
+        I[16], I[17], I[19], I[22] = L.EPI_XATTN, L.F16, 1, tile
+        I[24], I[25], I[26], I[27], I[28] = kbuf.ld, n_keys, vt.ld, n_keys * kbuf.ld, vt.rows // samples * vt.ld
+        assert I[27] < 2 ** 31 and I[28] < 2 ** 31 and vt.ld >= -(-n_keys // 32) * 32 and vt.rows % samples == 0
+        op.f[1] = scale
+        op.p[0], op.p[1], op.p[5], op.p[8], op.p[9] = a.ref, w, out.ref, kbuf.ref, vt.ref
+        op.flops = 2.0 * M * n * k + 4.0 * M * n_keys * n
+        op.out = out
+        op.meta = dict(M=M, N=n, K=k, gather=L.GATHER_PLAIN, conv={}, epi=L.EPI_XATTN, split=1, tile=tile, halo=False, ln=0, heads=heads, n_keys=n_keys)
+        return self._emit(op)
 
     @staticmethod
     def tattn_pixels_per_tile(frames: int) -> int:

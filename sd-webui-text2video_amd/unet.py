@@ -272,6 +272,8 @@ class UNetSD(nn.Module):
         # wrap (T2V_OP_GEMM i[12]); the reference runs the two forwards separately and computes it twice (gaussian_sampler.py:161-162).
         # Same arithmetic on the same values; 31 of 725 ops run at half their rows.  Part of the program cache key.
         self.share_cfg_prefix = os.environ.get("T2V_SHARE_PREFIX", "1") != "0"
+        # to_q projection + text cross-attention as ONE launch (T2V_EPI_XATTN, round 5): Q never reaches HBM; part of the program cache key
+        self.fused_cross_attention = os.environ.get("T2V_XATTN", "1") != "0"
         self.auto_refresh = True      # re-check parameter versions on every forward (~1 ms); the sampler
                                       # turns this off inside its loop after one explicit refresh
         self.device = torch.device("cpu")   # SamplerBase.register_buffers_to_model overwrites it (samplers_common.py:82)
@@ -460,6 +462,8 @@ class UNetSD(nn.Module):
         self._share_now = bool(getattr(self, "share_cfg_prefix", False)) and single
         key = self._program_key(B, F, H, W, y.shape[1], x.dtype, y.dtype, out_dtype, shard, Bx)
         comp = self._programs.get(key)
+        if comp is not None and comp.prog.gn_epilogue and L.exchange_disabled():
+            comp = None        # an asynchronous fault was reported: lower again, without the norms fused into GEMM epilogues (_lib.exchange_disabled)
         if comp is None:
             comp = self._compile(B, F, H, W, y.shape[1], _dt(x.dtype), _dt(out_dtype), _dt(y.dtype), shard=shard,
                                  x_batch=Bx if Bx != B else 0)
@@ -491,6 +495,7 @@ class UNetSD(nn.Module):
         """Lowering switches that change the program (part of the cache key)."""
         return ((("strips",),) if getattr(self, "gn_producer_stats", False) else ()) + \
             ((("share",),) if getattr(self, "_share_now", False) else ()) + \
+            ((("xattn",),) if getattr(self, "fused_cross_attention", False) else ()) + \
             ((("pattn",),) if getattr(self, "precise_attn_out", False) else ()) + ((("presample",),) if getattr(self, "precise_resample", False) else ()) + \
             ((("precise", str(self.precise_operands)),) if getattr(self, "precise_operands", False) else ()) + \
             ((("tattn", str(self.fused_temporal_attention)),) if getattr(self, "fused_temporal_attention", False) else ())
@@ -624,6 +629,9 @@ class _Lowering:
                                             else None)
         self.emb_slices: Dict[str, Tuple[int, int]] = {}
         self.kv_slices: Dict[str, Tuple[int, int]] = {}
+        # fused to_q + text cross-attention (T2V_EPI_XATTN, round 5): V^T of every site, [B][sum of inner][keys padded], step-invariant
+        self.vt_all: Optional[Buf] = None
+        self.vt_slices: Dict[str, int] = {}
 
     # -- packed-weight declarations ------------------------------------------------------------
     def w_linear(self, key) -> Ref:
@@ -930,9 +938,6 @@ class _Lowering:
         else:
             x2, n2 = self_attention(1, x1, n1, "norm2")
             if kind == "spatial":
-                q = P.alloc(Mrows, inner, "f16")
-                P.gemm(f"{prefix}.attn2.to_q", n2, self.w_linear(f"{prefix}.attn2.to_q"), inner, inner, q)
-                P.free(n2)
                 k0, k1 = self.kv_slices[prefix + ".attn2"]
                 kv = self.kv_all
                 kbuf, vbuf = kv.col_slice(k0, k0 + inner), kv.col_slice(k0 + inner, k1)
@@ -942,14 +947,29 @@ class _Lowering:
                 # residual row wrap — from here on every tensor has B samples.
                 parting = self.sharing
                 Bq, q_b_stride, Mshared = (self.B, 0, Mrows) if parting else (B, F * hw * inner, 0)
+                Mq = Mrows
                 if parting:
                     self.sharing, self.Bc = False, self.B
                     B, Mrows = self.B, self.B * Mrows
                 a = P.alloc(Mrows, inner, "f16")
-                P.attention(f"{prefix}.attn2", q.ref, kbuf.ref, vbuf.ref, a.ref, out_buf=a, nq=hw, nk=Lc, heads=heads,
-                            b_outer=Bq, b_inner=F, q_strides=(inner, q_b_stride, hw * inner),
-                            kv_strides=(kv.ld, Lc * kv.ld, 0), o_strides=(inner, F * hw * inner, hw * inner), scale=scale)
-                P.free(q)
+                fused_op = None
+                if self.vt_all is not None and (F * hw) % 32 == 0 and Lc <= 96:
+                    # to_q + the 77-key attention as ONE launch (round 5): q never reaches HBM.  (At the parting site the projection runs
+                    # for both samples from the one sample's rows: the A-operand row wrap.)
+                    v0 = self.vt_slices[prefix + ".attn2"]
+                    vt = self.vt_all.row_slice(v0, self.vt_all.rows)           # this site's rows first; sample stride = all rows of a sample
+                    vt_site = Buf(vt.ref, self.vt_all.rows, self.vt_all.cols, self.vt_all.ld, "f16", owns=False)
+                    fused_op = P.to_q_cross_attention(f"{prefix}.attn2.q_attn", n2, self.w_linear(f"{prefix}.attn2.to_q"), a, k=inner, heads=heads,
+                                                      kbuf=kbuf, vt=vt_site, n_keys=Lc, rows_per_sample=F * hw, samples=self.B, scale=scale,
+                                                      a_wrap=Mq if parting else 0)
+                if fused_op is None:
+                    q = P.alloc(Mq, inner, "f16")
+                    P.gemm(f"{prefix}.attn2.to_q", n2, self.w_linear(f"{prefix}.attn2.to_q"), inner, inner, q)
+                    P.attention(f"{prefix}.attn2", q.ref, kbuf.ref, vbuf.ref, a.ref, out_buf=a, nq=hw, nk=Lc, heads=heads,
+                                b_outer=Bq, b_inner=F, q_strides=(inner, q_b_stride, hw * inner),
+                                kv_strides=(kv.ld, Lc * kv.ld, 0), o_strides=(inner, F * hw * inner, hw * inner), scale=scale)
+                    P.free(q)
+                P.free(n2)
                 x3 = P.alloc(Mrows, inner, "f32")
                 n3 = P.alloc(Mrows, inner, "f16")
                 P.gemm(f"{prefix}.attn2.to_out", a, self.w_linear(f"{prefix}.attn2.to_out.0"), inner, inner, x3,
@@ -1104,6 +1124,17 @@ class _Lowering:
         # buffer of the program can alias it between two runs.
         if n_kv:
             self.kv_all = P.alloc(B * self.Lctx, n_kv, "f16")
+        # V^T of the text context for the fused to_q + cross-attention launches: rows = the value channels of every site, keys contiguous
+        # (padded to a multiple of 32, zero beyond the context length: allocated here, never freed before the end, zero from the bind)
+        n_vt = n_kv // 2
+        xattn = (n_kv and self.shard is None and self.Lctx <= 96 and bool(getattr(net, "fused_cross_attention", True))
+                 and all(c % 64 == 0 for _, c in st_prefixes))
+        if xattn:
+            off = 0
+            for p, c in st_prefixes:
+                self.vt_slices[p + ".transformer_blocks.0.attn2"] = off
+                off += c
+            self.vt_all = P.alloc(B * n_vt, -(-self.Lctx // 32) * 32, "f16")
         freqs = Ref("weight", 0, self.packer.add("time_freqs", "f32", lambda sd, d=dim: torch.pow(
             10000, -torch.arange(d // 2).to(torch.float32).div(d // 2))))
         te = P.alloc(B, dim, "f16")
@@ -1122,7 +1153,9 @@ class _Lowering:
         P.gemm("emb_layers.all", e_silu, w_emb, n_emb, emb, self.emb_out, bias=b_emb)
         P.free(e_silu)
 
-        ctx16 = P.alloc(B * self.Lctx, net.context_dim, "f16")
+        n4 = -(-self.Lctx // 4) * 4                 # keys of the V^T GEMMs (N % 4 == 0): the last sample reads n4 - Lctx rows past the context
+        ctx_all = P.alloc(B * self.Lctx + (n4 - self.Lctx), net.context_dim, "f16")
+        ctx16 = ctx_all.row_slice(0, B * self.Lctx)
         ctx_src = Buf(Ref("ext", L.EXT_CTX), B * self.Lctx, net.context_dim, net.context_dim, self.ctx_dt)
         P.copy2d("context.cast", ctx_src, ctx16).meta["step_invariant"] = True
         if n_kv:
@@ -1130,7 +1163,20 @@ class _Lowering:
                 [torch.cat([sd[p + ".transformer_blocks.0.attn2.to_k.weight"], sd[p + ".transformer_blocks.0.attn2.to_v.weight"]], dim=0)
                  for p in ps], dim=0)))
             P.gemm("attn2.kv.all", ctx16, w_kv, n_kv, net.context_dim, self.kv_all, step_invariant=True)
-        P.free(ctx16)
+        if self.vt_all is not None:
+            # V^T [value channels of all sites, keys] = W_v x context^T per sample: swapped operands (the weights are the "token" operand).
+            # Columns Lctx .. n4-1 come from the next sample's tokens (finite; they only ever meet probabilities that are exactly 0) — for
+            # the last sample from the zeroed rows behind the context.
+            if n4 > self.Lctx:
+                P.memset("context.pad", ctx_all.row_slice(B * self.Lctx, ctx_all.rows)).meta["step_invariant"] = True
+            w_v = Ref("weight", 0, self.packer.add("v_all:lin", "f16", lambda sd, ps=tuple(p for p, _ in st_prefixes): torch.cat(
+                [sd[p + ".transformer_blocks.0.attn2.to_v.weight"] for p in ps], dim=0)))
+            wv_as_a = Buf(w_v, n_vt, net.context_dim, net.context_dim, "f16")
+            for b in range(B):
+                P.gemm(f"attn2.vT.all.{b}", wv_as_a, ctx_all.row_slice(b * self.Lctx, b * self.Lctx + n4).ref, n4, net.context_dim,
+                       self.vt_all.row_slice(b * n_vt, (b + 1) * n_vt).col_slice(0, n4), ldw=net.context_dim, allow_splitk=False,
+                       step_invariant=True)
+        P.free(ctx_all)
 
         # ---- entry layout conversion: b c f h w -> tokens x 8 channels (4 real + 4 zero)
         xin = P.alloc(self.M(h, w), 8, "f16")
@@ -1214,5 +1260,7 @@ class _Lowering:
         P.free(y, self.emb_out)
         if n_kv:
             P.free(self.kv_all)
+        if self.vt_all is not None:
+            P.free(self.vt_all)
         P.finish()
         return P

@@ -81,10 +81,34 @@ class Interp:
         o = torch.einsum("bxhfg,bgxhd->bfxhd", torch.softmax(s, dim=-1), v).reshape(T, heads * 64)
         self._st(self.mat(op.p[5], T, heads * 64, ldc, torch.float16, ext), o, torch.float16)
 
+    def _op1_xattn(self, op, ext):
+        """T2V_EPI_XATTN: q = A W^T (fp32 accumulate, fp16 q), softmax(q k^T scale) v against the step-invariant text K / V^T, per (sample, head)."""
+        I = op.i
+        M, N, K, lda, ldc, aw, rps = I[0], I[1], I[2], I[3], I[5], I[13], I[15]
+        ldk, Lc, lcp, ks, vs = I[24], I[25], I[26], I[27], I[28]
+        A = self.mat(op.p[0], aw if aw else M, K, lda, torch.float16, ext).float()
+        if aw:
+            A = torch.cat([A, A[: M - aw]], dim=0)
+        W = self.mat(op.p[1], N, K, I[4], torch.float16, ext).float()
+        q = (A @ W.t()).half().float()
+        heads, samples = N // 64, M // rps
+        out = torch.empty(M, N)
+        for b in range(samples):
+            kb = self.mat(op.p[8].shifted(2 * b * ks), Lc, N, ldk, torch.float16, ext).float()            # [Lc, N]
+            vt = self.mat(op.p[9].shifted(2 * b * vs), N, Lc, lcp, torch.float16, ext).float()            # [N, Lc]
+            qb = q[b * rps:(b + 1) * rps].view(rps, heads, 64)
+            s_ = torch.einsum("mhd,khd->hmk", qb, kb.view(Lc, heads, 64)) * op.f[1]
+            pm = torch.exp(s_ - s_.max(dim=-1, keepdim=True).values)
+            o = torch.einsum("hmk,hdk->mhd", pm.half().float(), vt.view(heads, 64, Lc)) / pm.sum(dim=-1).permute(1, 0)[:, :, None]
+            out[b * rps:(b + 1) * rps] = o.reshape(rps, N)
+        self._st(self.mat(op.p[5], M, N, ldc, torch.float16, ext), out, torch.float16)
+
     def _op1(self, op, ext):
         I = op.i
         if I[16] == L.EPI_TATTN:
             return self._op1_tattn(op, ext)
+        if I[16] == L.EPI_XATTN:
+            return self._op1_xattn(op, ext)
         M, N, K, lda, ldw, ldc, ldr, gather = I[0:8]
         A16 = None
         if gather == L.GATHER_PLAIN:

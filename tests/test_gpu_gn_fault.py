@@ -53,6 +53,24 @@ arena.copy_(arena0.to(dev))                                                     
 bp.run({}, st); torch.cuda.synchronize(); L.async_status()                       # three-launch path from now on
 got.arena = arena.cpu()
 assert rel_l2(read(got, out).float(), read(it, out).float()) < 1e-3
+# ---- after the fault: a GEMM whose GroupNorm would have been fused into its epilogue is lowered WITHOUT the fusion (the library refuses
+# launches that need a co-resident grid once a wait has timed out) and is correct
+assert L.exchange_disabled()
+import math
+P2 = Program(); assert not P2.gn_epilogue
+M, C, K = 1536, 320, 128
+a2, y2, o2 = P2.alloc(M, K, "f16"), P2.alloc(M, C, "f32"), P2.alloc(M, C, "f16")
+w2 = {"w": (torch.randn(C, K, generator=g) / math.sqrt(K)).half(), "g": w["g"][:C].clone(), "b": w["b"][:C].clone()}
+w2["gb"] = torch.cat([w2["g"], w2["b"]])
+P2.gemm("l", a2, Ref("weight", 0, "w"), C, K, y2)
+P2.groupnorm("gn", y2, Ref("weight", 0, "g"), Ref("weight", 0, "b"), o2, n_inst=2, eps=1e-5, silu=True, gb=Ref("weight", 0, "gb"))
+assert len(P2.ops) == 2 and P2.ops[0].i[16] == L.EPI_NONE
+it2 = Interp(P2, w2, poison=False); fill(it2, a2, g); ar0 = it2.arena.clone(); it2.run({})
+ar = ar0.to(dev); wg2 = {k: v.to(dev) for k, v in w2.items()}
+bp2 = BoundProgram(P2, ar.data_ptr(), {k: v.data_ptr() for k, v in wg2.items()})
+bp2.run({}, st); torch.cuda.synchronize(); L.async_status()
+got2 = Interp(P2, w2, poison=False); got2.arena = ar.cpu()
+assert rel_l2(read(got2, o2).float(), read(it2, o2).float()) < 1e-3
 print(f"FAULT_OK bounded wait {dt * 1e3:.0f} ms")
 '''
 

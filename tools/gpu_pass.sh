@@ -46,7 +46,7 @@ stage_abgn() {      # same-box A/B: GroupNorm statistics from the producing GEMM
   prof nostrips2 T2V_GN_STRIPS=0
 }
 stage_gnepi() {     # round 5: GroupNorm inside the producing GEMM's epilogue (T2V_EPI_GN) — op tests, the bounded-barrier fault test
-  timeout 900 $PYT tests/test_gpu_ops.py -x -k "producer_epilogue or groupnorm or layernorm" > gpurun_out/${TAG}_gnepi.log 2>&1
+  timeout 900 $PYT tests/test_gpu_ops.py -x -k "producer_epilogue or groupnorm or layernorm or cross_attention or splitk" > gpurun_out/${TAG}_gnepi.log 2>&1
   echo "gnepi exit $?"; digest gpurun_out/${TAG}_gnepi.log
 }
 stage_abgnepi() {   # same-box A/B of the per-op UNet step: fused GroupNorm epilogues (default) vs T2V_GN_EPI=0, twice; then per level
@@ -63,7 +63,7 @@ stage_abgnepi() {   # same-box A/B of the per-op UNet step: fused GroupNorm epil
 stage_ab2() {       # short same-box A/B: fused norms on / off, ModelScope and VideoCrafter steps
   prof epi T2V_X=0
   prof noepi T2V_GN_EPI=0
-  prof nosplitk T2V_GN_EPI_SPLITK=0
+  prof noxattn T2V_XATTN=0
   for v in "T2V_X=0" "T2V_GN_EPI=0"; do
     env $v timeout 300 python tools/profile_unet.py 16 32 32 2 lvdm > gpurun_out/${TAG}_prof_lvdm_$(echo $v | tr '=' '_').log 2>&1
     echo "== lvdm $v"; sed -n 4,5p gpurun_out/${TAG}_prof_lvdm_$(echo $v | tr '=' '_').log
