@@ -103,7 +103,7 @@ enum t2v_gather {
                              channels), q = A W^T (no bias), keys = the i[25] (<= 96) text tokens.  p[8] = K fp16 [samples][i[25]][i[24]] (this
                              site's N columns; i[27] elements between samples), p[9] = V^T fp16 [samples][N][i[26]] (keys contiguous, finite
                              beyond i[25]; i[28] elements between samples), both written by step-invariant ops; the sample of row m is
-                             m / i[15].  N % 64 == 0; tiles 8 / 11 (N == 320) and 0 (N % 128 == 0); plain gather, no split-K, fp16 out. */
+                             m / i[15].  N % 64 == 0; tiles 8 / 11 (N == 320) and 0 / 5 (N % 128 == 0); plain gather, no split-K, fp16 out. */
 #define T2V_GN_PIECES 36  /* group pieces (group x column tile intersections) per column tile in the T2V_EPI_GN scratch */
 
 /* dtype tags */

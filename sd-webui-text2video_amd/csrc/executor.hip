@@ -70,7 +70,7 @@ int validate_op(const t2v_op& op, int idx) {
         const int tile = op.i[22];
         if (g != T2V_GATHER_PLAIN || N % 64 != 0 || K % 64 != 0 || op.i[17] != T2V_F16 || op.i[19] > 1 || op.i[18] != 0 || op.i[8] != 0 || op.i[11] == 1)
           return bad("fused cross-attention: plain gather, N = 64 * heads, K % 64 == 0, fp16 out, no split-K / activation / LayerNorm / hi + lo output");
-        if (!(((tile == 8 || tile == 11) && N == 320) || (tile == 0 && N % 128 == 0))) return bad("fused cross-attention: tile 8 / 11 with N == 320, or tile 0 with N % 128 == 0");
+        if (!(((tile == 8 || tile == 11) && N == 320) || ((tile == 0 || tile == 5) && N % 128 == 0))) return bad("fused cross-attention: tile 8 / 11 with N == 320, or tile 0 / 5 with N % 128 == 0");
         if (op.p[2] != 0 || op.p[3] != 0 || op.p[4] != 0 || op.p[8] == 0 || op.p[9] == 0 || !(op.f[1] > 0.f)) return bad("fused cross-attention: no bias / row bias / residual; K, V^T and a positive scale are required");
         if (op.i[25] < 1 || op.i[25] > 96 || op.i[24] < N || op.i[24] % 8 != 0 || op.i[26] < ((op.i[25] + 31) / 32) * 32 || op.i[26] % 8 != 0 || op.i[15] <= 0 || op.i[15] % 32 != 0 || op.i[27] < 0 || op.i[28] < 0)
           return bad("fused cross-attention: 1 .. 96 keys, ld(K) >= N, V^T rows of >= ceil32(keys) halfs, rows per sample a multiple of 32");

@@ -874,6 +874,12 @@ hipError_t launch_cfg(const GemmParams& pin, hipStream_t s) {
           break;
         }
       }
+      if constexpr (WM == 2 && WN == 4 && TM == 2 && TN == 1 && PP == 0) {                  // 128x128 on 8 waves (tile 5): two heads per column tile
+        if (p.xa_k != nullptr) {
+          e = launch_cfg_gather<WM, WN, TM, TN, BK, STAGES, MINW, T2V_GATHER_PLAIN, PP, 4>(p, s);
+          break;
+        }
+      }
       if (p.xa_k != nullptr) return hipErrorInvalidValue;
       if constexpr ((WM == 6 || WM == 4) && WN == 2 && TM == 1 && TN == 5 && PP != 1) {      // whole-row tiles: 192x320 / 128x320
         if (p.ln_out != nullptr) {

@@ -504,7 +504,7 @@ class Program:
         M = out.rows
         assert a.dtype == "f16" and out.dtype == "f16" and out.cols == n and k % 64 == 0 and n_keys <= 96 and rows_per_sample % 32 == 0
         tile, split = self.choose_tile(M, n, k, L.GATHER_PLAIN, allow_splitk=False)
-        if not (((tile in (8, 11)) and n == 320) or (tile == 0 and n % 128 == 0)) or split != 1:
+        if not (((tile in (8, 11)) and n == 320) or (tile in (0, 5) and n % 128 == 0)) or split != 1:
             return None
         op = Op(L.OP_GEMM, name)
         I = op.i

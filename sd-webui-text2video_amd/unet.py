@@ -251,6 +251,8 @@ class UNetSD(nn.Module):
         # 1e-3 without them at +0.4 / +0.6 ms per step; on VideoCrafter they move the 10-step output 1.08e-3 -> 0.92e-3 but the 50-step
         # output only 1.07e-3 -> 1.04e-3): the attention output in front of to_out (input-resolution level) and the fp32 -> fp16 cast in
         # front of the Down / Upsample convolutions, both as rows [hi | lo] against [W | W].  Part of the program cache key.
+        # (`precise_attn_out` is read by the VideoCrafter lowering only — videocrafter._LvdmLowering; the ModelScope lowering has no
+        #  [hi | lo] attention output, so the flag does not enter ITS cache key: `_lowering_options`.)
         self.precise_attn_out = os.environ.get("T2V_PRECISE_ATTN", "0") != "0"
         self.precise_resample = os.environ.get("T2V_PRECISE_RESAMPLE", "0") != "0"
         # TemporalTransformer self-attention as ONE launch per attention (QKV projection + attention of every pixel's frame
@@ -496,7 +498,7 @@ class UNetSD(nn.Module):
         return ((("strips",),) if getattr(self, "gn_producer_stats", False) else ()) + \
             ((("share",),) if getattr(self, "_share_now", False) else ()) + \
             ((("xattn",),) if getattr(self, "fused_cross_attention", False) else ()) + \
-            ((("pattn",),) if getattr(self, "precise_attn_out", False) else ()) + ((("presample",),) if getattr(self, "precise_resample", False) else ()) + \
+            ((("pattn",),) if (getattr(self, "precise_attn_out", False) and type(self) is not UNetSD) else ()) + ((("presample",),) if getattr(self, "precise_resample", False) else ()) + \
             ((("precise", str(self.precise_operands)),) if getattr(self, "precise_operands", False) else ()) + \
             ((("tattn", str(self.fused_temporal_attention)),) if getattr(self, "fused_temporal_attention", False) else ())
 

@@ -641,7 +641,8 @@ class LatentDiffusion(nn.Module):
         super()._apply(fn, *args, **kwargs)
         for n, v in keep.items():
             cur = self._buffers[n]
-            if cur.dtype != v.dtype:
+            # only a cast to a LOWER-precision float is undone (.half() / .bfloat16()); .double() / .to(torch.float64) take effect
+            if cur.dtype != v.dtype and cur.dtype in (torch.float16, torch.bfloat16):
                 self._buffers[n] = v.to(cur.device)
         return self
 

@@ -421,3 +421,33 @@ def test_round4_groupnorm_statistics_from_the_producing_gemm():
         m.gn_producer_stats = on
         keys.add(m._program_key(2, 3, 16, 16, 7, torch.float32, torch.float32, torch.float32))
     assert len(keys) == 2
+
+
+import pytest
+
+
+@pytest.mark.parametrize("tattn", [True, "force", False])
+@pytest.mark.parametrize("fusions", [True, False])
+def test_round5_lowering_variants_match_the_oracle(tattn, fusions, monkeypatch):
+    """the suite sets T2V_FUSED_TATTN=force (tests/conftest.py), so the product's DEFAULT lowering of short clips (the unfused
+    projection + attention pair) was not exercised — here the tiny UNet is lowered under the default, the forced and the unfused setting,
+    and with the round-5 fusions (GroupNorm in the producing GEMM's epilogue, cross-tile LayerNorm, to_q + text cross-attention, the
+    GroupNorm cast output) on and off; every program must match the reference golden in the interpreter."""
+    if not fusions:
+        for k in ("T2V_GN_EPI", "T2V_LN_X", "T2V_GN_CAST"):
+            monkeypatch.setenv(k, "0")
+    cfg, m, sd, x, t, y = _tiny()
+    m.fused_temporal_attention = tattn
+    m.fused_cross_attention = fusions
+    comp = m._compile(2, 3, 16, 16, 7, "f32", "f32", "f32")
+    ops = comp.prog.ops
+    n_gn = sum(1 for o in ops if o.kind == L.OP_GEMM and o.i[16] == L.EPI_GN)
+    n_xa = sum(1 for o in ops if o.kind == L.OP_GEMM and o.i[16] == L.EPI_XATTN)
+    n_ta = sum(1 for o in ops if o.kind == L.OP_GEMM and o.i[16] == L.EPI_TATTN)
+    assert (n_gn > 0) == fusions and (n_xa > 0) == fusions and (n_ta > 0) == (tattn == "force")      # (3-frame clip: fused only when forced)
+    packed = comp.packer.materialise(m.state_dict(), "cpu")
+    it = Interp(comp.prog, packed)
+    out = torch.empty(2, 4, 3, 16, 16)
+    it.run({L.EXT_X: x, L.EXT_T: t, L.EXT_CTX: y, L.EXT_OUT: out})
+    gold = torch.from_numpy(np.load(os.path.join(GOLD, "tiny.npz"))["unet_eps"])
+    assert not torch.isnan(out).any() and rel_l2(out, gold) < 4e-3

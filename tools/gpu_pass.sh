@@ -127,7 +127,7 @@ stage_e2e() {
   timeout 1500 $PYT tests/test_gpu_e2e.py tests/test_gpu_text_encoder.py tests/test_gpu_videocrafter.py > gpurun_out/${TAG}_e2e.log 2>&1; echo "e2e exit $?"; digest gpurun_out/${TAG}_e2e.log
 }
 stage_suite() {     # what the driver runs at round end
-  timeout -k 10 2400 python -m pytest tests -m gpu -q -rP --tb=short -p no:cacheprovider > gpurun_out/${TAG}_pytest_gpu.log 2>&1; echo "pytest -m gpu exit $?"; digest gpurun_out/${TAG}_pytest_gpu.log 12
+  timeout -k 10 2400 python -m pytest tests -m gpu -q -rP --tb=short --durations=12 -p no:cacheprovider > gpurun_out/${TAG}_pytest_gpu.log 2>&1; echo "pytest -m gpu exit $?"; digest gpurun_out/${TAG}_pytest_gpu.log 12
 }
 stage_roundend() {  # the measurements that go to profiles/r04_*: rocprofv3 kernel stats + PMC traffic + MFMA utilisation on this build, the other
                     # BASELINE geometries, per-kind step profiles, the stages either side of the loop
