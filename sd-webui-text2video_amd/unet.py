@@ -274,8 +274,11 @@ class UNetSD(nn.Module):
         # wrap (T2V_OP_GEMM i[12]); the reference runs the two forwards separately and computes it twice (gaussian_sampler.py:161-162).
         # Same arithmetic on the same values; 31 of 725 ops run at half their rows.  Part of the program cache key.
         self.share_cfg_prefix = os.environ.get("T2V_SHARE_PREFIX", "1") != "0"
-        # to_q projection + text cross-attention as ONE launch (T2V_EPI_XATTN, round 5): Q never reaches HBM; part of the program cache key
-        self.fused_cross_attention = os.environ.get("T2V_XATTN", "1") != "0"
+        # to_q projection + text cross-attention as ONE launch (T2V_EPI_XATTN, round 5): Q never reaches HBM; part of the program cache key.
+        # Built, parity-tested and MEASURED NEUTRAL: per-op events say -6 us (32x32 level) / -12 us (16x16) per site, but the back-to-back step
+        # is 26.09 vs 26.03 ms and 26.51 vs 26.37 ms on two boxes (the epilogue's K / V^T fragment loads from L2 are latency-bound: the fused
+        # launch takes 53 us where projection + attention take 28 + 32) -> opt-in (T2V_XATTN=1)
+        self.fused_cross_attention = os.environ.get("T2V_XATTN", "0") != "0"
         self.auto_refresh = True      # re-check parameter versions on every forward (~1 ms); the sampler
                                       # turns this off inside its loop after one explicit refresh
         self.device = torch.device("cpu")   # SamplerBase.register_buffers_to_model overwrites it (samplers_common.py:82)

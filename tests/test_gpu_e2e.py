@@ -179,6 +179,25 @@ def test_cfg_pair_shares_the_prefix_up_to_the_first_cross_attention(tiny):
     assert not torch.equal(two_t[1], a[1])
 
 
+def test_fused_cross_attention_option(tiny):
+    """Round 5 (opt-in, `UNetSD.fused_cross_attention`): to_q projection + text cross-attention as ONE launch per site (T2V_EPI_XATTN) gives the
+    same forward as the projection + attention pair up to the fp16 rounding of q."""
+    net, sd, _ = tiny
+    x, t, y, *_ = _tiny_inputs()
+    ref = tp.unet_forward(sd, configs.TINY_UNET, x, t, y)
+    base = net(x.to(DEV), t.to(DEV), y.to(DEV)).float().cpu()
+    net.fused_cross_attention = True
+    try:
+        fused = net(x.to(DEV), t.to(DEV), y.to(DEV)).float().cpu()
+        comp = next(c for k, c in net._programs.items() if ("xattn",) in k)
+        assert sum(1 for op in comp.prog.ops if op.kind == L.OP_GEMM and op.i[16] == L.EPI_XATTN) >= 3
+    finally:
+        net.fused_cross_attention = False
+    e0, e1 = rel_l2(base, ref), rel_l2(fused, ref)
+    print(f"fused to_q + cross-attention, tiny config: rel-L2 vs the oracle {e1:.3e} (pair: {e0:.3e}); between them {rel_l2(fused, base):.3e}")
+    assert e1 < 1.1 * e0 + 1e-4 and rel_l2(fused, base) < 1.5e-3
+
+
 def test_weight_mutation_is_picked_up(tiny):
     """LoRA-style in-place mutation between calls must invalidate the packed weights (SURVEY §2.1 #8)."""
     net, sd, _ = tiny

@@ -42,7 +42,9 @@ def _pipe(dev):
 FRAMES, STEPS, SEED = 7, 3, 99
 
 
-ETAS = (0.0, 0.6)
+# (round 5: the 4-process run time-slices one GPU with every exchange staged through the host — 275 s for both etas.  eta = 0.6 — the shared
+#  noise stream — includes everything the eta = 0 run exercises; both run with T2V_TEST_FULL=1)
+ETAS = (0.0, 0.6) if os.environ.get("T2V_TEST_FULL") == "1" else (0.6,)
 
 
 def _worker(rank, world, port, mode, ret):
@@ -60,7 +62,7 @@ def _worker(rank, world, port, mode, ret):
             out = runner(c.to(dev), uc.to(dev), SEED)
             # (four processes time-slicing one GPU with every exchange staged through the host: a T-sharded run costs ~70 s here,
             #  so the repeat runs only where they test something new)
-            if eta == 0.0 or mode == "pairs":
+            if eta == ETAS[0] or mode == "pairs":
                 if mode == "tshard":
                     # the advisor's scenario: an UNSHARDED forward between two sharded runs on the same module
                     x = torch.randn(1, 4, 2, 8, 8, device=dev)
@@ -109,7 +111,8 @@ def test_runner_layouts_multi_process_on_one_gpu(world, mode):
         # b = 1 per-role programs (other tiles / split-K than the b = 2 single-GPU forward): rounding-level differences only;
         # a wrong slice / halo / frame order is an O(100 %) error on the affected frames
         assert (d == 0).mean() > 0.85 and max(per_frame) < 0.02
-    assert not np.array_equal(ret[(0, 0.0)], ret[(0, 0.6)])      # eta really changed the run
+    if len(ETAS) > 1:
+        assert not np.array_equal(ret[(0, 0.0)], ret[(0, 0.6)])      # eta really changed the run
 
 
 @pytest.mark.skipif(os.environ.get("T2V_TEST_FULL") != "1", reason="the self-launch is covered on the CPU (tests/test_bench_contract.py); the one-GPU "
