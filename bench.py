@@ -443,6 +443,8 @@ def main_lvdm(args):
     n_gemm = sum(1 for op in prog.ops if op.kind == 1)
     step_ms = sum(ms)
     achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12
+    step_ms_b2b = forward_ms_back_to_back(net, x, t, y, dev, context_kw=True)
+    fused, plain_ms, plain_fl = fused_norm_split(prog, ms, gemm_ms, gemm_fl)
     named = "BASELINE.json configs[4]" if (frames, args.height, args.width, args.ddim_steps) == (16, 256, 256, 50) else "custom geometry"
     result = {
         "metric": f"denoised frames/sec (UNet+VAE), VideoCrafter LVDM {frames}f@{args.width}x{args.height}",
@@ -467,6 +469,29 @@ def main_lvdm(args):
                                      "frac": round(video_tflop / (ms_per_step * 1e-3) / MFMA_PEAK_TFLOPS, 4)}},
     }
     emit(result)
+
+
+def forward_ms_back_to_back(net, x, t, y, dev, n=10, context_kw=False):
+    """The same forward WITHOUT a HIP event after every op: two events on the launch stream around n back-to-back forwards."""
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def once():
+        net.single_timestep = True                   # (one timestep for the cond | uncond pair, as the samplers say: the prefix is shared)
+        return net(x, t, context=y) if context_kw else net(x, t, y)
+    once()
+    ev0.record()
+    for _ in range(n):
+        once()
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    return ev0.elapsed_time(ev1) / n
+
+
+def fused_norm_split(prog, ms, gemm_ms, gemm_fl):
+    """Members of the GEMM family that also carry a normalisation in their epilogue (round 5: GroupNorm / LayerNorm of the result, statistics
+    exchanged between the launch's workgroups) — their time includes that work, their FLOPs do not.  -> (those, ms of the rest, FLOPs of the rest)"""
+    fused = [(op, m) for op, m in zip(prog.ops, ms) if op.kind == 1 and (op.i[16] == 4 or (op.i[7] == 0 and op.i[8] in (1, 2) and op.i[16] == 0))]
+    return fused, gemm_ms - sum(m for _, m in fused), gemm_fl - sum(op.flops for op, _ in fused)
 
 
 _REAL_STDOUT = None
@@ -803,22 +828,8 @@ def main():
         traffic = pmc_traffic() if (args.videos, frames, args.height, args.width, world) == (1, 24, 256, 256, 1) else None
         step_ms = sum(ms)
         achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12
-        # the same forward WITHOUT a HIP event after every op: two events on the launch stream around 10 back-to-back forwards
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        net.single_timestep = True
-        net(x, t, y)
-        ev0.record()
-        for _ in range(10):
-            net.single_timestep = True               # (one timestep for the cond | uncond pair, as the samplers say: the prefix is shared)
-            net(x, t, y)
-        ev1.record()
-        torch.cuda.synchronize(dev)
-        step_ms_b2b = ev0.elapsed_time(ev1) / 10.0
-        # members of the family that also carry a normalisation in their epilogue (round 5: GroupNorm / LayerNorm of the result, statistics
-        # exchanged between the launch's workgroups) — their time includes that work, their FLOPs do not
-        fused = [(op, m) for op, m in zip(prog.ops, ms) if op.kind == 1 and (op.i[16] == 4 or (op.i[7] == 0 and op.i[8] in (1, 2) and op.i[16] == 0))]
-        plain_ms = gemm_ms - sum(m for _, m in fused)
-        plain_fl = gemm_fl - sum(op.flops for op, _ in fused)
+        step_ms_b2b = forward_ms_back_to_back(net, x, t, y, dev)
+        fused, plain_ms, plain_fl = fused_norm_split(prog, ms, gemm_ms, gemm_fl)
         result["roofline"] = {
             "bound": "mfma", "kernel": "gemm2_kernel<WM,WN,TM,TN,BK,STAGES,MINW,GATHER,PP> + gemm_kernel<BM,BN,WM,WN,GATHER> (one implicit-GEMM family: conv3x3 / temporal conv / linear)",
             "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),

@@ -189,6 +189,10 @@ enum t2v_gather {
  *      15 max relative position R, 16 q_off: the nq queries are frames [q_off, q_off + nq) of the clip (nq == nk, q_off == 0
  *      unless the clip is T-sharded: then s - t below is s - (t + q_off)); 17 = 1: use the MFMA kernel where it applies (nq == nk,
  *      q_off == 0, nk - 1 <= R <= 31, head_dim 40 | 64 | 80 | 160; the relative tables are staged as fp16) — else the VALU kernel;
+ *      17 = 2 (round 5): the persistent MFMA kernel for whole clips of nk <= 16 frames (nq == nk, q_off == 0, R >= nk - 1, same head
+ *      dims), with the tables ALSO given packed for it: p[6] = fp16 [32][DK] rows jl = Ek[jl + R - (nk-1)] (DK = head_dim rounded up
+ *      to 16; zero beyond the table / head_dim), p[7] = fp16 [DV][32] = Ev transposed, column jl = Ev[jl + R - (nk-1)] (DV = head_dim
+ *      rounded up to 32) — where it does not apply the VALU kernel runs on p[4], p[5];
  *      18 low-order output offset (as ATTENTION i[16]);  f: 0 scale;  p: 0 q, 1 k, 2 v, 3 out (fp16), 4 Ek fp32 [2R+1, head_dim],
  *      5 Ev fp32 [2R+1, head_dim]:  sim[t,s] = scale * q[t].(k[s] + Ek[clip(s-t)]),
  *      out[t] = sum_s softmax_s(sim)[t,s] * (v[s] + Ev[clip(s-t)])   (attention_temporal.py:107-144)

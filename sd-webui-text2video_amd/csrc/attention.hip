@@ -669,6 +669,226 @@ hipError_t launch_relpos_mfma(const SeqAttnParams& p, hipStream_t s) {
   return hipGetLastError();
 }
 
+// ---- relative-position temporal attention on MFMA, clips of <= 16 frames (round 5) ---------------------------------------
+// The same products as relpos_mfma_kernel, with the three things that made that kernel lose to the VALU kernel removed:
+//  * the tables arrive READY from the host — Ek as fp16 rows [32 slots][DK] and Ev TRANSPOSED as fp16 [DV][32 slots], slot jl = table
+//    row jl + R - (T-1), zero-padded (packing: videocrafter.py) — so staging them is a straight copy, not 10 k scalar conversions with a
+//    transposing gather per workgroup;
+//  * waves are PERSISTENT: the grid is what the chip holds at once and every wave walks its items, so the tables are staged once per
+//    workgroup for all of them (the 32x32 level: 8 items per wave);
+//  * T <= 16 means ONE 16-key step and ONE 32-slot table block: V^T, the skew buffer and the probability rows shrink to 6.7-10.5 KB per
+//    wave (was 21), the workgroup to 35 / 45 / 65 KB at head_dim 40 / 80 / 160 -> 4 / 3 / 2 workgroups per CU instead of one.
+struct Rel16Params {
+  SeqAttnParams a;
+  const f16* ek16;            // [32][DK]
+  const f16* evt16;           // [DV][32]
+};
+
+template <int D>
+__global__ __launch_bounds__(256) void relpos16_kernel(const Rel16Params pp) {
+  const SeqAttnParams& p = pp.a;
+  constexpr int DK = (D + 15) / 16 * 16, NKK = DK / 16;
+  constexpr int DV = (D + 31) / 32 * 32, NDT = DV / 32;
+  constexpr int EK_PITCH = DK * 2 + 16;          // bytes per Ek slot row
+  constexpr int EV_PITCH = 32 * 2 + 8;           // bytes per Ev^T row: 32 slots
+  constexpr int VT_PITCH = 16 * 2 + 8;           // bytes per V^T row: 16 keys
+  constexpr int QE_PITCH = 33;                   // floats per QE row (query t): 32 slots + 1
+  constexpr int P_PITCH = 64;                    // halves per probability row: [16 zeros | p[t, 0..16) | 32 zeros]
+  constexpr int WAVE_BYTES = DV * VT_PITCH + 16 * QE_PITCH * 4 + 16 * P_PITCH * 2;
+  static_assert(WAVE_BYTES % 16 == 0 && (DV * VT_PITCH) % 16 == 0 && (32 * EK_PITCH + DV * EV_PITCH) % 16 == 0, "LDS carve-up alignment");
+  extern __shared__ __attribute__((aligned(16))) unsigned char ssm[];
+  unsigned char* ekl = ssm;                                      // [32][EK_PITCH]
+  unsigned char* evt = ssm + 32 * EK_PITCH;                      // [DV][EV_PITCH]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  unsigned char* wbase = ssm + 32 * EK_PITCH + DV * EV_PITCH + wave * WAVE_BYTES;
+  unsigned char* vt = wbase;                                     // [DV][VT_PITCH]
+  float* qeb = reinterpret_cast<float*>(wbase + DV * VT_PITCH);  // [16][QE_PITCH]
+  f16* pb = reinterpret_cast<f16*>(wbase + DV * VT_PITCH + 16 * QE_PITCH * 4);   // [16][P_PITCH]
+  const int T = p.T;
+  for (int u = tid; u < 32 * (DK / 8); u += 256) {
+    const int jl = u / (DK / 8), c = u - jl * (DK / 8);
+    *reinterpret_cast<f16x8*>(ekl + jl * EK_PITCH + c * 16) = *reinterpret_cast<const f16x8*>(pp.ek16 + jl * DK + c * 8);
+  }
+  for (int u = tid; u < DV * 8; u += 256) {
+    const int d = u >> 3, c = u & 7;
+    *reinterpret_cast<f16x4*>(evt + d * EV_PITCH + c * 8) = *reinterpret_cast<const f16x4*>(pp.evt16 + d * 32 + c * 4);
+  }
+  // zero this wave's probability rows once: the pads stay zero, the 16 middle slots are rewritten per item
+  for (int u = lane; u < 16 * P_PITCH / 8; u += 64) {
+    const f16x8 z = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+    reinterpret_cast<f16x8*>(pb)[u] = z;
+  }
+  __syncthreads();                                               // the only workgroup barrier: the item loop below is per wave
+  const int frow = lane & 31, fhalf = lane >> 5;
+  const int trow = frow < 16 ? frow : 15;                        // LDS row of lanes that own no query (their results are discarded)
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const float sl2 = p.scale * 1.44269504088896340736f;
+  for (long item = (long)blockIdx.x * 4 + wave; item < p.n_items; item += (long)gridDim.x * 4) {
+    const int head = (int)(item % p.heads);
+    const long pos = item / p.heads;
+    const long bo = pos / p.b_inner, bi = pos % p.b_inner;
+    const f16* qb = p.q + bo * p.sq_out + bi * p.sq_in + head * D;
+    const f16* kb = p.k + bo * p.sk_out + bi * p.sk_in + head * D;
+    const f16* vb = p.v + bo * p.sk_out + bi * p.sk_in + head * D;
+    f16* ob = p.o + bo * p.so_out + bi * p.so_in + head * D;
+    // ---- V^T into LDS: unit = (key pair, 4 d)
+    for (int u = lane; u < 8 * (DV / 4); u += 64) {
+      const int kp = u / (DV / 4), dq = u - kp * (DV / 4);
+      const int key = 2 * kp;
+      const bool dok = dq * 4 < D;
+      f16x4 a, b;
+      if (dok && key < T) a = *reinterpret_cast<const f16x4*>(vb + (long)key * p.sk_seq + dq * 4);
+      else for (int e = 0; e < 4; ++e) a[e] = (f16)0.f;
+      if (dok && key + 1 < T) b = *reinterpret_cast<const f16x4*>(vb + (long)(key + 1) * p.sk_seq + dq * 4);
+      else for (int e = 0; e < 4; ++e) b[e] = (f16)0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        typedef f16 f16x2 __attribute__((ext_vector_type(2)));
+        f16x2 w = {a[e], b[e]};
+        *reinterpret_cast<f16x2*>(vt + (dq * 4 + e) * VT_PITCH + kp * 4) = w;
+      }
+    }
+    // ---- S^T = K Q^T (K fragments are used once, Q fragments again for the table product)
+    f16x8 qf[NKK];
+    f32x16 sc = zero16;
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+      const int d0 = kk * 16 + fhalf * 8;
+      f16x8 kf;
+      if (frow < T && d0 < D) {
+        qf[kk] = *reinterpret_cast<const f16x8*>(qb + (long)frow * p.sq_seq + d0);
+        kf = *reinterpret_cast<const f16x8*>(kb + (long)frow * p.sk_seq + d0);
+      } else {
+        for (int e = 0; e < 8; ++e) { qf[kk][e] = (f16)0.f; kf[e] = (f16)0.f; }
+      }
+      sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[kk], sc, 0, 0, 0);
+    }
+    // ---- QE^T = Ek Q^T over the 32 table slots, written skew-ready as [t][slot]
+    {
+      f32x16 qe = zero16;
+#pragma unroll
+      for (int kk = 0; kk < NKK; ++kk) {
+        const f16x8 ef = *reinterpret_cast<const f16x8*>(ekl + frow * EK_PITCH + ((kk * 2 + fhalf) << 4));
+        qe = __builtin_amdgcn_mfma_f32_32x32x16_f16(ef, qf[kk], qe, 0, 0, 0);
+      }
+      if (frow < 16) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)                   // accumulator rows (slots) 8 g + 4 fhalf + {0..3}, column t = frow
+#pragma unroll
+          for (int e = 0; e < 4; ++e) qeb[frow * QE_PITCH + 8 * g + 4 * fhalf + e] = qe[4 * g + e];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");        // the same wave reads back below
+    // ---- scores + softmax of this lane's query t = frow: keys (r & 3) + 8 (r >> 2) + 4 fhalf, r < 8 (keys 16 .. 31 do not exist)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int key = (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+      const float rel = qeb[trow * QE_PITCH + key - trow + 15 - (16 - T)];     // slot = key - t + (T - 1)
+      const float v = (key < T && frow < T) ? sc[r] + rel : -INFINITY;
+      sc[r] = v;
+      mx = fmaxf(mx, v);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    if (frow >= T) mx = 0.f;
+    const float neg_m = -mx * sl2;
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], sl2, neg_m));
+      sc[r] = pv;
+      psum += pv;
+    }
+    psum += __shfl_xor(psum, 32);
+    // probabilities (unnormalised) into this query's LDS row: slots 16 + key
+    if (frow < 16) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const f16x4 pw = {(f16)sc[4 * g], (f16)sc[4 * g + 1], (f16)sc[4 * g + 2], (f16)sc[4 * g + 3]};
+        *reinterpret_cast<f16x4*>(pb + frow * P_PITCH + 16 + 8 * g + 4 * fhalf) = pw;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    // ---- O^T = V^T P^T + Ev^T Pskew^T
+    f32x16 oacc[NDT];
+#pragma unroll
+    for (int d = 0; d < NDT; ++d) oacc[d] = zero16;
+    {
+      f16x8 pf;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pf[e] = (f16)sc[e];
+#pragma unroll
+      for (int d = 0; d < NDT; ++d) {
+        const unsigned char* vrow = vt + (d * 32 + frow) * VT_PITCH + 8 * fhalf;
+        const f16x4 lo = *reinterpret_cast<const f16x4*>(vrow);
+        const f16x4 hi = *reinterpret_cast<const f16x4*>(vrow + 16);
+        const f16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, oacc[d], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {                       // 16 table slots per step: slot = 16 u + 4 fhalf + (e & 3) + 8 (e >> 2)
+      f16x8 pf;
+      const f16* prow = pb + trow * P_PITCH + 16 + 16 * u + 4 * fhalf - (T - 1) + trow;       // column of slot e = 0 (s = slot + t - (T-1))
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pf[e] = prow[(e & 3) + 8 * (e >> 2)];
+      const int jofs = (16 * u + 4 * fhalf) * 2;
+#pragma unroll
+      for (int d = 0; d < NDT; ++d) {
+        const unsigned char* erow = evt + (d * 32 + frow) * EV_PITCH + jofs;
+        const f16x4 lo = *reinterpret_cast<const f16x4*>(erow);
+        const f16x4 hi = *reinterpret_cast<const f16x4*>(erow + 16);
+        const f16x8 ef = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ef, pf, oacc[d], 0, 0, 0);
+      }
+    }
+    if (frow < T) {
+      const float inv = 1.0f / psum;
+      f16* orow = ob + (long)frow * p.so_seq;
+#pragma unroll
+      for (int d = 0; d < NDT; ++d)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          const int col = d * 32 + 8 * qd + 4 * fhalf;
+          if (col < D) {
+            f16x4 o, lo;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float val = oacc[d][4 * qd + r] * inv;
+              o[r] = (f16)val;
+              lo[r] = (f16)(val - (float)o[r]);
+            }
+            *reinterpret_cast<f16x4*>(orow + col) = o;
+            if (p.lo_off) *reinterpret_cast<f16x4*>(orow + p.lo_off + col) = lo;
+          }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");        // this item's LDS reads before the next item's writes
+  }
+}
+
+template <int D>
+hipError_t launch_relpos16(const SeqAttnParams& p, const f16* ek16, const f16* evt16, hipStream_t s) {
+  constexpr int DK = (D + 15) / 16 * 16, DV = (D + 31) / 32 * 32;
+  constexpr int lds = 32 * (DK * 2 + 16) + DV * (32 * 2 + 8) + 4 * (DV * (16 * 2 + 8) + 16 * 33 * 4 + 16 * 64 * 2);
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  Rel16Params pp;
+  pp.a = p;
+  pp.ek16 = ek16;
+  pp.evt16 = evt16;
+  auto kern = relpos16_kernel<D>;
+  static t2v_device_flags attr_set;       // per (instantiation, device)
+  {
+    const hipError_t e = t2v_set_dynamic_lds(reinterpret_cast<const void*>(kern), lds, attr_set, s);
+    if (e != hipSuccess) return e;
+  }
+  const int per_cu = (160 * 1024 / lds) < 4 ? (160 * 1024 / lds) : 4;
+  const long want = (p.n_items + 3) / 4, hold = (long)t2v_num_cus(s) * per_cu;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(want < hold ? want : hold)), dim3(256), lds, s, pp);
+  return hipGetLastError();
+}
+
 template <bool REL>
 hipError_t launch_seqattn(const t2v_op& op, hipStream_t s) {
   SeqAttnParams p;
@@ -689,11 +909,24 @@ hipError_t launch_seqattn(const t2v_op& op, hipStream_t s) {
   if (p.T <= 0 || p.T > 32 || p.Tq <= 0 || p.q_off < 0 || p.q_off + p.Tq > p.T || p.D <= 0 || p.D % 8 != 0 || p.D > 160 || p.n_items <= 0)
     return hipErrorInvalidValue;
   if (REL && (p.R < 0 || p.ek == nullptr || p.ev == nullptr)) return hipErrorInvalidValue;
-  if (REL && op.i[17] != 0 && p.Tq == p.T && p.q_off == 0 && p.R >= p.T - 1 && p.R <= 31 && p.scale > 0.f) {
+  if (REL && op.i[17] == 2 && op.p[6] != 0 && op.p[7] != 0 && p.Tq == p.T && p.q_off == 0 && p.T <= 16 && p.R >= p.T - 1 && p.scale > 0.f) {
+    // i[17] = 2 (round 5): the persistent MFMA kernel for whole clips of <= 16 frames, tables pre-packed by the host (p[6], p[7])
+    const f16* ek16 = reinterpret_cast<const f16*>(op.p[6]);
+    const f16* evt16 = reinterpret_cast<const f16*>(op.p[7]);
+    switch (p.D) {
+      case 40: return launch_relpos16<40>(p, ek16, evt16, s);
+      case 64: return launch_relpos16<64>(p, ek16, evt16, s);
+      case 80: return launch_relpos16<80>(p, ek16, evt16, s);
+      case 160: return launch_relpos16<160>(p, ek16, evt16, s);
+      default: break;
+    }
+  }
+  if (REL && op.i[17] == 1 && p.Tq == p.T && p.q_off == 0 && p.R >= p.T - 1 && p.R <= 31 && p.scale > 0.f) {
     // i[17]: the MFMA kernel for the unclipped, unsharded form (the released model: 16 frames, R = 16).  Correct (op tests against
     // the interpreter and the explicit formula), but MEASURED SLOWER than the VALU kernel below on the VideoCrafter step (2.25 vs
     // 1.65 ms for the 32 launches): its LDS footprint (tables + skew buffers, ~100 KB per 4-wave workgroup) leaves 4 waves per CU
-    // against 24, and every workgroup re-stages the tables for four 16x16 problems.  Kept as an opt-in (T2V_RELPOS_MFMA=1).
+    // against 24, and every workgroup re-stages the tables for four 16x16 problems.  Kept as an opt-in (T2V_RELPOS_MFMA=1); round 5's
+    // relpos16_kernel (i[17] = 2, above) removes both and is the default for clips of <= 16 frames (0.80 ms for the same 32 launches).
     {
       switch (p.D) {
         case 40: return launch_relpos_mfma<40>(p, s);

@@ -185,6 +185,8 @@ int validate_op(const t2v_op& op, int idx) {
         if (op.i[k] < 0) return bad("negative attention stride");
       for (int k = 0; k < 6; ++k)
         if (op.p[k] == 0) return bad("null relative-position attention pointer");
+      if (op.i[17] < 0 || op.i[17] > 2) return bad("relative-position attention kernel selector i[17]: 0 | 1 | 2");
+      if (op.i[17] == 2 && (op.p[6] == 0 || op.p[7] == 0)) return bad("relative-position attention i[17] = 2 needs the packed fp16 tables p[6], p[7]");
       return 0;
     case T2V_OP_SOFTMAX:
       if (op.i[0] <= 0 || op.i[1] <= 0 || op.i[2] < op.i[1] || op.i[3] < op.i[1] || op.p[0] == 0 || op.p[1] == 0) return bad("bad softmax shape / pointer");

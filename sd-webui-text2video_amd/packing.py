@@ -59,6 +59,25 @@ def conv3x3_c8_dup(w: torch.Tensor) -> torch.Tensor:
     return conv3x3(torch.cat([w, w], dim=1))
 
 
+def relpos_table16(tab: torch.Tensor, frames: int, transposed: bool) -> torch.Tensor:
+    """A relative-position table [2R+1, d] (lvdm RelativePosition.embeddings_table, attention_temporal.py:21-41) as the persistent MFMA
+    kernel of clips of <= 16 frames reads it (csrc/attention.hip relpos16_kernel): only rows R-(F-1) .. R+(F-1) are ever addressed by
+    a clip of F frames (no clipping when R >= F-1), so slot jl = row jl + R-(F-1), 32 slots, fp16, zero-padded.
+    transposed=False: [32, DK] (K-side table, DK = d rounded up to 16);  True: [DV, 32] (V-side table, DV = d rounded up to 32)."""
+    n_rows, d = tab.shape
+    R = (n_rows - 1) // 2
+    assert frames <= 16 and R >= frames - 1
+    jbase = R - (frames - 1)
+    n = min(32, n_rows - jbase)
+    if transposed:
+        out = torch.zeros((d + 31) // 32 * 32, 32, dtype=torch.float16, device=tab.device)
+        out[:d, :n] = tab[jbase:jbase + n].t().to(torch.float16)
+    else:
+        out = torch.zeros(32, (d + 15) // 16 * 16, dtype=torch.float16, device=tab.device)
+        out[:n, :d] = tab[jbase:jbase + n].to(torch.float16)
+    return out.contiguous()
+
+
 def linear_dup(w: torch.Tensor) -> torch.Tensor:
     """[N, K] -> [N, 2K] = [W | W]: consumer of an operand laid out [hi (K) | lo (K)] per row."""
     w = linear(w)

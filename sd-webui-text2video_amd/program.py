@@ -792,7 +792,8 @@ class Program:
     def attention(self, name: str, q: Ref, k: Ref, v: Ref, o: Ref, *, out_buf: Optional[Buf] = None, nq: int, nk: int, heads: int,
                   b_outer: int, b_inner: int, q_strides, kv_strides, o_strides, scale: float, head_dim: int = 64,
                   rel_k: Optional[Ref] = None, rel_v: Optional[Ref] = None, max_rel: int = 0, causal: bool = False,
-                  q_offset: int = 0, relpos_mfma: Optional[bool] = None, lo_off: int = 0) -> Op:
+                  q_offset: int = 0, relpos_mfma: Optional[int] = None, lo_off: int = 0,
+                  rel_k16: Optional[Ref] = None, rel_vT16: Optional[Ref] = None) -> Op:
         """softmax(q k^T scale) v over strided (sequence, outer, inner) batches.  With rel_k / rel_v (fp32
         [2*max_rel+1, head_dim] tables) the LVDM relative-position temporal attention op is emitted instead.
         lo_off (elements): also store the low-order fp16 image of every output value at o + lo_off (rows [hi | lo] for a K-doubled
@@ -804,9 +805,17 @@ class Program:
         if rel_k is not None:
             assert nk <= 32 and 0 <= q_offset and q_offset + nq <= nk and head_dim % 8 == 0
             op.i[15], op.i[16] = max_rel, q_offset
-            # MFMA variant of the relative-position kernel: opt-in (measured slower than the VALU kernel, csrc/attention.hip)
-            op.i[17] = int(os.environ.get("T2V_RELPOS_MFMA", "0") != "0" if relpos_mfma is None else relpos_mfma)
+            # i[17]: 0 the VALU kernel; 1 the round-3 MFMA kernel (measured slower, opt-in); 2 the persistent MFMA kernel for whole
+            # clips of <= 16 frames on tables packed for it (rel_k16 / rel_vT16: packing.relpos_tables16) — the default where it applies
+            sel = int(os.environ.get("T2V_RELPOS_MFMA", "2")) if relpos_mfma is None else int(relpos_mfma)
+            fits16 = (rel_k16 is not None and rel_vT16 is not None and nq == nk and q_offset == 0 and nk <= 16 and max_rel >= nk - 1
+                      and head_dim in (40, 64, 80, 160))
+            if sel == 2 and not fits16:
+                sel = 0
+            op.i[17] = sel
             op.p[4], op.p[5] = rel_k, rel_v
+            if sel == 2:
+                op.p[6], op.p[7] = rel_k16, rel_vT16
             op.i[18] = lo_off
             assert not causal
         elif causal:

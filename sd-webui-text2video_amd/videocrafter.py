@@ -252,6 +252,13 @@ class _LvdmLowering(_Lowering):
     def table(self, key) -> Ref:
         return Ref("weight", 0, self.packer.add(key + ":tab", "f32", lambda sd, k=key: sd[k]))
 
+    def table16(self, key, frames: int, transposed: bool) -> Optional[Ref]:
+        """The same table packed for the persistent MFMA kernel (whole clips of <= 16 frames, no clipping of s - t): packing.relpos_table16."""
+        if frames > 16 or self.net.temporal_length < frames - 1:
+            return None
+        return Ref("weight", 0, self.packer.add(f"{key}:tab16{'T' if transposed else ''}.{frames}", "f16",
+                                                lambda sd, k=key, f=frames, t=transposed: pk.relpos_table16(sd[k].float(), f, t)))
+
     def w_conv133_hilo(self, key) -> Ref:
         return Ref("weight", 0, self.packer.add(key + ":c133hl", "f16", lambda sd, k=key: pk.pad_rows(pk.conv3x3(torch.cat([sd[k + ".weight"][:, :, 0]] * 2, dim=1)))))
 
@@ -389,6 +396,8 @@ class _LvdmLowering(_Lowering):
                             o_strides=(hw * lo, F * hw * lo, lo), scale=scale, head_dim=d, lo_off=c if attn_lo else 0,
                             rel_k=self.table(f"{tb}.{attn}.relative_position_k.embeddings_table"),
                             rel_v=self.table(f"{tb}.{attn}.relative_position_v.embeddings_table"),
+                            rel_k16=self.table16(f"{tb}.{attn}.relative_position_k.embeddings_table", F, False),
+                            rel_vT16=self.table16(f"{tb}.{attn}.relative_position_v.embeddings_table", F, True),
                             max_rel=net.temporal_length)
             P.free(qkv)
             return out_proj(attn, a, src, next_norm)

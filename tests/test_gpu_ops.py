@@ -322,6 +322,54 @@ def test_relpos_temporal_attention(D, T, R, mfma):
     _check(it, got, o, 2e-3, f"relpos attention d={D} T={T} mfma={mfma}")
 
 
+@pytest.mark.parametrize("D,T,R,hw,lo", [(40, 16, 16, 12, False), (80, 16, 16, 12, True), (160, 16, 16, 12, False), (64, 5, 8, 12, False),
+                                         (40, 9, 16, 7, True), (80, 16, 31, 5, False), (64, 16, 20, 12, False), (40, 1, 4, 3, False),
+                                         (160, 12, 11, 9, True), (40, 16, 16, 700, False), (160, 16, 16, 300, False)])
+def test_relpos_temporal_attention_persistent_mfma(D, T, R, hw, lo):
+    """Round 5: t2v_op.i[17] = 2 — whole clips of <= 16 frames on the persistent MFMA kernel with the tables packed for it
+    (packing.relpos_table16: 32 slots from row R-(T-1), fp16, the V-side table transposed) against the interpreter's explicit formula
+    (attention_temporal.py:107-144).  hw = 700 / 300: more items than the resident grid holds, so every wave walks several."""
+    from sd_webui_text2video_amd import packing as pk
+    heads, B = 8 if D < 160 else 2, 2
+    inner = heads * D
+    M = B * T * hw
+    P = Program()
+    g = _g(150 + D + T + hw)
+    qkv, o = P.alloc(M, 3 * inner, "f16"), P.alloc(M, 2 * inner if lo else inner, "f16")
+    ld, lo_ld = 3 * inner, o.ld
+    q, k, v = qkv.col_slice(0, inner), qkv.col_slice(inner, 2 * inner), qkv.col_slice(2 * inner, 3 * inner)
+    ek, ev = (torch.randn(2 * R + 1, D, generator=g) * 0.5).half().float(), (torch.randn(2 * R + 1, D, generator=g) * 0.5).half().float()
+    w = {"ek": ek, "ev": ev, "ek16": pk.relpos_table16(ek, T, False), "ev16": pk.relpos_table16(ev, T, True)}
+    P.attention("a", q.ref, k.ref, v.ref, o.ref, nq=T, nk=T, heads=heads, b_outer=B, b_inner=hw,
+                q_strides=(hw * ld, T * hw * ld, ld), kv_strides=(hw * ld, T * hw * ld, ld),
+                o_strides=(hw * lo_ld, T * hw * lo_ld, lo_ld), scale=D ** -0.5, head_dim=D, lo_off=inner if lo else 0,
+                rel_k=Ref("weight", 0, "ek"), rel_v=Ref("weight", 0, "ev"), rel_k16=Ref("weight", 0, "ek16"), rel_vT16=Ref("weight", 0, "ev16"),
+                max_rel=R, relpos_mfma=2)
+    assert P.ops[0].kind == L.OP_RELPOS_ATTN and P.ops[0].i[17] == 2
+
+    def init(it):
+        fill(it, qkv, g, 1.2)
+        fill(it, o, g, 3.0)
+    it, got, _, _ = run_both(P, w, {}, init)
+    _check(it, got, o.col_slice(0, inner), 2e-3, f"relpos attention (persistent MFMA) d={D} T={T} hw={hw}")
+    if lo:          # hi + lo is the fp32 result to ~2^-22: compare the sum with the interpreter's sum
+        want, have = read(it, o).float(), read(got, o).float()
+        s_w, s_h = want[:, :inner] + want[:, inner:], have[:, :inner] + have[:, inner:]
+        assert float((s_h - s_w).norm() / s_w.norm()) < 2e-3
+
+
+def test_relpos_persistent_mfma_falls_back_where_it_does_not_apply():
+    """A clip of more than 16 frames, a clipped table (R < T - 1) or missing packed tables: the op keeps i[17] = 0 (VALU kernel)."""
+    for T, R, packed in ((24, 24, True), (16, 8, True), (16, 16, False)):
+        P = Program()
+        qkv, o = P.alloc(T * 4, 3 * 40, "f16"), P.alloc(T * 4, 40, "f16")
+        extra = dict(rel_k16=Ref("weight", 0, "a"), rel_vT16=Ref("weight", 0, "b")) if packed else {}
+        P.attention("a", qkv.ref, qkv.ref, qkv.ref, o.ref, nq=T, nk=T, heads=1, b_outer=1, b_inner=4, q_strides=(480, 0, 120),
+                    kv_strides=(480, 0, 120), o_strides=(160, 0, 40), scale=0.1, head_dim=40, rel_k=Ref("weight", 0, "ek"),
+                    rel_v=Ref("weight", 0, "ev"), max_rel=R, relpos_mfma=2, **extra)
+        assert P.ops[0].i[17] == 0
+
+
 def test_attention_peaked_softmax():
     """Large logits: exercises the running-max rescale path of the online softmax."""
     hw, heads = 300, 1
