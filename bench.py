@@ -169,7 +169,7 @@ def pmc_traffic():
     """HBM bytes per launch of the GEMM family from the committed PMC passes (collected with
     tools/gpu_profile.sh -> tools/pmc_post.py; counters cannot be read from inside this process)."""
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    path = next((q for q in (os.path.join(here, f"r0{r}_pmc_traffic.json") for r in (4, 3, 2, 1)) if os.path.exists(q)), "")
+    path = next((q for q in (os.path.join(here, f"r0{r}_pmc_traffic.json") for r in (5, 4, 3, 2, 1)) if os.path.exists(q)), "")
     try:
         with open(path) as fh:
             return round(json.load(fh)["hbm_bytes_per_launch"])

@@ -47,6 +47,10 @@ def main():
         kinds[k][0] += m; kinds[k][1] += 1; kinds[k][2] += op.flops
     for k, (m, c, f) in sorted(kinds.items(), key=lambda kv: -kv[1][0]):
         print(f"{k:12s} {m:8.3f} ms {100 * m / tot:5.1f}% {c:4d} ops {f / max(m, 1e-9) / 1e9:8.1f} TF/s")
+    att = [(m, op) for m, op in zip(ms, prog.ops) if ".attn_1." in op.name]
+    core = [m for m, op in att if any(t in op.name for t in (".qk^T.", ".softmax.", ".pv."))]
+    print(f"mid attention block: {sum(m for m, _ in att):.3f} ms in {len(att)} ops = {100 * sum(m for m, _ in att) / tot:.1f}% of the frame; "
+          f"its score / softmax / PV core (what a fused d = 512 kernel would replace): {sum(core):.3f} ms = {100 * sum(core) / tot:.1f}%")
     print("slowest ops:")
     for m, op in rows[:25]:
         meta = {k: v for k, v in op.meta.items() if k in ("M", "N", "K", "tile", "split", "n_inst", "rows", "C", "dt", "fused")}
