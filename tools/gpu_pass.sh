@@ -120,6 +120,9 @@ except Exception as e:
     print("bench line:", e)
 PY
 }
+stage_bench20() {   # the driver's K: 20 timed videos after 2 warm-ups (sustained clocks), no CPU leg
+  timeout -k 10 900 python bench.py --steps 20 --warmup 2 --no-cpu-baseline --also-batched 0 > gpurun_out/${TAG}_bench_n1_steps20.json 2> gpurun_out/${TAG}_bench_n1_steps20.err; echo "bench20 exit $?"; cut -c1-330 gpurun_out/${TAG}_bench_n1_steps20.json
+}
 stage_multiproc() {
   timeout 1200 $PYT tests/test_gpu_multiproc.py tests/test_gpu_fake_rccl.py tests/test_gpu_boundary.py -rP > gpurun_out/${TAG}_multiproc.log 2>&1; echo "multiproc exit $?"; grep -E "identical|passed|failed" gpurun_out/${TAG}_multiproc.log | tail -n 8 | cut -c1-250
 }
@@ -129,7 +132,7 @@ stage_e2e() {
 stage_suite() {     # what the driver runs at round end
   timeout -k 10 2400 python -m pytest tests -m gpu -q -rP --tb=short --durations=12 -p no:cacheprovider > gpurun_out/${TAG}_pytest_gpu.log 2>&1; echo "pytest -m gpu exit $?"; digest gpurun_out/${TAG}_pytest_gpu.log 12
 }
-stage_roundend() {  # the measurements that go to profiles/r04_*: rocprofv3 kernel stats + PMC traffic + MFMA utilisation on this build, the other
+stage_roundend() {  # the measurements that go to profiles/r0N_*: rocprofv3 kernel stats + PMC traffic + MFMA utilisation on this build, the other
                     # BASELINE geometries, per-kind step profiles, the stages either side of the loop
   R=$GRAFT_REPO_ROOT
   bash tools/gpu_profile.sh > gpurun_out/gpu_profile.out 2>&1; tail -n 14 gpurun_out/gpu_profile.out | cut -c1-200
@@ -143,7 +146,7 @@ stage_roundend() {  # the measurements that go to profiles/r04_*: rocprofv3 kern
   timeout 600 python bench.py --frames 125 --steps 1 --warmup 1 --no-cpu-baseline --also-batched 0 > gpurun_out/bench_n1_125f.json 2> gpurun_out/bench_n1_125f.err; echo "bench125 exit $?"; cut -c1-200 gpurun_out/bench_n1_125f.json
   timeout 600 python bench.py --height 576 --width 1024 --steps 1 --warmup 1 --no-cpu-baseline --also-batched 0 > gpurun_out/bench_n1_zeroscope_xl.json 2> gpurun_out/bench_n1_zeroscope_xl.err; echo "bench XL exit $?"; cut -c1-200 gpurun_out/bench_n1_zeroscope_xl.json
   timeout 400 python bench.py --model lvdm --steps 2 --warmup 1 > gpurun_out/bench_n1_lvdm.json 2> gpurun_out/bench_n1_lvdm.err; echo "bench lvdm exit $?"; cut -c1-200 gpurun_out/bench_n1_lvdm.json
-  for g in "24 32 32 2 modelscope" "125 32 32 2 modelscope" "24 72 128 2 modelscope" "24 32 32 1 modelscope" "12 32 32 1 modelscope" "16 32 32 2 lvdm"; do
+  for g in "24 32 32 2 modelscope" "125 32 32 2 modelscope" "24 72 128 2 modelscope" "32 32 32 1 modelscope" "24 32 32 1 modelscope" "12 32 32 1 modelscope" "6 32 32 1 modelscope" "16 32 32 2 lvdm"; do
     timeout 300 python tools/profile_unet.py $g > "gpurun_out/profile_$(echo $g | tr ' ' '_').log" 2>&1; sed -n 4,5p "gpurun_out/profile_$(echo $g | tr ' ' '_').log"
   done
   timeout 300 python tools/profile_aux.py > gpurun_out/aux_stages.txt 2>&1; tail -n 8 gpurun_out/aux_stages.txt
