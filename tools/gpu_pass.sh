@@ -152,6 +152,21 @@ stage_roundend() {  # the measurements that go to profiles/r0N_*: rocprofv3 kern
   timeout 300 python tools/profile_aux.py > gpurun_out/aux_stages.txt 2>&1; tail -n 8 gpurun_out/aux_stages.txt
   timeout 300 python tools/profile_vae.py 1 72 128 > gpurun_out/profile_vae_xl.txt 2>&1; tail -n 6 gpurun_out/profile_vae_xl.txt
 }
+stage_r5a() {       # round 5, re-entry: the evidence the DESIGN tables cite, without the rocprofv3 / PMC passes (those are in profiles/ already)
+  stage_smoke
+  stage_bench
+  prof epi T2V_X=0
+  prof noepi T2V_GN_EPI=0
+  for v in "T2V_RELPOS_MFMA=2" "T2V_RELPOS_MFMA=0"; do
+    env $v timeout 300 python tools/profile_unet.py 16 32 32 2 lvdm > gpurun_out/${TAG}_prof_lvdm_$(echo $v | tr '=' '_').log 2>&1
+    echo "== lvdm $v"; sed -n 4,5p gpurun_out/${TAG}_prof_lvdm_$(echo $v | tr '=' '_').log
+  done
+  timeout 400 python bench.py --model lvdm --steps 2 --warmup 1 > gpurun_out/${TAG}_bench_n1_lvdm.json 2> gpurun_out/${TAG}_bench_n1_lvdm.err; echo "bench lvdm exit $?"; cut -c1-200 gpurun_out/${TAG}_bench_n1_lvdm.json
+  for g in "125 32 32 2 modelscope" "24 72 128 2 modelscope" "32 32 32 1 modelscope" "24 32 32 1 modelscope" "12 32 32 1 modelscope" "6 32 32 1 modelscope"; do
+    timeout 300 python tools/profile_unet.py $g > "gpurun_out/${TAG}_profile_$(echo $g | tr ' ' '_').log" 2>&1; sed -n 4,5p "gpurun_out/${TAG}_profile_$(echo $g | tr ' ' '_').log"
+  done
+  timeout 300 python tools/profile_vae.py 1 72 128 > gpurun_out/${TAG}_profile_vae_xl.txt 2>&1; tail -n 6 gpurun_out/${TAG}_profile_vae_xl.txt
+}
 for st in "$@"; do
   t0=$(date +%s); echo "######## stage $st"; stage_$st; echo "######## $st took $(( $(date +%s) - t0 )) s"
 done
