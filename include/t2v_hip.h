@@ -26,7 +26,10 @@
 extern "C" {
 #endif
 
-#define T2V_ABI_VERSION 5   /* 5 (round 5): T2V_OP_NI 32 / T2V_OP_NP 12 (record grew), T2V_EPI_GN — GroupNorm (+SiLU) of a GEMM's result fused into its epilogue;
+#define T2V_ABI_VERSION 6   /* 6 (round 5, second half): T2V_OP_STATS_HALO — the statistics parts of a T-sharded cross-frame GroupNorm and the RAW boundary
+                               frames of the temporal convolution behind it in ONE grouped exchange; GROUPNORM i[21] / i[22] (phase 2 also normalises the
+                               received boundary frames); t2v_comm_all_gather (eps pair / frame gathers over the library's communicators);
+                               5 (round 5): T2V_OP_NI 32 / T2V_OP_NP 12 (record grew), T2V_EPI_GN — GroupNorm (+SiLU) of a GEMM's result fused into its epilogue;
                                4 (round 4): t2v_async_status, t2v_sync_reset, T2V_ERR_ASYNC (bounded grid barrier of the single-pass GroupNorm);
                                3 (round 3): T2V_EPI_TATTN + tile 10, GROUPNORM i[15] / p[5], GEMM p[7] tickets, RELPOS i[17], low-order outputs of the cast ops, T2V_SYNC_* */
 
@@ -60,7 +63,8 @@ enum t2v_op_kind {
   T2V_OP_HALO_EXCHANGE = 17, /* +-1 frame neighbour exchange of a [F+2]-frame token buffer over the plan's communicator */
   T2V_OP_RESHARD_ROWS = 18,  /* chunked row regrouping (pack / unpack of a frame <-> pixel resharding), optional fp32 residual */
   T2V_OP_ALLTOALL = 19,      /* frame <-> pixel resharding of a T-sharded clip over the plan's communicator */
-  T2V_OP_KIND_MAX = 20
+  T2V_OP_STATS_HALO = 20,    /* GroupNorm statistics parts to every rank + raw boundary frames to the two neighbours: one grouped exchange */
+  T2V_OP_KIND_MAX = 21
 };
 
 /* GEMM gather modes: how row m / reduction index k of the A operand are addressed          */
@@ -171,6 +175,9 @@ enum t2v_gather {
  *         uses it when the instance chunks fit (else the launches above on the same scratch);
  *      16 = 1 (phases 0 / 2, ld_out >= 2C): hi + lo operand split — the low-order fp16 image fp16(y - float(fp16(y))) of every output
  *         value goes to column C + c of the same output row (consumer: a GEMM with K = 2C against weights [W | W]);
+ *      21 / 22 (phase 2, n_inst == 1): rows in front of / behind x that are normalised with the same statistics and written in front of /
+ *         behind `out` — the neighbours' RAW boundary frames of a halo-padded buffer (T2V_OP_STATS_HALO); i[1] stays this rank's own rows
+ *         (it sizes the scratch), i[14] the rows the statistics cover;
  *      scratch, phase 0: block partials [n_inst][nblk][groups][2] fp64, then {mean, rstd} fp32;  phases 1 / 2: gathered parts
  *      [nparts][n_inst][groups][2] fp64 (phase 1 folds this rank's block partials into its part; ALLGATHER of
  *      n_inst*groups*16 bytes per part), then this rank's block partials, then {mean, rstd};
@@ -228,6 +235,13 @@ enum t2v_gather {
  *      sends its first real frame to `prev` and its last to `next`, and receives their boundary frames into frame 0 / F+1.
  *      i: 0/1 bytes per frame (lo, hi), 2 F (local frames), 3 prev rank in the communicator (-1 none), 4 next rank (-1 none);
  *      p: 0 base.   The collectives need t2v_plan_set_comm unless they are no-ops.
+ * STATS_HALO: ALLGATHER of the statistics parts and HALO_EXCHANGE of the RAW (not yet normalised) boundary frames as ONE group of
+ *      point-to-point transfers: every rank sends its part (p0 + part*bytes) to every other rank; frame 1 of the halo-padded raw buffer
+ *      p1 goes to `prev`, frame F to `next`, theirs arrive in frame 0 / F + 1.  The consumer (GROUPNORM phase 2 with i[21] / i[22]) then
+ *      normalises its own frames AND the received ones with the same gathered statistics — bit-identical to what the neighbour wrote for
+ *      itself — so a T-sharded temporal convolution costs one exchange instead of two (t2v_model.py:1202-1229).
+ *      i: 0/1 bytes per statistics part (lo, hi), 2 nparts, 3 this rank's part, 4/5 bytes per frame (lo, hi), 6 F (local frames),
+ *      7 prev rank (-1 none), 8 next rank (-1 none);  p: 0 gathered parts, 1 raw buffer of F + 2 frames
  * RESHARD_ROWS: row r reads src row (r / P) * S_src + r % P and writes dst row (r / P) * S_dst + r % P (+ residual at the dst row)
  *      i: 0 rows, 1 cols, 2 P (rows per chunk), 3 S_src, 4 S_dst (chunk strides in rows), 5 ld_src, 6 ld_dst, 7 dtype (src == dst;
  *      fp16: cols % 8 == 0, fp32: cols % 4 == 0), 8 ld_res;  p: 0 src, 1 dst, 2 residual fp32 (optional, fp32 only)
@@ -289,6 +303,11 @@ int t2v_comm_create(const unsigned char id[128], int nranks, int rank, t2v_comm*
 int t2v_comm_size(const t2v_comm* comm);
 void t2v_comm_destroy(t2v_comm* comm);
 int t2v_plan_set_comm(t2v_plan* plan, t2v_comm* comm);   /* borrowed; must outlive the plan's runs */
+/* In-place all-gather outside a plan, on `stream`: part q of t2v_comm_size(comm) equal parts of `bytes` bytes lives at base + q*bytes,
+ * the caller's own part is in place.  The per-step exchanges around the UNet — the eps of a classifier-free-guidance pair
+ * (gaussian_sampler.py:161-163 evaluates the two forwards one after the other), the uint8 frames of the decoded clip
+ * (lvdm/utils/dist_utils.py:13-19) — use it, so a sharded run's data path has ONE collective stack. */
+int t2v_comm_all_gather(t2v_comm* comm, void* base, uint64_t bytes, void* stream);
 
 /* Drop-in entry points for the reference's call sites (thin wrappers over t2v_plan_run that
  * fix the external-slot convention):

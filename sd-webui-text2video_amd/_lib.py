@@ -10,14 +10,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("T2V_LIB_PATH") or os.path.join(_HERE, "libt2v_hip.so")   # T2V_LIB_PATH: A/B builds of the same ABI (tools/build_variant.py)
 
 # ---- mirrors of include/t2v_hip.h (checked against the header by tests/test_abi.py) -------
-ABI_VERSION = 5
+ABI_VERSION = 6
 OP_GEMM, OP_GROUPNORM, OP_LAYERNORM, OP_ATTENTION, OP_SOFTMAX = 1, 2, 3, 4, 5
 OP_NCTHW_TO_CL, OP_CL_TO_NCTHW, OP_TIME_EMBED, OP_COPY2D, OP_DDIM_STEP, OP_MEMSET = 6, 7, 8, 9, 10, 11
 OP_LINCOMB = 12
 OP_RELPOS_ATTN = 13
 OP_EMBED_ROWS = 14
 OP_TO_UINT8, OP_ALLGATHER, OP_HALO_EXCHANGE = 15, 16, 17
-OP_RESHARD_ROWS, OP_ALLTOALL = 18, 19
+OP_RESHARD_ROWS, OP_ALLTOALL, OP_STATS_HALO = 18, 19, 20
 GATHER_PLAIN, GATHER_CONV3X3, GATHER_TCONV3, GATHER_CONV3X3_C8 = 0, 1, 2, 3
 EPI_NONE, EPI_GEGLU, EPI_TATTN, EPI_STATS, EPI_GN, EPI_XATTN = 0, 1, 2, 3, 4, 5
 GN_PIECES = 36                  # T2V_GN_PIECES
@@ -33,7 +33,7 @@ EXPORTS = [
     "t2v_abi_version", "t2v_last_error", "t2v_device_info", "t2v_run_ops", "t2v_plan_create",
     "t2v_plan_num_ops", "t2v_plan_run", "t2v_plan_run_timed", "t2v_plan_destroy",
     "t2v_unet_forward", "t2v_vae_decode", "t2v_ddim_step",
-    "t2v_comm_unique_id", "t2v_comm_create", "t2v_comm_size", "t2v_comm_destroy", "t2v_plan_set_comm",
+    "t2v_comm_unique_id", "t2v_comm_create", "t2v_comm_size", "t2v_comm_destroy", "t2v_plan_set_comm", "t2v_comm_all_gather",
     "t2v_async_status", "t2v_sync_reset", "t2v_debug_poison_exchange",
 ]
 
@@ -84,6 +84,7 @@ def load():
     lib.t2v_comm_destroy.argtypes = [vp]
     lib.t2v_comm_destroy.restype = None
     lib.t2v_plan_set_comm.argtypes = [vp, vp]
+    lib.t2v_comm_all_gather.argtypes = [vp, vp, ctypes.c_uint64, vp]
     lib.t2v_async_status.restype = ctypes.c_int
     lib.t2v_sync_reset.argtypes = [vp, vp]
     lib.t2v_debug_poison_exchange.argtypes = [ctypes.c_int]

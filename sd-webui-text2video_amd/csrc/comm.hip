@@ -129,6 +129,10 @@ int t2v_comm_allgather(t2v_comm* c, void* base, size_t bytes, int nparts, int pa
   return T2V_OK;
 }
 
+int t2v_comm_impl_all_gather(t2v_comm* c, void* base, size_t bytes, hipStream_t s, std::string& err) {
+  return t2v_comm_allgather(c, base, bytes, c->nranks, c->rank, s, err);
+}
+
 // Token buffer of F+2 frames: send frame 1 to prev / frame F to next, receive into frame 0 / frame F+1.
 int t2v_comm_halo(t2v_comm* c, void* base, size_t frame_bytes, int F, int prev, int next, hipStream_t s, std::string& err) {
   if (prev < 0 && next < 0) return T2V_OK;
@@ -144,6 +148,35 @@ int t2v_comm_halo(t2v_comm* c, void* base, size_t frame_bytes, int F, int prev, 
   const ncclResult_t rc2 = r->GroupEnd();
   if (rc == ncclSuccess) rc = rc2;
   if (rc != ncclSuccess) { err = std::string("halo exchange (ncclSend/ncclRecv): ") + r->GetErrorString(rc); return T2V_ERR_COMM; }
+  return T2V_OK;
+}
+
+// Statistics parts of a cross-frame GroupNorm to every rank AND the raw boundary frames of the temporal convolution behind it to the
+// two neighbours, as ONE group of point-to-point transfers (T2V_OP_STATS_HALO).  parts: [nparts][part_bytes], this rank's part
+// in place; raw: halo-padded buffer of F + 2 frames whose interior the preceding kernels wrote.  Per peer the order of the
+// transfers is the same on both sides (part first, then the frame), which is how RCCL matches several sends to one peer.
+int t2v_comm_stats_halo(t2v_comm* c, void* parts, size_t part_bytes, int nparts, int part, void* raw, size_t frame_bytes, int F,
+                        int prev, int next, hipStream_t s, std::string& err) {
+  if (nparts <= 1 && !c) return T2V_OK;
+  const Rccl* r = rccl();
+  if (!r || !c) { err = c ? g_rccl.err : "collective op in a plan without a communicator (t2v_plan_set_comm)"; return T2V_ERR_COMM; }
+  if (c->nranks != nparts || c->rank != part) { err = "statistics + halo exchange: parts do not match the communicator (nranks / rank)"; return T2V_ERR_BAD_ARG; }
+  if (prev >= nparts || next >= nparts || prev == part || next == part) { err = "statistics + halo exchange: bad neighbour rank"; return T2V_ERR_BAD_ARG; }
+  unsigned char* pb = static_cast<unsigned char*>(parts);
+  unsigned char* rb = static_cast<unsigned char*>(raw);
+  ncclResult_t rc = r->GroupStart();
+  for (int q = 0; q < nparts && rc == ncclSuccess; ++q) {
+    if (q == part) continue;
+    rc = r->Send(pb + (size_t)part * part_bytes, part_bytes, ncclUint8, q, c->comm, s);
+    if (rc == ncclSuccess) rc = r->Recv(pb + (size_t)q * part_bytes, part_bytes, ncclUint8, q, c->comm, s);
+  }
+  if (rc == ncclSuccess && prev >= 0) rc = r->Send(rb + frame_bytes, frame_bytes, ncclUint8, prev, c->comm, s);
+  if (rc == ncclSuccess && prev >= 0) rc = r->Recv(rb, frame_bytes, ncclUint8, prev, c->comm, s);
+  if (rc == ncclSuccess && next >= 0) rc = r->Send(rb + (size_t)F * frame_bytes, frame_bytes, ncclUint8, next, c->comm, s);
+  if (rc == ncclSuccess && next >= 0) rc = r->Recv(rb + (size_t)(F + 1) * frame_bytes, frame_bytes, ncclUint8, next, c->comm, s);
+  const ncclResult_t rc2 = r->GroupEnd();
+  if (rc == ncclSuccess) rc = rc2;
+  if (rc != ncclSuccess) { err = std::string("statistics + halo exchange (ncclSend/ncclRecv): ") + r->GetErrorString(rc); return T2V_ERR_COMM; }
   return T2V_OK;
 }
 

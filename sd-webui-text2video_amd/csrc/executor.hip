@@ -235,6 +235,10 @@ int validate_op(const t2v_op& op, int idx) {
     case T2V_OP_HALO_EXCHANGE:
       if (op.i[2] < 1 || op.p[0] == 0 || op.i[3] < -1 || op.i[4] < -1) return bad("bad halo-exchange record");
       return 0;
+    case T2V_OP_STATS_HALO:
+      if (op.i[2] < 1 || op.i[3] < 0 || op.i[3] >= op.i[2] || op.p[0] == 0 || op.p[1] == 0) return bad("bad statistics + halo record");
+      if (op.i[6] < 1 || op.i[7] < -1 || op.i[8] < -1 || op.i[7] >= op.i[2] || op.i[8] >= op.i[2]) return bad("bad statistics + halo neighbours");
+      return 0;
     case T2V_OP_RESHARD_ROWS:
       if (op.i[0] <= 0 || op.i[1] <= 0 || op.i[2] <= 0 || op.i[3] < 0 || op.i[4] < 0) return bad("bad row-resharding shape");
       if (op.i[5] < op.i[1] || op.i[6] < op.i[1] || op.p[0] == 0 || op.p[1] == 0) return bad("row resharding: leading dimension / pointer");
@@ -366,10 +370,13 @@ int run_resolved(const t2v_op* ops, int n, const uint64_t* ext, int n_ext, hipSt
       snprintf(buf, sizeof buf, "op %d (tag %d): unresolved external pointer slot", k, op.tag);
       return fail(T2V_ERR_BAD_ARG, buf);
     }
-    if (op.kind == T2V_OP_ALLGATHER || op.kind == T2V_OP_HALO_EXCHANGE || op.kind == T2V_OP_ALLTOALL) {
+    if (op.kind == T2V_OP_ALLGATHER || op.kind == T2V_OP_HALO_EXCHANGE || op.kind == T2V_OP_ALLTOALL || op.kind == T2V_OP_STATS_HALO) {
       const size_t bytes = (size_t)(uint32_t)op.i[0] | ((size_t)(uint32_t)op.i[1] << 32);
       std::string err;
-      const int rc = op.kind == T2V_OP_ALLGATHER
+      const int rc = op.kind == T2V_OP_STATS_HALO
+                         ? t2v_comm_stats_halo(comm, reinterpret_cast<void*>(op.p[0]), bytes, op.i[2], op.i[3], reinterpret_cast<void*>(op.p[1]),
+                                               (size_t)(uint32_t)op.i[4] | ((size_t)(uint32_t)op.i[5] << 32), op.i[6], op.i[7], op.i[8], s, err)
+                     : op.kind == T2V_OP_ALLGATHER
                          ? t2v_comm_allgather(comm, reinterpret_cast<void*>(op.p[0]), bytes, op.i[2], op.i[3], s, err)
                          : op.kind == T2V_OP_HALO_EXCHANGE
                                ? t2v_comm_halo(comm, reinterpret_cast<void*>(op.p[0]), bytes, op.i[2], op.i[3], op.i[4], s, err)
@@ -497,6 +504,13 @@ int t2v_comm_create(const unsigned char id[128], int nranks, int rank, t2v_comm*
 int t2v_comm_size(const t2v_comm* comm) { return t2v_comm_impl_size(comm); }
 
 void t2v_comm_destroy(t2v_comm* comm) { t2v_comm_impl_destroy(comm); }
+
+int t2v_comm_all_gather(t2v_comm* comm, void* base, uint64_t bytes, void* stream) {
+  if (!comm || !base || bytes == 0) return fail(T2V_ERR_BAD_ARG, "all-gather needs a communicator, a base pointer and a part size");
+  std::string err;
+  const int rc = t2v_comm_impl_all_gather(comm, base, (size_t)bytes, reinterpret_cast<hipStream_t>(stream), err);
+  return rc == T2V_OK ? rc : fail(rc, err);
+}
 
 int t2v_unet_forward(t2v_plan* plan, const void* x, const float* t, const void* ctx, void* eps_out, void* stream) {
   uint64_t ext[T2V_EXT_SLOTS] = {0};

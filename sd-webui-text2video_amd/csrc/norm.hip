@@ -959,6 +959,7 @@ hipError_t t2v_launch_groupnorm(const t2v_op& op, hipStream_t s) {
       op.p[4] == 0 || part < 0 || part >= nparts || phase < 0 || phase > 3)
     return hipErrorInvalidValue;
   if (phase == 3 && (op.p[6] == 0 || rows % 32 != 0 || op.i[17] < C || nparts != 1)) return hipErrorInvalidValue;
+  if ((op.i[21] != 0 || op.i[22] != 0) && (phase != 2 || n_inst != 1 || op.i[21] < 0 || op.i[22] < 0 || op.p[8] != 0)) return hipErrorInvalidValue;
   // T-sharded clips (phase 1 / 2): every rank folds ITS OWN block partials to one {sum, sum of squares} pair per
   // (instance, group) — 512 bytes per instance — and only those are all-gathered; phase 2 sums the parts in rank order
   // (every rank: same values, same order => bit-identical statistics) over the rows of the whole clip (i[14]).
@@ -1030,10 +1031,16 @@ hipError_t t2v_launch_groupnorm(const t2v_op& op, hipStream_t s) {
         hipLaunchKernelGGL(gn_finalize_kernel, dim3(g2), dim3(256), 0, s, partials, finals, n_inst, phase == 0 ? nblk : 1, groups,
                            inv_n, op.f[0], nparts, static_cast<double*>(nullptr));
       const int rpa = R * GN_UNROLL;    // rows per normalise workgroup
-      const dim3 g3((rows + rpa - 1) / rpa, n_inst);
+      // phase 2 of a T-sharded clip (T2V_OP_STATS_HALO): i[21] / i[22] rows in front of / behind x hold the neighbours' RAW boundary
+      // frames; they take the same statistics and land in front of / behind `out` (what the neighbour wrote for itself, bit for bit)
+      const int before = phase == 2 ? op.i[21] : 0, after = phase == 2 ? op.i[22] : 0;
+      const int arows = rows + before + after;
+      const T* ax = x - (size_t)before * ld_in;
+      f16* aout = out - (size_t)before * ld_out;
+      const dim3 g3((arows + rpa - 1) / rpa, n_inst);
       const size_t lds3 = 2 * (size_t)C * sizeof(float);
-      if (silu) hipLaunchKernelGGL((gn_apply_kernel<T, true>), g3, dim3(256), lds3, s, x, finals, gamma, beta, out, rows, C, ld_in, ld_out, groups, lo_off, cast);
-      else hipLaunchKernelGGL((gn_apply_kernel<T, false>), g3, dim3(256), lds3, s, x, finals, gamma, beta, out, rows, C, ld_in, ld_out, groups, lo_off, cast);
+      if (silu) hipLaunchKernelGGL((gn_apply_kernel<T, true>), g3, dim3(256), lds3, s, ax, finals, gamma, beta, aout, arows, C, ld_in, ld_out, groups, lo_off, cast);
+      else hipLaunchKernelGGL((gn_apply_kernel<T, false>), g3, dim3(256), lds3, s, ax, finals, gamma, beta, aout, arows, C, ld_in, ld_out, groups, lo_off, cast);
     }
   };
   if (in_dt == T2V_F32) run(reinterpret_cast<const float*>(op.p[0]));

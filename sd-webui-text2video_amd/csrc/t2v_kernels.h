@@ -1150,6 +1150,9 @@ int t2v_comm_impl_create(const unsigned char id[128], int nranks, int rank, t2v_
 void t2v_comm_impl_destroy(t2v_comm* c);
 int t2v_comm_impl_size(const t2v_comm* c);
 int t2v_comm_allgather(t2v_comm* c, void* base, size_t bytes, int nparts, int part, hipStream_t s, std::string& err);
+int t2v_comm_impl_all_gather(t2v_comm* c, void* base, size_t bytes, hipStream_t s, std::string& err);
 int t2v_comm_halo(t2v_comm* c, void* base, size_t frame_bytes, int F, int prev, int next, hipStream_t s, std::string& err);
+int t2v_comm_stats_halo(t2v_comm* c, void* parts, size_t part_bytes, int nparts, int part, void* raw, size_t frame_bytes, int F,
+                        int prev, int next, hipStream_t s, std::string& err);
 int t2v_comm_alltoall(t2v_comm* c, void* send, void* recv, size_t chunk, int nparts, int part, int base_cnt, int last_cnt, int dir,
                       hipStream_t s, std::string& err);

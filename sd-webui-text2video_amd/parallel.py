@@ -7,8 +7,9 @@ all-gathered (scripts/videocrafter/lvdm/utils/dist_utils.py:13-19, sample_text2v
   * T-axis (frame) sharding x CFG pair (north_star's layout; even N >= 4, mode "tshard"): world = 2 roles x R frame slices.
     The clip's frames are split contiguously over the R ranks of a role (slices of ceil(F / R) frames, a shorter last
     one: 125 = 32 + 32 + 32 + 29); all spatial work is frame-local, and before each temporal op the lowering inserts
-    an exchange op into the denoise program (program.py: T2V_OP_ALLGATHER of GroupNorm statistics, T2V_OP_HALO_EXCHANGE of
-    one boundary frame for the (3,1,1) convolutions, T2V_OP_ALLTOALL resharding frames <-> pixels around each
+    an exchange op into the denoise program (program.py: T2V_OP_STATS_HALO — the GroupNorm statistics parts AND the raw boundary
+    frames of the (3,1,1) convolution behind that norm in one grouped exchange, T2V_OP_ALLGATHER of the other cross-frame
+    GroupNorm statistics, T2V_OP_ALLTOALL resharding frames <-> pixels around each
     TemporalTransformer — or an all-gather of its K/V where the pixel count does not divide).  The library
     executes them with RCCL on the launch stream (csrc/comm.hip), so a sharded forward is ONE host call.  The two
     roles evaluate the conditional / unconditional forward of the same frames; one eps all-gather per DDIM step
@@ -45,6 +46,43 @@ def all_gather_into(out: torch.Tensor, mine: torch.Tensor, group=None):
         out.copy_(o)
     else:
         dist.all_gather_into_tensor(out, mine, group=group)
+
+
+def _library_collectives(group, device) -> bool:
+    """Do this group's collectives on `device` run inside libt2v_hip.so (RCCL communicator owned by the library)?  CUDA tensors over an
+    RCCL-capable group by default; T2V_COLLECTIVES=host keeps torch.distributed, =library forces the library communicator even over a
+    gloo group (tests: several ranks on ONE GPU with T2V_RCCL_SONAME pointing at tests/fake_rccl)."""
+    mode = os.environ.get("T2V_COLLECTIVES", "auto")
+    return torch.device(device).type == "cuda" and mode != "host" and (not _host_staged(group) or mode == "library")
+
+
+class GroupComm:
+    """The library communicator of one torch.distributed group, created on first use, and the gathers that run over it.  The
+    per-step eps exchange of a CFG pair and the gather of the decoded uint8 frames go through `t2v_comm_all_gather` on the current
+    stream — the same RCCL stack the exchanges INSIDE a sharded forward use (csrc/comm.hip) — instead of torch.distributed's."""
+
+    def __init__(self, group, ranks: List[int], index: int):
+        self.group, self.ranks, self.index = group, list(ranks), index
+        self._comm: Optional["Communicator"] = None
+
+    def communicator(self, device) -> Optional["Communicator"]:
+        if len(self.ranks) < 2 or not _library_collectives(self.group, device):
+            return None
+        if self._comm is None:
+            self._comm = Communicator(self.group, self.ranks, self.index, device)
+        return self._comm
+
+    def all_gather_into(self, out: torch.Tensor, mine: torch.Tensor):
+        """out = concatenation over the group's ranks of `mine` (equal sizes)."""
+        comm = self.communicator(out.device)
+        if comm is None:
+            return all_gather_into(out, mine, group=self.group)
+        assert out.is_contiguous() and out.numel() * out.element_size() == len(self.ranks) * mine.numel() * mine.element_size()
+        nbytes = mine.numel() * mine.element_size()
+        flat = out.view(-1).view(torch.uint8)
+        flat[self.index * nbytes: (self.index + 1) * nbytes].copy_(mine.contiguous().view(-1).view(torch.uint8))
+        L.check(comm._lib.t2v_comm_all_gather(comm.handle, ctypes.c_void_p(out.data_ptr()), nbytes,
+                                              ctypes.c_void_p(torch.cuda.current_stream(out.device).cuda_stream)))
 
 
 def exchange_pairs(sends, recvs, group):
@@ -124,8 +162,7 @@ class TShard:
         """The in-library communicator for programs on `device`; None = run the exchanges from the host through
         torch.distributed (CPU / gloo groups, or T2V_COLLECTIVES=host).  T2V_COLLECTIVES=library forces the library communicator
         even over a gloo group (tests: several ranks on ONE GPU with T2V_RCCL_SONAME pointing at tests/fake_rccl)."""
-        mode = os.environ.get("T2V_COLLECTIVES", "auto")
-        if torch.device(device).type != "cuda" or mode == "host" or (_host_staged(self.group) and mode != "library"):
+        if not _library_collectives(self.group, device):
             return None
         if self._comm is None:
             self._comm = Communicator(self.group, self.ranks, self.index, device)
@@ -191,16 +228,25 @@ class ShardedExecutor:
                         recvs.append((self._bytes(rbase + q * cnt(me) * nb, cnt(me) * nb), shard.ranks[q]))
                 exchange_pairs(sends, recvs, shard.group)
             else:   # OP_HALO_EXCHANGE: frame 1 -> prev, frame F -> next; their boundary frames into frame 0 / F + 1
-                nf = i[2]
+                if item.kind == L.OP_STATS_HALO:
+                    # statistics parts to every rank, then the RAW boundary frames of the halo-padded buffer p[1] to the neighbours
+                    # (the library issues both as one group of transfers; the bytes and their places are the same)
+                    assert (i[2], i[3]) == (shard.size, shard.index)
+                    out = self._bytes(base, nb * shard.size)
+                    all_gather_into(out, out[shard.index * nb: (shard.index + 1) * nb], group=shard.group)
+                    base, nb = item.p[1].off, (i[4] & 0xFFFFFFFF) | (i[5] << 32)
+                    nf, prev, nxt = i[6], i[7], i[8]
+                else:
+                    nf, prev, nxt = i[2], i[3], i[4]
                 first, last = self._bytes(base + nb, nb), self._bytes(base + nf * nb, nb)
                 halo0, halo1 = self._bytes(base, nb), self._bytes(base + (nf + 1) * nb, nb)
                 sends, recvs = [], []
-                if i[3] >= 0:
-                    sends.append((first, shard.ranks[i[3]]))
-                    recvs.append((halo0, shard.ranks[i[3]]))
-                if i[4] >= 0:
-                    sends.append((last, shard.ranks[i[4]]))
-                    recvs.append((halo1, shard.ranks[i[4]]))
+                if prev >= 0:
+                    sends.append((first, shard.ranks[prev]))
+                    recvs.append((halo0, shard.ranks[prev]))
+                if nxt >= 0:
+                    sends.append((last, shard.ranks[nxt]))
+                    recvs.append((halo1, shard.ranks[nxt]))
                 exchange_pairs(sends, recvs, shard.group)
 
     # BoundProgram-compatible timing hook (per-op times are not defined across host-side collectives)
@@ -232,13 +278,14 @@ class CfgPair:
                     self.members = members
         else:
             self.members = [0]
+        self.gcomm = GroupComm(self.group, self.members, self.role) if self.size == 2 else None
 
     def exchange_eps(self, eps_local: torch.Tensor) -> torch.Tensor:
         """[1,C,F,h,w] on each rank -> [2,C,F,h,w] (index 0 = conditional, 1 = unconditional)."""
         if self.size == 1:
             return eps_local
         out = torch.empty((2,) + tuple(eps_local.shape[1:]), dtype=eps_local.dtype, device=eps_local.device)
-        all_gather_into(out, eps_local.contiguous(), group=self.group)
+        self.gcomm.all_gather_into(out, eps_local.contiguous())
         return out
 
     def my_frames(self, n_frames: int) -> Tuple[int, int]:
@@ -253,7 +300,7 @@ class CfgPair:
         send = torch.zeros((nmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         send[: local.shape[0]] = local
         recv = torch.empty((self.size * nmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        all_gather_into(recv, send, group=self.group)
+        self.gcomm.all_gather_into(recv, send)
         return torch.cat([recv[i * nmax: i * nmax + (b - a)] for i, (a, b) in enumerate(parts)], dim=0)
 
 
@@ -276,7 +323,9 @@ class _Runner:
         """What this layout created for its data path (bench.py reports it: `config.rccl_communicators`)."""
         if self.pair.size == 1:
             return []
-        return [{"kind": f"torch.distributed {dist.get_backend(self.pair.group)} group (eps all-gather per step, uint8 frame gather)",
+        lib = self.pair.gcomm._comm is not None
+        return [{"kind": ("libt2v_hip t2v_comm: RCCL communicator owned by the library" if lib else
+                          f"torch.distributed {dist.get_backend(self.pair.group)} group") + " (eps all-gather per step, uint8 frame gather)",
                  "size": self.pair.size}]
 
     @torch.no_grad()
@@ -322,10 +371,12 @@ class TShardTopology:
             g = dist.new_group(ranks=[t, self.R + t])
             if t == self.t:
                 self.pair_group = g
+        self.pair_comm = GroupComm(self.pair_group, [self.t, self.R + self.t], self.role)     # eps exchange per step
+        self.world_comm = GroupComm(None, list(range(world)), rank)                            # uint8 frame gather per video
 
     def exchange_eps(self, eps_local: torch.Tensor) -> torch.Tensor:
         out = torch.empty((2,) + tuple(eps_local.shape[1:]), dtype=eps_local.dtype, device=eps_local.device)
-        all_gather_into(out, eps_local.contiguous(), group=self.pair_group)
+        self.pair_comm.all_gather_into(out, eps_local.contiguous())
         return out                                       # index 0 = role 0 = conditional
 
     def decode_share(self) -> Tuple[int, int]:
@@ -375,10 +426,15 @@ class _TShardRunner:
         executor), the CFG pair group and the world group of the frame gather."""
         ts = self.topo.tshard
         lib_comm = ts._comm.size if ts._comm is not None else None
-        return [{"kind": "libt2v_hip t2v_comm: RCCL communicator owned by the library (statistics all-gather, halo send/recv, "
-                         "frame<->pixel all-to-all as program ops on the launch stream)", "size": lib_comm, "t_group_ranks": ts.size},
-                {"kind": f"torch.distributed {dist.get_backend(self.topo.pair_group)} group (eps all-gather per step)", "size": 2},
-                {"kind": f"torch.distributed {dist.get_backend()} world group (uint8 frame gather)", "size": self.topo.world}]
+
+        def stack(gc: GroupComm, backend: str) -> str:
+            return "libt2v_hip t2v_comm (RCCL, t2v_comm_all_gather on the launch stream)" if gc._comm is not None else f"torch.distributed {backend} group"
+
+        return [{"kind": "libt2v_hip t2v_comm: RCCL communicator owned by the library (statistics + raw boundary frames as one grouped "
+                         "exchange per temporal convolution, statistics / K-V all-gathers, frame<->pixel all-to-all as program ops on the "
+                         "launch stream)", "size": lib_comm, "t_group_ranks": ts.size},
+                {"kind": stack(self.topo.pair_comm, dist.get_backend(self.topo.pair_group)) + ": eps all-gather per step", "size": 2},
+                {"kind": stack(self.topo.world_comm, dist.get_backend()) + ": uint8 frame gather per video", "size": self.topo.world}]
 
     @torch.no_grad()
     def self_check(self, cond) -> dict:
@@ -419,6 +475,17 @@ class _TShardRunner:
                 os.environ.pop("T2V_COLLECTIVES", None)
             else:
                 os.environ["T2V_COLLECTIVES"] = saved_env
+        # the two gathers AROUND the forward (eps pair per step, uint8 frames per video): library communicators against torch.distributed
+        gathers_in_library = False
+        for gc, n in ((topo.pair_comm, 2), (topo.world_comm, topo.world)):
+            if gc.communicator(dev) is not None:
+                gathers_in_library = True
+                mine = torch.full((4099,), float(topo.rank + 1), device=dev) + torch.arange(4099, device=dev)
+                a, b = torch.empty(n * 4099, device=dev), torch.empty(n * 4099, device=dev)
+                gc.all_gather_into(a, mine)
+                all_gather_into(b, mine, group=gc.group)
+                torch.cuda.synchronize(dev)
+                equal = equal and bool(torch.equal(a, b))
         flag = torch.tensor([0 if equal else 1], dtype=torch.int32)
         if _host_staged(None):
             dist.all_reduce(flag)
@@ -429,7 +496,7 @@ class _TShardRunner:
         return {"ok": ok, "collective_ops_per_forward": n_coll,
                 "compared": ("library communicator (RCCL on the launch stream) vs host executor (torch.distributed): bit-equal on every rank"
                              if in_library else "exchanges already run through the host executor in this set-up (gloo group): nothing to compare"),
-                "in_library": bool(in_library)}
+                "in_library": bool(in_library), "eps_and_frame_gathers_in_library": bool(gathers_in_library)}
 
     @torch.no_grad()
     def __call__(self, cond, uncond, seed):
@@ -459,7 +526,7 @@ class _TShardRunner:
         if b > a:
             send[: b - a] = pipe.decode_frames(x0[:, :, a:b])
         out = torch.empty((topo.world * nmax, H, W, 3), dtype=torch.uint8, device=dev)
-        all_gather_into(out, send)
+        topo.world_comm.all_gather_into(out, send)
         return torch.cat([out[r * nmax: r * nmax + n] for r, _, n in order], dim=0)
 
 

@@ -15,7 +15,7 @@ from typing import Dict, List, Optional, Tuple
 from . import _lib as L
 
 _ITEM = {"f16": 2, "f32": 4, "f64": 8, "u8": 1}
-COLLECTIVE_KINDS = (L.OP_ALLGATHER, L.OP_HALO_EXCHANGE, L.OP_ALLTOALL)   # executed over the plan's communicator (RCCL) or by a host executor
+COLLECTIVE_KINDS = (L.OP_ALLGATHER, L.OP_HALO_EXCHANGE, L.OP_ALLTOALL, L.OP_STATS_HALO)   # executed over the plan's communicator (RCCL) or by a host executor
 _DT = {"f16": L.F16, "f32": L.F32}
 
 
@@ -635,7 +635,8 @@ class Program:
 
     def groupnorm(self, name: str, x: Buf, gamma: Ref, beta: Ref, out: Buf, *, n_inst: int, eps: float,
                   silu: bool, groups: int = 32, shard: Optional[TShardSpec] = None, lo: bool = False, stats: Optional[Buf] = None,
-                  gb: Optional[Ref] = None, x_dead: bool = False, cast: Optional[Buf] = None, cast_lo: bool = False) -> Op:
+                  gb: Optional[Ref] = None, x_dead: bool = False, cast: Optional[Buf] = None, cast_lo: bool = False,
+                  halo_raw: Optional[Buf] = None) -> Op:
         """GroupNorm(+SiLU).  gb (fp32 [2C] gamma | beta) + x produced by the op emitted last: the norm may become that GEMM's
         epilogue (`_fuse_groupnorm`; x_dead = nothing else reads x).
         cast (fp16 [x.rows, >= C (2C with cast_lo)]): second output — the RAW input as fp16 (+ its low-order image at column C): the operand
@@ -644,6 +645,10 @@ class Program:
         ordered fold of all parts + normalise; every rank ends up with bit-identical statistics.  Each rank folds its own
         block partials first, so a part is one {sum, sum of squares} pair per group: 512 bytes per instance, whatever the
         slice lengths (uneven slices need no special care).
+        halo_raw (with `shard`; the norm in front of a T-sharded temporal convolution): `x` is the interior of this halo-padded RAW buffer
+        [(frames + 2) * frame_rows, C] and `out` the interior of a halo-padded fp16 buffer of the same shape.  The statistics exchange then
+        also carries the raw boundary frames to the two neighbours (ONE T2V_OP_STATS_HALO instead of an all-gather and, after the
+        normalise, a halo exchange), and the apply pass normalises the received frames with the same statistics into out's halo slots.
         lo: `out` is the left half of a [rows, 2C] buffer; the low-order fp16 image of every output value goes to columns C .. 2C-1
         (hi + lo operand split of the consuming GEMM, precise_operands).
         stats: the T2V_EPI_STATS strips written by the GEMM that produced `x` (fp32 [x.rows / 32, 2 C]): the op folds them (phase 3)
@@ -718,8 +723,17 @@ class Program:
         else:
             self._emit(make(1, ".stats"))
             full = Buf(scratch.ref, nparts * part_bytes, 1, 1, "u8", scratch.alloc_off)
-            self.allgather(name + ".stats.allgather", full, part_bytes, shard)
-            op = make(2, ".apply")
+            if halo_raw is None:
+                self.allgather(name + ".stats.allgather", full, part_bytes, shard)
+                op = make(2, ".apply")
+            else:
+                frame_rows = rows // shard.frames
+                assert halo_raw.rows == rows + 2 * frame_rows and halo_raw.dtype == x.dtype and halo_raw.ld == x.ld and not lo and cast is None
+                assert x.ref.off == halo_raw.ref.off + frame_rows * x.ld * x.item and x.ref.space == halo_raw.ref.space
+                self.stats_halo(name + ".stats_halo", full, part_bytes, halo_raw, frame_rows, shard.frames, shard)
+                op = make(2, ".apply")
+                op.i[21] = frame_rows if shard.index > 0 else 0                       # the clip's two ends keep the convolution's zero padding
+                op.i[22] = frame_rows if shard.index + 1 < shard.size else 0
             op.out = out
             self._emit(op)
         self.free(scratch)      # stream order makes immediate reuse safe
@@ -733,6 +747,19 @@ class Program:
         op.i[0], op.i[1], op.i[2], op.i[3] = part_bytes & 0xFFFFFFFF, part_bytes >> 32, shard.size, shard.index
         op.p[0] = full.ref
         op.meta = dict(type="allgather", full=full, part_bytes=part_bytes)
+        return self._emit(op)
+
+    def stats_halo(self, name: str, full: Buf, part_bytes: int, raw: Buf, frame_rows: int, frames: int, shard: TShardSpec) -> Op:
+        """T2V_OP_STATS_HALO: the statistics parts of `full` to every rank of the T group and the first / last frame of the halo-padded
+        RAW buffer `raw` to the previous / next slice's halo slot, in one grouped exchange (include/t2v_hip.h)."""
+        op = Op(L.OP_STATS_HALO, name)
+        fb = frame_rows * raw.ld * raw.item
+        op.i[0], op.i[1], op.i[2], op.i[3] = part_bytes & 0xFFFFFFFF, part_bytes >> 32, shard.size, shard.index
+        op.i[4], op.i[5], op.i[6] = fb & 0xFFFFFFFF, fb >> 32, frames
+        op.i[7] = shard.index - 1 if shard.index > 0 else -1
+        op.i[8] = shard.index + 1 if shard.index + 1 < shard.size else -1
+        op.p[0], op.p[1] = full.ref, raw.ref
+        op.meta = dict(type="stats_halo", full=full, part_bytes=part_bytes, buf=raw, frame_rows=frame_rows, frames=frames)
         return self._emit(op)
 
     def halo_exchange(self, name: str, buf: Buf, frame_rows: int, frames: int, shard: TShardSpec) -> Op:

@@ -713,7 +713,8 @@ class _Lowering:
         return Ref("weight", 0, self.packer.add(key + ":gn_gb", "f32", lambda sd, k=key: torch.cat([sd[k + ".weight"], sd[k + ".bias"]])))
 
     def gn(self, name, x: Buf, key, *, per_frame: bool, eps, silu, out: Optional[Buf] = None, lo: bool = False,
-           stats: Optional[Buf] = None, x_dead: bool = False, cast: Optional[Buf] = None, cast_lo: bool = False) -> Buf:
+           stats: Optional[Buf] = None, x_dead: bool = False, cast: Optional[Buf] = None, cast_lo: bool = False,
+           halo_raw: Optional[Buf] = None) -> Buf:
         """lo (precise_operands): the result is a [rows, 2C] buffer of rows [hi | lo] — fp16(y) and the low-order image of that
         rounding — for a consumer GEMM with weights [W | W] (K = 2C)."""
         if lo:
@@ -730,7 +731,7 @@ class _Lowering:
         #  x_dead: only this norm reads x)
         self.P.groupnorm(name, x, self.vec(key + ".weight"), self.vec(key + ".bias"), out, n_inst=n_inst, eps=eps, silu=silu,
                          shard=shard, lo=lo, stats=stats, gb=self.gn_gb(key) if self.shard is None and x.cols % 4 == 0 else None, x_dead=x_dead,
-                         cast=cast, cast_lo=cast_lo)
+                         cast=cast, cast_lo=cast_lo, halo_raw=halo_raw if shard is not None else None)
         return full
 
     def strips_for(self, rows: int, n: int, inst_rows: int) -> Optional[Buf]:
@@ -804,7 +805,14 @@ class _Lowering:
         else:
             skip = x
         st = self.strips_for(x.rows, cout, self.F * h * w) if self.shard is None else None
-        h2 = self.conv3(prefix + ".out_layers.3", b, prefix + ".out_layers.3", cout, h, w, residual=skip, stats=st)
+        # T-sharded: every tensor a cross-frame GroupNorm + (3,1,1) convolution pair reads lives in a buffer with one halo frame either
+        # side, RAW: the statistics exchange of that norm carries the boundary frames along (T2V_OP_STATS_HALO) and the norm's apply pass
+        # normalises them on arrival — one exchange per temporal convolution instead of two (T2V_STATS_HALO=0: the two-exchange form)
+        merged = self.shard is not None and os.environ.get("T2V_STATS_HALO", "1") != "0"
+        hwp = h * w
+        raw = P.alloc((self.F + 2) * hwp, cout, "f32") if merged else None
+        h2 = self.conv3(prefix + ".out_layers.3", b, prefix + ".out_layers.3", cout, h, w, residual=skip, stats=st,
+                        dest=raw.row_slice(hwp, (self.F + 1) * hwp) if merged else None)
         st_live = self.last_stats
         P.free(b)
         if skip is not x:
@@ -821,18 +829,24 @@ class _Lowering:
                 # T-sharded: normalised activations go into a buffer with one halo frame either side;
                 # neighbours fill the halos (zeros at the two ends of the clip = the conv's zero padding)
                 R, r = self.shard.size, self.shard.index
-                hwp = h * w
                 nrm = P.alloc((self.F + 2) * hwp, cout, "f16")
                 if r == 0:
                     P.memset(f"{tp}.{name}.halo0", nrm.row_slice(0, hwp))
                 if r == R - 1:
                     P.memset(f"{tp}.{name}.halo1", nrm.row_slice((self.F + 1) * hwp, (self.F + 2) * hwp))
                 self.gn(f"{tp}.{name}.0", t, f"{tp}.{name}.0", per_frame=False, eps=1e-5, silu=True,
-                        out=nrm.row_slice(hwp, (self.F + 1) * hwp))
-                P.halo_exchange(f"{tp}.{name}.halo", nrm, hwp, self.F, self.shard)
+                        out=nrm.row_slice(hwp, (self.F + 1) * hwp), halo_raw=raw)
+                if not merged:
+                    P.halo_exchange(f"{tp}.{name}.halo", nrm, hwp, self.F, self.shard)
             if t is not h2:
                 P.free(t)
-            t = self._dest(dest, h2.rows, cout, "f32") if name == "conv4" else P.alloc(h2.rows, cout, self.net.norm_input_dtype)
+            if name == "conv4":
+                t = self._dest(dest, h2.rows, cout, "f32")
+            elif merged:
+                raw = P.alloc((self.F + 2) * hwp, cout, self.net.norm_input_dtype)
+                t = raw.row_slice(hwp, (self.F + 1) * hwp)
+            else:
+                t = P.alloc(h2.rows, cout, self.net.norm_input_dtype)
             key = f"{tp}.{name}.{idx}"
             if name != "conv4" and self.shard is None:
                 st = self.strips_for(h2.rows, cout, self.F * h * w)            # conv1 .. conv3 feed the next cross-frame GroupNorm

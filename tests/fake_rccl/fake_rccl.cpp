@@ -2,7 +2,7 @@
 // ONE GPU (the build environment only has 1-GPU boxes, and RCCL itself refuses several ranks on one device).
 //
 // libt2v_hip.so resolves RCCL with dlopen; T2V_RCCL_SONAME points it at this library instead.  Every entry point the product
-// uses is implemented with the semantics RCCL documents — ncclAllGather (in-place allowed), grouped ncclSend / ncclRecv — on
+// uses is implemented with the semantics RCCL documents — ncclAllGather (in-place allowed), grouped ncclSend / ncclRecv (several transfers to one peer are matched in issue order) — on
 // top of a POSIX shared-memory segment: data is staged device -> host -> shared memory -> host -> device, ordered with the
 // caller's stream by hipStreamSynchronize and between ranks by a sense-reversing barrier in the segment.  What this proves is
 // everything in csrc/comm.hip that is NOT RCCL itself: which bytes go to which peer at which offsets, in-place parts, uneven
@@ -33,9 +33,12 @@ namespace {
 constexpr size_t MAX_RANKS = 8;
 constexpr size_t SLOT = 32u << 20;          // bytes one rank may publish per call (all its sends / its all-gather part)
 
+constexpr int MAX_MSGS = 4;                 // transfers one rank may queue for ONE peer inside one group (matched in issue order, as RCCL does)
+
 struct Shared {
   std::atomic<int> arrived, generation, attached;
-  size_t send_off[MAX_RANKS][MAX_RANKS], send_len[MAX_RANKS][MAX_RANKS];   // [src][dst] inside src's slot
+  int send_cnt[MAX_RANKS][MAX_RANKS];                                                            // [src][dst]
+  size_t send_off[MAX_RANKS][MAX_RANKS][MAX_MSGS], send_len[MAX_RANKS][MAX_RANKS][MAX_MSGS];     // inside src's slot
 };
 
 struct PendingOp { bool send; void* ptr; size_t bytes; int peer; };
@@ -70,23 +73,29 @@ ncclResult_t flush_group(FakeComm* c) {
   if (hipStreamSynchronize(c->stream) != hipSuccess) return ncclSystemError;
   // publish every send of this rank into its own slot
   size_t off = 0;
-  for (int d = 0; d < c->nranks; ++d) c->sh->send_len[c->rank][d] = 0;
+  for (int d = 0; d < c->nranks; ++d) c->sh->send_cnt[c->rank][d] = 0;
   for (const PendingOp& op : c->pending) {
     if (!op.send) continue;
-    if (off + op.bytes > SLOT || c->sh->send_len[c->rank][op.peer] != 0) return ncclInvalidArgument;   // one send per peer per group
+    int& k = c->sh->send_cnt[c->rank][op.peer];
+    if (off + op.bytes > SLOT || k >= MAX_MSGS) return ncclInvalidArgument;
     if (hipMemcpy(c->slots + (size_t)c->rank * SLOT + off, op.ptr, op.bytes, hipMemcpyDeviceToHost) != hipSuccess) return ncclSystemError;
-    c->sh->send_off[c->rank][op.peer] = off;
-    c->sh->send_len[c->rank][op.peer] = op.bytes;
+    c->sh->send_off[c->rank][op.peer][k] = off;
+    c->sh->send_len[c->rank][op.peer][k] = op.bytes;
+    ++k;
     off += op.bytes;
   }
   barrier(c);
   ncclResult_t rc = ncclSuccess;
+  int taken[MAX_RANKS] = {0};                   // the k-th receive from a peer takes that peer's k-th send to this rank
   for (const PendingOp& op : c->pending) {
     if (op.send) continue;
-    if (c->sh->send_len[op.peer][c->rank] != op.bytes) { rc = ncclInvalidArgument; continue; }       // size mismatch between the two sides
-    if (hipMemcpy(op.ptr, c->slots + (size_t)op.peer * SLOT + c->sh->send_off[op.peer][c->rank], op.bytes, hipMemcpyHostToDevice) != hipSuccess)
+    const int k = taken[op.peer]++;
+    if (k >= c->sh->send_cnt[op.peer][c->rank] || c->sh->send_len[op.peer][c->rank][k] != op.bytes) { rc = ncclInvalidArgument; continue; }   // count / size mismatch between the two sides
+    if (hipMemcpy(op.ptr, c->slots + (size_t)op.peer * SLOT + c->sh->send_off[op.peer][c->rank][k], op.bytes, hipMemcpyHostToDevice) != hipSuccess)
       rc = ncclSystemError;
   }
+  for (int q = 0; q < c->nranks; ++q)
+    if (q != c->rank && taken[q] != c->sh->send_cnt[q][c->rank]) rc = ncclInvalidArgument;       // a send nobody received
   barrier(c);                                   // nobody overwrites its slot before every peer has read it
   c->pending.clear();
   return rc;

@@ -62,7 +62,7 @@ def run_lockstep(executors, exts, stream):
             continue
         ops = [steps[r][k][1] for r in range(n)]
         nb = (ops[0].i[0] & 0xFFFFFFFF) | (ops[0].i[1] << 32)
-        if ops[0].kind == L.OP_ALLGATHER:
+        if ops[0].kind in (L.OP_ALLGATHER, L.OP_STATS_HALO):
             parts = []
             for r in range(n):
                 assert (ops[r].i[2], ops[r].i[3]) == (n, r)
@@ -89,15 +89,20 @@ def run_lockstep(executors, exts, stream):
                     moves.append((executors[src[0]].arena[src[1]: src[1] + src[2]].clone(), dst))
             for data, (q, off) in moves:
                 executors[q].arena[off: off + data.numel()] = data
-        else:  # halo exchange: frame 1 -> prev's frame F+1 ... (byte counts / neighbours read from the op records)
+        if ops[0].kind in (L.OP_HALO_EXCHANGE, L.OP_STATS_HALO):
+            # frame 1 -> prev's frame F+1 ... (byte counts / neighbours read from the op records); STATS_HALO: the halo-padded RAW buffer p[1]
+            merged = ops[0].kind == L.OP_STATS_HALO
+            if merged:
+                nb = (ops[0].i[4] & 0xFFFFFFFF) | (ops[0].i[5] << 32)
+            geo = lambda op: (op.p[1].off, op.i[6], op.i[7], op.i[8]) if merged else (op.p[0].off, op.i[2], op.i[3], op.i[4])
             firsts, lasts = [], []
             for r in range(n):
-                base, nf = ops[r].p[0].off, ops[r].i[2]
+                base, nf, _, _ = geo(ops[r])
                 firsts.append(executors[r].arena[base + nb: base + 2 * nb].clone())
                 lasts.append(executors[r].arena[base + nf * nb: base + (nf + 1) * nb].clone())
             for r in range(n):
-                base, nf = ops[r].p[0].off, ops[r].i[2]
-                assert ops[r].i[3] == (r - 1 if r > 0 else -1) and ops[r].i[4] == (r + 1 if r + 1 < n else -1)
+                base, nf, prev, nxt = geo(ops[r])
+                assert prev == (r - 1 if r > 0 else -1) and nxt == (r + 1 if r + 1 < n else -1)
                 if r > 0:
                     executors[r].arena[base: base + nb] = lasts[r - 1]
                 if r + 1 < n:

@@ -241,13 +241,21 @@ class Interp:
                 self._st(self.view(op.p[8].shifted(2 * op.i[20]), (n_inst * rows, C), (op.i[19], 1), torch.float16, ext), raw - raw.half().float(), torch.float16)
         mean = (s1 / n).view(n_inst, 1, groups, 1)
         var = (s2 / n).view(n_inst, 1, groups, 1) - mean * mean
+        before, after = (op.i[21], op.i[22]) if phase == 2 else (0, 0)
+        out_ref = op.p[3]
+        if before or after:      # the neighbours' RAW boundary frames in front of / behind x take the same statistics (T2V_OP_STATS_HALO)
+            assert n_inst == 1
+            item = 4 if _TD[in_dt] == torch.float32 else 2
+            rows = rows + before + after
+            x = self.mat(op.p[0].shifted(-before * ld_in * item), rows, C, ld_in, _TD[in_dt], ext).double().view(1, rows, groups, cpg)
+            out_ref = op.p[3].shifted(-before * ld_out * 2)
         y = ((x - mean) / torch.sqrt(var.clamp_min(0) + op.f[0])).view(n_inst * rows, C).float()
         g = self.view(op.p[1], (C,), (1,), torch.float32, ext)
         b = self.view(op.p[2], (C,), (1,), torch.float32, ext)
         y = y * g + b
         if silu:
             y = F.silu(y)
-        self._st(self.mat(op.p[3], n_inst * rows, C, ld_out, torch.float16, ext), y, torch.float16)
+        self._st(self.mat(out_ref, n_inst * rows, C, ld_out, torch.float16, ext), y, torch.float16)
         if op.i[16]:                                           # low-order image of the fp16 rounding at columns C .. 2C-1
             lo_view = self.view(op.p[3].shifted(2 * C), (n_inst * rows, C), (ld_out, 1), torch.float16, ext)
             self._st(lo_view, y.float() - y.half().float(), torch.float16)

@@ -46,7 +46,7 @@ out_lib = net(xl, t, y).clone()
 comp = next(c for k, c in net._programs.items() if spec in k)
 assert isinstance(comp.bound, BoundProgram) and comp.bound.comm is not None and comp.bound.comm.size == world
 kinds = [op.kind for op in comp.prog.ops if op.kind in COLLECTIVE_KINDS]
-assert L.OP_ALLGATHER in kinds and L.OP_HALO_EXCHANGE in kinds and (L.OP_ALLTOALL in kinds or 64 % world)
+assert L.OP_ALLGATHER in kinds and L.OP_STATS_HALO in kinds and (L.OP_ALLTOALL in kinds or 64 % world)
 out_lib2 = net(xl, t, y).clone()
 torch.cuda.synchronize()
 # (2) the same op records through the host executor (torch.distributed collectives on views of the arena)
@@ -55,6 +55,27 @@ comp.bound = None
 out_host = net(xl, t, y).clone()
 assert isinstance(comp.bound, parallel.ShardedExecutor)
 torch.cuda.synchronize()
+# (3) the two-exchange lowering of rounds 1-4 (statistics all-gather, normalise, halo exchange of the NORMALISED frames), in the library:
+# a neighbour that normalises my raw boundary frame with the gathered statistics must produce the bits I produced for it
+os.environ["T2V_COLLECTIVES"], os.environ["T2V_STATS_HALO"] = "library", "0"
+net._programs.clear()
+out_two = net(xl, t, y).clone()
+comp2 = next(c for k, c in net._programs.items() if spec in k)
+kinds2 = [op.kind for op in comp2.prog.ops if op.kind in COLLECTIVE_KINDS]
+assert L.OP_STATS_HALO not in kinds2 and kinds2.count(L.OP_HALO_EXCHANGE) == kinds.count(L.OP_STATS_HALO)
+torch.cuda.synchronize()
+os.environ.pop("T2V_STATS_HALO")
+# (4) the gathers AROUND the forward (eps of a CFG pair per step, uint8 frames per video) through t2v_comm_all_gather on a second
+# library communicator, against torch.distributed
+os.environ["T2V_COLLECTIVES"] = "library"
+gc = parallel.GroupComm(dist.group.WORLD, list(range(world)), rank)
+mine = (torch.arange(3001, device=dev, dtype=torch.float32) * (rank + 1)).half()
+via_lib, via_torch = torch.empty(world * 3001, device=dev, dtype=torch.float16), torch.empty(world * 3001, device=dev, dtype=torch.float16)
+gc.all_gather_into(via_lib, mine)
+assert gc._comm is not None and gc._comm.size == world
+parallel.all_gather_into(via_torch, mine, group=dist.group.WORLD)
+torch.cuda.synchronize()
+gathers_equal = bool(torch.equal(via_lib, via_torch))
 pad = torch.zeros(1, 4, spec.max_frames, 8, 8, device=dev, dtype=out_lib.dtype)
 pad[:, :, :spec.frames] = out_lib
 if backend == "nccl":
@@ -66,7 +87,8 @@ else:
     allp = [h.to(dev) for h in host]
 res = {"rank": rank, "lib_vs_host_equal": bool(torch.equal(out_lib, out_host)), "rerun_equal": bool(torch.equal(out_lib, out_lib2)),
        "n_collectives": len(kinds), "alltoall": kinds.count(L.OP_ALLTOALL), "halo": kinds.count(L.OP_HALO_EXCHANGE),
-       "allgather": kinds.count(L.OP_ALLGATHER)}
+       "stats_halo": kinds.count(L.OP_STATS_HALO), "allgather": kinds.count(L.OP_ALLGATHER),
+       "two_exchange_form_equal": bool(torch.equal(out_lib, out_two)), "group_comm_gather_equal": gathers_equal, "n_collectives_two_exchange_form": len(kinds2)}
 if rank == 0:
     net.t_shard = None
     os.environ.pop("T2V_COLLECTIVES")

@@ -28,6 +28,7 @@ def test_header_constants_match_binding():
         "T2V_OP_NP": L.OP_NP, "T2V_GN_ROWS_PER_BLOCK": L.GN_ROWS_PER_BLOCK, "T2V_SYNC_INTS": L.SYNC_INTS, "T2V_SYNC_BARRIER_INTS": L.SYNC_BARRIER_INTS,
         "T2V_OP_EMBED_ROWS": L.OP_EMBED_ROWS, "T2V_OP_TO_UINT8": L.OP_TO_UINT8, "T2V_OP_ALLGATHER": L.OP_ALLGATHER,
         "T2V_OP_HALO_EXCHANGE": L.OP_HALO_EXCHANGE, "T2V_OP_RESHARD_ROWS": L.OP_RESHARD_ROWS, "T2V_OP_ALLTOALL": L.OP_ALLTOALL,
+        "T2V_OP_STATS_HALO": L.OP_STATS_HALO,
     }
     for k, v in expect.items():
         assert allc[k] == v, (k, allc[k], v)
@@ -90,18 +91,23 @@ def test_validation_covers_every_op_kind_without_gpu(built_lib):
     refused(L.OP_TO_UINT8, i=(1, 3, 0, 8, 8), p=(ptr, ptr), needle=b"uint8")
     refused(L.OP_ALLGATHER, i=(512, 0, 2, 2), p=(ptr,), needle=b"all-gather")                                # part >= nparts
     refused(L.OP_HALO_EXCHANGE, i=(512, 0, 0, -1, -1), p=(ptr,), needle=b"halo")
+    refused(L.OP_STATS_HALO, i=(512, 0, 2, 1, 4096, 0, 3, 0, 2), p=(ptr, ptr), needle=b"statistics + halo")   # next rank outside the communicator
+    refused(L.OP_STATS_HALO, i=(512, 0, 2, 1, 4096, 0, 3, 0, -1), p=(ptr,), needle=b"statistics + halo")      # no raw buffer
     refused(L.OP_RESHARD_ROWS, i=(8, 64, 0, 4, 4, 64, 64, 0), p=(ptr, ptr), needle=b"resharding")            # chunk of 0 rows
     refused(L.OP_ALLTOALL, i=(512, 0, 4, 1, 3, 4, 0), p=(ptr, ptr), needle=b"all-to-all")                    # last slice longer than the others
     refused(L.OP_GEMM, i=(256, 640, 64, 64, 64, 640, 0, 0, 1, 640, 0, 0, 0, 0, 0, 0, 0, 1, 0, 1, 0, 0, 8), p=(ptr, ptr, 0, ptr, 0, ptr, 0, ptr),
             needle=b"fused LayerNorm")                                                                        # N != 320 on the LN-fused form
     # and a well-formed record of each collective kind is accepted (nothing runs at plan creation)
-    ok = (L.T2VOp * 2)()
-    ok[0].kind, ok[1].kind = L.OP_ALLGATHER, L.OP_ALLTOALL
+    ok = (L.T2VOp * 3)()
+    ok[0].kind, ok[1].kind, ok[2].kind = L.OP_ALLGATHER, L.OP_ALLTOALL, L.OP_STATS_HALO
+    for k, v in enumerate((512, 0, 4, 1, 4096, 0, 3, 0, 2)):
+        ok[2].i[k] = v
+    ok[2].p[0], ok[2].p[1] = ptr, ptr
     ok[0].i[0], ok[0].i[2], ok[0].i[3], ok[0].p[0] = 512, 4, 1, ptr
     for k, v in enumerate((1024, 0, 4, 1, 32, 29, 1)):
         ok[1].i[k] = v
     ok[1].p[0], ok[1].p[1] = ptr, ptr
-    assert built_lib.t2v_plan_create(ok, 2, ctypes.byref(h)) == 0 and built_lib.t2v_plan_num_ops(h) == 2
+    assert built_lib.t2v_plan_create(ok, 3, ctypes.byref(h)) == 0 and built_lib.t2v_plan_num_ops(h) == 3
     built_lib.t2v_plan_destroy(h)
 
 

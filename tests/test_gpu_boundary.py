@@ -203,19 +203,26 @@ def test_collective_ops_run_through_rccl_single_rank_communicator():
     assert lib.t2v_comm_size(comm) == 1
     buf = torch.arange(4096, dtype=torch.uint8, device=DEV).contiguous()
     want = buf.clone()
-    ops = (L.T2VOp * 2)()
+    ops = (L.T2VOp * 3)()
     ops[0].kind = L.OP_ALLGATHER
     ops[0].i[0], ops[0].i[2], ops[0].i[3] = 1024, 1, 0
     ops[0].p[0] = buf.data_ptr()
     ops[1].kind = L.OP_HALO_EXCHANGE
     ops[1].i[0], ops[1].i[2], ops[1].i[3], ops[1].i[4] = 1024, 2, -1, -1
     ops[1].p[0] = buf.data_ptr()
+    ops[2].kind = L.OP_STATS_HALO          # statistics parts + raw boundary frames in one group: empty on one rank
+    for k, v in enumerate((512, 0, 1, 0, 1024, 0, 2, -1, -1)):
+        ops[2].i[k] = v
+    ops[2].p[0], ops[2].p[1] = buf.data_ptr(), buf.data_ptr()
     plan = ctypes.c_void_p()
-    L.check(lib.t2v_plan_create(ops, 2, ctypes.byref(plan)))
+    L.check(lib.t2v_plan_create(ops, 3, ctypes.byref(plan)))
     L.check(lib.t2v_plan_set_comm(plan, comm))
-    L.check(lib.t2v_plan_run(plan, None, 0, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    L.check(lib.t2v_plan_run(plan, None, 0, stream))
+    L.check(lib.t2v_comm_all_gather(comm, ctypes.c_void_p(buf.data_ptr()), 4096, stream))      # the eps / frame gathers' entry point
     torch.cuda.synchronize()
     assert torch.equal(buf, want)
+    assert lib.t2v_comm_all_gather(None, ctypes.c_void_p(buf.data_ptr()), 4096, stream) == -1
     # a 2-part gather on a 1-rank communicator is refused (parts must match the communicator)
     ops[0].i[2] = 2
     plan2 = ctypes.c_void_p()

@@ -126,6 +126,11 @@ stage_bench20() {   # the driver's K: 20 timed videos after 2 warm-ups (sustaine
 stage_multiproc() {
   timeout 1200 $PYT tests/test_gpu_multiproc.py tests/test_gpu_fake_rccl.py tests/test_gpu_boundary.py -rP > gpurun_out/${TAG}_multiproc.log 2>&1; echo "multiproc exit $?"; grep -E "identical|passed|failed" gpurun_out/${TAG}_multiproc.log | tail -n 8 | cut -c1-250
 }
+stage_coll() {      # round 5: one exchange per temporal convolution (T2V_OP_STATS_HALO), eps / frame gathers through t2v_comm_all_gather
+  timeout 1200 $PYT tests/test_gpu_fake_rccl.py tests/test_gpu_boundary.py tests/test_gpu_multiproc.py tests/test_gpu_e2e.py -rP \
+    -k "library_collectives or single_rank_communicator or runner_layouts or tsharded" > gpurun_out/${TAG}_coll.log 2>&1; echo "coll exit $?"
+  grep -E "library collectives|identical|passed|failed|Error" gpurun_out/${TAG}_coll.log | tail -n 10 | cut -c1-600
+}
 stage_e2e() {
   timeout 1500 $PYT tests/test_gpu_e2e.py tests/test_gpu_text_encoder.py tests/test_gpu_videocrafter.py > gpurun_out/${TAG}_e2e.log 2>&1; echo "e2e exit $?"; digest gpurun_out/${TAG}_e2e.log
 }

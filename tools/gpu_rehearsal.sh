@@ -23,9 +23,11 @@ except Exception as e:
 PY
   grep "\[bench\]" gpurun_out/rehearsal_$name.err | tail -n 3 | cut -c1-400
 }
+if [ "${T2V_REHEARSAL_ONLY:-}" != "fake_rccl" ]; then      # T2V_REHEARSAL_ONLY=fake_rccl: only the last run (library collectives)
 run n4 4 --frames 6 --also-frames 10
 run n2 2 --frames 6 --also-frames 10
 T2V_BENCH_INJECT_FAILURE=all run n4_fallback 4 --frames 6 --also-frames 10      # the frame-parallel job fails -> replicas headline + reason
+fi
 # the same N = 4 run with the exchanges INSIDE the library (csrc/comm.hip) over the shared-memory RCCL stand-in of tests/fake_rccl: the
 # self-check then really compares the library's collectives with the host executor (config.self_check.in_library == true)
 FAKE=tests/fake_rccl/libfakerccl.so
