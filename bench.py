@@ -851,7 +851,9 @@ def main():
             # box calibration either side of the timed region: the same kernel family on an 8192^3 fp16 GEMM (random data)
             "calibration": {"gemm_8192_tflops_before": cal_before, **(cal0 or {}),
                             "note": "8192^3 fp16 GEMM, 256x256 tile of gemm2_kernel, N(0,1) operands, median of 8 launches (HIP events); "
-                                    "boxes of the pool differ by +-5-10 % on it (power-limited clocks) — divide to compare lines"},
+                                    "boxes of the pool differ by +-5-10 % on it (power-limited clocks).  It identifies the box; it does NOT normalise "
+                                    "the line (rounds 4-5: 1094 -> 17.75, 1108 -> 18.69, 1128 -> 17.04, 1160 -> 18.77 frames/s: sustained power under the "
+                                    "real kernel mix differs too) — compare builds only by same-box A/B"},
             "algorithmic_bytes_per_launch": round(alg_bytes / n_gemm),
             "strict_bytes_per_launch": round(strict_bytes / n_gemm),
             "traffic_over_strict": round(traffic / (strict_bytes / n_gemm), 3) if traffic else None,

@@ -730,7 +730,7 @@ class _Lowering:
         # (x produced by the op emitted last, on a tile with the instantiation: the norm becomes that GEMM's epilogue — Program._fuse_groupnorm;
         #  x_dead: only this norm reads x)
         self.P.groupnorm(name, x, self.vec(key + ".weight"), self.vec(key + ".bias"), out, n_inst=n_inst, eps=eps, silu=silu,
-                         shard=shard, lo=lo, stats=stats, gb=self.gn_gb(key) if self.shard is None and x.cols % 4 == 0 else None, x_dead=x_dead,
+                         shard=shard, lo=lo, stats=stats, gb=self.gn_gb(key) if shard is None and x.cols % 4 == 0 else None, x_dead=x_dead,
                          cast=cast, cast_lo=cast_lo, halo_raw=halo_raw if shard is not None else None)
         return full
 

@@ -131,6 +131,15 @@ stage_coll() {      # round 5: one exchange per temporal convolution (T2V_OP_STA
     -k "library_collectives or single_rank_communicator or runner_layouts or tsharded" > gpurun_out/${TAG}_coll.log 2>&1; echo "coll exit $?"
   grep -E "library collectives|identical|passed|failed|Error" gpurun_out/${TAG}_coll.log | tail -n 10 | cut -c1-600
 }
+stage_tshardrank() {   # compute time of ONE rank's real T-sharded program (collectives left out), fused per-frame norms on / off
+  for g in "24 4 1" "24 2 0" "125 4 1" "125 2 0"; do
+    for v in "T2V_X=0" "T2V_GN_EPI=0"; do
+      env $v timeout 300 python tools/profile_tshard_rank.py $g > "gpurun_out/${TAG}_tshard_rank_$(echo $g | tr ' ' '_')_$(echo $v | tr '=' '_').log" 2>&1
+      echo "== $g $v"; grep -E "T-shard rank|Error|error" "gpurun_out/${TAG}_tshard_rank_$(echo $g | tr ' ' '_')_$(echo $v | tr '=' '_').log" | cut -c1-400
+    done
+  done
+  timeout 600 $PYT tests/test_gpu_e2e.py -k "tsharded" > gpurun_out/${TAG}_tshard_e2e.log 2>&1; echo "tsharded e2e exit $?"; digest gpurun_out/${TAG}_tshard_e2e.log 3
+}
 stage_e2e() {
   timeout 1500 $PYT tests/test_gpu_e2e.py tests/test_gpu_text_encoder.py tests/test_gpu_videocrafter.py > gpurun_out/${TAG}_e2e.log 2>&1; echo "e2e exit $?"; digest gpurun_out/${TAG}_e2e.log
 }
