@@ -702,8 +702,8 @@ def main():
         if hasattr(runner, "self_check"):
             # first forward of the T-sharded UNet twice: exchanges inside the library (RCCL on the launch stream) vs the host
             # executor the gloo tests pin — bit-equal on every rank, or nothing is timed
-            self_check = runner.self_check(cond)
-            if not self_check.get("ok", False):
+            self_check = runner.self_check(cond)          # None: a layout without data-path collectives (replicas, one GPU)
+            if self_check is not None and not self_check.get("ok", False):
                 raise RuntimeError(f"frame-parallel self-check failed: {self_check}")
         runner(cond, uncond, 999)
         sync()

@@ -226,6 +226,29 @@ __device__ __forceinline__ float t2v_silu(float x) {
 // that 8 lanes cover one whole 128-byte row: 8 lines per instruction for the stores, the residual and the row-bias
 // loads alike.  Same-box A/B on the 24-frame UNet step: 31.4 ms vs 31.9 ms with per-lane row-strided stores.
 // Handles T2V_EPI_NONE (bias / row bias / SiLU / fp32 residual / fp16|fp32 out) and the split-K slab stores.
+// The fp32 residual stream: read once by the GEMM that adds to it, written once for the next residual GEMM (tens of MB per launch at the
+// 32x32 / 16x16 levels).  T2V_NT_RES / T2V_NT_OUT = 1 mark those accesses non-temporal (experiment switches, tools/build_variant.py).
+#ifndef T2V_NT_RES
+#define T2V_NT_RES 0
+#endif
+#ifndef T2V_NT_OUT
+#define T2V_NT_OUT 0
+#endif
+__device__ __forceinline__ f32x4 t2v_ld_stream(const float* p) {
+#if T2V_NT_RES
+  return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+#else
+  return *reinterpret_cast<const f32x4*>(p);
+#endif
+}
+__device__ __forceinline__ void t2v_st_stream(float* p, f32x4 v) {
+#if T2V_NT_OUT
+  __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+#else
+  *reinterpret_cast<f32x4*>(p) = v;
+#endif
+}
+
 constexpr int T2V_EPI_SP = 36;     // floats per staged row: 16-lane phases of the 16-byte LDS accesses hit disjoint banks
 
 template <int TM, int TN>
@@ -245,7 +268,7 @@ __device__ __forceinline__ void t2v_epilogue_rows(const GemmParams& p, const f32
       const int m = mt + rrow + 8 * i;
       const int mr = (p.res_wrap && m >= p.res_wrap) ? m - p.res_wrap : m;          // shared (one-sample) residual: rows wrap once
       const float* src = (m < p.M && n < p.N) ? p.res + (size_t)mr * p.ldr + n : p.res;
-      r[i] = *reinterpret_cast<const f32x4*>(src);
+      r[i] = t2v_ld_stream(src);
     }
   };
   f32x4 rcur[4], rnxt[4];
@@ -288,7 +311,7 @@ __device__ __forceinline__ void t2v_epilogue_rows(const GemmParams& p, const f32
           if (p.act == 1) { v[0] = t2v_silu(v[0]); v[1] = t2v_silu(v[1]); v[2] = t2v_silu(v[2]); v[3] = t2v_silu(v[3]); }
           if (has_res) v += rcur[i];
           if (p.out_f32) {
-            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n) = v;
+            t2v_st_stream(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n, v);
             if (p.stats) { ssum += v; ssq += v * v; }
           } else {
             f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
@@ -370,7 +393,7 @@ __device__ __forceinline__ void t2v_epilogue_rows(const GemmParams& p, const f32
         if (p.act == 1) { v[0] = t2v_silu(v[0]); v[1] = t2v_silu(v[1]); v[2] = t2v_silu(v[2]); v[3] = t2v_silu(v[3]); }
         if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.ldr + n);
         if (p.out_f32) {
-          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n) = v;
+          t2v_st_stream(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n, v);
         } else {
           f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
           f16* dst = reinterpret_cast<f16*>(p.out) + (size_t)m * p.ldc + n;
@@ -402,7 +425,7 @@ __device__ __forceinline__ void t2v_epilogue_rows_ln(const GemmParams& p, f32x16
       const int m = m_wave + rrow + 8 * i;
       const int mr = (p.res_wrap && m >= p.res_wrap) ? m - p.res_wrap : m;
       const float* src = (m < p.M && n < p.N) ? p.res + (size_t)mr * p.ldr + n : p.res;
-      r[i] = *reinterpret_cast<const f32x4*>(src);
+      r[i] = t2v_ld_stream(src);
     }
   };
   f32x4 rcur[4];
@@ -428,7 +451,7 @@ __device__ __forceinline__ void t2v_epilogue_rows_ln(const GemmParams& p, f32x16
       const int m = m_wave + row;
       v += cb;
       if (has_res) v += rcur[i];
-      if (m < p.M) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n) = v;
+      if (m < p.M) t2v_st_stream(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n, v);
       acc[0][b][4 * i] = v[0]; acc[0][b][4 * i + 1] = v[1]; acc[0][b][4 * i + 2] = v[2]; acc[0][b][4 * i + 3] = v[3];   // row-major now
       rs[i] += (v[0] + v[1]) + (v[2] + v[3]);
     }
@@ -671,7 +694,7 @@ __device__ __forceinline__ void t2v_epilogue_rows_gn(const GemmParams& p, f32x16
           const int m = mt + rrow + 8 * i;
           const int mr = (p.res_wrap && m >= p.res_wrap) ? m - p.res_wrap : m;
           const float* src = (m < p.M && ncol) ? p.res + (size_t)mr * p.ldr + n : p.res;
-          r[i] = *reinterpret_cast<const f32x4*>(src);
+          r[i] = t2v_ld_stream(src);
         }
       }
 #pragma unroll
@@ -762,7 +785,7 @@ __device__ __forceinline__ void t2v_epilogue_rows_gn(const GemmParams& p, f32x16
           if (m >= p.M) continue;
           const f32x4 v = {acc[a][b][4 * i], acc[a][b][4 * i + 1], acc[a][b][4 * i + 2], acc[a][b][4 * i + 3]};
           if (p.out_f32) {
-            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n) = v;
+            t2v_st_stream(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n, v);
           } else {
             const f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
             *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(p.out) + (size_t)m * p.ldc + n) = o;
@@ -896,7 +919,7 @@ __device__ __forceinline__ void t2v_epilogue_rows_lnx(const GemmParams& p, f32x1
           const int m = mt + rrow + 8 * i;
           const int mr = (p.res_wrap && m >= p.res_wrap) ? m - p.res_wrap : m;
           const float* src = (m < p.M && ncol) ? p.res + (size_t)mr * p.ldr + n : p.res;
-          r[i] = *reinterpret_cast<const f32x4*>(src);
+          r[i] = t2v_ld_stream(src);
         }
       }
 #pragma unroll
@@ -962,8 +985,8 @@ __device__ __forceinline__ void t2v_epilogue_rows_lnx(const GemmParams& p, f32x1
       for (int i = 0; i < 4; ++i) {
         const int m = mt + rrow + 8 * i;
         if (m < p.M)
-          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n) =
-              f32x4{acc[a][b][4 * i], acc[a][b][4 * i + 1], acc[a][b][4 * i + 2], acc[a][b][4 * i + 3]};
+          t2v_st_stream(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldc + n,
+                        f32x4{acc[a][b][4 * i], acc[a][b][4 * i + 1], acc[a][b][4 * i + 2], acc[a][b][4 * i + 3]});
       }
     }
   }

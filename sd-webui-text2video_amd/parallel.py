@@ -329,6 +329,30 @@ class _Runner:
                  "size": self.pair.size}]
 
     @torch.no_grad()
+    def self_check(self, cond) -> Optional[dict]:
+        """CFG pair: the eps exchange / frame gather through the pair's library communicator (`t2v_comm_all_gather`, RCCL) against
+        torch.distributed's all-gather on the same seeded data — equal on both ranks, or bench.py times nothing.  None for a layout
+        without data-path collectives.  Collective: every rank of the job calls it."""
+        if self.pair.size == 1:
+            return None
+        gc, dev = self.pair.gcomm, self.pipe.device
+        in_library, equal = gc.communicator(dev) is not None, True
+        if in_library:
+            mine = torch.full((4099,), float(self.pair.rank + 1), device=dev) + torch.arange(4099, device=dev)
+            a, b = torch.empty(2 * 4099, device=dev), torch.empty(2 * 4099, device=dev)
+            gc.all_gather_into(a, mine)
+            all_gather_into(b, mine, group=gc.group)
+            torch.cuda.synchronize(dev)
+            equal = bool(torch.equal(a, b))
+        flag = torch.tensor([0 if equal else 1], dtype=torch.int32)
+        if not _host_staged(None):
+            flag = flag.to(dev)
+        dist.all_reduce(flag)
+        return {"ok": int(flag.item()) == 0, "eps_and_frame_gathers_in_library": bool(in_library),
+                "compared": ("t2v_comm_all_gather on the pair's library communicator vs torch.distributed: equal on every rank" if in_library
+                             else "the pair's gathers run through torch.distributed in this set-up: nothing to compare")}
+
+    @torch.no_grad()
     def __call__(self, cond, uncond, seed):
         pipe, pair = self.pipe, self.pair
         seed = seed + 1000 * pair.index            # every pair makes its own video

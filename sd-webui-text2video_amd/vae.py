@@ -19,6 +19,8 @@ from __future__ import annotations
 
 from typing import Dict
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -332,12 +334,21 @@ class _VaeLowering:
             q_i = qk.row_slice(rows.start, rows.stop).col_slice(0, c)
             k_i = qk.row_slice(rows.start, rows.stop).col_slice(c, 2 * c)
             # Scores are materialised per QUERY BLOCK, never for the whole image (round 4): at 1024x576 (9216
-            # tokens) the [hw, hw] fp32 matrix was 340 MB + 170 MB of fp16 probabilities per frame; a block of `bq` query rows is
-            # 38 + 19 MB, re-used by every block and every frame (the arena of the 24-frame decode shrinks accordingly).  Softmax rows
-            # are independent, so the result is bit-identical to the one-shot form.  (A fused flash kernel at d = 512 was sized again:
-            # DESIGN.md §5 — single pass needs the 128-query x 512 O tile spread over 8 waves with K / V ping-ponged through one LDS
-            # buffer each; the two-pass form recomputes Q K^T per 128-wide O slice = 3x the FLOPs of this GEMM form.)
-            bq = hw if hw <= 4096 else next(b for b in (1152, 1024, 768, 512, 256, hw) if hw % b == 0)
+            # tokens) the [hw, hw] fp32 matrix is 340 MB + 170 MB of fp16 probabilities per frame.  Softmax rows are independent, so
+            # blocking does not change a bit.  Round 5: the block is as LARGE as 256 MB of scores + probabilities allow (4608 rows at
+            # 9216 tokens, two blocks per image) and the P V GEMM may split its reduction: 1152-row blocks made 36-workgroup P V
+            # launches (M = 1152, N = 512 on 128 x 128 tiles, K = 9216 deep) on a 256-CU chip — 154 TF/s; measured on a 1024x576
+            # frame (tools/gpu_pass.sh vaeattn, profiles/r05_vae_mid_attention_blocks.txt): score / softmax / P V core 1.113 ms
+            # (1152 rows) -> 0.837 (1152 + split-K) -> 0.630 (2304 + split-K) -> 0.580 ms (4608), frame 11.48 -> 11.02 ms.  Memory is
+            # not the constraint on a 288 GB part; launch fill is.  (A fused flash kernel at d = 512 was sized again: DESIGN.md §5 —
+            # single pass needs the 128-query x 512 O tile spread over 8 waves with K / V ping-ponged through one LDS buffer each;
+            # the two-pass form recomputes Q K^T per 128-wide O slice = 3x the FLOPs of this GEMM form.)
+            cap = (256 << 20) // (6 * hw)                    # rows whose fp32 scores + fp16 probabilities fit 256 MB
+            bq = hw if hw <= 4096 else next(b for b in (4608, 4096, 3072, 2304, 2048, 1152, 1024, 768, 512, 256, hw) if hw % b == 0 and (b <= cap or b == hw))
+            if os.environ.get("T2V_VAE_BQ"):                 # experiment switch (tools/profile_vae.py): query rows per block
+                bq = int(os.environ["T2V_VAE_BQ"])
+                assert hw % bq == 0
+            pv_split = os.environ.get("T2V_VAE_PV_SPLITK", "1") == "1"
             for q0 in range(0, hw, bq):
                 s = P.alloc(bq, hw, "f32")
                 P.gemm(f"{p}.qk^T.{img}.{q0}", q_i.row_slice(q0, q0 + bq), k_i.ref, hw, c, s, ldw=k_i.ld, allow_splitk=False)
@@ -345,7 +356,7 @@ class _VaeLowering:
                 P.softmax(f"{p}.softmax.{img}.{q0}", s, pm, float(int(c) ** (-0.5)))
                 P.free(s)
                 P.gemm(f"{p}.pv.{img}.{q0}", pm, vt.ref, c, hw, out_attn.row_slice(rows.start + q0, rows.start + q0 + bq), ldw=vt.ld,
-                       allow_splitk=False)
+                       allow_splitk=pv_split)
                 P.free(pm)
             P.free(vt)
         P.free(nrm, qk)

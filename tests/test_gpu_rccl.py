@@ -2,7 +2,7 @@
 
 One process per GPU.  Each rank lowers the T-sharded tiny UNet (uneven frame slices), binds it with a t2v_comm created from
 a unique id that travels over torch.distributed, and runs the forward as ONE t2v_plan_run: T2V_OP_ALLGATHER (GroupNorm
-statistics), T2V_OP_HALO_EXCHANGE (temporal-conv boundary frames) and T2V_OP_ALLTOALL (frame <-> pixel resharding around
+statistics), T2V_OP_STATS_HALO (statistics + raw temporal-conv boundary frames in one group) and T2V_OP_ALLTOALL (frame <-> pixel resharding around
 the TemporalTransformers) all execute through csrc/comm.hip on the launch stream.  The same records are then executed by
 parallel.ShardedExecutor (collectives through torch.distributed — the path the gloo CPU tests pin) and the two results must
 be bit-identical; the concatenated frames are checked against the unsharded forward of rank 0.
@@ -62,4 +62,7 @@ def test_library_rccl_collectives_multi_rank(world, frames):
     print(f"RCCL x{world}: {results}")
     for res in results:
         assert res["lib_vs_host_equal"] and res["rerun_equal"] and res["n_collectives"] > 100
+        # round 5: one grouped statistics + boundary-frame exchange per temporal convolution, bit-equal to the two-exchange lowering;
+        # the gathers around the forward through t2v_comm_all_gather on a second communicator
+        assert res["stats_halo"] == 88 and res["two_exchange_form_equal"] and res["group_comm_gather_equal"]
     assert results[0]["rel_l2_vs_unsharded"] < 4e-3

@@ -140,6 +140,30 @@ stage_tshardrank() {   # compute time of ONE rank's real T-sharded program (coll
   done
   timeout 600 $PYT tests/test_gpu_e2e.py -k "tsharded" > gpurun_out/${TAG}_tshard_e2e.log 2>&1; echo "tsharded e2e exit $?"; digest gpurun_out/${TAG}_tshard_e2e.log 3
 }
+stage_abnt() {      # round 5: non-temporal hints on the fp32 residual stream (reads / writes / both) — variant libraries of tools/build_variant.py
+  prof base T2V_X=0
+  for v in ntboth ntres ntout; do
+    [ -f tools/variants/libt2v_hip_$v.so ] && prof $v T2V_LIB_PATH=$PWD/tools/variants/libt2v_hip_$v.so
+  done
+  prof base2 T2V_X=0
+}
+stage_vaepar() {    # VAE parity after the mid-attention blocking change + the new default's profile + the two other end-to-end bench lines
+  timeout 900 $PYT tests/test_gpu_fullsize.py tests/test_gpu_e2e.py -rP -k "vae" > gpurun_out/${TAG}_vaepar.log 2>&1; echo "vae parity exit $?"
+  grep -E "rel-L2|passed|failed" gpurun_out/${TAG}_vaepar.log | cut -c1-220 | tail -n 12
+  timeout 300 python tools/profile_vae.py 1 72 128 > gpurun_out/${TAG}_profile_vae_xl.txt 2>&1; grep -E "^VAE decode|mid attention|qk\^T|softmax\.|\.pv\." gpurun_out/${TAG}_profile_vae_xl.txt | head -6 | cut -c1-260
+  timeout 600 python bench.py --frames 125 --steps 1 --warmup 1 --no-cpu-baseline --also-batched 0 > gpurun_out/${TAG}_bench_n1_125f.json 2> gpurun_out/${TAG}_bench_n1_125f.err; echo "bench125 exit $?"; cut -c1-200 gpurun_out/${TAG}_bench_n1_125f.json
+  timeout 600 python bench.py --height 576 --width 1024 --steps 1 --warmup 1 --no-cpu-baseline --also-batched 0 > gpurun_out/${TAG}_bench_n1_zeroscope_xl.json 2> gpurun_out/${TAG}_bench_n1_zeroscope_xl.err; echo "bench XL exit $?"; cut -c1-200 gpurun_out/${TAG}_bench_n1_zeroscope_xl.json
+}
+stage_vae24() {     # the headline's own VAE stage: 24 frames at 256x256 in one decode
+  timeout 300 python tools/profile_vae.py 24 32 32 > gpurun_out/${TAG}_vae_24f_256.txt 2>&1; head -n 40 gpurun_out/${TAG}_vae_24f_256.txt | cut -c1-200
+}
+stage_vaeattn() {   # ZeroScope-XL VAE mid-attention (9216 tokens, d = 512): query rows per block x split-K of the P V GEMM
+  for cfg in "T2V_X=0" "T2V_VAE_PV_SPLITK=1" "T2V_VAE_BQ=2304" "T2V_VAE_BQ=2304 T2V_VAE_PV_SPLITK=1" "T2V_VAE_BQ=4608" "T2V_VAE_BQ=4608 T2V_VAE_PV_SPLITK=1" "T2V_VAE_BQ=9216"; do
+    tag=$(echo $cfg | tr ' =' '__')
+    env $cfg timeout 300 python tools/profile_vae.py 1 72 128 > gpurun_out/${TAG}_vae_$tag.txt 2>&1
+    echo "== $cfg"; grep -E "^VAE decode|mid attention|qk\^T|softmax\.|\.pv\." gpurun_out/${TAG}_vae_$tag.txt | head -6 | cut -c1-260
+  done
+}
 stage_e2e() {
   timeout 1500 $PYT tests/test_gpu_e2e.py tests/test_gpu_text_encoder.py tests/test_gpu_videocrafter.py > gpurun_out/${TAG}_e2e.log 2>&1; echo "e2e exit $?"; digest gpurun_out/${TAG}_e2e.log
 }

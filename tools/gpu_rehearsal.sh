@@ -33,3 +33,5 @@ fi
 FAKE=tests/fake_rccl/libfakerccl.so
 [ -f $FAKE ] || /opt/rocm/bin/hipcc -O2 -std=c++17 -fPIC -shared tests/fake_rccl/fake_rccl.cpp -o $FAKE -lrt
 T2V_COLLECTIVES=library T2V_RCCL_SONAME=$PWD/$FAKE run n4_fake_rccl 4 --frames 6 --also-frames 0
+# N = 2 the same way: the CFG pair's eps exchange and frame gather through t2v_comm_all_gather on the pair's library communicator
+T2V_COLLECTIVES=library T2V_RCCL_SONAME=$PWD/$FAKE run n2_fake_rccl 2 --frames 6 --also-frames 0

@@ -51,6 +51,11 @@ def main():
     core = [m for m, op in att if any(t in op.name for t in (".qk^T.", ".softmax.", ".pv."))]
     print(f"mid attention block: {sum(m for m, _ in att):.3f} ms in {len(att)} ops = {100 * sum(m for m, _ in att) / tot:.1f}% of the frame; "
           f"its score / softmax / PV core (what a fused d = 512 kernel would replace): {sum(core):.3f} ms = {100 * sum(core) / tot:.1f}%")
+    for tkn in (".qk^T.", ".softmax.", ".pv."):
+        sel = [(m, op) for m, op in att if tkn in op.name]
+        if sel:
+            meta = {k: v for k, v in sel[0][1].meta.items() if k in ("M", "N", "K", "tile", "split")}
+            print(f"  {tkn:10s} {sum(m for m, _ in sel):7.3f} ms in {len(sel):3d} ops  {sum(op.flops for _, op in sel) / max(sum(m for m, _ in sel), 1e-9) / 1e9:7.1f} TF/s  {meta}")
     print("slowest ops:")
     for m, op in rows[:25]:
         meta = {k: v for k, v in op.meta.items() if k in ("M", "N", "K", "tile", "split", "n_inst", "rows", "C", "dt", "fused")}
