@@ -451,3 +451,42 @@ def test_round5_lowering_variants_match_the_oracle(tattn, fusions, monkeypatch):
     it.run({L.EXT_X: x, L.EXT_T: t, L.EXT_CTX: y, L.EXT_OUT: out})
     gold = torch.from_numpy(np.load(os.path.join(GOLD, "tiny.npz"))["unet_eps"])
     assert not torch.isnan(out).any() and rel_l2(out, gold) < 4e-3
+
+
+def test_round5_sharded_lowering_one_exchange_per_temporal_convolution(monkeypatch):
+    """A T-sharded program (round 5): every (cross-frame GroupNorm, (3,1,1) convolution) pair exchanges ONCE — T2V_OP_STATS_HALO names the
+    statistics parts and a halo-padded RAW buffer whose interior the norm's input is, the norm's apply pass covers the neighbours' frames
+    (i[21] / i[22]; none at the clip's two ends) — and the rank-local per-frame norms ride in their producers' epilogues as in an unsharded
+    program.  T2V_STATS_HALO=0 / T2V_GN_COOP=0 give the two-exchange / unfused forms."""
+    from sd_webui_text2video_amd.program import COLLECTIVE_KINDS, TShardSpec
+    net = U.UNetSD(**configs.TINY_UNET, init_weights=False)
+
+    def lower(index):
+        return net._compile(1, TShardSpec.make(7, 3, index).frames, 8, 8, 5, "f32", "f32", "f32", shard=TShardSpec.make(7, 3, index)).prog
+
+    for index in (0, 1, 2):
+        prog = lower(index)
+        by_name = {op.name: op for op in prog.ops}
+        sh = [op for op in prog.ops if op.kind == L.OP_STATS_HALO]
+        assert len(sh) == 88 and not any(op.kind == L.OP_HALO_EXCHANGE for op in prog.ops)
+        assert sum(1 for op in prog.ops if op.kind in COLLECTIVE_KINDS) == 139
+        F = TShardSpec.make(7, 3, index).frames
+        for op in sh:
+            apply_op = by_name[op.name.replace(".stats_halo", ".apply")]
+            stats_op = by_name[op.name.replace(".stats_halo", ".stats")]
+            fb = (op.i[4] & 0xFFFFFFFF) | (op.i[5] << 32)
+            frame_rows = apply_op.i[1] // F
+            item = 4 if apply_op.i[5] == L.F32 else 2
+            assert (op.i[2], op.i[3], op.i[6]) == (3, index, F) and fb == frame_rows * apply_op.i[3] * item
+            assert (op.i[7], op.i[8]) == (index - 1 if index > 0 else -1, index + 1 if index < 2 else -1)
+            # the norm reads the INTERIOR of the raw buffer the exchange names: one frame behind its base
+            assert stats_op.p[0].off == apply_op.p[0].off == op.p[1].off + fb
+            assert (apply_op.i[21], apply_op.i[22]) == (frame_rows if index > 0 else 0, frame_rows if index < 2 else 0)
+            assert op.p[0].off == apply_op.p[4].off                      # the gathered parts are the head of the norm's scratch
+        assert sum(1 for op in prog.ops if op.kind == L.OP_GEMM and op.i[16] == L.EPI_GN) > 0      # per-frame norms: fused, rank-local
+    monkeypatch.setenv("T2V_STATS_HALO", "0")
+    two = lower(1)
+    assert sum(1 for op in two.ops if op.kind in COLLECTIVE_KINDS) == 227 and sum(1 for op in two.ops if op.kind == L.OP_HALO_EXCHANGE) == 88
+    monkeypatch.delenv("T2V_STATS_HALO")
+    monkeypatch.setenv("T2V_GN_COOP", "0")        # what the several-processes-on-one-GPU tests set: no launch may wait for another workgroup
+    assert not any(op.kind == L.OP_GEMM and op.i[16] == L.EPI_GN for op in lower(1).ops)

@@ -133,3 +133,21 @@ def test_make_runner_default_layouts():
             return "rgb", None
     r8.pipe = P2()
     assert r8(None, None, 100) == "rgb" and calls == [(100 + 1000 * 5, 2)]      # every rank draws its own seeds
+
+
+def test_collective_stack_selection(monkeypatch):
+    """Which stack carries a group's data-path collectives (parallel._library_collectives): the library's RCCL communicator for CUDA
+    tensors unless T2V_COLLECTIVES=host; over a gloo group only when forced (the one-GPU tests over tests/fake_rccl); never for CPU
+    tensors.  A GroupComm of one rank, or on the host path, creates no communicator."""
+    from sd_webui_text2video_amd import parallel as P
+    monkeypatch.setattr(P, "_host_staged", lambda group: group == "gloo")
+    monkeypatch.delenv("T2V_COLLECTIVES", raising=False)
+    assert P._library_collectives("nccl", "cuda:0") and not P._library_collectives("gloo", "cuda:0")
+    assert not P._library_collectives("nccl", "cpu")
+    monkeypatch.setenv("T2V_COLLECTIVES", "host")
+    assert not P._library_collectives("nccl", "cuda:0")
+    monkeypatch.setenv("T2V_COLLECTIVES", "library")
+    assert P._library_collectives("gloo", "cuda:0") and not P._library_collectives("gloo", "cpu")
+    assert P.GroupComm("nccl", [3], 0).communicator("cuda:0") is None          # a group of one: nothing to exchange
+    monkeypatch.setenv("T2V_COLLECTIVES", "host")
+    assert P.GroupComm("nccl", [0, 1], 0).communicator("cuda:0") is None
