@@ -344,3 +344,26 @@ def test_c2_125f_sampled_output_20_steps(modelscope_full_fp16):
           f"worst single frame {worst:.3e}")
     assert abs(float(x0.std()) - float(gold["x0_std"])) < 3e-3 * float(gold["x0_std"])
     assert r < 1.2e-3 and worst < 1.3e-3
+
+
+def test_c2_125f_sampled_output_50_steps(modelscope_full_fp16):
+    """configs[2] at the config's OWN step count (round 5, VERDICT r04 missing #3): 50-step DDIM_Gaussian CFG 9 latent of the 125-frame
+    clip against the reference's own sampler on the deployed weights (100 reference forwards of 125 frames on the CPU), frames at the
+    slice edges of the 4-way T split and both clip ends.  Gate: the 50-step gate of configs[1] (1.0e-3).  Skips until the fixture is
+    generated (tests/golden/make_golden_full.py w16 c2s50)."""
+    net, betas = modelscope_full_fp16
+    gold = _need("modelscope_125f_s50_w16.npz")
+    frames = [int(f) for f in gold["frames"]]
+    _, cond, uncond = synth.synth_inputs(125, 256, 256)
+    smp = samplers.Txt2VideoSampler(net, torch.device(DEV), betas=betas, sampler_name="DDIM_Gaussian")
+    smp.progress = False
+    _, nz, shape = smp.get_noise(1, 4, 125, 256, 256, seed=1234)
+    x0 = smp.sample_loop(steps=50, strength=None, conditioning=cond.to(DEV).half(), unconditional_conditioning=uncond.to(DEV).half(),
+                         batch_size=1, shape=shape, noise=nz, guidance_scale=9.0, eta=0.0, sampler_name="DDIM_Gaussian").float().cpu()
+    want = torch.from_numpy(gold["sampler_x0_50_frames"])
+    r = rel_l2(x0[:, :, frames], want)
+    worst = max(rel_l2(x0[:, :, f], want[:, :, k]) for k, f in enumerate(frames))
+    print(f"configs[2] 125f, 50-step DDIM_Gaussian CFG 9 vs the reference on the DEPLOYED weights: x0 rel-L2 {r:.3e} over frames {frames}, "
+          f"worst single frame {worst:.3e}")
+    assert abs(float(x0.std()) - float(gold["x0_std"])) < 3e-3 * float(gold["x0_std"])
+    assert r < GATE_VIDEO_W16 and worst < 1.1e-3
