@@ -104,7 +104,7 @@ int validate_op(const t2v_op& op, int idx) {
       }
       if (op.i[19] > 1 && op.p[6] == 0) return bad("split-K without workspace");
       if (op.p[3] != 0 && op.i[15] <= 0 && !(g == T2V_GATHER_PLAIN && (op.i[8] == 1 || op.i[8] == 2))) return bad("rowbias without rows_per_batch");
-      if (op.i[22] < 0 || op.i[22] > 21) return bad("unknown tile id");
+      if (op.i[22] < 0 || op.i[22] > 24) return bad("unknown tile id");
       if ((op.i[16] == T2V_EPI_TATTN) != (op.i[22] == 10)) return bad("tile 10 is the fused QKV + temporal attention tile (T2V_EPI_TATTN), and only that");
       if (op.i[16] == T2V_EPI_TATTN) {
         const int F = op.i[8], HW = op.i[9], tpix = op.i[10];
@@ -325,7 +325,7 @@ hipError_t launch_op(const t2v_op& op, hipStream_t s) {
         }
       }
       // the large-tile kernel advances its source pointers by whole k-tiles: needs K % BK == 0
-      if (tile >= 1 && tile <= 21 && tile != 10 && p.gather != T2V_GATHER_CONV3X3_C8 && p.K % 64 == 0) return t2v_launch_gemm2(p, tile, s);
+      if (tile >= 1 && tile <= 24 && tile != 10 && p.gather != T2V_GATHER_CONV3X3_C8 && p.K % 64 == 0) return t2v_launch_gemm2(p, tile, s);
       return t2v_launch_gemm(p, s);
     }
     case T2V_OP_GROUPNORM: return t2v_launch_groupnorm(op, s);

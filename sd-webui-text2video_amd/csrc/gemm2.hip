@@ -43,6 +43,18 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// the same with a count that is a constant only after loop unrolling (the switch folds away); n < 0: no wait
+__device__ __forceinline__ void wait_vmcnt_n(int n) {
+#define T2V_W(N) case N: wait_vmcnt<N>(); break;
+  switch (n) {
+    T2V_W(0) T2V_W(1) T2V_W(2) T2V_W(3) T2V_W(4) T2V_W(5) T2V_W(6) T2V_W(7) T2V_W(8) T2V_W(9) T2V_W(10) T2V_W(11) T2V_W(12) T2V_W(13) T2V_W(14) T2V_W(15)
+    T2V_W(16) T2V_W(17) T2V_W(18) T2V_W(19) T2V_W(20) T2V_W(21) T2V_W(22) T2V_W(23) T2V_W(24) T2V_W(25) T2V_W(26) T2V_W(27) T2V_W(28) T2V_W(29) T2V_W(30)
+    T2V_W(31) T2V_W(32) T2V_W(33) T2V_W(34) T2V_W(35) T2V_W(36) T2V_W(37) T2V_W(38) T2V_W(39) T2V_W(40)
+    default: break;
+  }
+#undef T2V_W
+}
+
 // ---- epilogue helpers (identical semantics to gemm.hip) ----------------------------------
 __device__ __forceinline__ void epi_store(const GemmParams& p, int m, int n, float v0, float v1, float v2, float v3) {
   if (p.bias) {
@@ -92,6 +104,75 @@ __device__ __forceinline__ void epi_store_geglu(const GemmParams& p, int m, int 
   *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(p.out) + (size_t)m * p.ldc + n_out) = o;
 }
 
+#ifndef T2V_G2_PRIO
+#define T2V_G2_PRIO 1          // experiment switch: 0 no priorities, 1 the MFMA segment at priority 1, 2 the load segment at priority 1
+#endif
+#ifndef T2V_G2_DMAFIRST
+#define T2V_G2_DMAFIRST 0      // experiment switch: 1 = the phase's DMA pieces before its fragment reads
+#endif
+// ---- region schedule of the staggered two-group main loop (PP == 4, round 6) -----------------------------------------------------------
+// A k-tile is cut into P = (TM / 2) * TN phases of 8 MFMAs (one PAIR of token sub-tiles x one weight sub-tile x BK); the operands of a
+// k-tile are staged as REGIONS — X pair a (read by every wave in phase a * TN only) and W sub-tile b (read in phase b only: the
+// fragments stay in registers for the second pair) — so that a region's LDS can be refilled for k-tile t + 2 two phases after its
+// only read in k-tile t, long before the rest of the buffer is free.  The table below places every DMA piece of a wave in the
+// earliest phase its region allows (at most CAP pieces per phase) and derives, per phase, the `s_waitcnt vmcnt(N)` that retires
+// exactly the regions first read in the NEXT phase: nothing is ever drained, every piece has about one whole k-tile to land.
+template <int WM, int WN, int TM, int TN>
+struct G2Sched {
+  static constexpr int NAP = TM / 2, P = NAP * TN;
+  static constexpr int XR = WM, WR = WN / 2;                 // DMA pieces per wave per X-pair region / per W region
+  static constexpr int NREG = NAP + TN, LPS = NAP * XR + TN * WR;
+  static constexpr int CAP = (LPS + P - 1) / P;
+  int u[LPS] = {};           // piece j is staged in phase u % P of k-tile T for k-tile T + 2 - u / P
+  int pos[LPS] = {};         // position of piece j in the issue stream of one period
+  int vm[P] = {};            // vmcnt after the staging of phase q (-1: no region becomes due)
+  static constexpr int first_of(int r) { return r < NAP ? r * TN : r - NAP; }
+  static constexpr int region_of(int j) { return j < NAP * XR ? j / XR : NAP + (j - NAP * XR) / WR; }
+  constexpr G2Sched() {
+    int order[NREG] = {};
+    bool used[NREG] = {};
+    for (int i = 0; i < NREG; ++i) {             // regions by the phase they become free (= read phase + 2), X before W
+      int best = -1;
+      for (int r = 0; r < NREG; ++r)
+        if (!used[r] && (best < 0 || first_of(r) < first_of(best))) best = r;
+      used[best] = true;
+      order[i] = best;
+    }
+    int cur = 0, cnt = 0, n = 0;
+    for (int i = 0; i < NREG; ++i) {
+      const int r = order[i], f = first_of(r) + 2;
+      for (int j = 0; j < LPS; ++j) {
+        if (region_of(j) != r) continue;
+        if (f > cur) { cur = f; cnt = 0; }
+        u[j] = cur;
+        pos[j] = n++;
+        if (++cnt == CAP) { ++cur; cnt = 0; }
+      }
+    }
+    for (int q = 0; q < P; ++q) {
+      const int due = (q + 1) % P, t_req = (q + 1) / P;       // regions first read in the next phase (of k-tile t_req relative to this one)
+      int best = -1;
+      for (int j = 0; j < LPS; ++j) {
+        if (first_of(region_of(j)) != due) continue;
+        const int gj = P * (t_req - 2) + u[j];              // when piece j of that k-tile was issued (this k-tile's phase 0 = 0)
+        int c = 0;
+        for (int k = 0; k < LPS; ++k)
+          for (int m = -4; m <= 2; ++m) {
+            const int g = u[k] + P * m;
+            if ((g > gj && g <= q) || (g == gj && pos[k] > pos[j])) ++c;
+          }
+        if (best < 0 || c < best) best = c;
+      }
+      vm[q] = best;
+    }
+  }
+  constexpr bool feasible() const {
+    for (int j = 0; j < LPS; ++j)
+      if (u[j] > 2 * P + first_of(region_of(j)) - 1 || u[j] >= 2 * P) return false;
+    return true;
+  }
+};
+
 // WM x WN waves; each wave owns TM x TN MFMA tiles (32 tokens x 32 channels each).
 // XE: extra epilogue of the plain (T2V_EPI_NONE) path — 0 none, 1 fused LayerNorm second output (whole-row tiles), 2 fused GroupNorm
 // (+SiLU) of the result with a grid barrier (T2V_EPI_GN); separate instantiations, so the plain kernels keep their register budgets.
@@ -107,6 +188,8 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm2_kernel(const GemmPar
   constexpr int XPW = XSLABS / NW;
   constexpr int WPW = (WSLABS + NW - 1) / NW;                // the last may be a dummy piece
   constexpr int LPS = XPW + WPW;                             // DMA instructions per wave per stage
+  constexpr bool REGION = PP == 4;                           // pieces grouped by region (G2Sched) instead of interleaved over the tile
+  static_assert(!REGION || (NW == 8 && TM % 2 == 0 && (WN == 2 || WN == 4) && WSLABS % NW == 0), "region schedule: 8 waves, token sub-tiles in pairs");
   constexpr int STAGE_BYTES = (XSLABS + WSLABS) * 1024;
   constexpr int DUMMY_OFF = STAGES * STAGE_BYTES;            // 1 KiB scratch for dummy pieces
   static_assert(LPS * (STAGES - 1) < 64, "vmcnt is a 6-bit counter");
@@ -149,9 +232,28 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm2_kernel(const GemmPar
   unsigned xmask[XPW];             // conv: bit t set <=> tap t of this row is inside the image / clip
   long xoff[general ? XPW : 1];    // only the upsample path keeps per-row coordinates
   int xy[general ? XPW : 1], xx[general ? XPW : 1];
+  // first tile row of DMA piece j of this wave.  Interleaved: piece s = wave + j * NW of the tile.  Region order (PP == 4): X piece
+  // j = a * WM + i is piece idx = wave + 8 i of the WM * 8 pieces of pair a (rows wm' * TM * 32 + a * 64 + ...), W piece j = b * (WN / 2) + i
+  // piece idx = wave + 8 i of the WN * 4 pieces of weight sub-tile b (rows wn' * TN * 32 + b * 32 + ...)
+  auto xrow0 = [&](int j) {
+    if constexpr (REGION) {
+      const int a = j / WM, idx = wave + 8 * (j % WM);
+      return (idx >> 3) * (TM * 32) + a * 64 + (idx & 7) * 8;
+    } else {
+      return (wave + j * NW) * RPS;
+    }
+  };
+  auto wrow0 = [&](int j) {
+    if constexpr (REGION) {
+      const int b = j / (WN / 2), idx = wave + 8 * (j % (WN / 2));
+      return (idx >> 2) * (TN * 32) + b * 32 + (idx & 3) * 8;
+    } else {
+      return (wave + j * NW) * RPS;
+    }
+  };
 #pragma unroll
   for (int j = 0; j < XPW; ++j) {
-    const int r = (wave + j * NW) * RPS + lrow;   // row inside the token tile
+    const int r = xrow0(j) + lrow;                // row inside the token tile
     const int m = m0 + r;
     const int lc = pchunk ^ swz(r);
     const bool valid = m < p.M;
@@ -168,8 +270,11 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm2_kernel(const GemmPar
           xptr[j] = reinterpret_cast<const unsigned char*>(p.A + mm * p.lda + (long)kt_begin * BK + lc * 8);
           xstep[j] = STEP;
         }
-      } else if (valid) {
-        const int ma = (p.a_wrap && m >= p.a_wrap) ? m - p.a_wrap : m;        // shared (one-sample) operand: rows wrap once
+      } else if (valid || REGION) {
+        // (region schedule: rows past M read the last row instead of the zero page — their results are never stored — so that every
+        //  pointer advances by the same constant and no per-piece step register is needed)
+        const int mc = REGION ? min(m, p.M - 1) : m;
+        const int ma = (p.a_wrap && mc >= p.a_wrap) ? mc - p.a_wrap : mc;     // shared (one-sample) operand: rows wrap once
         xptr[j] = reinterpret_cast<const unsigned char*>(p.A + (long)ma * p.lda + (long)kt_begin * BK + lc * 8);
         xstep[j] = STEP;
       }
@@ -210,12 +315,12 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm2_kernel(const GemmPar
   bool wdummy[WPW];
 #pragma unroll
   for (int j = 0; j < WPW; ++j) {
-    const int s = wave + j * NW;                 // piece index inside the weight tile
-    const int r = s * RPS + lrow;
+    const int r = wrow0(j) + lrow;               // row inside the weight tile
     const int n = n0 + r;
-    wdummy[j] = s >= WSLABS;                     // wave-uniform
-    const bool ok = !wdummy[j] && n < p.N;
-    wptr[j] = ok ? reinterpret_cast<const unsigned char*>(p.W + (size_t)n * p.ldw + kt_begin * BK + (pchunk ^ swz(r)) * 8) : zero;
+    wdummy[j] = wrow0(j) >= BN;                  // wave-uniform
+    const bool ok = REGION || (!wdummy[j] && n < p.N);
+    const int nc = REGION ? min(n, p.N - 1) : n;     // (region schedule: channels past N read the last row, see the token rows above)
+    wptr[j] = ok ? reinterpret_cast<const unsigned char*>(p.W + (size_t)nc * p.ldw + kt_begin * BK + (pchunk ^ swz(r)) * 8) : zero;
     wstep[j] = ok ? STEP : 0;
   }
 
@@ -267,9 +372,9 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm2_kernel(const GemmPar
   };
   auto piece_dst = [&](int slot, int j) -> unsigned char* {
     unsigned char* base = smem + slot * STAGE_BYTES;
-    if (j < XPW) return base + (wave + j * NW) * 1024;
+    if (j < XPW) return base + (xrow0(j) / RPS) * 1024;
     const int jw = j - XPW;
-    return wdummy[jw] ? (smem + DUMMY_OFF) : (base + (XSLABS + wave + jw * NW) * 1024);
+    return wdummy[jw] ? (smem + DUMMY_OFF) : (base + (XSLABS + wrow0(jw) / RPS) * 1024);
   };
   auto stage_piece = [&](int slot, int j) {
 #ifdef T2V_G2_NODMA      // timing experiment only (wrong results): the main loop WITHOUT its operand DMA — what do the LDS-DMA instructions cost?
@@ -294,7 +399,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm2_kernel(const GemmPar
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   // prologue: STAGES-1 k-tiles in flight (the register-staged schedule, PP == 3, has its own)
-  if constexpr (PP != 3) {
+  if constexpr (PP != 3 && PP != 4) {
 #pragma unroll
     for (int g = 0; g < STAGES - 1; ++g) {
       stage_begin();
@@ -322,138 +427,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm2_kernel(const GemmPar
   }
 
   constexpr int KSTEPS = BK / 16;
-  if constexpr (PP == 3) {
-    // ---- operands staged through REGISTERS (global_load_dwordx4 -> ds_write_b128) instead of LDS-DMA (round 5) -------------------
-    // Finding of round 5 (tools/gemm_pf_probe.py on a build whose main loop issues no DMA): the LDS-DMA instructions cost 27 % of the
-    // loop (256x256 tile 1041 -> 1422 TF/s on 8192^3 without them) — not the barrier (the two waves of a SIMD run their k-tiles one
-    // after the other: the leader's barrier wait is the follower's MFMA time), not the fragment latency (prefetching it across the
-    // barrier: +-0).  A `global_load_lds_dwordx4` moves 1 KiB per instruction and holds the issuing wave's port ~60-185 cycles while
-    // the address unit walks its 64 lanes: 64 KiB per k-tile = 64 such instructions per CU against 2048 MFMA cycles per SIMD.  The
-    // plain vector load is four times cheaper to issue per KiB and ds_write_b128 costs ~13 LDS cycles; the price is LPS * 4 staging
-    // registers per lane and one more pipeline level: tile t+2 is in flight to registers while tile t+1 goes from registers to the
-    // other LDS slot and tile t is being multiplied.  Two LDS slots (the slot written in iteration t held tile t-1: everyone finished
-    // reading it before the barrier that ended iteration t-1), one barrier per k-tile, as before.
-    static_assert(STAGES == 2, "register staging: two LDS slots");
-    f32x4 rg[LPS];
-    stage_begin();
-#pragma unroll
-    for (int j = 0; j < LPS; ++j) rg[j] = *reinterpret_cast<const f32x4*>(piece_src(j));
-    stage_end();
-#pragma unroll
-    for (int j = 0; j < LPS; ++j) *reinterpret_cast<f32x4*>(piece_dst(0, j) + lane * 16) = rg[j];
-    stage_begin();
-#pragma unroll
-    for (int j = 0; j < LPS; ++j) rg[j] = *reinterpret_cast<const f32x4*>(piece_src(j));
-    stage_end();
-    __syncthreads();
-    int slot = 0;
-    for (int t = 0; t < nkt; ++t) {
-      const unsigned char* st = smem + slot * STAGE_BYTES;
-      const int nslot = slot ^ 1;
-      stage_begin();                                   // (tile t+2: the zero page past the end)
-#pragma unroll
-      for (int kk = 0; kk < KSTEPS; ++kk) {
-        const int lc4 = (kk * 2 + fhalf) << 4;
-        f16x8 xf[TM], wf[TN];
-#pragma unroll
-        for (int a = 0; a < TM; ++a) xf[a] = *reinterpret_cast<const f16x8*>(st + xbase[a] + (lc4 ^ xsw[a]));
-#pragma unroll
-        for (int b = 0; b < TN; ++b) wf[b] = *reinterpret_cast<const f16x8*>(st + wbase[b] + (lc4 ^ wsw[b]));
-        // this k-step's share of the pieces: tile t+1 from the registers into the other slot, then tile t+2 on its way into them
-#pragma unroll
-        for (int j = (LPS * kk) / KSTEPS; j < (LPS * (kk + 1)) / KSTEPS; ++j) {
-          *reinterpret_cast<f32x4*>(piece_dst(nslot, j) + lane * 16) = rg[j];
-          rg[j] = *reinterpret_cast<const f32x4*>(piece_src(j));
-        }
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-          for (int b = 0; b < TN; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[b], xf[a], acc[a][b], 0, 0, 0);
-      }
-      stage_end();
-      __syncthreads();                                 // (waits for this wave's ds_writes, then everyone's)
-      slot = nslot;
-    }
-  } else if constexpr (PP == 2) {
-    // ---- lock-step schedule with the fragments of the NEXT k-tile prefetched across the barrier (round 5) ------------------------
-    // Phase stamps of the plain schedule below (tools/gemm_phase_probe.py, 256x256 tile, 8192^3): of ~3060 cycles per k-tile a wave
-    // spends ~40 waiting for its DMA, ~550 at the barrier (the two waves of a SIMD run their MFMAs one after the other — the leader
-    // waits for the follower, the matrix pipe is busy meanwhile) and ~340 between the barrier and its first MFMA, waiting for the
-    // first fragment reads: THAT is when the pipe idles.  Here the barrier sits before the LAST k-step's MFMAs: a wave that has its
-    // fragments for that step (lgkmcnt(0)) and its DMA pieces of the next tile (vmcnt) meets the others, issues the ds_reads of the
-    // next tile's first k-step and only then runs the last step's MFMAs — the LDS latency hides under them.  Same number of
-    // barriers; every DMA piece of an iteration is issued in k-steps 0 .. KSTEPS-2, so that the vmcnt count at the barrier is exact;
-    // the slot a DMA overwrites was last read before the previous barrier (reads complete: lgkmcnt(0) precedes it).
-    static_assert(KSTEPS >= 2, "needs a k-step to hide the prefetch under");
-    wait_vmcnt<LPS*(STAGES - 2)>();
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    f16x8 xc[TM], wc[TN];
-    {
-      const int lc4 = fhalf << 4;
-#pragma unroll
-      for (int a = 0; a < TM; ++a) xc[a] = *reinterpret_cast<const f16x8*>(smem + xbase[a] + (lc4 ^ xsw[a]));
-#pragma unroll
-      for (int b = 0; b < TN; ++b) wc[b] = *reinterpret_cast<const f16x8*>(smem + wbase[b] + (lc4 ^ wsw[b]));
-    }
-    int slot = 0;
-    for (int t = 0; t < nkt; ++t) {
-      int fs = slot + STAGES - 1;
-      if (fs >= STAGES) fs -= STAGES;
-      const int nslot = slot + 1 == STAGES ? 0 : slot + 1;
-      stage_begin();
-      const unsigned char* st = smem + slot * STAGE_BYTES;
-      const unsigned char* stn = smem + nslot * STAGE_BYTES;
-#pragma unroll
-      for (int kk = 0; kk < KSTEPS; ++kk) {
-        f16x8 xn[TM], wn[TN];
-        if (kk + 1 < KSTEPS) {
-          const int lc4 = ((kk + 1) * 2 + fhalf) << 4;
-#pragma unroll
-          for (int a = 0; a < TM; ++a) xn[a] = *reinterpret_cast<const f16x8*>(st + xbase[a] + (lc4 ^ xsw[a]));
-#pragma unroll
-          for (int b = 0; b < TN; ++b) wn[b] = *reinterpret_cast<const f16x8*>(st + wbase[b] + (lc4 ^ wsw[b]));
-        } else {
-#pragma unroll
-          for (int a = 0; a < TM; ++a) xn[a] = xc[a];
-#pragma unroll
-          for (int b = 0; b < TN; ++b) wn[b] = wc[b];
-          if (t + 1 < nkt) {                                           // wave-uniform
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // this step's fragments are in; every read of the current slot is done
-            wait_vmcnt<LPS*(STAGES - 2)>();                            // my pieces of the next tile have landed
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            const int lc4 = fhalf << 4;
-#pragma unroll
-            for (int a = 0; a < TM; ++a) xn[a] = *reinterpret_cast<const f16x8*>(stn + xbase[a] + (lc4 ^ xsw[a]));
-#pragma unroll
-            for (int b = 0; b < TN; ++b) wn[b] = *reinterpret_cast<const f16x8*>(stn + wbase[b] + (lc4 ^ wsw[b]));
-          }
-        }
-        constexpr int SPREAD = STAGES == 2 ? (KSTEPS / 2 > 0 ? KSTEPS / 2 : 1) : KSTEPS - 1;
-        if (kk < SPREAD) {
-#pragma unroll
-          for (int j = (LPS * kk) / SPREAD; j < (LPS * (kk + 1)) / SPREAD; ++j) stage_piece(fs, j);
-        }
-        if (kk + 1 == KSTEPS && t + 1 < nkt) {
-          // the MFMAs of the last step read fragments fetched BEFORE the barrier; keep the compiler from sinking the prefetch below them
-          __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-          for (int b = 0; b < TN; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wc[b], xc[a], acc[a][b], 0, 0, 0);
-#pragma unroll
-        for (int a = 0; a < TM; ++a) xc[a] = xn[a];
-#pragma unroll
-        for (int b = 0; b < TN; ++b) wc[b] = wn[b];
-      }
-      stage_end();
-      slot = nslot;
-    }
-  } else if constexpr (PP == 0) {
+  if constexpr (PP == 0) {
     int slot = 0;
 #ifdef T2V_G2_TIMING     // experiment build (tools/build_variant.py): where does a wave park in a k-tile?  cycles -> p.ws[wave slot][4]
     unsigned long long tm_vm = 0, tm_bar = 0, tm_lds = 0;
@@ -511,85 +485,12 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm2_kernel(const GemmPar
       dst[0] = (float)tm_vm; dst[1] = (float)tm_bar; dst[2] = (float)tm_lds; dst[3] = (float)(clock64() - tm_begin);
     }
 #endif
-  } else {
-    // ---- ping-pong schedule ---------------------------------------------------------------------
-    // The 8 waves form two groups (waves 0-3 / 4-7: one wave of each group per SIMD).  A k-tile is
-    // cut into P phases of 8 MFMAs (one pair of token sub-tiles x one weight sub-tile x BK); each
-    // phase is  [fragment ds_reads + a share of the next tile's DMA | s_barrier | MFMAs | s_barrier].
-    // Group 1 runs ONE barrier behind group 0, so on every SIMD one wave is in its MFMA segment while
-    // its partner is in its LDS/DMA segment: the LDS pipe (fragment reads + DMA writes ~ the MFMA
-    // time of a 256-wide tile) and the matrix pipe work concurrently instead of alternating.
-    // Hazards (counted by barrier intervals, group 1 = group 0 + 1):
-    //   RAW: every wave retires its DMA pieces of tile t+1 (vmcnt(0)) before barrier #2k'-1, k' = first
-    //        phase of t+1 — group 0 after its last MFMA segment, group 1 after its last read segment —
-    //        and the first read of the slot is after that barrier.
-    //   WAR: a slot is re-staged from phase ISSUE0 of the following k-tile, >= 2 phases after the last
-    //        ds_read of either group from it.
-    static_assert(STAGES == 2 && TM % 2 == 0 && NW == 8, "ping-pong: 2 slots, token sub-tiles in pairs, 8 waves");
-    constexpr int NAP = TM / 2;                       // token sub-tile pairs per wave
-    constexpr int P = NAP * TN;                       // phases per k-tile
-    constexpr bool WCACHE = NAP > 1;                  // weight fragments stay in registers for the 2nd pair
-    constexpr bool LAST_READS = !WCACHE || TN == 1;   // does the last phase read LDS?
-    constexpr int ISSUE0 = LAST_READS ? 1 : 0;
-    static_assert(ISSUE0 + 1 < P - 1 || !LAST_READS, "DMA must be issued at least one phase before its wait");
-    const int grp = wave >> 2;                        // wave-uniform (SGPR)
-    f16x8 xf[2][KSTEPS];
-    f16x8 wf[WCACHE ? TN : 1][KSTEPS];
-    wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    if (grp) __builtin_amdgcn_s_barrier();
-    int slot = 0;
-    for (int t = 0; t < nkt; ++t) {
-      const unsigned char* st = smem + slot * STAGE_BYTES;
-      const int fs = slot ^ 1;
-#pragma unroll
-      for (int ph = 0; ph < P; ++ph) {
-        const int ap = ph / TN, j = ph % TN;
-        const int b = (ap & 1) ? TN - 1 - j : j;
-        const int wslot = WCACHE ? b : 0;
-        // ---- load segment
-        if (WCACHE ? ap == 0 : true) {
-#pragma unroll
-          for (int kk = 0; kk < KSTEPS; ++kk)
-            wf[wslot][kk] = *reinterpret_cast<const f16x8*>(st + wbase[b] + ((((kk * 2 + fhalf) << 4)) ^ wsw[b]));
-        }
-        if (j == 0) {
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int kk = 0; kk < KSTEPS; ++kk)
-              xf[q][kk] = *reinterpret_cast<const f16x8*>(st + xbase[2 * ap + q] + ((((kk * 2 + fhalf) << 4)) ^ xsw[2 * ap + q]));
-        }
-        if (ph == ISSUE0) stage_begin();
-        if (ph == ISSUE0 || ph == ISSUE0 + 1) {
-          constexpr int HALF = (LPS + 1) / 2;
-#pragma unroll
-          for (int q = 0; q < LPS; ++q)
-            if ((ph == ISSUE0) == (q < HALF)) stage_piece(fs, q);
-        }
-        if (ph == ISSUE0 + 1) stage_end();
-        if (ph == P - 1 && grp) wait_vmcnt<0>();
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- MFMA segment
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < KSTEPS; ++kk)
-#pragma unroll
-          for (int q = 0; q < 2; ++q)
-            acc[2 * ap + q][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[wslot][kk], xf[q][kk], acc[2 * ap + q][b], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        if (ph == P - 1 && !grp) wait_vmcnt<0>();
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-      }
-      slot ^= 1;
-    }
-    if (!grp) __builtin_amdgcn_s_barrier();
   }
+#ifdef T2V_G2_EXPERIMENTS
+#include "gemm2_experiments.inc"
+#else
+  static_assert(PP == 0, "experimental schedules: build with -DT2V_G2_EXPERIMENTS");
+#endif
   wait_vmcnt<0>();   // drain the zero-page loads of the dead stages before the LDS goes away
 
   // ---- epilogue ---------------------------------------------------------------------------------
@@ -851,15 +752,26 @@ hipError_t launch_cfg(const GemmParams& pin, hipStream_t s) {
     if (p.splitk <= 1 || p.epi != T2V_EPI_NONE || tiles > T2V_SYNC_INTS || p.gn_out != nullptr) p.tickets = nullptr;
   }
   // tiles with a T2V_EPI_GN instantiation (validated by the executor): the whole-row tiles 8 / 11, and the 128-row tiles 3 / 5
-  constexpr bool GN_TILE = PP != 1 && (((WM == 6 || WM == 4) && WN == 2 && TM == 1 && TN == 5) || (WM == 2 && WN == 4 && TM == 2 && (TN == 1 || TN == 2)));
+  constexpr bool GN_TILE = PP != 1 && PP != 4 && (((WM == 6 || WM == 4) && WN == 2 && TM == 1 && TN == 5) || (WM == 2 && WN == 4 && TM == 2 && (TN == 1 || TN == 2)));
   // (with split-K the norm runs in the reduction's launch instead: any tile, t2v_launch_splitk_reduce_gn below)
   const bool gn_here = p.gn_out != nullptr && p.splitk == 1;
   if (gn_here && (!GN_TILE || (p.gather == T2V_GATHER_CONV3X3 && p.up))) return hipErrorInvalidValue;
   // ... and with a cross-tile LayerNorm instantiation: 5 (128x128), 12 (64x64), 9 (192x256), 3 (128x256); plain gather only
-  constexpr bool LNX_TILE = PP != 1 && ((WM == 2 && WN == 4 && TM == 2 && (TN == 1 || TN == 2)) || (WM == 2 && WN == 2 && TM == 1 && TN == 1) ||
+  constexpr bool LNX_TILE = PP != 1 && PP != 4 && ((WM == 2 && WN == 4 && TM == 2 && (TN == 1 || TN == 2)) || (WM == 2 && WN == 2 && TM == 1 && TN == 1) ||
                                     (WM == 6 && WN == 2 && TM == 1 && TN == 4));
   if (p.ln_x && (!LNX_TILE || p.gather != T2V_GATHER_PLAIN)) return hipErrorInvalidValue;
   hipError_t e;
+#ifdef T2V_G2_DEV        // development build (seconds instead of minutes): the plain gather and the 3x3 convolution, no fused-norm instantiations
+  if (p.gather == T2V_GATHER_PLAIN && p.epi != T2V_EPI_TATTN && p.xa_k == nullptr && p.ln_out == nullptr && !gn_here && !p.ln_x)
+    e = launch_cfg_gather<WM, WN, TM, TN, BK, STAGES, MINW, T2V_GATHER_PLAIN, PP>(p, s);
+  else if (p.gather == T2V_GATHER_CONV3X3 && !p.up && !gn_here)
+    e = launch_cfg_gather<WM, WN, TM, TN, BK, STAGES, MINW, T2V_GATHER_CONV3X3, PP>(p, s);
+  else
+    return hipErrorInvalidValue;
+  if (e != hipSuccess) return e;
+  if (p.splitk > 1 && p.tickets == nullptr) e = p.gn_out != nullptr ? t2v_launch_splitk_reduce_gn(p, s) : t2v_launch_splitk_reduce(p, s);
+  return e;
+#else
   switch (p.gather) {
     case T2V_GATHER_PLAIN:
       if constexpr (WM == 6 && WN == 2 && TM == 1 && TN == 3 && PP == 0) {
@@ -914,6 +826,7 @@ hipError_t launch_cfg(const GemmParams& pin, hipStream_t s) {
   // (split-K whose result feeds a fused GroupNorm: the reduction is the loader of a cooperative GroupNorm launch, norm.hip)
   if (p.splitk > 1 && p.tickets == nullptr) e = p.gn_out != nullptr ? t2v_launch_splitk_reduce_gn(p, s) : t2v_launch_splitk_reduce(p, s);
   return e;
+#endif
 }
 
 }  // namespace
@@ -922,6 +835,24 @@ hipError_t launch_cfg(const GemmParams& pin, hipStream_t s) {
 // (few-row levels: latency-bound, keep 96 KiB per CU in flight) — 64-wide k-tiles
 // (full 128-byte lines per row = one conv reduction chunk), 2-3 stage ring, one workgroup per CU.
 hipError_t t2v_launch_gemm2(const GemmParams& p, int tile, hipStream_t s) {
+#ifdef T2V_G2_DEVMIN
+  switch (tile) {
+    case 1: return launch_cfg<2, 4, 4, 2, 64, 2, 2>(p, s);
+    case 22: return launch_cfg<2, 4, 4, 2, 64, 2, 2, 4>(p, s);
+    default: return hipErrorInvalidValue;
+  }
+#endif
+#ifdef T2V_G2_DEV
+  switch (tile) {
+    case 1: return launch_cfg<2, 4, 4, 2, 64, 2, 2>(p, s);
+    case 2: return launch_cfg<4, 2, 2, 5, 64, 2, 2>(p, s);
+    case 3: return launch_cfg<2, 4, 2, 2, 64, 3, 2>(p, s);
+    case 22: return launch_cfg<2, 4, 4, 2, 64, 2, 2, 4>(p, s);
+    case 23: return launch_cfg<4, 2, 2, 5, 64, 2, 2, 4>(p, s);
+    case 24: return launch_cfg<2, 4, 2, 2, 64, 2, 2, 4>(p, s);
+    default: return hipErrorInvalidValue;
+  }
+#endif
 #ifdef T2V_G2_FEW        // experiment build (with -DT2V_G2_EXPERIMENTS): only the tiles under study (compile time)
   switch (tile) {
     case 1: return launch_cfg<2, 4, 4, 2, 64, 2, 2>(p, s);
@@ -965,10 +896,22 @@ hipError_t t2v_launch_gemm2(const GemmParams& p, int tile, hipStream_t s) {
     case 20: return launch_cfg<6, 2, 1, 5, 64, 2, 3, 3>(p, s);
     case 21: return launch_cfg<2, 4, 2, 2, 64, 2, 2, 3>(p, s);
 #endif
-    case 6: return launch_cfg<2, 4, 4, 2, 64, 2, 2, 1>(p, s);   // 256x256 ping-pong (two staggered wave groups)
-    case 7:                                                         // 256x320 ping-pong
+#ifdef T2V_G2_EXPERIMENTS
+    // 22 / 23 / 24 = 256x256 / 256x320 / 128x256 on the round-6 schedule: two wave groups one barrier apart, region staging two k-tiles
+    // ahead, counted vmcnt (PP == 4).  Correct, and measured equal to lock-step (+-3 % long K, -7 .. -20 % short K): the calibration GEMM
+    // spends the same cycles at 62 % MFMA busy under either schedule and the chip clocks 1.55-1.68 GHz on random operands (2.3 GHz on
+    // zeros) — power, not the issue schedule, is the ceiling (profiles/r06_gemm_mainloop_findings.txt)
+    case 22: return launch_cfg<2, 4, 4, 2, 64, 2, 2, 4>(p, s);
+    case 23:
+      if (p.gather == T2V_GATHER_CONV3X3 && p.up) return launch_cfg<4, 2, 2, 5, 64, 2, 2>(p, s);   // (upsample gather: register budget)
+      return launch_cfg<4, 2, 2, 5, 64, 2, 2, 4>(p, s);
+    case 24: return launch_cfg<2, 4, 2, 2, 64, 2, 2, 4>(p, s);
+    // 6 / 7 = 256x256 / 256x320 on the round-1 ping-pong (the next k-tile's DMA drained with vmcnt(0)): equal to lock-step
+    case 6: return launch_cfg<2, 4, 4, 2, 64, 2, 2, 1>(p, s);
+    case 7:
       if (p.gather == T2V_GATHER_CONV3X3 && p.up) return launch_cfg<4, 2, 2, 5, 64, 2, 2>(p, s);   // (upsample gather: register budget)
       return launch_cfg<4, 2, 2, 5, 64, 2, 2, 1>(p, s);
+#endif
     default: return hipErrorInvalidValue;
   }
 }

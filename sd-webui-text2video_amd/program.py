@@ -239,8 +239,9 @@ class Program:
     # ---- GEMM tiling policy ----------------------------------------------------------------
     def choose_tile(self, M: int, n: int, k: int, gather: int, allow_splitk: bool = True):
         """-> (tile id, split_k).  Tile ids as in t2v_op.i[22]: 0 = 128x128-class kernel (any N, the C8
-        stem); 1 256x256, 2 256x320, 3 128x256, 4/5 128x128 with a 4-deep ring (csrc/gemm2.hip); 6/7 = 1/2
-        with the two-group ping-pong schedule (measured equal to 1/2, kept for experiments).
+        stem); 1 256x256, 2 256x320, 3 128x256, 4/5 128x128 with a 4-deep ring, 8 / 9 / 11 / 12 192x320 / 192x256 /
+        128x320 / 64x64 (csrc/gemm2.hip); 6 / 7 / 13-24 exist only in -DT2V_G2_EXPERIMENTS builds (other main-loop
+        schedules, csrc/gemm2_experiments.inc).
         Policy for a 256-CU chip: the widest tile whose grid still gives >= ~0.75 wave of
         workgroups; otherwise the 128x256 tile, then split-K over the (long) reduction."""
         cus = self.target_cus
@@ -314,7 +315,8 @@ class Program:
             bm, bn, bk = {1: (256, 256, 64), 2: (256, 320, 64), 3: (128, 256, 64), 4: (128, 128, 64), 5: (128, 128, 64),
                           6: (256, 256, 64), 7: (256, 320, 64), 8: (192, 320, 64), 9: (192, 256, 64), 11: (128, 320, 64), 12: (64, 64, 64),
                           13: (256, 256, 64), 14: (256, 320, 64), 15: (128, 256, 64), 16: (128, 128, 64), 17: (192, 320, 64),
-                          18: (256, 256, 64), 19: (256, 320, 64), 20: (192, 320, 64), 21: (128, 256, 64)}[tile]
+                          18: (256, 256, 64), 19: (256, 320, 64), 20: (192, 320, 64), 21: (128, 256, 64),
+                          22: (256, 256, 64), 23: (256, 320, 64), 24: (128, 256, 64)}[tile]
         tiles = math.ceil(M / bm) * math.ceil(n / bn)
         kt = math.ceil(k / bk)
         split = 1

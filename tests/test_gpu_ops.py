@@ -13,7 +13,7 @@ from sd_webui_text2video_amd.program import BoundProgram, Buf, Program, Ref
 
 pytestmark = pytest.mark.gpu
 
-GEMM2_TILES = [1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 12]     # csrc/gemm2.hip configurations (t2v_op.i[22])
+GEMM2_TILES = [1, 2, 3, 4, 5, 8, 9, 11, 12]     # csrc/gemm2.hip configurations (t2v_op.i[22]); 6 / 7 / 13-24: experiment builds only
 
 
 def _g(seed=0):
