@@ -26,7 +26,9 @@
 extern "C" {
 #endif
 
-#define T2V_ABI_VERSION 6   /* 6 (round 5, second half): T2V_OP_STATS_HALO — the statistics parts of a T-sharded cross-frame GroupNorm and the RAW boundary
+#define T2V_ABI_VERSION 7   /* 7 (round 6): T2V_ERR_RESIDENCY — a launch that needs its whole grid co-resident was refused by the occupancy check (the caller
+                               lowers again without norms fused into GEMM epilogues); a launch refused because a fault was raised mid-run reports T2V_ERR_ASYNC;
+                               6 (round 5, second half): T2V_OP_STATS_HALO — the statistics parts of a T-sharded cross-frame GroupNorm and the RAW boundary
                                frames of the temporal convolution behind it in ONE grouped exchange; GROUPNORM i[21] / i[22] (phase 2 also normalises the
                                received boundary frames); t2v_comm_all_gather (eps pair / frame gathers over the library's communicators);
                                5 (round 5): T2V_OP_NI 32 / T2V_OP_NP 12 (record grew), T2V_EPI_GN — GroupNorm (+SiLU) of a GEMM's result fused into its epilogue;
@@ -41,6 +43,7 @@ extern "C" {
 #define T2V_ERR_NO_DEVICE (-4)
 #define T2V_ERR_COMM (-5)      /* RCCL not loadable / communicator call failed */
 #define T2V_ERR_ASYNC (-6)     /* a kernel of an EARLIER run raised a fault (bounded grid barrier timed out): that run's results are invalid */
+#define T2V_ERR_RESIDENCY (-7) /* a fused-norm launch (T2V_EPI_GN, cross-tile LayerNorm, cooperative GroupNorm) does not fit co-resident on this device */
 
 /* ---- op kinds ------------------------------------------------------------------------- */
 enum t2v_op_kind {
@@ -137,6 +140,7 @@ enum t2v_gather {
  * stream (call it when the program is bound to an arena, before the first run — never while a run is in flight). */
 #define T2V_SYNC_INTS 4096
 #define T2V_SYNC_BARRIER_INTS 512
+#define T2V_GN_PART_BYTES 2097152 /* bytes of the statistics-exchange scratch (GEMM p[10]) every fused-norm launch may use: the launcher sizes its row chunks by it */
 
 #define T2V_OP_NI 32
 #define T2V_OP_NF 8

@@ -9,8 +9,28 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("T2V_LIB_PATH") or os.path.join(_HERE, "libt2v_hip.so")   # T2V_LIB_PATH: A/B builds of the same ABI (tools/build_variant.py)
 
+# ---- run-time switches ---------------------------------------------------------------------
+# SUPPORTED, always honoured:
+#   T2V_LIB_PATH      another build of the same ABI            T2V_DEVICE_CUS   override the compute-unit count the tile policy plans for
+#   T2V_COLLECTIVES   auto | lib | host (parallel.py)          T2V_RCCL_SONAME  the RCCL library to dlopen (csrc/comm.hip)
+#   T2V_GN_EPI=0 / T2V_GN_COOP=0   no in-launch statistics exchange / no single-pass cooperative GroupNorm: the setting for a GPU that is
+#                     SHARED with other work (the fused norms need every workgroup of a launch co-resident)
+#   T2V_PRECISE       0 | 1 | r3 | all: which fp16 operand classes are split hi + lo (unet.py)
+#   T2V_EXCHANGE      records | barrier (csrc/norm.hip)
+# Everything else that starts with T2V_ is the A/B switch of a measured experiment and is read ONLY when
+# T2V_EXPERIMENTAL=1 (tests/conftest.py and the tools/ scripts set it): a deployment cannot land on an untested combination by accident.
+EXPERIMENTAL = os.environ.get("T2V_EXPERIMENTAL", "0") == "1"
+
+
+def knob(name: str, default):
+    """Value of an experiment switch: the environment's only under T2V_EXPERIMENTAL=1, else `default`."""
+    if os.environ.get("T2V_EXPERIMENTAL", "0") == "1":
+        return os.environ.get(name, default)
+    return default
+
+
 # ---- mirrors of include/t2v_hip.h (checked against the header by tests/test_abi.py) -------
-ABI_VERSION = 6
+ABI_VERSION = 7
 OP_GEMM, OP_GROUPNORM, OP_LAYERNORM, OP_ATTENTION, OP_SOFTMAX = 1, 2, 3, 4, 5
 OP_NCTHW_TO_CL, OP_CL_TO_NCTHW, OP_TIME_EMBED, OP_COPY2D, OP_DDIM_STEP, OP_MEMSET = 6, 7, 8, 9, 10, 11
 OP_LINCOMB = 12
@@ -28,6 +48,7 @@ OP_NI, OP_NF, OP_NP = 32, 8, 12
 GN_ROWS_PER_BLOCK = 64           # T2V_GN_ROWS_PER_BLOCK
 SYNC_INTS = 4096                 # T2V_SYNC_INTS
 SYNC_BARRIER_INTS = 512          # T2V_SYNC_BARRIER_INTS
+GN_PART_BYTES = 2 << 20          # T2V_GN_PART_BYTES
 
 EXPORTS = [
     "t2v_abi_version", "t2v_last_error", "t2v_device_info", "t2v_run_ops", "t2v_plan_create",
@@ -100,7 +121,8 @@ _exchange_disabled = False
 
 def exchange_disabled() -> bool:
     """True once the library has reported an asynchronous fault (T2V_ERR_ASYNC: a workgroup of a fused-norm launch gave up waiting for the
-    others — the device is shared with a client that holds compute units).  The library then refuses the launches that rely on a
+    others — the device is shared with a client that holds compute units) or refused a co-resident launch (T2V_ERR_RESIDENCY: the
+    lowering's occupancy table does not hold on this device).  The library then refuses the launches that rely on a
     co-resident grid; programs are lowered WITHOUT norms fused into GEMM epilogues from then on (program.Program.gn_epilogue), and cached
     programs that have them are lowered again (unet.UNetSD.forward)."""
     return _exchange_disabled
@@ -109,7 +131,7 @@ def exchange_disabled() -> bool:
 def check(rc: int):
     global _exchange_disabled
     if rc != 0:
-        if rc == -6:                     # T2V_ERR_ASYNC
+        if rc in (-6, -7):               # T2V_ERR_ASYNC / T2V_ERR_RESIDENCY: lower without fused norms from now on (exchange_disabled)
             _exchange_disabled = True
         msg = load().t2v_last_error()
         raise T2VError(f"libt2v_hip error {rc}: {msg.decode() if msg else '?'}")

@@ -391,6 +391,17 @@ int run_resolved(const t2v_op* ops, int n, const uint64_t* ext, int n_ext, hipSt
       continue;
     }
     const hipError_t e = launch_op(op, s);
+    if (e == hipErrorCooperativeLaunchTooLarge) {
+      // A launch that needs its whole grid co-resident was refused.  Either a workgroup of an EARLIER launch of this run gave up waiting
+      // and raised the fault word (the co-resident path switches off mid-run): that is the asynchronous fault, report it as such now —
+      // or the lowering's occupancy table disagrees with this device (other architecture / LDS size / T2V_DEVICE_CUS): a distinct code,
+      // so that the caller lowers again without fused norms instead of failing the same way on every call.
+      std::string why;
+      if (t2v_async_fault_consume(&why)) return fail(T2V_ERR_ASYNC, why);
+      char buf[260];
+      snprintf(buf, sizeof buf, "op %d (kind %d, tag %d): the launch needs its whole grid co-resident and the occupancy check refused it", k, op.kind, op.tag);
+      return fail(T2V_ERR_RESIDENCY, buf);
+    }
     if (e != hipSuccess) {
       char buf[200];
       snprintf(buf, sizeof buf, "op %d (kind %d, tag %d) launch failed: %s", k, op.kind, op.tag, hipGetErrorString(e));

@@ -110,10 +110,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmParams p) 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
 
-  const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+  const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M - p.m_begin + BM - 1) / BM;     // (m_begin: t2v_launch_coresident; else 0)
   int tile_m, tile_n;
   t2v_tile_of_block(blockIdx.x, tiles_m, tiles_n, p.panel, tile_m, tile_n);   // XCD-aware order
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int m0 = p.m_begin + tile_m * BM, n0 = tile_n * BN;
 
   const int KT = (p.K + BK - 1) / BK;
   const int kt_begin = blockIdx.y * p.kt_per_split;
@@ -380,9 +380,13 @@ hipError_t launch_tile(const GemmParams& pin, hipStream_t s) {
       if (p.splitk != 1 || !t2v_coop_allowed() || p.gather == T2V_GATHER_CONV3X3_C8) return hipErrorInvalidValue;
       auto launch = [&](auto k, int* occ, t2v_device_flags& once) {
         (void)t2v_set_dynamic_lds(reinterpret_cast<const void*>(k), lds, once, s);
-        if (!t2v_grid_fits(reinterpret_cast<const void*>(k), WM * WN * 64, lds, tiles, s, occ)) return hipErrorCooperativeLaunchTooLarge;
-        hipLaunchKernelGGL(k, grid, block, lds, s, p);
-        return hipGetLastError();
+        // (round 6: a grid the device does not hold co-resident is cut into row chunks of whole tiles and whole instances)
+        const long cap = t2v_grid_capacity(reinterpret_cast<const void*>(k), WM * WN * 64, lds, s, occ);
+        return t2v_launch_coresident(p, BM, (p.N + BN - 1) / BN, cap, p.ln_x ? BM : t2v_lcm(BM, p.gn_rows), p.ln_x ? BM * 16 : 2 * T2V_GN_PIECES * 16,
+                                     [&](const GemmParams& q, int nwg) {
+          hipLaunchKernelGGL(k, dim3(nwg, 1), block, lds, s, q);
+          return hipGetLastError();
+        });
       };
       static int occ0[T2V_MAX_DEVICES] = {}, occ1[T2V_MAX_DEVICES] = {}, occ2[T2V_MAX_DEVICES] = {};
       static t2v_device_flags g0, g1, g2;

@@ -203,10 +203,10 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm2_kernel(const GemmPar
 
   // ---- XCD-aware tile order (t2v_kernels.h): each XCD walks one contiguous run of the panel numbering
   const int tiles_n = (p.N + BN - 1) / BN;
-  const int tiles_m = (p.M + BM - 1) / BM;
+  const int tiles_m = (p.M - p.m_begin + BM - 1) / BM;        // (m_begin: row chunk of a fused-norm launch, t2v_launch_coresident; else 0)
   int tile_m, tile_n;
   t2v_tile_of_block(blockIdx.x, tiles_m, tiles_n, p.panel, tile_m, tile_n);
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int m0 = p.m_begin + tile_m * BM, n0 = tile_n * BN;
 
   const int KT = (p.K + BK - 1) / BK;
   const int kt_begin = blockIdx.y * p.kt_per_split;          // in units of BK-wide k-tiles
@@ -718,7 +718,8 @@ hipError_t launch_cfg_gather(const GemmParams& p, hipStream_t s) {
   constexpr int xa_lds = t2v_xattn_epilogue_lds(BM, BN);
   constexpr int lds = TAT ? (BM * 272 + 12 * 64 * 72 > ring ? BM * 272 + 12 * 64 * 72 : ring)
                           : (XE == 2 && gn_lds > ring ? gn_lds : (XE == 3 && lnx_lds > ring ? lnx_lds : (XE == 4 && xa_lds > ring ? xa_lds : ring)));
-  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tiles = ((p.M - p.m_begin + BM - 1) / BM) * tiles_n;
   auto k = gemm2_kernel<WM, WN, TM, TN, BK, STAGES, MINW, GATHER, PP, XE, TAT>;
   static t2v_device_flags attr_set;     // once per (instantiation, device): the call costs microseconds on the host
   {
@@ -728,9 +729,15 @@ hipError_t launch_cfg_gather(const GemmParams& p, hipStream_t s) {
   if constexpr (XE == 2 || XE == 3) {
     // the epilogue's grid barrier needs every workgroup of the launch resident: no split-K, and the grid within what the occupancy
     // API grants this instantiation on the stream's device (cached); a process in which a barrier already timed out stays off it
+    // (round 6: a grid larger than that is cut into row chunks of whole tiles AND whole statistics instances, one launch each)
     static int occ[T2V_MAX_DEVICES] = {};
-    if (p.splitk != 1 || !t2v_coop_allowed() || !t2v_grid_fits(reinterpret_cast<const void*>(k), WM * WN * 64, lds, tiles, s, occ))
-      return hipErrorCooperativeLaunchTooLarge;
+    if (p.splitk != 1 || !t2v_coop_allowed()) return hipErrorCooperativeLaunchTooLarge;
+    const long cap = t2v_grid_capacity(reinterpret_cast<const void*>(k), WM * WN * 64, lds, s, occ);
+    return t2v_launch_coresident(p, BM, tiles_n, cap, XE == 2 ? t2v_lcm(BM, p.gn_rows) : BM, XE == 2 ? 2 * T2V_GN_PIECES * 16 : BM * 16,
+                                 [&](const GemmParams& q, int nwg) {
+      hipLaunchKernelGGL(k, dim3(nwg, 1), dim3(WM * WN * 64), lds, s, q);
+      return hipGetLastError();
+    });
   }
   hipLaunchKernelGGL(k, dim3(tiles, p.splitk > 1 ? p.splitk : 1), dim3(WM * WN * 64), lds, s, p);
   return hipGetLastError();

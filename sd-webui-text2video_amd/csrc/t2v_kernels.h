@@ -24,6 +24,8 @@ struct GemmParams {
   void* out;
   float* ws;
   int M, N, K;
+  int m_begin;                                 // the launch covers token rows [m_begin, M) (0 except in the row chunks of a fused-norm launch larger than
+                                               // the device holds co-resident: t2v_launch_coresident); every row index below stays GLOBAL
   int lda, ldw, ldc, ldr, ldrb;
   int gather;
   int Hin, Win, Cin, stride, up, Hout, Wout;  // conv3x3: input / output spatial dims
@@ -183,6 +185,11 @@ inline bool t2v_grid_fits(const void* kernel, int threads, size_t lds, long nwg,
   return cache[d] > 0 && nwg <= (long)cache[d] * t2v_num_cus(s);
 }
 
+// workgroups of `kernel` the stream's device holds at once (occupancy API x compute units; 0: unknown)
+inline long t2v_grid_capacity(const void* kernel, int threads, size_t lds, hipStream_t s, int* cache) {
+  return t2v_grid_fits(kernel, threads, lds, 0, s, cache) ? (long)cache[t2v_device_of(s)] * t2v_num_cus(s) : 0;
+}
+
 // Asynchronous faults (norm.hip): a kernel that gives up waiting for a co-resident workgroup (bounded grid barrier of the
 // single-pass GroupNorm) raises a flag in host-mapped memory instead of hanging the device.  The executor reads it at the entry
 // of every run: the run that raised it produced invalid results, the NEXT call reports it (t2v_async_status() reports it at once)
@@ -192,6 +199,32 @@ unsigned* t2v_coop_fault_word();                        // the host-mapped fault
 bool t2v_coop_allowed();                                // false once a barrier timed out in this process (or the word could not be mapped)
 int t2v_async_fault_pending();                          // 1 = a fault was raised and not yet reported
 int t2v_async_fault_consume(std::string* msg);          // returns 1 (and clears "pending", keeps the path disabled) if a fault was raised
+
+// A GEMM whose epilogue exchanges statistics between its workgroups (fused GroupNorm / cross-tile LayerNorm) needs the grid of ONE launch
+// co-resident.  A problem with more tiles than the device holds (125-frame clips, 1024x576, round 6) is cut into ROW CHUNKS of whole units —
+// unit_rows is a multiple of the tile's rows and of the statistics instance's rows, so that no tile and no instance straddles a chunk —
+// each chunk its own launch over rows [m_begin, M) with its own exchange sequence number (the scratch records are re-used: stream order).
+// launch(q, tiles) launches `tiles` workgroups for the parameter block q.  capacity: t2v_grid_capacity of the instantiation.
+template <typename LaunchFn>
+inline hipError_t t2v_launch_coresident(const GemmParams& p, int BM, int tiles_n, long capacity, long unit_rows, long scratch_per_tile, LaunchFn launch) {
+  const long rows = (long)p.M - p.m_begin, tiles_all = ((rows + BM - 1) / BM) * tiles_n;
+  if (capacity > T2V_GN_PART_BYTES / scratch_per_tile) capacity = T2V_GN_PART_BYTES / scratch_per_tile;   // the exchange records of ONE launch (p.gn_part)
+  if (capacity <= 0) return hipErrorCooperativeLaunchTooLarge;
+  if (tiles_all <= capacity) return launch(p, (int)tiles_all);
+  const long unit_tiles = (unit_rows / BM) * tiles_n;
+  if (unit_rows <= 0 || unit_rows % BM != 0 || unit_tiles > capacity) return hipErrorCooperativeLaunchTooLarge;
+  const long chunk_rows = (capacity / unit_tiles) * unit_rows;
+  for (long m = p.m_begin; m < p.M; m += chunk_rows) {
+    GemmParams q = p;
+    q.m_begin = (int)m;
+    q.M = (int)(m + chunk_rows < p.M ? m + chunk_rows : p.M);
+    if (m != p.m_begin && p.gn_seq != 0u) t2v_exchange_ids(&q.gn_seq, &q.gn_want);
+    const hipError_t e = launch(q, (int)((((long)q.M - m + BM - 1) / BM) * tiles_n));
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+inline long t2v_lcm(long a, long b) { long x = a, y = b; while (y) { const long t = x % y; x = y; y = t; } return a / x * b; }
 
 // Each returns hipSuccess or the launch error.
 hipError_t t2v_launch_gemm(const GemmParams& p, hipStream_t s);             // 128x128 / 128x64 tiles (any N, C8 stem)
@@ -227,27 +260,9 @@ __device__ __forceinline__ float t2v_silu(float x) {
 // loads alike.  Same-box A/B on the 24-frame UNet step: 31.4 ms vs 31.9 ms with per-lane row-strided stores.
 // Handles T2V_EPI_NONE (bias / row bias / SiLU / fp32 residual / fp16|fp32 out) and the split-K slab stores.
 // The fp32 residual stream: read once by the GEMM that adds to it, written once for the next residual GEMM (tens of MB per launch at the
-// 32x32 / 16x16 levels).  T2V_NT_RES / T2V_NT_OUT = 1 mark those accesses non-temporal (experiment switches, tools/build_variant.py).
-#ifndef T2V_NT_RES
-#define T2V_NT_RES 0
-#endif
-#ifndef T2V_NT_OUT
-#define T2V_NT_OUT 0
-#endif
-__device__ __forceinline__ f32x4 t2v_ld_stream(const float* p) {
-#if T2V_NT_RES
-  return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
-#else
-  return *reinterpret_cast<const f32x4*>(p);
-#endif
-}
-__device__ __forceinline__ void t2v_st_stream(float* p, f32x4 v) {
-#if T2V_NT_OUT
-  __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
-#else
-  *reinterpret_cast<f32x4*>(p) = v;
-#endif
-}
+// 32x32 / 16x16 levels).  (Non-temporal hints on these accesses were measured neutral in round 4 and are gone.)
+__device__ __forceinline__ f32x4 t2v_ld_stream(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void t2v_st_stream(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
 constexpr int T2V_EPI_SP = 36;     // floats per staged row: 16-lane phases of the 16-byte LDS accesses hit disjoint banks
 
@@ -578,7 +593,10 @@ __device__ __forceinline__ void t2v_grid_barrier(unsigned* bar, unsigned nwg, un
 // one of THIS launch needs none of that: the 16-byte record carries the launch's 32-bit sequence number (handed out by the library,
 // never 0, never repeated within 2^32 launches) in the 16 low mantissa bits of each double — 2^-36 relative, far below the fp32
 // inputs of the sums — and a consumer simply loads the records it needs (device-scope loads) and re-loads the ones whose tag is not
-// this launch's yet: publish -> (flight) -> load.  A torn 16-byte record shows two different tag halves and is just re-polled.  Every
+// this launch's yet: publish -> (flight) -> load.  Tearing: the record leaves as ONE 16-byte store and is read by ONE 16-byte load (observed
+// untorn on gfx950, not an architectural guarantee), so BOTH 8-byte halves carry bits that change on every launch — double 0 the low 16
+// bits of the sequence number, double 1 those bits XOR the high 16 (the pair still encodes all 32 bits): a record torn at the 8-byte
+// boundary between two launches (new {sum, tag} beside a stale {sum of squares, tag}) fails the test and is just re-polled.  Every
 // consumer strips the tags the same way and adds the records in index order only once ALL of a round are fresh: bit-identical
 // statistics in every workgroup, run to run.  The wait is bounded exactly as the barrier's (fault word, 0.25 s).
 __device__ __forceinline__ f32x4 t2v_rec_pack(double a, double b, unsigned seq) {
@@ -586,13 +604,13 @@ __device__ __forceinline__ f32x4 t2v_rec_pack(double a, double b, unsigned seq) 
   r.d[0] = a;
   r.d[1] = b;
   r.u[0] = (r.u[0] & ~0xFFFFull) | (unsigned long long)(seq & 0xFFFFu);
-  r.u[1] = (r.u[1] & ~0xFFFFull) | (unsigned long long)(seq >> 16);
+  r.u[1] = (r.u[1] & ~0xFFFFull) | (unsigned long long)((seq ^ (seq >> 16)) & 0xFFFFu);
   return r.v;
 }
 __device__ __forceinline__ bool t2v_rec_fresh(const f32x4& v, unsigned want) {
   union { f32x4 v; unsigned long long u[2]; } r;
   r.v = v;
-  return (unsigned)(r.u[0] & 0xFFFFull) == (want & 0xFFFFu) && (unsigned)(r.u[1] & 0xFFFFull) == (want >> 16);
+  return (unsigned)(r.u[0] & 0xFFFFull) == (want & 0xFFFFu) && (unsigned)(r.u[1] & 0xFFFFull) == ((want ^ (want >> 16)) & 0xFFFFu);
 }
 __device__ __forceinline__ void t2v_rec_add(const f32x4& v, double& a, double& b) {
   union { f32x4 v; unsigned long long u[2]; double d[2]; } r;
@@ -808,14 +826,15 @@ __device__ __forceinline__ void t2v_epilogue_rows_gn(const GemmParams& p, f32x16
     double ds = 0.0, dq = 0.0;
     if (active) {
       const int g = g_lo + pc, inst = inst0 + slot;
-      const int t_lo = (int)(((long)inst * R) / BM), t_hi = min((int)((((long)inst + 1) * R - 1) / BM), tiles_m - 1);
+      const int tb = p.m_begin / BM;                              // first (global) row tile of this launch: the records are indexed by LOCAL tile
+      const int t_lo = (int)(((long)inst * R) / BM), t_hi = min((int)((((long)inst + 1) * R - 1) / BM), tb + tiles_m - 1);
       const int tn_a = (g * cpg) / BN, ntn = ((g + 1) * cpg - 1) / BN - tn_a + 1;
       const int count = (t_hi - t_lo + 1) * ntn;
       auto src = [&](int u) {
         const int t = t_lo + u / ntn, tn = tn_a + u % ntn;
         const int sl = inst - (int)(((long)t * BM) / R);            // slot of this instance in tile t
         const int pp = g - (tn * BN) / cpg;                         // piece of this group in column tile tn
-        return reinterpret_cast<const float*>(p.gn_part + ((((size_t)t * 2 + sl) * tiles_n + tn) * T2V_GN_PIECES + pp) * 2);
+        return reinterpret_cast<const float*>(p.gn_part + ((((size_t)(t - tb) * 2 + sl) * tiles_n + tn) * T2V_GN_PIECES + pp) * 2);
       };
       constexpr int NREC = 4;                                       // records in flight per lane and round (register room: the tile is live)
       for (int u = sub; u < count; u += NREC * lpi) {

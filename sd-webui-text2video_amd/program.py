@@ -167,8 +167,8 @@ class Program:
         # GroupNorm as ONE launch when a statistics slice (rows x C/groups) is small (bytes; tools/gn_bench.py: the
         # per-frame instances of the 16x16 and lower levels and the cross-frame ones of the 4x4 level gain 8-19 us each,
         # larger slices on only 64 workgroups do not)
-        self.gn_fused_slice_bytes = int(os.environ.get("T2V_GN_FUSED_SLICE", 64 * 1024))
-        self.gn_fused_total_bytes = int(os.environ.get("T2V_GN_FUSED_TOTAL", 128 * 1024 * 1024))
+        self.gn_fused_slice_bytes = int(L.knob("T2V_GN_FUSED_SLICE", 64 * 1024))
+        self.gn_fused_total_bytes = int(L.knob("T2V_GN_FUSED_TOTAL", 128 * 1024 * 1024))
         # precision option: weight Ref -> Ref of its low-order image (packing.WeightPacker.add_lo) or None; set by a lowering
         self.weight_lo = None
         # Device-side synchronisation words (never freed, zero from the bind-time fill, self-resetting): L.SYNC_INTS tickets of
@@ -180,14 +180,14 @@ class Program:
         # split-K fold in the last-arriving workgroup of a tile instead of a reduction launch: implemented and bit-identical, but
         # MEASURED SLOWER (same box, 83 split-K ops of a step: 5.24 vs 4.73 ms): only `tiles` workgroups fold, each behind a chain
         # of device-scope load latencies, where the reduction kernel uses the whole chip -> off by default
-        self.splitk_tickets = os.environ.get("T2V_SPLITK_TICKETS", "0") != "0"
+        self.splitk_tickets = L.knob("T2V_SPLITK_TICKETS", "0") != "0"
         self.gn_coop = os.environ.get("T2V_GN_COOP", "1") != "0"
         # GroupNorm inside the epilogue of the GEMM that produces its input (T2V_EPI_GN, round 5): a peephole of groupnorm() below.
         # It relies on the same co-residency as the single-pass kernel (one grid barrier per launch), so T2V_GN_COOP=0 turns it off too.
         self.gn_epilogue = self.gn_coop and os.environ.get("T2V_GN_EPI", "1") != "0" and not L.exchange_disabled()
         # its exchange scratch ([tiles_m][2][tiles_n][GN_PIECES] fp64 pairs, <= 512 tiles): ONE region for every fused op of the program
         # (launches are stream-ordered and each rewrites every word it reads), allocated here for the reason given above for the sync words
-        self._gn_part: Optional[Buf] = self.alloc(2 << 20, 1, "u8") if self.gn_epilogue else None
+        self._gn_part: Optional[Buf] = self.alloc(L.GN_PART_BYTES, 1, "u8") if self.gn_epilogue else None
         # Buffers whose free() is postponed: operands of the GEMM emitted last.  If the next groupnorm() makes itself that GEMM's
         # epilogue, its output is written by the SAME launch that still reads these — it must not be allocated over them.
         self._deferred: List[Buf] = []
@@ -216,7 +216,8 @@ class Program:
         if op.kind != L.OP_GEMM or op.i[16] != L.EPI_NONE or op.meta.get("tile") not in self._GN_EPI_TILES or op.meta.get("split", 1) != 1:
             return False
         lo, hi = b.alloc_off, b.alloc_off + self.arena.live.get(b.alloc_off, 0)
-        return any(r.space == "arena" and lo <= r.off < hi for r in (op.p[0], op.p[4]))
+        # every arena-space input of the launch: A, an arena-resident weight operand (V^T / q k^T GEMMs), bias, row bias, residual
+        return any(r is not None and r.space == "arena" and lo <= r.off < hi for r in (op.p[0], op.p[1], op.p[2], op.p[3], op.p[4]))
 
     def _flush_deferred(self):
         pending, self._deferred = self._deferred, []
@@ -257,26 +258,26 @@ class Program:
             # 256 rows on 256 CUs; measured (tools/gemm_sweep.py L0) +13 % / +6 % on the C -> C and QKV linears, +3-6 % on the
             # K = 960 .. 2880 convolutions, -7 % on the 8-wave-deep GEGLU GEMM (LDS traffic per MFMA is higher) -> only where
             # the 256-row grid is a few, badly filled waves
-            if n % 320 == 0 and math.ceil(M / 256) * (n // 320) <= 640 and os.environ.get("T2V_TILE8", "1") != "0":
+            if n % 320 == 0 and math.ceil(M / 256) * (n // 320) <= int(L.knob("T2V_TILE8_LIMIT", 640)) and L.knob("T2V_TILE8", "1") != "0":
                 tile = 8
                 # 128x320 on 8 waves (tile 11, round 4): VideoCrafter's M = 32768 makes 171 / 513 workgroups of 192 rows for N = 320 / 960
                 # (0.67 of the last wave of CUs) and exactly 256 / 768 of 128 rows; M = 49152 never gets here (192 rows fill it)
                 w8, w11 = math.ceil(M / 192) * (n // 320), math.ceil(M / 128) * (n // 320)
                 fill = lambda wgs: wgs / (math.ceil(wgs / cus) * cus)
-                if fill(w11) > fill(w8) + 0.05 and os.environ.get("T2V_TILE11", "1") != "0":
+                if fill(w11) > fill(w8) + 0.05 and L.knob("T2V_TILE11", "1") != "0":
                     tile = 11
-            elif tile == 1 and n % 256 == 0 and os.environ.get("T2V_TILE8", "1") != "0":
+            elif tile == 1 and n % 256 == 0 and L.knob("T2V_TILE8", "1") != "0":
                 # the stem TemporalTransformer (inner = 512): 192 x 2 tiles of 256x256 = 384 workgroups, 192x256 gives 512
                 w1, w9 = math.ceil(M / 256) * (n // 256), math.ceil(M / 192) * (n // 256)
                 fill = lambda wgs: wgs / (math.ceil(wgs / cus) * cus)
                 if w1 <= 1280 and fill(w9) > fill(w1) + 0.05:
                     tile = 9
         elif M >= 8192:                                # 16x16 level (b=2) / 32x32 level of a single CFG role (b=1)
-            if M >= 16384 and n <= 1024 and os.environ.get("T2V_TILE8", "1") != "0":
+            if M >= 16384 and n <= 1024 and L.knob("T2V_TILE8", "1") != "0":
                 # one CFG role per GPU (pairs / T-shard layouts: M = 24576): 192x256 on 12 waves gives 128 x ceil(N / 256)
                 # workgroups; measured (SWEEP_BATCH=1 tools/gemm_sweep.py L0) +7 % QKV, +9 % feed-forward, +13 % temporal conv
                 tile = 9
-                if n == 320 and os.environ.get("T2V_TILE11", "1") != "0":
+                if n == 320 and L.knob("T2V_TILE11", "1") != "0":
                     # 128x320 on 8 waves: 192 workgroups, no padded columns (N = 320 on 256-wide tiles wastes 37 %); measured
                     # (SWEEP_BATCH=1 tools/gemm_sweep.py L0, round 4): ff2 497 vs 461 TF/s, conv3x3 681 vs 598, tconv 442 vs 419, C -> C
                     # 216 vs 213; N = 960 stays on 192x256 (324 vs 263)
@@ -286,7 +287,7 @@ class Program:
             elif n >= 2560:
                 tile = 2 if n % 320 == 0 else 1
             elif n >= 1536:
-                tile = 9 if os.environ.get("T2V_TILE8", "1") != "0" else 3      # 16x16-level QKV (12288, 1920, 640): 492 vs 452 TF/s
+                tile = 9 if L.knob("T2V_TILE8", "1") != "0" else 3      # 16x16-level QKV (12288, 1920, 640): 492 vs 452 TF/s
             else:
                 tile = 0               # (the 4-deep-ring 128x128 tile measured 640 vs 668 TF/s on the K = 2560 feed-forward GEMM)
         else:                                          # 8x8 / 4x4 levels: few rows, latency-bound
@@ -295,7 +296,7 @@ class Program:
             elif n >= 2560:
                 tile = 1 if M >= 2048 else (3 if M >= 1024 else 5)
                 # 256-row tiles of M = 3072 x N = 3840 are 180 workgroups for 256 CUs; 192-row tiles give 240
-                if tile == 1 and n % 256 == 0 and os.environ.get("T2V_TILE8", "1") != "0":
+                if tile == 1 and n % 256 == 0 and L.knob("T2V_TILE8", "1") != "0":
                     w1, w9 = math.ceil(M / 256) * (n // 256), math.ceil(M / 192) * (n // 256)
                     fill = lambda wgs: wgs / (math.ceil(wgs / cus) * cus)
                     if fill(w9) > fill(w1) + 0.05:
@@ -304,7 +305,7 @@ class Program:
                 tile = 2 if (M >= 4096 and n % 320 == 0) else 3
             else:
                 tile = 5                               # 128x128, 4-deep ring: 96 KiB per CU in flight
-                if M <= 1024 and n <= 1280 and k <= 1280 and os.environ.get("T2V_TILE12", "1") != "0":
+                if M <= 1024 and n <= 1280 and k <= 1280 and L.knob("T2V_TILE12", "1") != "0":
                     # the 4x4 level's C -> C linears (768, 1280, 1280): 64x64 tiles with the FULL reduction = 240 workgroups, no
                     # split-K slabs and no reduction launch: 201 vs 146 TF/s (tools/gemm_sweep.py L3, round 4); longer K / wider N
                     # stay on the split-K configurations (ff2 381 vs 341, conv3x3 525 vs 410, qkv 365 vs 331)
@@ -340,7 +341,7 @@ class Program:
         """256x320 (tile 2) or 192x320 on 12 waves (tile 8) for a long-K convolution with N = 320 * j: whichever grid,
         after its split-K, fills the last wave of workgroups better (M = 12288, N = 640: 96 x 2 splits = 192 of 256 CUs
         against 128 x 2 = 256)."""
-        if os.environ.get("T2V_TILE8", "1") == "0":
+        if L.knob("T2V_TILE8", "1") == "0":
             return 2
         cus, kt = self.target_cus, math.ceil(k / 64)
         best, best_fill = 2, -1.0
@@ -450,16 +451,19 @@ class Program:
             gb, gamma, beta, ln_out, ln_eps = ln
             assert out.dtype == "f32" and ln_out.dtype == "f16" and ln_out.cols == n and ln_out.rows >= M
             ln_fused = (tile in (8, 11) and split == 1 and n == 320 and gather == L.GATHER_PLAIN and epi == L.EPI_NONE and act == 0
-                        and rowbias is None and not bias_along_m and k % 64 == 0 and os.environ.get("T2V_LN_FUSE", "1") != "0")
+                        and rowbias is None and not bias_along_m and k % 64 == 0 and L.knob("T2V_LN_FUSE", "1") != "0")
             # ... or ACROSS the column tiles of the launch (round 5, t2v_epilogue_rows_lnx): the partial row sums meet at a grid barrier, so
             # the whole grid must be resident at once (the 16x16 / 8x8 / 4x4-level C -> C linears: 480 / 240 / 240 workgroups)
             ln_x = False
-            if not ln_fused and self.gn_epilogue and tile in self._LNX_TILES and os.environ.get("T2V_LN_X", "1") != "0":
+            if not ln_fused and self.gn_epilogue and tile in self._LNX_TILES and L.knob("T2V_LN_X", "1") != "0":
                 bm, bn, per_cu = self._LNX_TILES[tile]
                 tiles_m, tiles_n = -(-M // bm), -(-n // bn)
                 ln_x = (split == 1 and gather == L.GATHER_PLAIN and epi == L.EPI_NONE and act == 0 and rowbias is None and not bias_along_m
-                        and k % 64 == 0 and not out_lo and (tile != 0 or n % 128 == 0) and tiles_m * tiles_n <= per_cu * self.device_cus()
-                        and tiles_m * tiles_n * bm * 16 <= self._gn_part.rows and ln_out.ld % 4 == 0)
+                        and k % 64 == 0 and not out_lo and (tile != 0 or n % 128 == 0) and ln_out.ld % 4 == 0)
+                if ln_x:
+                    # rows are independent: a grid larger than the device holds (or the scratch has records for) runs as row chunks (round 6)
+                    cap = min(per_cu * self.device_cus(), self._gn_part.rows // (bm * 16))
+                    ln_x = tiles_n <= cap and (tiles_m * tiles_n <= cap or L.knob("T2V_GN_EPI_CHUNKS", "1") != "0")
             if ln_fused or ln_x:
                 I[8], I[9] = (2 if ln_x else 1), ln_out.ld
                 op.f[0] = ln_eps
@@ -557,6 +561,20 @@ class Program:
     # ... with a cross-tile LayerNorm instantiation (t2v_epilogue_rows_lnx)
     _LNX_TILES = {0: (128, 128, 2), 5: (128, 128, 1), 12: (64, 64, 2), 9: (192, 256, 1), 3: (128, 256, 1)}
 
+    def gn_instance_too_large(self, M: int, n: int, k: int, gather: int, inst_rows: int) -> bool:
+        """Would the GroupNorm that consumes this GEMM's [M, n] result (statistics instances of `inst_rows` rows) be refused as the GEMM's
+        epilogue ONLY because one instance spans more row tiles than a co-resident launch may have?  (Then the producer-statistics route
+        pays: unet.strips_for.)"""
+        if not self.gn_epilogue:
+            return False
+        tile, split = self.choose_tile(M, n, k, gather, True)
+        if split != 1 or tile not in self._GN_EPI_TILES:
+            return False
+        bm, bn, per_cu = self._GN_EPI_TILES[tile]
+        tiles_n = -(-n // bn)
+        cap = min(per_cu * self.device_cus(), self._gn_part.rows // (2 * L.GN_PIECES * 16))
+        return -(-M // bm) * tiles_n > cap and math.lcm(bm, inst_rows) // bm * tiles_n > cap
+
     _DEVICE_CUS = None
 
     @classmethod
@@ -596,7 +614,7 @@ class Program:
         if split > 1:
             # split-K: the norm runs in the REDUCTION's launch (norm.hip splitk_gn_kernel: 512 threads, a thread = rows x 8 channels in
             # registers) — a co-resident grid of n_inst x chunks workgroups must exist for some rows-per-thread count
-            if os.environ.get("T2V_GN_EPI_SPLITK", "1") == "0" or op.p[7].space != "null" or N % 8 or N // 8 > 512 or groups > 32:
+            if L.knob("T2V_GN_EPI_SPLITK", "1") == "0" or op.p[7].space != "null" or N % 8 or N // 8 > 512 or groups > 32:
                 return None
             rpass = 512 // (N // 8)
             chunks = [n_inst * -(-rows // (rpass * kr)) for kr in (1, 2, 4, 8, 12, 16, 20)]
@@ -604,7 +622,7 @@ class Program:
             if not fit or fit[0] * groups * 16 > self._gn_part.rows:
                 return None
         else:
-            if tile not in self._GN_EPI_TILES or os.environ.get(f"T2V_GN_EPI_TILE{tile}", "1") == "0":
+            if tile not in self._GN_EPI_TILES or L.knob(f"T2V_GN_EPI_TILE{tile}", "1") == "0":
                 return None
             bm, bn, per_cu = self._GN_EPI_TILES[tile]
             if tile == 0 and N % 128 != 0:
@@ -612,15 +630,20 @@ class Program:
             if N // groups > bn or rows % 32 or not (rows >= bm or 2 * rows == bm):
                 return None                               # (a row tile may touch at most two statistics instances)
             tiles_m, tiles_n = -(-M // bm), -(-N // bn)
-            if tiles_m * tiles_n > per_cu * self.device_cus():
-                return None                               # the grid barrier needs every workgroup resident
-            if tiles_m * 2 * tiles_n * L.GN_PIECES * 16 > self._gn_part.rows:
-                return None
+            # workgroups ONE launch may have: what the device holds at once (the exchange needs the grid resident) and what the exchange
+            # scratch has records for
+            cap = min(per_cu * self.device_cus(), self._gn_part.rows // (2 * L.GN_PIECES * 16))
+            if tiles_m * tiles_n > cap:
+                # round 6: the launcher cuts such a grid into row chunks of whole tiles AND whole instances (t2v_launch_coresident),
+                # one co-resident launch each — possible when one such unit fits (per-frame norms of long / large clips; a cross-frame
+                # instance of a 125-frame clip does not: that norm takes the producer-statistics route, `gn_instance_too_large`)
+                if math.lcm(bm, rows) // bm * tiles_n > cap or L.knob("T2V_GN_EPI_CHUNKS", "1") == "0":
+                    return None
             # the normalised tensor is written by the launch that reads the GEMM's operands: never over them (free() defers those)
             o_lo = out.ref.off
             o_hi = o_lo + ((out.rows - 1) * out.ld + out.cols * (2 if lo else 1)) * 2
-            for r in (op.p[0], op.p[4]):
-                if r.space == "arena":
+            for r in (op.p[0], op.p[1], op.p[2], op.p[3], op.p[4]):
+                if r is not None and r.space == "arena":
                     a_lo = max((off for off in self.arena.live if off <= r.off), default=None)
                     a_hi = a_lo + self.arena.live[a_lo] if a_lo is not None else None
                     if a_lo is None or not (o_hi <= a_lo or o_lo >= a_hi):
@@ -812,7 +835,7 @@ class Program:
         assert x.dtype == "f32" and out.dtype == "f16"
         op = Op(L.OP_LAYERNORM, name)
         op.i[0:4] = [x.rows, x.cols, x.ld, out.ld]
-        op.i[4] = int(os.environ.get("T2V_LN_CAP", 0))      # workgroup cap of the grid-stride kernel (0 = library default; A/B knob)
+        op.i[4] = int(L.knob("T2V_LN_CAP", 0))      # workgroup cap of the grid-stride kernel (0 = library default; A/B knob)
         op.f[0] = eps
         op.p[0:4] = [x.ref, gamma, beta, out.ref]
         op.out = out
@@ -836,7 +859,7 @@ class Program:
             op.i[15], op.i[16] = max_rel, q_offset
             # i[17]: 0 the VALU kernel; 1 the round-3 MFMA kernel (measured slower, opt-in); 2 the persistent MFMA kernel for whole
             # clips of <= 16 frames on tables packed for it (rel_k16 / rel_vT16: packing.relpos_tables16) — the default where it applies
-            sel = int(os.environ.get("T2V_RELPOS_MFMA", "2")) if relpos_mfma is None else int(relpos_mfma)
+            sel = int(L.knob("T2V_RELPOS_MFMA", "2")) if relpos_mfma is None else int(relpos_mfma)
             fits16 = (rel_k16 is not None and rel_vT16 is not None and nq == nk and q_offset == 0 and nk <= 16 and max_rel >= nk - 1
                       and head_dim in (40, 64, 80, 160))
             if sel == 2 and not fits16:

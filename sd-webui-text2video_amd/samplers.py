@@ -314,7 +314,7 @@ _RUN_COUNTER = itertools.count(1)
 def _want_fp32_eps(model):
     """Inside a sampling loop the UNet hands eps over in fp32 (UNetSD.eps_out_dtype): the guided combination u + s (c - u) would
     otherwise amplify the independent fp16 roundings of the two predictions ~12x at s = 9.  -> token for _restore_eps."""
-    if not hasattr(model, "eps_out_dtype") or os.environ.get("T2V_EPS_FP32", "1") == "0":
+    if not hasattr(model, "eps_out_dtype") or L.knob("T2V_EPS_FP32", "1") == "0":
         return "absent"
     prev = model.eps_out_dtype
     model.eps_out_dtype = torch.float32

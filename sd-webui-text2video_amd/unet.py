@@ -221,13 +221,13 @@ class UNetSD(nn.Module):
         # Storage type of tensors that are consumed ONLY by a GroupNorm (ResBlock's first conv output
         # and the three inner temporal-conv outputs): "f16" halves their HBM traffic (what the
         # reference's .half() path stores everywhere), "f32" keeps them in the fp32 stream.
-        self.norm_input_dtype = os.environ.get("T2V_NORM_INPUT", "f16")
+        self.norm_input_dtype = L.knob("T2V_NORM_INPUT", "f16")
         # GroupNorm statistics as a by-product of the GEMM that produces the normalised tensor (T2V_EPI_STATS strips, round 4): the
         # ResBlock's conv -> norm pairs and the temporal-conv chain then run "fold strips + apply" instead of the statistics pass /
         # the single-pass kernel with its grid barrier.  Part of the program cache key.
         # MEASURED SLOWER than the single-pass kernel it replaces (same box, round 4: 31.8 vs 25.2 us at the 32x32 level, 22.9 vs 18.8 us at
         # 8x8, GroupNorm 3.40 vs 3.21 ms per step) — two launches cost what one grid barrier costs — so it is OFF by default.
-        self.gn_producer_stats = os.environ.get("T2V_GN_STRIPS", "0") != "0"
+        self.gn_producer_stats = L.knob("T2V_GN_STRIPS", "0") != "0"
         self.context_token = None     # one-shot hint consumed by the next forward (see forward_cfg_pair)
         # one-shot hint consumed by the next forward: every sample of the batch has the SAME timestep (forward_cfg_pair and the samplers
         # of this package set it).  Only then may the cond | uncond pair share its prefix — the shared ops use sample 0's time embedding,
@@ -253,13 +253,13 @@ class UNetSD(nn.Module):
         # front of the Down / Upsample convolutions, both as rows [hi | lo] against [W | W].  Part of the program cache key.
         # (`precise_attn_out` is read by the VideoCrafter lowering only — videocrafter._LvdmLowering; the ModelScope lowering has no
         #  [hi | lo] attention output, so the flag does not enter ITS cache key: `_lowering_options`.)
-        self.precise_attn_out = os.environ.get("T2V_PRECISE_ATTN", "0") != "0"
-        self.precise_resample = os.environ.get("T2V_PRECISE_RESAMPLE", "0") != "0"
+        self.precise_attn_out = L.knob("T2V_PRECISE_ATTN", "0") != "0"
+        self.precise_resample = L.knob("T2V_PRECISE_RESAMPLE", "0") != "0"
         # TemporalTransformer self-attention as ONE launch per attention (QKV projection + attention of every pixel's frame
         # sequence in the GEMM epilogue, T2V_EPI_TATTN): Q / K / V never reach HBM.  Clips of 2..32 frames; longer clips (and the
         # K/V-gather form of a T-sharded clip) keep the projection GEMM + attention kernel pair, and so do clips whose sequences fill
         # less than 144 of the tile's 192 rows (fewer than 12 frames) unless the option is "force".  Part of the program cache key.
-        self.fused_temporal_attention = {"0": False, "force": "force"}.get(os.environ.get("T2V_FUSED_TATTN", "1"), True)
+        self.fused_temporal_attention = {"0": False, "force": "force"}.get(L.knob("T2V_FUSED_TATTN", "1"), True)
         self.t_shard = None           # parallel.TShard: this rank holds a contiguous slice of the clip's frames
         # Output dtype override for the package's own samplers.  `forward` returns what the reference's autocast path returns (fp16
         # for a `.half()` model) — but a guided step combines the two predictions as u + s (c - u): the INDEPENDENT fp16 roundings of
@@ -273,12 +273,12 @@ class UNetSD(nn.Module):
         # (default on) the lowering computes that prefix ONCE (one sample's rows) and the first per-sample GEMMs read it through a row
         # wrap (T2V_OP_GEMM i[12]); the reference runs the two forwards separately and computes it twice (gaussian_sampler.py:161-162).
         # Same arithmetic on the same values; 31 of 725 ops run at half their rows.  Part of the program cache key.
-        self.share_cfg_prefix = os.environ.get("T2V_SHARE_PREFIX", "1") != "0"
+        self.share_cfg_prefix = L.knob("T2V_SHARE_PREFIX", "1") != "0"
         # to_q projection + text cross-attention as ONE launch (T2V_EPI_XATTN, round 5): Q never reaches HBM; part of the program cache key.
         # Built, parity-tested and MEASURED NEUTRAL: per-op events say -6 us (32x32 level) / -12 us (16x16) per site, but the back-to-back step
         # is 26.09 vs 26.03 ms and 26.51 vs 26.37 ms on two boxes (the epilogue's K / V^T fragment loads from L2 are latency-bound: the fused
         # launch takes 53 us where projection + attention take 28 + 32) -> opt-in (T2V_XATTN=1)
-        self.fused_cross_attention = os.environ.get("T2V_XATTN", "0") != "0"
+        self.fused_cross_attention = L.knob("T2V_XATTN", "0") != "0"
         self.auto_refresh = True      # re-check parameter versions on every forward (~1 ms); the sampler
                                       # turns this off inside its loop after one explicit refresh
         self.device = torch.device("cpu")   # SamplerBase.register_buffers_to_model overwrites it (samplers_common.py:82)
@@ -436,6 +436,9 @@ class UNetSD(nn.Module):
                 mask_last_frame_num=0):
         """eps = model(x[b,4,F,h,w], t[b], y[b,L,ctx])  — reference t2v_model.py:386-459.
         Output dtype follows the reference under autocast: fp16 for fp16 weights, else x.dtype."""
+        # one-shot hint of the samplers ("every sample of this call has the same timestep"): consumed before anything can raise, so that
+        # a failed call never leaves it set for a later call with genuinely different timesteps (ADVICE r05)
+        hint_single, self.single_timestep = bool(self.single_timestep), False
         if not x.is_cuda:
             raise L.T2VError("UNetSD.forward needs device tensors on an AMD GPU (no CPU fallback); "
                              "use oracle/torch_port.py for a CPU reference")
@@ -461,7 +464,7 @@ class UNetSD(nn.Module):
             shard = self.t_shard.spec                             # x holds only this rank's frames
             if shard.frames != F:
                 raise L.T2VError(f"T-sharded forward: this rank holds {shard.frames} of {shard.total} frames, got {F}")
-        single, self.single_timestep = self.single_timestep or tf.numel() == 1 or t.ndim == 0, False
+        single = hint_single or tf.numel() == 1 or t.ndim == 0
         if not single and not tf.is_cuda:
             single = bool((tf == tf.reshape(-1)[0]).all())
         self._share_now = bool(getattr(self, "share_cfg_prefix", False)) and single
@@ -734,13 +737,19 @@ class _Lowering:
                          cast=cast, cast_lo=cast_lo, halo_raw=halo_raw if shard is not None else None)
         return full
 
-    def strips_for(self, rows: int, n: int, inst_rows: int) -> Optional[Buf]:
+    def strips_for(self, rows: int, n: int, inst_rows: int, k: Optional[int] = None, gather: int = L.GATHER_PLAIN) -> Optional[Buf]:
         """Buffer for the column statistics a GEMM's epilogue leaves for the GroupNorm that consumes its output (T2V_EPI_STATS:
         fp32 [rows / 32][2][n]) — round 4, VERDICT r03 next #4: that GroupNorm then needs neither a statistics pass over the
         tensor nor a grid barrier.  None when the option is off or the consumer's statistics instances (`inst_rows` rows each) are
         not whole 32-row strips."""
-        if not self.gn_strips or inst_rows % 32 != 0:
+        if inst_rows % 32 != 0:
             return None
+        if not self.gn_strips:
+            # round 6: automatically where the consuming norm can NOT run in its producer's epilogue because ONE statistics instance
+            # has more row tiles than the device holds co-resident (cross-frame norms of 125-frame / 1024x576 clips): strips + fold +
+            # one apply pass instead of the three-launch GroupNorm (two passes over the tensor + one)
+            if k is None or not self.P.gn_instance_too_large(rows, n, k, gather, inst_rows) or L.knob("T2V_GN_STRIPS_AUTO", "1") == "0":
+                return None
         return self.P.alloc(-(-rows // 32), 2 * n, "f32")
 
     def conv3(self, name, a: Buf, key, cout, h, w, *, stride=1, up=0, out_dtype="f32", rowbias=None,
@@ -774,13 +783,13 @@ class _Lowering:
         # (its input is a skip-connection concat: two producers), that norm writes the cast as a second output — no separate pass over the
         # concat tensor (round 5).  Elsewhere (the norm is fused into its producer's epilogue) the cast op stays.
         x16 = None
-        cast_in_norm = (cin != cout and self.shard is None and x.cols % 8 == 0 and os.environ.get("T2V_GN_CAST", "1") != "0"
+        cast_in_norm = (cin != cout and self.shard is None and x.cols % 8 == 0 and L.knob("T2V_GN_CAST", "1") != "0"
                         and not (P.ops and P.ops[-1].kind == L.OP_GEMM and P.ops[-1].out is x))
         if cast_in_norm:
             x16 = P.alloc(x.rows, 2 * cin if self.precise else cin, "f16")
         a = self.gn(prefix + ".in_layers.0", x, prefix + ".in_layers.0", per_frame=True, eps=1e-5, silu=True, cast=x16, cast_lo=self.precise and cast_in_norm)
         e0, e1 = self.emb_slices[prefix]
-        st = self.strips_for(x.rows, cout, h * w)
+        st = self.strips_for(x.rows, cout, h * w, 9 * cin, L.GATHER_CONV3X3)
         h1 = self.conv3(prefix + ".in_layers.2", a, prefix + ".in_layers.2", cout, h, w,
                         rowbias=self.emb_out.col_slice(e0, e1), out_dtype=self.net.norm_input_dtype, stats=st)
         P.free(a)
@@ -804,11 +813,11 @@ class _Lowering:
             P.free(x16)
         else:
             skip = x
-        st = self.strips_for(x.rows, cout, self.F * h * w) if self.shard is None else None
+        st = self.strips_for(x.rows, cout, self.F * h * w, 9 * cout, L.GATHER_CONV3X3) if self.shard is None else None
         # T-sharded: every tensor a cross-frame GroupNorm + (3,1,1) convolution pair reads lives in a buffer with one halo frame either
         # side, RAW: the statistics exchange of that norm carries the boundary frames along (T2V_OP_STATS_HALO) and the norm's apply pass
         # normalises them on arrival — one exchange per temporal convolution instead of two (T2V_STATS_HALO=0: the two-exchange form)
-        merged = self.shard is not None and os.environ.get("T2V_STATS_HALO", "1") != "0"
+        merged = self.shard is not None and L.knob("T2V_STATS_HALO", "1") != "0"
         hwp = h * w
         raw = P.alloc((self.F + 2) * hwp, cout, "f32") if merged else None
         h2 = self.conv3(prefix + ".out_layers.3", b, prefix + ".out_layers.3", cout, h, w, residual=skip, stats=st,
@@ -849,7 +858,7 @@ class _Lowering:
                 t = P.alloc(h2.rows, cout, self.net.norm_input_dtype)
             key = f"{tp}.{name}.{idx}"
             if name != "conv4" and self.shard is None:
-                st = self.strips_for(h2.rows, cout, self.F * h * w)            # conv1 .. conv3 feed the next cross-frame GroupNorm
+                st = self.strips_for(h2.rows, cout, self.F * h * w, 3 * cout, L.GATHER_TCONV3)    # conv1 .. conv3 feed the next cross-frame GroupNorm
             op = P.gemm(key, nrm, self.w_tconv(key), cout, 3 * cout, t, bias=self.vec(key + ".bias"),
                         gather=L.GATHER_TCONV3, conv=dict(F=self.F, HW=h * w, Cin=cout),
                         residual=h2 if name == "conv4" else None, halo=self.shard is not None, stats=st if name != "conv4" else None)
@@ -1172,9 +1181,9 @@ class _Lowering:
         P.gemm("emb_layers.all", e_silu, w_emb, n_emb, emb, self.emb_out, bias=b_emb)
         P.free(e_silu)
 
-        n4 = -(-self.Lctx // 4) * 4                 # keys of the V^T GEMMs (N % 4 == 0): the last sample reads n4 - Lctx rows past the context
-        ctx_all = P.alloc(B * self.Lctx + (n4 - self.Lctx), net.context_dim, "f16")
-        ctx16 = ctx_all.row_slice(0, B * self.Lctx)
+        n4 = -(-self.Lctx // 4) * 4                 # keys of the V^T GEMMs (N % 4 == 0)
+        ctx_all = P.alloc(B * self.Lctx, net.context_dim, "f16")
+        ctx16 = ctx_all
         ctx_src = Buf(Ref("ext", L.EXT_CTX), B * self.Lctx, net.context_dim, net.context_dim, self.ctx_dt)
         P.copy2d("context.cast", ctx_src, ctx16).meta["step_invariant"] = True
         if n_kv:
@@ -1184,17 +1193,26 @@ class _Lowering:
             P.gemm("attn2.kv.all", ctx16, w_kv, n_kv, net.context_dim, self.kv_all, step_invariant=True)
         if self.vt_all is not None:
             # V^T [value channels of all sites, keys] = W_v x context^T per sample: swapped operands (the weights are the "token" operand).
-            # Columns Lctx .. n4-1 come from the next sample's tokens (finite; they only ever meet probabilities that are exactly 0) — for
-            # the last sample from the zeroed rows behind the context.
+            # The GEMM wants N % 4 == 0 keys: every sample's tokens are copied into its own zero-padded [n4, ctx] block, and the whole V^T
+            # buffer is zeroed first, so that key columns Lctx .. lcp-1 are exactly 0 whatever the arena held and whatever the NEXT
+            # sample's context contains (0 x Inf = NaN: a non-finite context must not leak into its neighbour's output).
+            P.memset("attn2.vT.zero", self.vt_all).meta["step_invariant"] = True
+            ctx_pad = ctx16
             if n4 > self.Lctx:
-                P.memset("context.pad", ctx_all.row_slice(B * self.Lctx, ctx_all.rows)).meta["step_invariant"] = True
+                ctx_pad = P.alloc(B * n4, net.context_dim, "f16")
+                P.memset("context.pad", ctx_pad).meta["step_invariant"] = True
+                for b in range(B):
+                    P.copy2d(f"context.pad.{b}", ctx16.row_slice(b * self.Lctx, (b + 1) * self.Lctx),
+                             ctx_pad.row_slice(b * n4, b * n4 + self.Lctx)).meta["step_invariant"] = True
             w_v = Ref("weight", 0, self.packer.add("v_all:lin", "f16", lambda sd, ps=tuple(p for p, _ in st_prefixes): torch.cat(
                 [sd[p + ".transformer_blocks.0.attn2.to_v.weight"] for p in ps], dim=0)))
             wv_as_a = Buf(w_v, n_vt, net.context_dim, net.context_dim, "f16")
             for b in range(B):
-                P.gemm(f"attn2.vT.all.{b}", wv_as_a, ctx_all.row_slice(b * self.Lctx, b * self.Lctx + n4).ref, n4, net.context_dim,
+                P.gemm(f"attn2.vT.all.{b}", wv_as_a, ctx_pad.row_slice(b * n4, (b + 1) * n4).ref, n4, net.context_dim,
                        self.vt_all.row_slice(b * n_vt, (b + 1) * n_vt).col_slice(0, n4), ldw=net.context_dim, allow_splitk=False,
                        step_invariant=True)
+            if ctx_pad is not ctx16:
+                P.free(ctx_pad)
         P.free(ctx_all)
 
         # ---- entry layout conversion: b c f h w -> tokens x 8 channels (4 real + 4 zero)

@@ -345,10 +345,10 @@ class _VaeLowering:
             # the two-pass form recomputes Q K^T per 128-wide O slice = 3x the FLOPs of this GEMM form.)
             cap = (256 << 20) // (6 * hw)                    # rows whose fp32 scores + fp16 probabilities fit 256 MB
             bq = hw if hw <= 4096 else next(b for b in (4608, 4096, 3072, 2304, 2048, 1152, 1024, 768, 512, 256, hw) if hw % b == 0 and (b <= cap or b == hw))
-            if os.environ.get("T2V_VAE_BQ"):                 # experiment switch (tools/profile_vae.py): query rows per block
-                bq = int(os.environ["T2V_VAE_BQ"])
+            if L.knob("T2V_VAE_BQ", None):           # experiment switch (tools/profile_vae.py): query rows per block
+                bq = int(L.knob("T2V_VAE_BQ", None))
                 assert hw % bq == 0
-            pv_split = os.environ.get("T2V_VAE_PV_SPLITK", "1") == "1"
+            pv_split = L.knob("T2V_VAE_PV_SPLITK", "1") == "1"
             for q0 in range(0, hw, bq):
                 s = P.alloc(bq, hw, "f32")
                 P.gemm(f"{p}.qk^T.{img}.{q0}", q_i.row_slice(q0, q0 + bq), k_i.ref, hw, c, s, ldw=k_i.ld, allow_splitk=False)

@@ -28,7 +28,7 @@ def test_header_constants_match_binding():
         "T2V_OP_NP": L.OP_NP, "T2V_GN_ROWS_PER_BLOCK": L.GN_ROWS_PER_BLOCK, "T2V_SYNC_INTS": L.SYNC_INTS, "T2V_SYNC_BARRIER_INTS": L.SYNC_BARRIER_INTS,
         "T2V_OP_EMBED_ROWS": L.OP_EMBED_ROWS, "T2V_OP_TO_UINT8": L.OP_TO_UINT8, "T2V_OP_ALLGATHER": L.OP_ALLGATHER,
         "T2V_OP_HALO_EXCHANGE": L.OP_HALO_EXCHANGE, "T2V_OP_RESHARD_ROWS": L.OP_RESHARD_ROWS, "T2V_OP_ALLTOALL": L.OP_ALLTOALL,
-        "T2V_OP_STATS_HALO": L.OP_STATS_HALO,
+        "T2V_OP_STATS_HALO": L.OP_STATS_HALO, "T2V_GN_PART_BYTES": L.GN_PART_BYTES,
     }
     for k, v in expect.items():
         assert allc[k] == v, (k, allc[k], v)

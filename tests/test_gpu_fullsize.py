@@ -28,7 +28,14 @@ DEV = "cuda:0"
 # (5 / 10 steps: the trajectory has not contracted yet and CFG amplifies each step's error) <= 1.5e-3.
 GATE_FWD_W16 = 1.2e-3          # measured round 4: 8.4e-4 (125 f) ... 9.6e-4 (ZeroScope-XL geometry)
 GATE_VIDEO_W16 = 1.0e-3        # configs[1] 50-step video: 6e-4 ... 7e-4
-GATE_FEWSTEP_W16 = 1.8e-3      # 5- / 10-step outputs: 1.55e-3 ... 1.68e-3 (each step's error x the CFG-9 amplification, not yet contracted)
+# Few-step outputs (5 / 10 steps: each step's forward error x the CFG-9 amplification, not yet contracted — outside north_star's 1e-3, stated
+# in DESIGN section 3): ONE gate PER LINE at the round-5 measurement + 10 % (profiles/r05_parity_measurements.txt), not a blanket figure
+GATE_FEWSTEP_W16 = {"c1_ddimg_10": 1.19e-3,     # configs[1] 10-step DDIM_Gaussian: 1.078e-3
+                    "c1_ddim_10": 1.61e-3,      # configs[1] 10-step DDIM: 1.46e-3
+                    "c1_unipc_10": 1.51e-3,     # configs[1] 10-step UniPC: 1.37e-3
+                    "c3_5": 1.78e-3,            # configs[3] geometry, 4 frames, 5 steps: 1.619e-3
+                    "c2_10": 1.12e-3,           # configs[2] 125 frames, 10 steps: 1.014e-3 (worst frame 1.061e-3 -> 1.17e-3)
+                    "c0_5": 1.57e-3}            # configs[0] 8 frames, 5 steps (its OWN step count): 1.428e-3
 GATE_LVDM_VIDEO_W16 = 8.0e-4   # configs[4] 50-step output: 4.96e-4 (10 steps: 9.4e-4) once the DDIM coefficients come from the fp32 schedule —
                                # rounds 3-4 measured 1.06-1.13e-3 because `LatentDiffusion.half()` rounded alphas_cumprod to fp16
 GATE_LVDM_FEWSTEP_W16 = 1.2e-3
@@ -95,7 +102,7 @@ def test_c1_24f_sampling_10_and_50_steps_and_frames(modelscope_full_fp16, vae16)
         if _gold16("modelscope_24f.npz") is not None:
             ra = rel_l2(x0[steps].float().cpu(), torch.from_numpy(_gold16("modelscope_24f.npz")[f"sampler_x0_{steps}"]))
             print(f"configs[1] {steps}-step DDIM_Gaussian CFG 9 vs the reference on the DEPLOYED weights: x0 rel-L2 {ra:.3e}")
-            assert ra < (GATE_FEWSTEP_W16 if steps == 10 else GATE_VIDEO_W16)
+            assert ra < (GATE_FEWSTEP_W16["c1_ddimg_10"] if steps == 10 else GATE_VIDEO_W16)
     # frames 0 / 23 of the 50-step video: VAE decode + tensor2vid as ONE program, against the reference's uint8 frames
     z = (x0[50][:, :, [0, 23]] / configs.SCALE_FACTOR).permute(0, 2, 1, 3, 4).reshape(2, 4, 32, 32)
     u8 = vae16.decode_to_uint8(z, videos=1).cpu().numpy()
@@ -169,6 +176,30 @@ def test_c3_zeroscope_xl_forward_12_frames(modelscope_full_fp16):
     print(f"configs[3] ZeroScope-XL geometry, 12 frames @1024x576 vs the reference on the DEPLOYED weights: rel-L2 {r:.3e} over frames {frames}")
     assert abs(float(eps.std()) - float(gold["eps_std"])) < 2e-3 * float(gold["eps_std"])
     assert r < GATE_FWD_W16
+
+
+def test_c3_zeroscope_xl_24_frames_bench_geometry_sanity(modelscope_full_fp16):
+    """configs[3] at its STATED 24 frames (the program `bench.py --model zeroscope_xl` times: 730 ops, other tile choices than the 4- / 12-frame
+    ones).  No reference output exists at this size — the reference's fp32 CPU attention over 24 x 9216 tokens does not fit the build
+    container — so this is a sanity check, not parity: finite, the output's standard deviation within 1 % of the
+    12-frame golden's (same weights, same kind of input), and the b = 1 forward equal to the conditional half of the b = 2 CFG forward
+    (different row counts -> different tiles / split-K for the same arithmetic)."""
+    net, _ = modelscope_full_fp16
+    path = os.path.join(GOLD, "zeroscope_xl_12f_w16.npz")
+    if not os.path.exists(path):
+        pytest.skip("zeroscope_xl_12f_w16.npz not generated (make_golden_full.py w16 c3x12)")
+    gold = np.load(path)
+    noise, cond, uncond = synth.synth_inputs(24, 576, 1024)
+    t1 = torch.tensor([801], device=DEV)
+    eps1 = net(noise.to(DEV), t1, cond.to(DEV).half()).float()
+    assert bool(torch.isfinite(eps1).all())
+    sd = float(eps1.std())
+    assert abs(sd - float(gold["eps_std"])) < 1e-2 * float(gold["eps_std"]), (sd, float(gold["eps_std"]))
+    eps2 = net.forward_cfg_pair(noise.to(DEV), t1, torch.cat([cond, uncond]).to(DEV).half())[:1].float()
+    r = rel_l2(eps2.cpu(), eps1.cpu())
+    print(f"configs[3] ZeroScope-XL at 24 frames @1024x576: finite, std {sd:.4f} (12-frame golden {float(gold['eps_std']):.4f}), "
+          f"b = 1 vs the conditional half of the CFG pair: rel-L2 {r:.3e}")
+    assert r < 5e-4
 
 
 def test_c3_vae_decode_1024x576(vae16):
@@ -245,7 +276,7 @@ def test_c1_other_samplers_full_size(modelscope_full_fp16, name):
                          batch_size=1, shape=shape, noise=nz, guidance_scale=9.0, eta=0.0, sampler_name=name)
     r = rel_l2(x0.float().cpu(), torch.from_numpy(gold[f"{name.lower()}_x0_10"]))
     print(f"configs[1] 24f, 10-step {name} CFG 9 vs the reference's own sampler on the DEPLOYED weights: x0 rel-L2 {r:.3e}")
-    assert r < GATE_FEWSTEP_W16
+    assert r < GATE_FEWSTEP_W16[f"c1_{name.lower()}_10"]
 
 
 @pytest.mark.parametrize("name", ["DDIM", "UniPC"])
@@ -281,7 +312,7 @@ def test_c3_zeroscope_xl_sampled_output_5_steps(modelscope_full_fp16):
                          batch_size=1, shape=shape, noise=nz, guidance_scale=9.0, eta=0.0, sampler_name="DDIM_Gaussian")
     r = rel_l2(x0.float().cpu(), torch.from_numpy(gold["sampler_x0_5"]))
     print(f"configs[3] ZeroScope-XL geometry, 4f, 5-step DDIM_Gaussian CFG 9 vs the reference on the DEPLOYED weights: x0 rel-L2 {r:.3e}")
-    assert r < GATE_FEWSTEP_W16
+    assert r < GATE_FEWSTEP_W16["c3_5"]
 
 
 def test_c2_125f_sampled_output_10_steps(modelscope_full_fp16):
@@ -302,7 +333,7 @@ def test_c2_125f_sampled_output_10_steps(modelscope_full_fp16):
     print(f"configs[2] 125f, 10-step DDIM_Gaussian CFG 9 vs the reference on the DEPLOYED weights: x0 rel-L2 {r:.3e} over frames {frames}, "
           f"worst single frame {worst:.3e}")
     assert abs(float(x0.std()) - float(gold["x0_std"])) < 3e-3 * float(gold["x0_std"])
-    assert r < GATE_FEWSTEP_W16 and worst < 1.15 * GATE_FEWSTEP_W16
+    assert r < GATE_FEWSTEP_W16["c2_10"] and worst < 1.05 * GATE_FEWSTEP_W16["c2_10"]
 
 
 def test_c0_8f_forward_and_5_steps_on_the_deployed_weights(modelscope_full_fp16):
@@ -322,7 +353,7 @@ def test_c0_8f_forward_and_5_steps_on_the_deployed_weights(modelscope_full_fp16)
                          batch_size=1, shape=shape, noise=nz, guidance_scale=9.0, eta=0.0, sampler_name="DDIM_Gaussian")
     rs = rel_l2(x0.float().cpu(), torch.from_numpy(g16["sampler_x0"]))
     print(f"configs[0] 8f forward / 5-step DDIM_Gaussian CFG 9 vs the reference on the DEPLOYED weights: rel-L2 {r:.3e} / {rs:.3e}")
-    assert r < GATE_FWD_W16 and rs < GATE_FEWSTEP_W16
+    assert r < GATE_FWD_W16 and rs < GATE_FEWSTEP_W16["c0_5"]
 
 
 def test_c2_125f_sampled_output_20_steps(modelscope_full_fp16):

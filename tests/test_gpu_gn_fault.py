@@ -80,3 +80,59 @@ def test_poisoned_grid_barrier_times_out_and_is_reported():
     out = subprocess.run([sys.executable, "-c", WORKER, root], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "FAULT_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
     print(out.stdout.strip().splitlines()[-1])
+
+
+RESIDENCY_WORKER = r'''
+import math, os, sys, torch
+os.environ["T2V_DEVICE_CUS"] = "4096"           # the lowering believes in a chip 16x this one: it fuses a norm into a grid that cannot be co-resident
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from harness import fill, read, rel_l2
+from interp import Interp
+from sd_webui_text2video_amd import _lib as L
+from sd_webui_text2video_amd.program import BoundProgram, Program, Ref
+
+def lower():
+    P = Program()
+    M, C, K = 192 * 600, 320, 64                # 600 row tiles of 192: more than 256 compute units hold
+    a, y, o = P.alloc(M, K, "f16"), P.alloc(M, C, "f32"), P.alloc(M, C, "f16")
+    P.gemm("l", a, Ref("weight", 0, "w"), C, K, y)
+    # ONE statistics instance over all 600 tiles: no row chunk of whole instances exists (t2v_launch_coresident cannot split it)
+    P.groupnorm("gn", y, Ref("weight", 0, "g"), Ref("weight", 0, "b"), o, n_inst=1, eps=1e-5, silu=True, gb=Ref("weight", 0, "gb"))
+    return P, a, o
+
+g = torch.Generator().manual_seed(3)
+P, a, o = lower()
+assert len(P.ops) == 1 and P.ops[0].i[16] == L.EPI_GN, "the mis-set CU count did not make the lowering fuse"
+C, K = 320, 64
+w = {"w": (torch.randn(C, K, generator=g) / math.sqrt(K)).half(), "g": 1 + 0.1 * torch.randn(C, generator=g), "b": 0.1 * torch.randn(C, generator=g)}
+w["gb"] = torch.cat([w["g"], w["b"]])
+dev = torch.device("cuda:0")
+wg = {k: v.to(dev) for k, v in w.items()}
+arena = torch.zeros(P.arena.high + 256, dtype=torch.uint8, device=dev)
+bp = BoundProgram(P, arena.data_ptr(), {k: v.data_ptr() for k, v in wg.items()})
+st = torch.cuda.current_stream(dev).cuda_stream
+try:
+    bp.run({}, st); raise SystemExit("the over-sized co-resident launch was not refused")
+except L.T2VError as e:
+    assert "error -7" in str(e) and "co-resident" in str(e), str(e)
+assert L.exchange_disabled(), "T2V_ERR_RESIDENCY must switch the fused lowering off"
+# lowered again: no fusion, and correct
+P2, a2, o2 = lower()
+assert len(P2.ops) >= 2 and P2.ops[0].i[16] == L.EPI_NONE
+it = Interp(P2, w, poison=False); fill(it, a2, g); ar0 = it.arena.clone(); it.run({})
+ar = ar0.to(dev)
+bp2 = BoundProgram(P2, ar.data_ptr(), {k: v.data_ptr() for k, v in wg.items()})
+bp2.run({}, st); torch.cuda.synchronize(); L.async_status()
+got = Interp(P2, w, poison=False); got.arena = ar.cpu()
+assert rel_l2(read(got, o2).float(), read(it, o2).float()) < 1e-3
+print("RESIDENCY_OK")
+'''
+
+
+def test_refused_coresident_launch_switches_the_fused_lowering_off():
+    """ADVICE r05: the lowering decides norm fusion from a table of workgroups per CU x device_cus(); when the launcher's occupancy check
+    disagrees (here: T2V_DEVICE_CUS mis-set) the library returns T2V_ERR_RESIDENCY (not a generic launch error), the binding switches
+    the fused lowering off, and the re-lowered program runs and is correct."""
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    out = subprocess.run([sys.executable, "-c", RESIDENCY_WORKER, root], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "RESIDENCY_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]

@@ -1378,6 +1378,79 @@ def test_layernorm_across_column_tiles_against_torch(tile, N, K, M):
     assert rel_l2(read(got2, ln_out).float(), ref2) < 2e-3
 
 
+# ---- round 6: fused norms on grids LARGER than the device holds co-resident: row chunks of whole tiles and whole instances ---------------
+@pytest.mark.parametrize("kind,tile,C,HW,frames", [("conv", 8, 320, 1024, 66), ("tconv", 11, 320, 256, 160), ("plain", 0, 640, 256, 300),
+                                                    ("conv", 3, 640, 256, 200), ("plain", 5, 1280, 64, 900)])
+def test_fused_groupnorm_on_a_grid_larger_than_the_device_runs_in_row_chunks(kind, tile, C, HW, frames):
+    """at 125 frames / 1024x576 a fused-norm GEMM has more tiles than compute units, and the statistics exchange
+    needs the grid of ONE launch co-resident.  The launcher (t2v_launch_coresident) cuts the rows into chunks of whole tiles AND whole
+    statistics instances (per-frame norms: lcm(tile rows, frame rows)), one launch each, every row index staying global (row bias per
+    sample, conv image mapping, frame index of the temporal taps).  352 (192-row) ... 1350 (128 x 128) workgroups here.  Checked
+    against the interpreter and torch; the same op on ONE chunk-sized problem is bitwise equal to its rows of the chunked run."""
+    H = W = int(math.isqrt(HW))
+    M = frames * HW
+    P = Program()
+    P.force_tile = tile
+    g = _g(1100 + tile + C)
+    y, res, out = P.alloc(M, C, "f32"), P.alloc(M, C, "f32"), P.alloc(M, C, "f16")
+    rb = P.alloc(2, C, "f32") if kind == "conv" else None
+    w = {"b": torch.randn(C, generator=g), "g": 1 + 0.1 * torch.randn(C, generator=g), "be": 0.1 * torch.randn(C, generator=g)}
+    w["gb"] = torch.cat([w["g"], w["be"]])
+    cin = 64
+    a = P.alloc(M, cin, "f16")
+    if kind == "conv":
+        w["w"] = pk.conv3x3((torch.randn(C, cin, 3, 3, generator=g) / math.sqrt(9 * cin)).half().float()).half()
+        op = P.gemm("c", a, Ref("weight", 0, "w"), C, 9 * cin, y, bias=Ref("weight", 0, "b"), gather=L.GATHER_CONV3X3,
+                    conv=dict(Hin=H, Win=W, Cin=cin, stride=1, up=0, Hout=H, Wout=W), residual=res, rowbias=rb, rows_per_batch=M // 2,
+                    allow_splitk=False)
+    elif kind == "tconv":
+        w["w"] = pk.tconv3((torch.randn(C, cin, 3, 1, 1, generator=g) / math.sqrt(3 * cin)).half().float()).half()
+        op = P.gemm("t", a, Ref("weight", 0, "w"), C, 3 * cin, y, bias=Ref("weight", 0, "b"), gather=L.GATHER_TCONV3,
+                    conv=dict(F=frames // 2, HW=HW, Cin=cin), residual=res, allow_splitk=False)
+    else:
+        w["w"] = (torch.randn(C, cin, generator=g) / math.sqrt(cin)).half()
+        op = P.gemm("l", a, Ref("weight", 0, "w"), C, cin, y, bias=Ref("weight", 0, "b"), residual=res, allow_splitk=False)
+    assert op.meta["tile"] == tile and op.meta["split"] == 1
+    fused = P.groupnorm("gn", y, Ref("weight", 0, "g"), Ref("weight", 0, "be"), out, n_inst=frames, eps=1e-5, silu=True, gb=Ref("weight", 0, "gb"))
+    assert fused is op and op.i[16] == L.EPI_GN and len(P.ops) == 1, "the norm did not become the GEMM's epilogue"
+    bm, bn, per_cu = Program._GN_EPI_TILES[tile]
+    assert -(-M // bm) * -(-C // bn) > 256 * per_cu, "the grid must exceed what the device holds"
+
+    def init(it):
+        fill(it, a, g); fill(it, res, g, 2.0)
+        if rb is not None:
+            fill(it, rb, g)
+    it, got = _gpu_run(P, w, init)
+    _check(it, got, y, 2e-5, "the fp32 stream of the chunked launch")
+    _check(it, got, out, 1e-3, "chunked fused GroupNorm vs the interpreter")
+    v = read(got, y).float()
+    ref = torch.nn.functional.silu(torch.nn.functional.group_norm(v.view(frames, HW, C).permute(0, 2, 1), 32, w["g"], w["be"], 1e-5))
+    assert rel_l2(read(got, out).float(), ref.permute(0, 2, 1).reshape(M, C)) < 1e-3
+
+
+@pytest.mark.parametrize("tile,N,K,M", [(0, 640, 128, 20000), (12, 1280, 128, 2500), (9, 512, 128, 30000)])
+def test_layernorm_across_column_tiles_on_a_grid_larger_than_the_device(tile, N, K, M):
+    """The cross-tile LayerNorm epilogue (round 5) on more row tiles than the device holds: rows are independent, so the launcher runs
+    row chunks of whole tiles (round 6); ragged M."""
+    P = Program()
+    P.force_tile = tile
+    g = _g(1200 + tile)
+    a, res, out, ln_out = P.alloc(M, K, "f16"), P.alloc(M, N, "f32"), P.alloc(M, N, "f32"), P.alloc(M, N, "f16")
+    w = {"w": (torch.randn(N, K, generator=g) / math.sqrt(K)).half(), "b": torch.randn(N, generator=g),
+         "g": 1 + 0.1 * torch.randn(N, generator=g), "be": 0.1 * torch.randn(N, generator=g)}
+    w["gb"] = torch.cat([w["g"], w["be"]])
+    op = P.gemm("l", a, Ref("weight", 0, "w"), N, K, out, bias=Ref("weight", 0, "b"), residual=res, allow_splitk=False,
+                ln=(Ref("weight", 0, "gb"), Ref("weight", 0, "g"), Ref("weight", 0, "be"), ln_out, 1e-5))
+    assert op.meta["tile"] == tile and op.i[8] == 2 and len(P.ops) == 1, "the LayerNorm did not become the GEMM's epilogue"
+    bm, bn, per_cu = Program._LNX_TILES[tile]
+    assert -(-M // bm) * -(-N // bn) > per_cu * 256
+    it, got = _gpu_run(P, w, lambda it: (fill(it, a, g), fill(it, res, g, 3.0)))
+    _check(it, got, out, 2e-5, "fp32 stream")
+    _check(it, got, ln_out, 1e-3, "chunked cross-tile LayerNorm vs the interpreter")
+    ref = torch.nn.functional.layer_norm(read(got, out).float() + 0.0, (N,), w["g"], w["be"], 1e-5)
+    assert rel_l2(read(got, ln_out).float(), ref) < 1e-3
+
+
 @pytest.mark.parametrize("kind,C,per_frame,dead,lo", [("conv", 640, True, True, False), ("conv", 1280, False, False, True), ("plain", 640, False, True, False),
                                                        ("plain", 320, True, False, False)])
 def test_groupnorm_in_splitk_reduction_against_torch(kind, C, per_frame, dead, lo):

@@ -5,6 +5,7 @@
 set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp
+export T2V_EXPERIMENTAL=1     # the A/B switches used below are experiment knobs (sd_webui_text2video_amd._lib.knob)
 TAG=${T2V_PASS_TAG:-p}
 PYT="python -m pytest -q --tb=short -p no:cacheprovider"
 digest() { grep -E "passed|failed|FAILED|ERROR|error" "$1" | tail -n "${2:-6}" | cut -c1-300; }
