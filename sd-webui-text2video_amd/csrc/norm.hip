@@ -180,8 +180,9 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* partials
 
 // Phase 3 — statistics from the producing GEMM's epilogue (T2V_EPI_STATS): strips[(inst * nstrips + s)][0 | 1][c] = sum / sum of squares
 // of one 32-row strip of column c.  One wave per (instance, group) folds nstrips x cpg pairs in a fixed order in fp64 -> {mean, rstd}.
+// raw != nullptr (T-sharded clip, round 6): this rank's {sum, sum of squares} per (instance, group) for the exchange instead of {mean, rstd}.
 __global__ __launch_bounds__(256) void gn_finalize_strips_kernel(const float* __restrict__ strips, float* finals, int n_inst, int nstrips,
-                                                                 int groups, int cpg, int ldn, double inv_n, float eps) {
+                                                                 int groups, int cpg, int ldn, double inv_n, float eps, double* raw) {
   const int lane = threadIdx.x & 63;
   const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (idx >= n_inst * groups) return;
@@ -196,7 +197,10 @@ __global__ __launch_bounds__(256) void gn_finalize_strips_kernel(const float* __
     q += (double)p[ldn];
   }
   for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
-  if (lane == 0) {
+  if (lane == 0 && raw != nullptr) {
+    raw[2 * idx] = s;
+    raw[2 * idx + 1] = q;
+  } else if (lane == 0) {
     const double m = s * inv_n;
     double var = q * inv_n - m * m;
     var = var < 0.0 ? 0.0 : var;
@@ -209,7 +213,7 @@ __global__ __launch_bounds__(256) void gn_finalize_strips_kernel(const float* __
 // channels at the 32x32 level — one wave per pair walked them in 120 dependent-latency rounds, 46 us; 256 threads keep ~60 independent
 // loads each in flight).  Thread t takes strips t, t + 256, ...; fixed reduction order (wave xor-tree, then the 4 waves in order).
 __global__ __launch_bounds__(256) void gn_finalize_strips_wg_kernel(const float* __restrict__ strips, float* finals, int nstrips, int groups,
-                                                                    int cpg, int ldn, double inv_n, float eps) {
+                                                                    int cpg, int ldn, double inv_n, float eps, double* raw) {
   __shared__ double red[8];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int idx = blockIdx.x, inst = idx / groups, g = idx - inst * groups;
@@ -228,6 +232,7 @@ __global__ __launch_bounds__(256) void gn_finalize_strips_wg_kernel(const float*
   if (tid == 0) {
     double a = 0.0, b = 0.0;
     for (int w = 0; w < 4; ++w) { a += red[2 * w]; b += red[2 * w + 1]; }
+    if (raw != nullptr) { raw[2 * idx] = a; raw[2 * idx + 1] = b; return; }
     const double m = a * inv_n;
     double var = b * inv_n - m * m;
     var = var < 0.0 ? 0.0 : var;
@@ -959,6 +964,10 @@ hipError_t t2v_launch_groupnorm(const t2v_op& op, hipStream_t s) {
       op.p[4] == 0 || part < 0 || part >= nparts || phase < 0 || phase > 3)
     return hipErrorInvalidValue;
   if (phase == 3 && (op.p[6] == 0 || rows % 32 != 0 || op.i[17] < C || nparts != 1)) return hipErrorInvalidValue;
+  // phase 1 with producer strips (p[6] != 0, round 6): this rank's part of a T-sharded cross-frame norm comes from the T2V_EPI_STATS strips of
+  // the GEMM that produced x — ONE small fold launch instead of a statistics pass over the tensor + a fold
+  const bool strips1 = phase == 1 && op.p[6] != 0;
+  if (strips1 && (rows % 32 != 0 || op.i[17] < C)) return hipErrorInvalidValue;
   if ((op.i[21] != 0 || op.i[22] != 0) && (phase != 2 || n_inst != 1 || op.i[21] < 0 || op.i[22] < 0 || op.p[8] != 0)) return hipErrorInvalidValue;
   // T-sharded clips (phase 1 / 2): every rank folds ITS OWN block partials to one {sum, sum of squares} pair per
   // (instance, group) — 512 bytes per instance — and only those are all-gathered; phase 2 sums the parts in rank order
@@ -1015,15 +1024,16 @@ hipError_t t2v_launch_groupnorm(const t2v_op& op, hipStream_t s) {
                               ld_in, ld_out, groups, op.f[0], lo_off, cast);
       return;
     }
-    if (phase == 3 && (long)(rows / 32) * (C / groups) > 1024)
+    double* raw_part = strips1 ? partials + part_len * part : nullptr;
+    if ((phase == 3 || strips1) && (long)(rows / 32) * (C / groups) > 1024)
       hipLaunchKernelGGL(gn_finalize_strips_wg_kernel, dim3(n_inst * groups), dim3(256), 0, s, reinterpret_cast<const float*>(op.p[6]), finals,
-                         rows / 32, groups, C / groups, op.i[17], inv_n, op.f[0]);
-    else if (phase == 3)
+                         rows / 32, groups, C / groups, op.i[17], inv_n, op.f[0], raw_part);
+    else if (phase == 3 || strips1)
       hipLaunchKernelGGL(gn_finalize_strips_kernel, dim3(g2), dim3(256), 0, s, reinterpret_cast<const float*>(op.p[6]), finals, n_inst, rows / 32,
-                         groups, C / groups, op.i[17], inv_n, op.f[0]);
+                         groups, C / groups, op.i[17], inv_n, op.f[0], raw_part);
     else if (phase != 2)
       hipLaunchKernelGGL(gn_stats_kernel<T>, g1, dim3(256), lds, s, x, local, rows, C, ld_in, groups, rpb);
-    if (phase == 1)
+    if (phase == 1 && !strips1)
       hipLaunchKernelGGL(gn_finalize_kernel, dim3(g2), dim3(256), 0, s, local, finals, n_inst, nblk, groups, 0.0, 0.f, 1,
                          partials + part_len * part);
     if (phase != 1) {

@@ -746,7 +746,12 @@ class Program:
             op.out = out
             self._emit(op)
         else:
-            self._emit(make(1, ".stats"))
+            op1 = make(1, ".stats")
+            if stats is not None:
+                # round 6: this rank's part folded from the producing GEMM's T2V_EPI_STATS strips — no statistics pass over the tensor
+                assert rows % 32 == 0 and stats.ld == 2 * x.cols and stats.rows * 32 >= x.rows
+                op1.p[6], op1.i[17] = stats.ref, x.cols
+            self._emit(op1)
             full = Buf(scratch.ref, nparts * part_bytes, 1, 1, "u8", scratch.alloc_off)
             if halo_raw is None:
                 self.allgather(name + ".stats.allgather", full, part_bytes, shard)

@@ -728,8 +728,8 @@ class _Lowering:
             full = out = self.P.alloc(x.rows, x.cols, "f16") if out is None else out
         n_inst = self.Bc * self.F if per_frame else self.Bc
         shard = None if per_frame else self.shard
-        if stats is not None and (shard is not None or (x.rows // n_inst) % 32 != 0):
-            stats = None                  # (a T-sharded cross-frame norm exchanges its own partials; strips are 32 rows)
+        if stats is not None and (x.rows // n_inst) % 32 != 0:
+            stats = None                  # (strips are 32 rows; a T-sharded cross-frame norm folds ITS part from them, round 6)
         # (x produced by the op emitted last, on a tile with the instantiation: the norm becomes that GEMM's epilogue — Program._fuse_groupnorm;
         #  x_dead: only this norm reads x)
         self.P.groupnorm(name, x, self.vec(key + ".weight"), self.vec(key + ".bias"), out, n_inst=n_inst, eps=eps, silu=silu,
@@ -744,7 +744,12 @@ class _Lowering:
         not whole 32-row strips."""
         if inst_rows % 32 != 0:
             return None
-        if not self.gn_strips:
+        if self.shard is not None and inst_rows == self.F * (rows // (self.Bc * self.F)):
+            # T-sharded cross-frame norm (never an epilogue: its statistics cross ranks): this rank's part folded from the producer's
+            # strips instead of a statistics pass over the tensor (round 6) — one small launch instead of two, per norm
+            if L.knob("T2V_TSHARD_STRIPS", "1") == "0":
+                return None
+        elif not self.gn_strips:
             # round 6: automatically where the consuming norm can NOT run in its producer's epilogue because ONE statistics instance
             # has more row tiles than the device holds co-resident (cross-frame norms of 125-frame / 1024x576 clips): strips + fold +
             # one apply pass instead of the three-launch GroupNorm (two passes over the tensor + one)
@@ -813,7 +818,7 @@ class _Lowering:
             P.free(x16)
         else:
             skip = x
-        st = self.strips_for(x.rows, cout, self.F * h * w, 9 * cout, L.GATHER_CONV3X3) if self.shard is None else None
+        st = self.strips_for(x.rows, cout, self.F * h * w, 9 * cout, L.GATHER_CONV3X3)
         # T-sharded: every tensor a cross-frame GroupNorm + (3,1,1) convolution pair reads lives in a buffer with one halo frame either
         # side, RAW: the statistics exchange of that norm carries the boundary frames along (T2V_OP_STATS_HALO) and the norm's apply pass
         # normalises them on arrival — one exchange per temporal convolution instead of two (T2V_STATS_HALO=0: the two-exchange form)
@@ -844,7 +849,9 @@ class _Lowering:
                 if r == R - 1:
                     P.memset(f"{tp}.{name}.halo1", nrm.row_slice((self.F + 1) * hwp, (self.F + 2) * hwp))
                 self.gn(f"{tp}.{name}.0", t, f"{tp}.{name}.0", per_frame=False, eps=1e-5, silu=True,
-                        out=nrm.row_slice(hwp, (self.F + 1) * hwp), halo_raw=raw)
+                        out=nrm.row_slice(hwp, (self.F + 1) * hwp), halo_raw=raw, stats=st_live)
+                P.free(st)
+                st = st_live = None
                 if not merged:
                     P.halo_exchange(f"{tp}.{name}.halo", nrm, hwp, self.F, self.shard)
             if t is not h2:
@@ -857,7 +864,7 @@ class _Lowering:
             else:
                 t = P.alloc(h2.rows, cout, self.net.norm_input_dtype)
             key = f"{tp}.{name}.{idx}"
-            if name != "conv4" and self.shard is None:
+            if name != "conv4":
                 st = self.strips_for(h2.rows, cout, self.F * h * w, 3 * cout, L.GATHER_TCONV3)    # conv1 .. conv3 feed the next cross-frame GroupNorm
             op = P.gemm(key, nrm, self.w_tconv(key), cout, 3 * cout, t, bias=self.vec(key + ".bias"),
                         gather=L.GATHER_TCONV3, conv=dict(F=self.F, HW=h * w, Cin=cout),

@@ -229,6 +229,12 @@ class Interp:
             # scratch head: gathered fp64 {sum, sum of squares} [nparts][n_inst][groups][2] (each rank folds its own block
             # partials before the all-gather)
             pv = self.view(op.p[4], (nparts, n_inst, groups, 2), (n_inst * groups * 2, groups * 2, 2, 1), torch.float64, ext)
+            if phase == 1 and op.p[6].space != "null":        # this rank's part from the producing GEMM's strips (round 6)
+                ldn = op.i[17]
+                sv = self.view(op.p[6], (n_inst, rows // 32, 2, groups, cpg), (rows // 32 * 2 * ldn, 2 * ldn, ldn, cpg, 1), torch.float32, ext).double()
+                pv[part, :, :, 0] = sv[:, :, 0].sum(dim=(1, 3))
+                pv[part, :, :, 1] = sv[:, :, 1].sum(dim=(1, 3))
+                return
             if phase == 1:
                 pv[part, :, :, 0] = x.sum(dim=(1, 3))
                 pv[part, :, :, 1] = (x * x).sum(dim=(1, 3))
