@@ -26,7 +26,8 @@
 extern "C" {
 #endif
 
-#define T2V_ABI_VERSION 7   /* 7 (round 6): T2V_ERR_RESIDENCY — a launch that needs its whole grid co-resident was refused by the occupancy check (the caller
+#define T2V_ABI_VERSION 8   /* 8 (round 6): peer windows (t2v_comm_window_create / _open / t2v_comm_counters): exchanges as device-initiated stores into IPC-mapped mailboxes;
+                               7 (round 6): ATTENTION p[6] / i[17] / i[18] (V^T scratch: spatial self-attention with LDS-DMA tiles); T2V_ERR_RESIDENCY — a launch that needs its whole grid co-resident was refused by the occupancy check (the caller
                                lowers again without norms fused into GEMM epilogues); a launch refused because a fault was raised mid-run reports T2V_ERR_ASYNC;
                                6 (round 5, second half): T2V_OP_STATS_HALO — the statistics parts of a T-sharded cross-frame GroupNorm and the RAW boundary
                                frames of the temporal convolution behind it in ONE grouped exchange; GROUPNORM i[21] / i[22] (phase 2 also normalises the
@@ -196,6 +197,9 @@ enum t2v_gather {
  *      outer, inner), 8..10 k/v strides, 11..13 out strides (elements; head h at +head_dim*h),
  *      14 head_dim (0 = 64), 15 causal (1: key s visible to query t iff s <= t), 16 low-order output offset (elements, 0 = none): also
  *      store fp16(o - float(fp16(o))) at out + i[16] — rows [hi | lo] for a K-doubled output projection;  f: 0 scale; p: 0 q, 1 k, 2 v, 3 out (all fp16)
+ *      ABI 7, optional: p 6 = scratch fp16 [batch_outer * batch_inner * heads * 64, i[17]] with i[17] = nk rounded up to a multiple of 64
+ *      (head_dim 64, not causal): V is transposed into it once per launch and the K / V^T tiles are staged by LDS-DMA (same bits as without
+ *      the scratch; pays from ~512 keys); i[18] = waves per 64-key tile (0 = 8 | 4 | 8)
  * RELPOS_ATTN: i: as ATTENTION with nk == frames of the clip (<= 32), 14 head_dim (multiple of 8, <= 160),
  *      15 max relative position R, 16 q_off: the nq queries are frames [q_off, q_off + nq) of the clip (nq == nk, q_off == 0
  *      unless the clip is T-sharded: then s - t below is s - (t + q_off)); 17 = 1: use the MFMA kernel where it applies (nq == nk,
@@ -307,6 +311,18 @@ int t2v_comm_create(const unsigned char id[128], int nranks, int rank, t2v_comm*
 int t2v_comm_size(const t2v_comm* comm);
 void t2v_comm_destroy(t2v_comm* comm);
 int t2v_plan_set_comm(t2v_plan* plan, t2v_comm* comm);   /* borrowed; must outlive the plan's runs */
+/* Peer windows (ABI 8, csrc/comm.hip): device-initiated exchanges instead of RCCL calls.  Every rank creates a window on its
+ * communicator (memory of the library on the current device; each message gets one of two slots of `slot_bytes` per peer) and
+ * receives its 64-byte hipIpcMemHandle; the host gathers the handles of all ranks ([nranks][64], communicator order — the reference's
+ * launcher has the same out-of-band channel, ddp_wrapper.py:9-13) and every rank opens them.  From then on a collective op of a plan
+ * (and t2v_comm_all_gather) whose largest message fits a slot is ONE kernel of this library: workgroups store their share of the
+ * message into the peer's window over xGMI, raise a sequence flag there, and wait (bounded: T2V_PEER_TIMEOUT_MS, default 20 s ->
+ * T2V_ERR_ASYNC at the next call) for the peer's flag in their own window.  Larger ops keep going through RCCL.
+ * t2v_comm_window_open(comm, NULL) releases the window again (the group found a rank that could not map a peer: nobody uses them).
+ * t2v_comm_counters: out[0] = exchanges that went over the window, out[1] = exchanges that went through RCCL since creation. */
+int t2v_comm_window_create(t2v_comm* comm, uint64_t slot_bytes, unsigned char handle_out[64]);
+int t2v_comm_window_open(t2v_comm* comm, const unsigned char* handles);
+void t2v_comm_counters(const t2v_comm* comm, uint64_t out[2]);
 /* In-place all-gather outside a plan, on `stream`: part q of t2v_comm_size(comm) equal parts of `bytes` bytes lives at base + q*bytes,
  * the caller's own part is in place.  The per-step exchanges around the UNet — the eps of a classifier-free-guidance pair
  * (gaussian_sampler.py:161-163 evaluates the two forwards one after the other), the uint8 frames of the decoded clip

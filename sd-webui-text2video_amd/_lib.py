@@ -30,7 +30,7 @@ def knob(name: str, default):
 
 
 # ---- mirrors of include/t2v_hip.h (checked against the header by tests/test_abi.py) -------
-ABI_VERSION = 7
+ABI_VERSION = 8
 OP_GEMM, OP_GROUPNORM, OP_LAYERNORM, OP_ATTENTION, OP_SOFTMAX = 1, 2, 3, 4, 5
 OP_NCTHW_TO_CL, OP_CL_TO_NCTHW, OP_TIME_EMBED, OP_COPY2D, OP_DDIM_STEP, OP_MEMSET = 6, 7, 8, 9, 10, 11
 OP_LINCOMB = 12
@@ -55,6 +55,7 @@ EXPORTS = [
     "t2v_plan_num_ops", "t2v_plan_run", "t2v_plan_run_timed", "t2v_plan_destroy",
     "t2v_unet_forward", "t2v_vae_decode", "t2v_ddim_step",
     "t2v_comm_unique_id", "t2v_comm_create", "t2v_comm_size", "t2v_comm_destroy", "t2v_plan_set_comm", "t2v_comm_all_gather",
+    "t2v_comm_window_create", "t2v_comm_window_open", "t2v_comm_counters",
     "t2v_async_status", "t2v_sync_reset", "t2v_debug_poison_exchange",
 ]
 
@@ -106,6 +107,10 @@ def load():
     lib.t2v_comm_destroy.restype = None
     lib.t2v_plan_set_comm.argtypes = [vp, vp]
     lib.t2v_comm_all_gather.argtypes = [vp, vp, ctypes.c_uint64, vp]
+    lib.t2v_comm_window_create.argtypes = [vp, ctypes.c_uint64, ctypes.c_char_p]
+    lib.t2v_comm_window_open.argtypes = [vp, ctypes.c_char_p]
+    lib.t2v_comm_counters.argtypes = [vp, u64p]
+    lib.t2v_comm_counters.restype = None
     lib.t2v_async_status.restype = ctypes.c_int
     lib.t2v_sync_reset.argtypes = [vp, vp]
     lib.t2v_debug_poison_exchange.argtypes = [ctypes.c_int]
@@ -131,9 +136,11 @@ def exchange_disabled() -> bool:
 def check(rc: int):
     global _exchange_disabled
     if rc != 0:
-        if rc in (-6, -7):               # T2V_ERR_ASYNC / T2V_ERR_RESIDENCY: lower without fused norms from now on (exchange_disabled)
-            _exchange_disabled = True
         msg = load().t2v_last_error()
+        if rc in (-6, -7) and not (msg or b"").startswith(b"peer exchange"):
+            # T2V_ERR_ASYNC / T2V_ERR_RESIDENCY: lower without fused norms from now on (exchange_disabled).  (A peer-window wait that gave
+            # up is T2V_ERR_ASYNC too: the library itself sends the exchanges through RCCL from then on, the programs stay as they are.)
+            _exchange_disabled = True
         raise T2VError(f"libt2v_hip error {rc}: {msg.decode() if msg else '?'}")
 
 

@@ -146,6 +146,9 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnParams p) {
 
   for (int kt0 = 0; kt0 < p.nk; kt0 += KT) {
     __syncthreads();  // previous tile fully consumed
+#ifdef T2V_ATTN_NOSTAGE   // timing experiment only (wrong results): the K / V tile staged once
+    if (kt0 == 0)
+#endif
     if constexpr (PF) {
       lstore();
     } else {
@@ -233,7 +236,11 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnParams p) {
     for (int T = 0; T < NKT; ++T)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
+#ifdef T2V_ATTN_NOEXP     // timing experiment only (wrong results): the softmax without its transcendental
+        const float pv = __builtin_fmaf(s[T][r], p.scale_log2, neg_m);
+#else
         const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[T][r], p.scale_log2, neg_m));
+#endif
         s[T][r] = pv;
         psum += pv;
       }
@@ -281,6 +288,362 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnParams p) {
           *reinterpret_cast<f16x4*>(orow + col) = o;
           if (p.lo_off) *reinterpret_cast<f16x4*>(orow + p.lo_off + col) = lo;
         }
+      }
+  }
+}
+
+// ---- spatial self-attention at head_dim 64 with the K / V^T tiles staged by LDS-DMA (round 6) ---------------------------------------
+// Ablation of attn_kernel on the 9216-token level (profiles/r06_attention.txt): the exp2 costs 3 %, the K / V staging 32 % — every
+// workgroup (128 queries) re-stages every 64-key tile through registers, synchronously, and TRANSPOSES V with 4-byte scattered LDS writes;
+// at 9216 tokens 72 workgroups per (frame, head) repeat that transposition.  Here
+//  * V is transposed ONCE per launch in HBM by vt_transpose_kernel: vt[(batch, head)][d][key] with n_pad (multiple of 64) keys per row,
+//    zero beyond nk, the keys of every 16 stored in the order the MFMA's K-slots take them from the score registers (see attn_kernel:
+//    lane-half f, element e <-> key 4 f + (e & 3) + 8 (e >> 2)), so that one 16-byte LDS read is a whole A fragment of V^T;
+//  * a 64-key tile is then two [64 rows][128 B] images — K rows = keys, V^T rows = d — staged by 16 `global_load_lds` pieces (8 rows x
+//    128 B each, XOR chunk swizzle on the per-lane source address and on the fragment read, exactly gemm2.hip's operand tiles), no
+//    registers, no ds_write, double-buffered: the pieces of tile t + 1 are issued after the one barrier of tile t and land under its
+//    MFMAs / softmax;
+//  * NW = 8 waves (256 queries) share a tile.
+// Scores, online softmax, P fragments and the epilogue are attn_kernel's, unchanged (same values, same order: bit-identical results).
+__device__ __attribute__((aligned(256))) unsigned char attn_zero_page[256];
+
+__global__ __launch_bounds__(256) void vt_transpose_kernel(const AttnParams p, f16* vt, int n_pad) {
+  __shared__ f16 tile[64][66];                                // [key][d], 132-byte rows: the 2-byte column reads below spread over the banks
+  const int tid = threadIdx.x;
+  const int head = blockIdx.y, bo = blockIdx.z / p.b_inner, bi = blockIdx.z % p.b_inner;
+  const int k0 = blockIdx.x * 64;
+  const f16* vb = p.v + bo * p.sk_out + bi * p.sk_in + head * 64;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int u = tid + i * 256, key = u >> 3, c = u & 7;
+    f16x8 val;
+    if (k0 + key < p.nk) val = *reinterpret_cast<const f16x8*>(vb + (long)(k0 + key) * p.sk_seq + c * 8);
+    else for (int e = 0; e < 8; ++e) val[e] = (f16)0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) tile[key][c * 8 + e] = val[e];
+  }
+  __syncthreads();
+  f16* out = vt + ((long)blockIdx.z * p.heads + head) * 64 * n_pad + k0;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int u = tid + i * 256, d = u >> 3, c = u & 7;      // 8 key positions c * 8 .. c * 8 + 7 of row d
+    f16x8 val;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int g = c >> 1, f = c & 1;                         // 16-key group, lane-half slot
+      val[e] = tile[16 * g + 4 * f + (e & 3) + 8 * (e >> 2)][d];
+    }
+    *reinterpret_cast<f16x8*>(out + (long)d * n_pad + c * 8) = val;
+  }
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 4) void attn2_kernel(const AttnParams p, const f16* __restrict__ vt, int n_pad) {
+  constexpr int D = 64, KT = 64, NKK = 4, NDT = 2, NKT = 2;
+  constexpr int PIECES = 16, PPW = PIECES / NW;               // 1-KiB DMA pieces per tile (8 K + 8 V^T), per wave
+  static_assert(PIECES % NW == 0, "pieces must divide over the waves");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 16384];      // [buffer][K image 8 KiB | V^T image 8 KiB]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int head = blockIdx.y;
+  const int bo = blockIdx.z / p.b_inner, bi = blockIdx.z % p.b_inner;
+  const int q0 = blockIdx.x * (32 * NW) + wave * 32;
+  const int frow = lane & 31, fhalf = lane >> 5;
+
+  const f16* qb = p.q + bo * p.sq_out + bi * p.sq_in + head * D;
+  const f16* kb = p.k + bo * p.sk_out + bi * p.sk_in + head * D;
+  const f16* vtb = vt + ((long)blockIdx.z * p.heads + head) * 64 * n_pad;
+  f16* ob = p.o + bo * p.so_out + bi * p.so_in + head * D;
+
+  const int qrow = q0 + frow;
+  f16x8 qf[NKK];
+#pragma unroll
+  for (int kk = 0; kk < NKK; ++kk) {
+    if (qrow < p.nq) qf[kk] = *reinterpret_cast<const f16x8*>(qb + (long)qrow * p.sq_seq + kk * 16 + fhalf * 8);
+    else for (int e = 0; e < 8; ++e) qf[kk][e] = (f16)0.f;
+  }
+  f32x16 oacc[NDT];
+#pragma unroll
+  for (int d = 0; d < NDT; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  // per-lane DMA sources of this wave's pieces: piece j < 8 = keys 8 j .. 8 j + 7 of the tile, j >= 8 = rows d = 8 (j - 8) .. of V^T
+  const int lrow = lane >> 3, pch = lane & 7;
+  const f16* src0[PPW];        // source of tile 0 (K: advanced by 64 keys per tile; V^T: by 64 columns)
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int j = wave + NW * i, row = 8 * (j & 7) + lrow, lc = pch ^ ((row >> 1) & 7);
+    src0[i] = j < 8 ? kb + (long)row * p.sk_seq + lc * 8 : vtb + (long)row * n_pad + lc * 8;
+  }
+  auto stage = [&](int t, int buf) {
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int j = wave + NW * i;                            // wave-uniform
+      const f16* src = src0[i] + (long)t * (j < 8 ? (long)KT * p.sk_seq : (long)KT);
+      if (j < 8 && t * KT + 8 * (j & 7) + lrow >= p.nk) src = reinterpret_cast<const f16*>(attn_zero_page);   // K rows past the sequence
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(smem + buf * 16384 + (j >> 3) * 8192 + (j & 7) * 1024), 16, 0, 0);
+    }
+  };
+  const int nt = (p.nk + KT - 1) / KT;
+  const int sw = ((frow >> 1) & 7);                           // swizzle term of every fragment row (sub-tile rows are multiples of 32)
+  stage(0, 0);
+  for (int t = 0; t < nt; ++t) {
+    const int kt0 = t * KT;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of tile t have landed (and, at t = 0, its Q fragments)
+    __builtin_amdgcn_s_barrier();                             // ... everyone's have; everyone is done reading tile t - 1
+    asm volatile("" ::: "memory");
+    if (t + 1 < nt) stage(t + 1, (t + 1) & 1);                // wave-uniform
+    const unsigned char* kl = smem + (t & 1) * 16384;
+    const unsigned char* vl = kl + 8192;
+    const bool t1_live = (kt0 + 32) < p.nk;                   // wave-uniform
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 s[NKT];
+#pragma unroll
+    for (int T = 0; T < NKT; ++T) {
+      s[T] = zero16;
+      if (T == 1 && !t1_live) continue;
+#pragma unroll
+      for (int kk = 0; kk < NKK; ++kk) {
+        const f16x8 kf = *reinterpret_cast<const f16x8*>(kl + (T * 32 + frow) * 128 + (((kk * 2 + fhalf) ^ sw) << 4));
+        s[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[kk], kk == 0 ? zero16 : s[T], 0, 0, 0);
+      }
+    }
+    if (kt0 + KT > p.nk) {                                    // ragged last tile (wave-uniform)
+#pragma unroll
+      for (int T = 0; T < NKT; ++T)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kt0 + T * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf >= p.nk) s[T][r] = -INFINITY;
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int T = 0; T < NKT; ++T)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[T][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_tile = mx * p.scale_log2;
+    const bool grow = m_tile - m_run > 8.0f;
+    if (__builtin_amdgcn_ballot_w64(grow) != 0) {
+      const float alpha = grow ? __builtin_amdgcn_exp2f(m_run - m_tile) : 1.0f;
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < NDT; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+      m_run = grow ? m_tile : m_run;
+    }
+    float psum = 0.f;
+    const float neg_m = -m_run;
+#pragma unroll
+    for (int T = 0; T < NKT; ++T)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[T][r], p.scale_log2, neg_m));
+        s[T][r] = pv;
+        psum += pv;
+      }
+    psum += __shfl_xor(psum, 32);
+    l_run += psum;
+#pragma unroll
+    for (int T = 0; T < NKT; ++T) {
+      if (T == 1 && !t1_live) continue;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        f16x8 pf;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pf[e] = (f16)s[T][8 * u + e];
+#pragma unroll
+        for (int d = 0; d < NDT; ++d) {
+          const f16x8 vf = *reinterpret_cast<const f16x8*>(vl + (d * 32 + frow) * 128 + (((4 * T + 2 * u + fhalf) ^ sw) << 4));
+          oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, oacc[d], 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (qrow < p.nq) {
+    const float inv = 1.0f / l_run;
+    f16* orow = ob + (long)qrow * p.so_seq;
+#pragma unroll
+    for (int d = 0; d < NDT; ++d)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const int col = d * 32 + 8 * qd + 4 * fhalf;
+        f16x4 o, lo;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float val = oacc[d][4 * qd + r] * inv;
+          o[r] = (f16)val;
+          lo[r] = (f16)(val - (float)o[r]);
+        }
+        *reinterpret_cast<f16x4*>(orow + col) = o;
+        if (p.lo_off) *reinterpret_cast<f16x4*>(orow + p.lo_off + col) = lo;
+      }
+  }
+}
+
+// The same kernel with the scores of tile t + 1 issued BEFORE the softmax of tile t (experiment, round 6): the 8 Q K^T MFMAs run in the matrix
+// pipe while this wave's own VALU works on the previous tile's scores.  K tiles in a 3-deep ring (K(t + 1) is read one tile early), V^T in 2.
+template <int NW, int MINW>
+__global__ __launch_bounds__(NW * 64, MINW) void attn2p_kernel(const AttnParams p, const f16* __restrict__ vt, int n_pad) {
+  constexpr int D = 64, KT = 64, NKK = 4, NDT = 2, NKT = 2;
+  constexpr int PIECES = 16, PPW = PIECES / NW;               // 1-KiB DMA pieces per tile (8 K + 8 V^T), per wave
+  static_assert(PIECES % NW == 0, "pieces must divide over the waves");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[5 * 8192];       // K ring [3][8 KiB] | V^T ring [2][8 KiB]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int head = blockIdx.y;
+  const int bo = blockIdx.z / p.b_inner, bi = blockIdx.z % p.b_inner;
+  const int q0 = blockIdx.x * (32 * NW) + wave * 32;
+  const int frow = lane & 31, fhalf = lane >> 5;
+
+  const f16* qb = p.q + bo * p.sq_out + bi * p.sq_in + head * D;
+  const f16* kb = p.k + bo * p.sk_out + bi * p.sk_in + head * D;
+  const f16* vtb = vt + ((long)blockIdx.z * p.heads + head) * 64 * n_pad;
+  f16* ob = p.o + bo * p.so_out + bi * p.so_in + head * D;
+
+  const int qrow = q0 + frow;
+  f16x8 qf[NKK];
+#pragma unroll
+  for (int kk = 0; kk < NKK; ++kk) {
+    if (qrow < p.nq) qf[kk] = *reinterpret_cast<const f16x8*>(qb + (long)qrow * p.sq_seq + kk * 16 + fhalf * 8);
+    else for (int e = 0; e < 8; ++e) qf[kk][e] = (f16)0.f;
+  }
+  f32x16 oacc[NDT];
+#pragma unroll
+  for (int d = 0; d < NDT; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  // per-lane DMA sources of this wave's pieces: piece j < 8 = keys 8 j .. 8 j + 7 of the tile, j >= 8 = rows d = 8 (j - 8) .. of V^T
+  const int lrow = lane >> 3, pch = lane & 7;
+  const f16* src0[PPW];        // source of tile 0 (K: advanced by 64 keys per tile; V^T: by 64 columns)
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int j = wave + NW * i, row = 8 * (j & 7) + lrow, lc = pch ^ ((row >> 1) & 7);
+    src0[i] = j < 8 ? kb + (long)row * p.sk_seq + lc * 8 : vtb + (long)row * n_pad + lc * 8;
+  }
+  auto stage = [&](int t, bool want_k, bool want_v) {          // K(t) -> K ring slot t % 3, V^T(t) -> V ring slot t & 1
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int j = wave + NW * i;                            // wave-uniform
+      if (j < 8 ? !want_k : !want_v) continue;
+      const f16* src = src0[i] + (long)t * (j < 8 ? (long)KT * p.sk_seq : (long)KT);
+      if (j < 8 && t * KT + 8 * (j & 7) + lrow >= p.nk) src = reinterpret_cast<const f16*>(attn_zero_page);
+      unsigned char* dst = j < 8 ? smem + (t % 3) * 8192 + (j & 7) * 1024 : smem + 3 * 8192 + (t & 1) * 8192 + (j & 7) * 1024;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+  };
+  const int nt = (p.nk + KT - 1) / KT;
+  const int sw = ((frow >> 1) & 7);
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  auto scores = [&](int t, f32x16 (&s)[NKT]) {                // S^T of tile t from its K ring slot
+    const unsigned char* kl = smem + (t % 3) * 8192;
+    const bool t1_live = (t * KT + 32) < p.nk;
+#pragma unroll
+    for (int T = 0; T < NKT; ++T) {
+      s[T] = zero16;
+      if (T == 1 && !t1_live) continue;
+#pragma unroll
+      for (int kk = 0; kk < NKK; ++kk) {
+        const f16x8 kf = *reinterpret_cast<const f16x8*>(kl + (T * 32 + frow) * 128 + (((kk * 2 + fhalf) ^ sw) << 4));
+        s[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[kk], kk == 0 ? zero16 : s[T], 0, 0, 0);
+      }
+    }
+  };
+  stage(0, true, true);
+  if (nt > 1) stage(1, true, false);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  f32x16 s[NKT], sn[NKT];
+  scores(0, s);
+  for (int t = 0; t < nt; ++t) {
+    const int kt0 = t * KT;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // K(t + 1), V^T(t): this wave's pieces have landed
+    __builtin_amdgcn_s_barrier();                             // ... everyone's; everyone is done with K(t) [scores issued last iteration], V^T(t - 1)
+    asm volatile("" ::: "memory");
+    if (t + 2 < nt) stage(t + 2, true, false);
+    if (t + 1 < nt) stage(t + 1, false, true);
+    if (t + 1 < nt) scores(t + 1, sn);                        // in the matrix pipe while the VALU below works on tile t
+    const unsigned char* vl = smem + 3 * 8192 + (t & 1) * 8192;
+    const bool t1_live = (kt0 + 32) < p.nk;                   // wave-uniform
+    if (kt0 + KT > p.nk) {                                    // ragged last tile (wave-uniform)
+#pragma unroll
+      for (int T = 0; T < NKT; ++T)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kt0 + T * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf >= p.nk) s[T][r] = -INFINITY;
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int T = 0; T < NKT; ++T)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[T][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_tile = mx * p.scale_log2;
+    const bool grow = m_tile - m_run > 8.0f;
+    if (__builtin_amdgcn_ballot_w64(grow) != 0) {
+      const float alpha = grow ? __builtin_amdgcn_exp2f(m_run - m_tile) : 1.0f;
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < NDT; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+      m_run = grow ? m_tile : m_run;
+    }
+    float psum = 0.f;
+    const float neg_m = -m_run;
+#pragma unroll
+    for (int T = 0; T < NKT; ++T)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[T][r], p.scale_log2, neg_m));
+        s[T][r] = pv;
+        psum += pv;
+      }
+    psum += __shfl_xor(psum, 32);
+    l_run += psum;
+#pragma unroll
+    for (int T = 0; T < NKT; ++T) {
+      if (T == 1 && !t1_live) continue;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        f16x8 pf;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pf[e] = (f16)s[T][8 * u + e];
+#pragma unroll
+        for (int d = 0; d < NDT; ++d) {
+          const f16x8 vf = *reinterpret_cast<const f16x8*>(vl + (d * 32 + frow) * 128 + (((4 * T + 2 * u + fhalf) ^ sw) << 4));
+          oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, oacc[d], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int T = 0; T < NKT; ++T) s[T] = sn[T];
+  }
+  if (qrow < p.nq) {
+    const float inv = 1.0f / l_run;
+    f16* orow = ob + (long)qrow * p.so_seq;
+#pragma unroll
+    for (int d = 0; d < NDT; ++d)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const int col = d * 32 + 8 * qd + 4 * fhalf;
+        f16x4 o, lo;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float val = oacc[d][4 * qd + r] * inv;
+          o[r] = (f16)val;
+          lo[r] = (f16)(val - (float)o[r]);
+        }
+        *reinterpret_cast<f16x4*>(orow + col) = o;
+        if (p.lo_off) *reinterpret_cast<f16x4*>(orow + p.lo_off + col) = lo;
       }
   }
 }
@@ -1003,6 +1366,21 @@ hipError_t t2v_launch_attention(const t2v_op& op, hipStream_t s) {
   if (p.nq <= 0 || p.nk <= 0 || !(op.f[0] > 0.f)) return hipErrorInvalidValue;
   const int nbatch = p.b_outer * p.b_inner;
   const int hd = op.i[14] > 0 ? op.i[14] : 64;
+  if (op.p[6] != 0) {
+    // round 6: V transposed once in HBM into the scratch p[6] (fp16 [batch * heads * 64, i[17]]), K / V^T tiles by LDS-DMA (attn2_kernel);
+    // validated by the executor: head_dim 64, not causal, i[17] = keys padded to a multiple of 64
+    f16* vt = reinterpret_cast<f16*>(op.p[6]);
+    const int n_pad = op.i[17];
+    hipLaunchKernelGGL(vt_transpose_kernel, dim3(n_pad / 64, p.heads, nbatch), dim3(256), 0, s, p, vt, n_pad);
+    if (op.i[18] == 4) hipLaunchKernelGGL((attn2_kernel<4>), dim3((p.nq + 127) / 128, p.heads, nbatch), dim3(256), 0, s, p, vt, n_pad);
+#ifdef T2V_ATTN2_EXPERIMENTS   // the score-pipelined variant: i[18] = 12 (4 waves, 3 per SIMD) / 16 (8 waves, 2 per SIMD) / 20 (8 waves, 3 per SIMD)
+    else if (op.i[18] == 12) hipLaunchKernelGGL((attn2p_kernel<4, 3>), dim3((p.nq + 127) / 128, p.heads, nbatch), dim3(256), 0, s, p, vt, n_pad);
+    else if (op.i[18] == 16) hipLaunchKernelGGL((attn2p_kernel<8, 2>), dim3((p.nq + 255) / 256, p.heads, nbatch), dim3(512), 0, s, p, vt, n_pad);
+    else if (op.i[18] == 20) hipLaunchKernelGGL((attn2p_kernel<8, 3>), dim3((p.nq + 255) / 256, p.heads, nbatch), dim3(512), 0, s, p, vt, n_pad);
+#endif
+    else hipLaunchKernelGGL((attn2_kernel<8>), dim3((p.nq + 255) / 256, p.heads, nbatch), dim3(512), 0, s, p, vt, n_pad);
+    return hipGetLastError();
+  }
   const bool small = p.nq <= 32;
   static const bool prefetch_env = [] { const char* e = getenv("T2V_ATTN_PREFETCH"); return e ? atoi(e) != 0 : false; }();
   const bool prefetch = prefetch_env && p.nk > KT_MAIN;

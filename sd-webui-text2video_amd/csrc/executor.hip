@@ -174,6 +174,8 @@ int validate_op(const t2v_op& op, int idx) {
       if (op.i[16] < 0) return bad("negative low-order output offset");
       if (!(op.f[0] > 0.f)) return bad("attention scale must be > 0");
       if (op.p[0] == 0 || op.p[1] == 0 || op.p[2] == 0 || op.p[3] == 0) return bad("null attention pointer");
+      if (op.p[6] != 0 && (d != 64 || op.i[15] != 0 || op.i[17] < op.i[1] || op.i[17] % 64 != 0 || (op.i[18] != 0 && op.i[18] != 4 && op.i[18] != 8)))
+        return bad("attention with a V^T scratch (p[6]): head_dim 64, not causal, i[17] = keys padded to a multiple of 64, i[18] = 0 | 4 | 8 waves");
       return 0;
     }
     case T2V_OP_RELPOS_ATTN:
@@ -513,6 +515,27 @@ int t2v_comm_create(const unsigned char id[128], int nranks, int rank, t2v_comm*
 }
 
 int t2v_comm_size(const t2v_comm* comm) { return t2v_comm_impl_size(comm); }
+
+int t2v_comm_window_create(t2v_comm* comm, uint64_t slot_bytes, unsigned char handle_out[64]) {
+  if (!comm || !handle_out || slot_bytes == 0) return fail(T2V_ERR_BAD_ARG, "window_create needs a communicator, a slot size and room for the handle");
+  std::string err;
+  const int rc = t2v_comm_impl_window_create(comm, (size_t)slot_bytes, handle_out, err);
+  return rc == T2V_OK ? rc : fail(rc, err);
+}
+
+int t2v_comm_window_open(t2v_comm* comm, const unsigned char* handles) {
+  if (!comm) return fail(T2V_ERR_BAD_ARG, "window_open needs a communicator");
+  std::string err;
+  const int rc = t2v_comm_impl_window_open(comm, handles, err);
+  return rc == T2V_OK ? rc : fail(rc, err);
+}
+
+void t2v_comm_counters(const t2v_comm* comm, uint64_t out[2]) {
+  unsigned long long v[2];
+  t2v_comm_impl_counters(comm, v);
+  out[0] = v[0];
+  out[1] = v[1];
+}
 
 void t2v_comm_destroy(t2v_comm* comm) { t2v_comm_impl_destroy(comm); }
 

@@ -547,7 +547,7 @@ __global__ __launch_bounds__(GNC_THREADS) void gn_coop_kernel(const T* __restric
 // number of workgroups of that kernel the occupancy API allows per CU.
 struct CoopState {
   unsigned* fault = nullptr;     // hipHostMalloc'ed, mapped: written by a timed-out waiter, read by the host
-  bool tried = false, disabled = false, reported = false;
+  bool tried = false, disabled = false, reported = false, peer_reported = false;
 };
 CoopState g_coop;
 
@@ -557,7 +557,8 @@ unsigned* coop_fault_word() {
     void* p = nullptr;
     if (hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess && p != nullptr) {
       g_coop.fault = static_cast<unsigned*>(p);
-      *g_coop.fault = 0u;
+      g_coop.fault[0] = 0u;      // word 0: a fused-norm wait gave up;  word 1: a peer-window wait gave up (comm.hip)
+      g_coop.fault[1] = 0u;
     } else {
       (void)hipGetLastError();
       g_coop.disabled = true;      // no way to report a timeout -> never take the barrier path
@@ -936,12 +937,26 @@ bool t2v_coop_allowed() {
   return true;
 }
 
+unsigned* t2v_peer_fault_word() {
+  unsigned* f = coop_fault_word();
+  return f ? f + 1 : nullptr;
+}
+
 int t2v_async_fault_pending() {
-  return g_coop.fault != nullptr && __atomic_load_n(g_coop.fault, __ATOMIC_RELAXED) != 0u && !g_coop.reported;
+  if (g_coop.fault == nullptr) return 0;
+  if (__atomic_load_n(g_coop.fault + 1, __ATOMIC_RELAXED) != 0u && !g_coop.peer_reported) return 1;
+  return __atomic_load_n(g_coop.fault, __ATOMIC_RELAXED) != 0u && !g_coop.reported;
 }
 
 int t2v_async_fault_consume(std::string* msg) {
   if (!t2v_async_fault_pending()) return 0;
+  if (__atomic_load_n(g_coop.fault + 1, __ATOMIC_RELAXED) != 0u && !g_coop.peer_reported) {
+    g_coop.peer_reported = true;
+    if (msg) *msg = "peer exchange: a workgroup gave up waiting for a peer rank's message in its window (T2V_PEER_TIMEOUT_MS; the peer died, "
+                    "ran a different program, or its stores are not visible here); the results of the run that was in flight are invalid.  "
+                    "The exchanges of this process go through RCCL from now on (T2V_PEER_WINDOW=0 selects that from the start)";
+    return 1;
+  }
   g_coop.reported = true;
   g_coop.disabled = true;
   if (msg) *msg = "fused normalisation: a workgroup gave up waiting for the statistics of the other workgroups of its launch (the device is "

@@ -196,6 +196,7 @@ inline long t2v_grid_capacity(const void* kernel, int threads, size_t lds, hipSt
 // and the cooperative path stays off for the rest of the process.
 void t2v_exchange_ids(unsigned* seq, unsigned* want);     // sequence number of the next fused-norm launch (0, 0: barrier mode — T2V_EXCHANGE=barrier)
 unsigned* t2v_coop_fault_word();                        // the host-mapped fault word of the bounded grid barriers (null: unavailable)
+unsigned* t2v_peer_fault_word();                        // its neighbour: raised by a peer-window wait that gave up (comm.hip)
 bool t2v_coop_allowed();                                // false once a barrier timed out in this process (or the word could not be mapped)
 int t2v_async_fault_pending();                          // 1 = a fault was raised and not yet reported
 int t2v_async_fault_consume(std::string* msg);          // returns 1 (and clears "pending", keeps the path disabled) if a fault was raised
@@ -1191,6 +1192,9 @@ int t2v_comm_impl_unique_id(unsigned char id[128], std::string& err);
 int t2v_comm_impl_create(const unsigned char id[128], int nranks, int rank, t2v_comm** out, std::string& err);
 void t2v_comm_impl_destroy(t2v_comm* c);
 int t2v_comm_impl_size(const t2v_comm* c);
+int t2v_comm_impl_window_create(t2v_comm* c, size_t slot_bytes, unsigned char handle_out[64], std::string& err);
+int t2v_comm_impl_window_open(t2v_comm* c, const unsigned char* handles, std::string& err);
+void t2v_comm_impl_counters(const t2v_comm* c, unsigned long long out[2]);
 int t2v_comm_allgather(t2v_comm* c, void* base, size_t bytes, int nparts, int part, hipStream_t s, std::string& err);
 int t2v_comm_impl_all_gather(t2v_comm* c, void* base, size_t bytes, hipStream_t s, std::string& err);
 int t2v_comm_halo(t2v_comm* c, void* base, size_t frame_bytes, int F, int prev, int next, hipStream_t s, std::string& err);

@@ -129,6 +129,43 @@ class Communicator:
         handle = ctypes.c_void_p()
         L.check(lib.t2v_comm_create(box[0], len(ranks), index, ctypes.byref(handle)))
         self.handle, self._lib, self.size = handle, lib, len(ranks)
+        self.window = self._attach_window(group, ranks, device)
+
+    def _attach_window(self, group, ranks, device) -> Optional[str]:
+        """Peer window (include/t2v_hip.h ABI 8, csrc/comm.hip): every rank allocates a mailbox, the 64-byte IPC handles travel over
+        torch.distributed, every rank maps the others' — from then on an exchange whose messages fit a slot is one kernel of the library
+        (stores into the peer's window over xGMI + a sequence flag) instead of an RCCL group call.  Collective decision: the window is
+        used only if EVERY rank of the group could create and open it (otherwise all stay on RCCL).  T2V_PEER_WINDOW=0 switches it off;
+        T2V_PEER_SLOT_MB sizes a slot (default 16: the largest reshard chunk of a 32-frame slice at the 32x32 level is 8.4 MB).
+        -> a description for bench.py's `rccl_communicators`, None when not attached."""
+        n = len(ranks)
+        if n < 2 or n > 8 or os.environ.get("T2V_PEER_WINDOW", "1") == "0":
+            return None
+        slot = int(float(os.environ.get("T2V_PEER_SLOT_MB", "16")) * (1 << 20))
+        cpu = torch.device("cpu") if _host_staged(group) else torch.device(device)
+        buf = ctypes.create_string_buffer(64)
+        ok = self._lib.t2v_comm_window_create(self.handle, slot, buf) == 0
+        mine = torch.tensor([1 if ok else 0] + list(buf.raw), dtype=torch.uint8, device=cpu)
+        allh = [torch.empty_like(mine) for _ in range(n)]
+        dist.all_gather(allh, mine, group=group)
+        if not all(int(h[0]) == 1 for h in allh):
+            self._lib.t2v_comm_window_open(self.handle, None)
+            return None
+        blob = b"".join(bytes(h[1:].cpu().tolist()) for h in allh)
+        ok = self._lib.t2v_comm_window_open(self.handle, blob) == 0
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=cpu)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if int(flag.item()) != 1:
+            # some rank could not map a peer: nobody may use the windows (a rank that opened them would push into mailboxes nobody reads)
+            self._lib.t2v_comm_window_open(self.handle, None)
+            return None
+        return f"peer window: {n} ranks x 2 slots x {slot >> 20} MiB per rank, device-initiated stores + sequence flags (csrc/comm.hip)"
+
+    def counters(self) -> Tuple[int, int]:
+        """(exchanges that went over the peer window, exchanges that went through RCCL) since this communicator was created."""
+        out = (ctypes.c_uint64 * 2)()
+        self._lib.t2v_comm_counters(self.handle, out)
+        return int(out[0]), int(out[1])
 
     def __del__(self):
         try:
@@ -336,19 +373,39 @@ class _Runner:
         if self.pair.size == 1:
             return None
         gc, dev = self.pair.gcomm, self.pipe.device
-        in_library, equal = gc.communicator(dev) is not None, True
-        if in_library:
-            mine = torch.full((4099,), float(self.pair.rank + 1), device=dev) + torch.arange(4099, device=dev)
-            a, b = torch.empty(2 * 4099, device=dev), torch.empty(2 * 4099, device=dev)
-            gc.all_gather_into(a, mine)
-            all_gather_into(b, mine, group=gc.group)
-            torch.cuda.synchronize(dev)
-            equal = bool(torch.equal(a, b))
-        flag = torch.tensor([0 if equal else 1], dtype=torch.int32)
-        if not _host_staged(None):
-            flag = flag.to(dev)
-        dist.all_reduce(flag)
-        return {"ok": int(flag.item()) == 0, "eps_and_frame_gathers_in_library": bool(in_library),
+        in_library = gc.communicator(dev) is not None
+        released = None
+
+        def once() -> bool:
+            equal = True
+            for n in (4099, 4100) if in_library else ():      # 16 396 bytes: RCCL carries it; 16 400 bytes = 16-byte units: eligible for the peer window
+                mine = torch.full((n,), float(self.pair.rank + 1), device=dev) + torch.arange(n, device=dev)
+                a, b = torch.empty(2 * n, device=dev), torch.empty(2 * n, device=dev)
+                try:
+                    gc.all_gather_into(a, mine)
+                    torch.cuda.synchronize(dev)
+                    L.async_status()                            # a peer-window wait that gave up shows here
+                except L.T2VError:
+                    equal = False
+                    a.zero_()
+                all_gather_into(b, mine, group=gc.group)
+                torch.cuda.synchronize(dev)
+                equal = equal and bool(torch.equal(a, b))
+            flag = torch.tensor([0 if equal else 1], dtype=torch.int32)
+            if not _host_staged(None):
+                flag = flag.to(dev)
+            dist.all_reduce(flag)
+            return int(flag.item()) == 0
+
+        ok = once()
+        if not ok and in_library and gc._comm.window:
+            # round 6: the gathers went over the peer window and differ (or a wait gave up): release it on both ranks (same verdict
+            # everywhere: all-reduced) and check the RCCL transport before giving the layout up
+            gc._comm._lib.t2v_comm_window_open(gc._comm.handle, None)
+            gc._comm.window, released = None, "released after a failed check over the peer window; this result is the RCCL transport's"
+            ok = once()
+        return {"ok": ok, "eps_and_frame_gathers_in_library": bool(in_library),
+                "peer_windows": released or (gc._comm.window if in_library else None),
                 "compared": ("t2v_comm_all_gather on the pair's library communicator vs torch.distributed: equal on every rank" if in_library
                              else "the pair's gathers run through torch.distributed in this set-up: nothing to compare")}
 
@@ -456,7 +513,9 @@ class _TShardRunner:
 
         return [{"kind": "libt2v_hip t2v_comm: RCCL communicator owned by the library (statistics + raw boundary frames as one grouped "
                          "exchange per temporal convolution, statistics / K-V all-gathers, frame<->pixel all-to-all as program ops on the "
-                         "launch stream)", "size": lib_comm, "t_group_ranks": ts.size},
+                         "launch stream)", "size": lib_comm, "t_group_ranks": ts.size,
+                 "peer_window": (ts._comm.window if ts._comm is not None else None),
+                 "exchanges_via_window_and_via_rccl": (list(ts._comm.counters()) if ts._comm is not None else None)},
                 {"kind": stack(self.topo.pair_comm, dist.get_backend(self.topo.pair_group)) + ": eps all-gather per step", "size": 2},
                 {"kind": stack(self.topo.world_comm, dist.get_backend()) + ": uint8 frame gather per video", "size": self.topo.world}]
 
@@ -467,6 +526,33 @@ class _TShardRunner:
         through `ShardedExecutor`, whose collectives go through torch.distributed (the path the gloo CPU tests pin against the
         unsharded forward).  Both must be BIT-equal on every rank; bench.py times nothing if they are not (a wrong
         answer must not be timed).  Collective: every rank of the job calls it."""
+        first = self._self_check_once(cond)
+        if first["ok"] or not first.pop("_windows"):
+            first.pop("_windows", None)
+            return first
+        # Round 6: the exchanges went over peer windows (device-initiated stores into IPC-mapped mailboxes) and the result differs from the
+        # host executor's, or a wait gave up.  Every rank has the same verdict (all-reduced): release the windows everywhere and check the
+        # RCCL transport before anything is given up.
+        for comm in self._library_comms():
+            comm._lib.t2v_comm_window_open(comm.handle, None)
+            comm.window = None
+        second = self._self_check_once(cond)
+        second.pop("_windows", None)
+        second["peer_windows"] = "released: the first check over peer windows failed (" + first["compared"] + "); this result is the RCCL transport's"
+        return second
+
+    def _library_comms(self) -> List[Communicator]:
+        topo = self.topo
+        return [c for c in (topo.tshard._comm, topo.pair_comm._comm, topo.world_comm._comm) if c is not None]
+
+    def _all_ok(self, ok: bool) -> bool:
+        flag = torch.tensor([0 if ok else 1], dtype=torch.int32)
+        if not _host_staged(None):
+            flag = flag.to(self.pipe.device)
+        dist.all_reduce(flag)
+        return int(flag.item()) == 0
+
+    def _self_check_once(self, cond) -> dict:
         from .program import BoundProgram
         net, topo, dev = self.pipe.sd_model, self.topo, self.pipe.device
         spec = topo.spec
@@ -477,13 +563,24 @@ class _TShardRunner:
         c = cond.to(dev)
         saved_env = os.environ.get("T2V_COLLECTIVES")
         net.t_shard = topo.tshard
+        n_coll, in_library, equal, why = 0, False, True, ""
         try:
-            out_lib = net(x, t, c).clone()
-            comp = next(cmp for key, cmp in net._programs.items() if spec in key)
-            n_coll = sum(1 for op in comp.prog.ops if op.kind in COLLECTIVE_KINDS)
-            in_library = isinstance(comp.bound, BoundProgram) and comp.bound.comm is not None
-            equal = True
-            if in_library:
+            try:
+                out_lib = net(x, t, c).clone()
+                torch.cuda.synchronize(dev)
+                L.async_status()                                    # a peer-window wait that gave up shows here, not in the forward's status
+            except L.T2VError as e:
+                equal, why = False, f"the library forward failed: {e}"
+            # every rank learns whether every rank's library forward went through BEFORE the host-executor forward (a collective) starts
+            lib_ok = self._all_ok(equal)
+            comp = next((cmp for key, cmp in net._programs.items() if spec in key), None)
+            if comp is not None:
+                n_coll = sum(1 for op in comp.prog.ops if op.kind in COLLECTIVE_KINDS)
+                in_library = isinstance(comp.bound, BoundProgram) and comp.bound.comm is not None
+            if not lib_ok:
+                equal = False
+                why = why or "the library forward failed on another rank"
+            elif in_library:
                 keep_bound, keep_arena = comp.bound, comp.arena
                 os.environ["T2V_COLLECTIVES"] = "host"
                 comp.bound = None                                   # re-bind: fresh arena, exchanges from the host
@@ -502,25 +599,24 @@ class _TShardRunner:
         # the two gathers AROUND the forward (eps pair per step, uint8 frames per video): library communicators against torch.distributed
         gathers_in_library = False
         for gc, n in ((topo.pair_comm, 2), (topo.world_comm, topo.world)):
-            if gc.communicator(dev) is not None:
+            if equal and gc.communicator(dev) is not None:
                 gathers_in_library = True
-                mine = torch.full((4099,), float(topo.rank + 1), device=dev) + torch.arange(4099, device=dev)
-                a, b = torch.empty(n * 4099, device=dev), torch.empty(n * 4099, device=dev)
+                mine = torch.full((4100,), float(topo.rank + 1), device=dev) + torch.arange(4100, device=dev)     # 16-byte units: window-eligible
+                a, b = torch.empty(n * 4100, device=dev), torch.empty(n * 4100, device=dev)
                 gc.all_gather_into(a, mine)
                 all_gather_into(b, mine, group=gc.group)
                 torch.cuda.synchronize(dev)
                 equal = equal and bool(torch.equal(a, b))
-        flag = torch.tensor([0 if equal else 1], dtype=torch.int32)
-        if _host_staged(None):
-            dist.all_reduce(flag)
-        else:
-            flag = flag.to(dev)
-            dist.all_reduce(flag)
-        ok = int(flag.item()) == 0
+        windows = [c.window for c in self._library_comms() if c.window]
+        via = [c.counters() for c in self._library_comms()]
+        ok = self._all_ok(equal)
+        transport = (f"peer windows ({sum(v[0] for v in via)} exchanges as device-initiated stores, {sum(v[1] for v in via)} through RCCL)" if windows
+                     else "RCCL on the launch stream")
         return {"ok": ok, "collective_ops_per_forward": n_coll,
-                "compared": ("library communicator (RCCL on the launch stream) vs host executor (torch.distributed): bit-equal on every rank"
-                             if in_library else "exchanges already run through the host executor in this set-up (gloo group): nothing to compare"),
-                "in_library": bool(in_library), "eps_and_frame_gathers_in_library": bool(gathers_in_library)}
+                "compared": (why or (f"library communicator ({transport}) vs host executor (torch.distributed): bit-equal on every rank"
+                                     if in_library else "exchanges already run through the host executor in this set-up (gloo group): nothing to compare")),
+                "in_library": bool(in_library), "eps_and_frame_gathers_in_library": bool(gathers_in_library),
+                "peer_windows": windows or None, "_windows": bool(windows)}
 
     @torch.no_grad()
     def __call__(self, cond, uncond, seed):

@@ -850,7 +850,7 @@ class Program:
                   b_outer: int, b_inner: int, q_strides, kv_strides, o_strides, scale: float, head_dim: int = 64,
                   rel_k: Optional[Ref] = None, rel_v: Optional[Ref] = None, max_rel: int = 0, causal: bool = False,
                   q_offset: int = 0, relpos_mfma: Optional[int] = None, lo_off: int = 0,
-                  rel_k16: Optional[Ref] = None, rel_vT16: Optional[Ref] = None) -> Op:
+                  rel_k16: Optional[Ref] = None, rel_vT16: Optional[Ref] = None, vt_scratch: Optional[Buf] = None, waves: int = 0) -> Op:
         """softmax(q k^T scale) v over strided (sequence, outer, inner) batches.  With rel_k / rel_v (fp32
         [2*max_rel+1, head_dim] tables) the LVDM relative-position temporal attention op is emitted instead.
         lo_off (elements): also store the low-order fp16 image of every output value at o + lo_off (rows [hi | lo] for a K-doubled
@@ -880,6 +880,13 @@ class Program:
             op.i[15] = 1
         if rel_k is None:
             op.i[16] = lo_off
+            if vt_scratch is not None:
+                # round 6 (csrc/attention.hip attn2_kernel): V transposed once per launch into this scratch — fp16 [b_outer * b_inner * heads * 64,
+                # keys padded to a multiple of 64] — and the K / V^T tiles staged by LDS-DMA; head_dim 64, not causal
+                n_pad = -(-nk // 64) * 64
+                assert head_dim == 64 and not causal and vt_scratch.dtype == "f16" and vt_scratch.ld == n_pad
+                assert vt_scratch.rows >= b_outer * b_inner * heads * 64 and waves in (0, 4, 8)
+                op.p[6], op.i[17], op.i[18] = vt_scratch.ref, n_pad, waves
         op.i[5:8] = list(q_strides)
         op.i[8:11] = list(kv_strides)
         op.i[11:14] = list(o_strides)

@@ -49,6 +49,8 @@ kinds = [op.kind for op in comp.prog.ops if op.kind in COLLECTIVE_KINDS]
 assert L.OP_ALLGATHER in kinds and L.OP_STATS_HALO in kinds and (L.OP_ALLTOALL in kinds or 64 % world)
 out_lib2 = net(xl, t, y).clone()
 torch.cuda.synchronize()
+via_window, via_rccl = comp.bound.comm.counters()          # two forwards: how many of their exchanges were kernels of the library (peer window)
+window_desc = comp.bound.comm.window
 # (2) the same op records through the host executor (torch.distributed collectives on views of the arena)
 os.environ["T2V_COLLECTIVES"] = "host"
 comp.bound = None
@@ -76,6 +78,13 @@ assert gc._comm is not None and gc._comm.size == world
 parallel.all_gather_into(via_torch, mine, group=dist.group.WORLD)
 torch.cuda.synchronize()
 gathers_equal = bool(torch.equal(via_lib, via_torch))
+# (the 6002-byte parts above are not made of 16-byte units: RCCL carries them even with a peer window; an eps-sized part goes over the window)
+mine2 = torch.randn(4 * F * 64, device=dev, generator=torch.Generator(device=dev).manual_seed(rank)).float()
+via_lib2, via_torch2 = torch.empty(world * mine2.numel(), device=dev), torch.empty(world * mine2.numel(), device=dev)
+gc.all_gather_into(via_lib2, mine2)
+parallel.all_gather_into(via_torch2, mine2, group=dist.group.WORLD)
+torch.cuda.synchronize()
+gathers_equal = gathers_equal and bool(torch.equal(via_lib2, via_torch2))
 pad = torch.zeros(1, 4, spec.max_frames, 8, 8, device=dev, dtype=out_lib.dtype)
 pad[:, :, :spec.frames] = out_lib
 if backend == "nccl":
@@ -88,7 +97,8 @@ else:
 res = {"rank": rank, "lib_vs_host_equal": bool(torch.equal(out_lib, out_host)), "rerun_equal": bool(torch.equal(out_lib, out_lib2)),
        "n_collectives": len(kinds), "alltoall": kinds.count(L.OP_ALLTOALL), "halo": kinds.count(L.OP_HALO_EXCHANGE),
        "stats_halo": kinds.count(L.OP_STATS_HALO), "allgather": kinds.count(L.OP_ALLGATHER),
-       "two_exchange_form_equal": bool(torch.equal(out_lib, out_two)), "group_comm_gather_equal": gathers_equal, "n_collectives_two_exchange_form": len(kinds2)}
+       "two_exchange_form_equal": bool(torch.equal(out_lib, out_two)), "group_comm_gather_equal": gathers_equal, "n_collectives_two_exchange_form": len(kinds2),
+       "via_window": via_window, "via_rccl": via_rccl, "window": window_desc, "gather_via_window": gc._comm.counters()[0]}
 if rank == 0:
     net.t_shard = None
     os.environ.pop("T2V_COLLECTIVES")

@@ -45,14 +45,19 @@ def _free_port():
 CASES = [(3, 7)] + ([(2, 5), (4, 10)] if os.environ.get("T2V_TEST_FULL") == "1" else [])      # (round 5: 3 ranks, uneven 3 + 3 + 1, is the default case)
 
 
+@pytest.mark.parametrize("window", [0, 1])
 @pytest.mark.parametrize("world,frames", CASES)
-def test_library_collectives_multi_process_one_gpu(fake_rccl, world, frames):
+def test_library_collectives_multi_process_one_gpu(fake_rccl, world, frames, window):
+    """window = 1 (round 6): the exchanges as device-initiated stores into IPC-mapped peer windows (csrc/comm.hip peer_exchange_kernel) —
+    the processes map each other's mailboxes with hipIpcOpenMemHandle, which works between processes on one device exactly as between
+    the GPUs of a node; NO call of the RCCL stand-in may carry an exchange of the forward.  window = 0: every exchange through the
+    (stand-in) RCCL entry points."""
     port = _free_port()
     procs = []
     for r in range(world):
         env = {**os.environ, "RANK": str(r), "WORLD_SIZE": str(world), "LOCAL_RANK": str(r), "MASTER_ADDR": "127.0.0.1",
                "MASTER_PORT": str(port), "T2V_TEST_FRAMES": str(frames), "T2V_TEST_BACKEND": "gloo", "T2V_TEST_ONE_DEVICE": "1",
-               "T2V_RCCL_SONAME": fake_rccl, "T2V_GN_COOP": "0"}        # several processes on one GPU: no grid-barrier kernels
+               "T2V_RCCL_SONAME": fake_rccl, "T2V_GN_COOP": "0", "T2V_PEER_WINDOW": str(window)}        # several processes on one GPU: no grid-barrier kernels
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "rccl_worker.py")], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -70,6 +75,10 @@ def test_library_collectives_multi_process_one_gpu(fake_rccl, world, frames):
         results.append(json.loads(next(ln for ln in out.splitlines() if ln.startswith("RESULT "))[7:]))
     print(f"library collectives over tests/fake_rccl, {world} processes on one GPU: {results[0]}")
     for res in results:
+        if window:
+            assert res["window"] and res["via_rccl"] == 0 and res["via_window"] == 2 * res["n_collectives"] and res["gather_via_window"] == 1
+        else:
+            assert res["window"] is None and res["via_window"] == 0 and res["via_rccl"] == 2 * res["n_collectives"]
         assert res["lib_vs_host_equal"] and res["rerun_equal"] and res["n_collectives"] <= 139 + 2 * 17
         # round 5: one T2V_OP_STATS_HALO per temporal convolution (statistics parts + raw boundary frames in ONE group of transfers)
         # instead of an all-gather and a halo exchange; bit-equal to the two-exchange lowering
@@ -79,3 +88,32 @@ def test_library_collectives_multi_process_one_gpu(fake_rccl, world, frames):
     if 64 % world == 0:
         assert results[0]["alltoall"] > 0          # frame <-> pixel resharding of the TemporalTransformers
     assert results[0]["rel_l2_vs_unsharded"] < 4e-3
+
+
+def test_peer_window_wait_is_bounded(fake_rccl):
+    """A peer that never sends: the exchange kernel gives up after T2V_PEER_TIMEOUT_MS, the host gets T2V_ERR_ASYNC ("peer exchange")
+    instead of a hung device, and after both ranks released their windows the same gather runs through the RCCL entry points."""
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = {**os.environ, "RANK": str(r), "WORLD_SIZE": "2", "LOCAL_RANK": str(r), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+               "T2V_RCCL_SONAME": fake_rccl, "T2V_PEER_WINDOW": "1", "T2V_PEER_TIMEOUT_MS": "400"}
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "peer_fault_worker.py")], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = []
+    try:
+        for p in procs:
+            out, _ = p.communicate(timeout=240)
+            outs.append(out)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    res = []
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{out[-3000:]}"
+        res.append(json.loads(next(ln for ln in out.splitlines() if ln.startswith("RESULT "))[7:]))
+    print(f"peer window, bounded wait: {res}")
+    assert all(x["healthy_first"] and x["after_release_equal"] for x in res)
+    assert res[0]["fault"] and "peer exchange" in res[0]["fault"] and 0.3 < res[0]["waited_s"] < 5.0
+    assert res[1]["fault"] is None
