@@ -253,6 +253,9 @@ enum t2v_gather {
  * RESHARD_ROWS: row r reads src row (r / P) * S_src + r % P and writes dst row (r / P) * S_dst + r % P (+ residual at the dst row)
  *      i: 0 rows, 1 cols, 2 P (rows per chunk), 3 S_src, 4 S_dst (chunk strides in rows), 5 ld_src, 6 ld_dst, 7 dtype (src == dst;
  *      fp16: cols % 8 == 0, fp32: cols % 4 == 0), 8 ld_res;  p: 0 src, 1 dst, 2 residual fp32 (optional, fp32 only)
+ *      ABI 8: i[9] = nparts > 1: that many regroupings of this shape in ONE launch — part q reads p0 + q*i[10] elements, writes p1 + q*i[11]
+ *      elements (residual p2 + q*i[12]); part i[13] (-1: none) is the rank's own, which does not travel: its source (i[14] = 1) or its
+ *      destination (i[14] = 0) is p3 instead (the R packs in front of a frames -> pixels ALLTOALL, the R unpacks behind the way back)
  * ALLTOALL: slice q of the clip holds cnt(q) frames (i[4] each, i[5] on the LAST slice); chunk = bytes of one frame's share for one
  *      rank.  direction 0 (frames -> pixels): send cnt(me) chunks to every peer q from p0 + q*cnt(me)*chunk, receive cnt(q) chunks
  *      from q at p1 + q*i[4]*chunk;  direction 1 (pixels -> frames): send cnt(q) chunks to q from p0 + q*i[4]*chunk, receive cnt(me)

@@ -179,10 +179,18 @@ __global__ __launch_bounds__(256) void lincomb_kernel(const LinParams p) {
 // [frames][hw / R] rows): row r of the op reads source row (r / P) * S_src + r % P and writes destination row
 // (r / P) * S_dst + r % P (chunks of P rows, chunk strides in rows); optional fp32 residual, indexed like the
 // destination, added on the way (the TemporalTransformer's `+ x` after its output is resharded back to frames).
+// Round 6: blockIdx.y = part q of `nparts` regroupings of the same shape in ONE launch (the R packs in front of a frames -> pixels
+// all-to-all, the R unpacks behind the way back): part q reads src + q * ps_src and writes dst + q * ps_dst (residual + q * ps_res),
+// except the rank's own part `own`, whose source (own_is_src) or destination lives elsewhere (`alt`: it does not travel).
 template <typename T>
 __global__ __launch_bounds__(256) void reshard_rows_kernel(const T* src, T* dst, const float* res, int rows, int cols, int P,
-                                                           long s_src, long s_dst, int ld_src, int ld_dst, int ld_res) {
+                                                           long s_src, long s_dst, int ld_src, int ld_dst, int ld_res,
+                                                           long ps_src, long ps_dst, long ps_res, int own, int own_is_src, T* alt) {
   constexpr int V = 16 / sizeof(T);               // elements per 16-byte unit
+  const int q = blockIdx.y;
+  src = (q == own && own_is_src) ? alt : src + q * ps_src;
+  dst = (q == own && !own_is_src) ? alt : dst + q * ps_dst;
+  if (res) res += q * ps_res;
   const int cv = cols / V;
   const long total = (long)rows * cv;
   for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < total; u += (long)gridDim.x * 256) {
@@ -297,15 +305,20 @@ hipError_t t2v_launch_reshard_rows(const t2v_op& op, hipStream_t s) {
   if (rows <= 0 || cols <= 0 || P <= 0 || cols % (f32 ? 4 : 8) != 0 || ld_src % (f32 ? 4 : 8) != 0 || ld_dst % (f32 ? 4 : 8) != 0)
     return hipErrorInvalidValue;
   if (op.p[2] != 0 && (!f32 || ld_res % 4 != 0)) return hipErrorInvalidValue;
-  const int g = grid_for((long)rows * (cols / (f32 ? 4 : 8)));
+  const int nparts = op.i[9] > 1 ? op.i[9] : 1;
+  const int own = nparts > 1 ? op.i[13] : -1, own_is_src = op.i[14];
+  const int v = f32 ? 4 : 8;
+  if (nparts > 1 && (op.i[10] % v != 0 || op.i[11] % v != 0 || op.i[12] % 4 != 0 || own >= nparts || (own >= 0 && op.p[3] == 0) || nparts > 64))
+    return hipErrorInvalidValue;
+  const int g = grid_for((long)rows * (cols / v));
   if (f32)
-    hipLaunchKernelGGL(reshard_rows_kernel<float>, dim3(g), dim3(256), 0, s, reinterpret_cast<const float*>(op.p[0]),
+    hipLaunchKernelGGL(reshard_rows_kernel<float>, dim3(g, nparts), dim3(256), 0, s, reinterpret_cast<const float*>(op.p[0]),
                        reinterpret_cast<float*>(op.p[1]), reinterpret_cast<const float*>(op.p[2]), rows, cols, P, s_src, s_dst,
-                       ld_src, ld_dst, ld_res);
+                       ld_src, ld_dst, ld_res, (long)op.i[10], (long)op.i[11], (long)op.i[12], own, own_is_src, reinterpret_cast<float*>(op.p[3]));
   else
-    hipLaunchKernelGGL(reshard_rows_kernel<f16>, dim3(g), dim3(256), 0, s, reinterpret_cast<const f16*>(op.p[0]),
+    hipLaunchKernelGGL(reshard_rows_kernel<f16>, dim3(g, nparts), dim3(256), 0, s, reinterpret_cast<const f16*>(op.p[0]),
                        reinterpret_cast<f16*>(op.p[1]), static_cast<const float*>(nullptr), rows, cols, P, s_src, s_dst, ld_src,
-                       ld_dst, 0);
+                       ld_dst, 0, (long)op.i[10], (long)op.i[11], 0L, own, own_is_src, reinterpret_cast<f16*>(op.p[3]));
   return hipGetLastError();
 }
 

@@ -245,6 +245,9 @@ int validate_op(const t2v_op& op, int idx) {
       if (op.i[0] <= 0 || op.i[1] <= 0 || op.i[2] <= 0 || op.i[3] < 0 || op.i[4] < 0) return bad("bad row-resharding shape");
       if (op.i[5] < op.i[1] || op.i[6] < op.i[1] || op.p[0] == 0 || op.p[1] == 0) return bad("row resharding: leading dimension / pointer");
       if (op.p[2] != 0 && op.i[7] != T2V_F32) return bad("row resharding: the residual form is fp32");
+      if (op.i[9] > 1 && (op.i[9] > 64 || op.i[10] < 0 || op.i[11] < 0 || op.i[12] < 0 || op.i[13] < -1 || op.i[13] >= op.i[9] ||
+                          (op.i[14] != 0 && op.i[14] != 1) || (op.i[13] >= 0 && op.p[3] == 0)))
+        return bad("row resharding: bad multi-part record (parts, part strides, own part)");
       return 0;
     case T2V_OP_ALLTOALL:
       if (op.i[2] < 1 || op.i[3] < 0 || op.i[3] >= op.i[2] || op.i[4] < 1 || op.i[5] < 1 || op.i[5] > op.i[4]) return bad("bad all-to-all record");

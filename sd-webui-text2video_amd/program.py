@@ -819,6 +819,27 @@ class Program:
         op.out = dst
         return self._emit(op)
 
+    def reshard_parts(self, name: str, src: Buf, dst: Buf, *, parts: int, rows: int, chunk: int, s_src: int, s_dst: int,
+                      part_rows_src: int, part_rows_dst: int, own: int, own_other: Buf, own_is_src: bool,
+                      residual: Optional[Buf] = None) -> Op:
+        """`parts` regroupings of reshard_rows' shape in ONE launch (RESHARD_ROWS, ABI 8 multi-part form): part q reads the view `src`
+        shifted by q * part_rows_src rows and writes `dst` shifted by q * part_rows_dst rows (the residual moves with the destination's
+        rows when its part stride equals the destination's: see below), except part `own`, whose source (own_is_src) or destination is
+        `own_other` — the rank's own share of an all-to-all never goes through the staging buffer."""
+        assert src.dtype == dst.dtype == own_other.dtype and src.cols == dst.cols == own_other.cols
+        assert src.cols % (8 if src.dtype == "f16" else 4) == 0 and 0 <= own < parts
+        assert own_other.ld == (src.ld if own_is_src else dst.ld)
+        op = Op(L.OP_RESHARD_ROWS, name)
+        op.i[0:8] = [rows, src.cols, chunk, s_src, s_dst, src.ld, dst.ld, _DT[src.dtype]]
+        op.i[9:15] = [parts, part_rows_src * src.ld, part_rows_dst * dst.ld, 0, own, 1 if own_is_src else 0]
+        op.p[0], op.p[1], op.p[3] = src.ref, dst.ref, own_other.ref
+        if residual is not None:
+            assert residual.dtype == "f32" and src.dtype == "f32"
+            op.i[8], op.i[12] = residual.ld, part_rows_dst * residual.ld
+            op.p[2] = residual.ref
+        op.out = dst
+        return self._emit(op)
+
     def alltoall(self, name: str, send: Buf, recv: Buf, chunk_bytes: int, shard: TShardSpec, direction: int) -> Op:
         """Frame <-> pixel resharding over the T group (T2V_OP_ALLTOALL; layouts in include/t2v_hip.h).  direction 0:
         frames -> pixels, 1: pixels -> frames.  The rank's own part is moved by reshard_rows ops."""

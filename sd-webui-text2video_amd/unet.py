@@ -1089,9 +1089,10 @@ class _Lowering:
         # ---- frames -> pixels: part q of `n` (pixels [q*hwr, (q+1)*hwr) of my frames) goes to rank q
         xp = P.alloc(Ft * hwr, c, "f16")
         stage = P.alloc(R * Fl * hwr, c, "f16")
-        for q in range(R):
-            dst = xp.row_slice(sh.offset * hwr, (sh.offset + Fl) * hwr) if q == r else stage.row_slice(q * Fl * hwr, (q + 1) * Fl * hwr)
-            P.reshard_rows(f"{prefix}.f2p.pack{q}", n.row_slice(q * hwr, n.rows), dst, rows=Fl * hwr, chunk=hwr, s_src=hw, s_dst=hwr)
+        # (round 6: the R packs are ONE launch — part q = pixels [q*hwr, (q+1)*hwr) of my frames -> stage slot q; my own part straight
+        #  into its place in xp)
+        P.reshard_parts(prefix + ".f2p.pack", n, stage, parts=R, rows=Fl * hwr, chunk=hwr, s_src=hw, s_dst=hwr, part_rows_src=hwr,
+                        part_rows_dst=Fl * hwr, own=r, own_other=xp.row_slice(sh.offset * hwr, (sh.offset + Fl) * hwr), own_is_src=False)
         P.alltoall(prefix + ".f2p", stage, xp, hwr * c * 2, sh, 0)
         P.free(n, stage)
         x1 = P.alloc(Ft * hwr, inner, "f32")
@@ -1109,10 +1110,8 @@ class _Lowering:
         back = P.alloc(R * Fl * hwr, c, "f32")
         P.alltoall(prefix + ".p2f", yp, back, hwr * c * 4, sh, 1)
         out = self._dest(dest, x.rows, c, "f32")
-        for q in range(R):
-            src = yp.row_slice(sh.offset * hwr, (sh.offset + Fl) * hwr) if q == r else back.row_slice(q * Fl * hwr, (q + 1) * Fl * hwr)
-            P.reshard_rows(f"{prefix}.p2f.unpack{q}", src, out.row_slice(q * hwr, out.rows), rows=Fl * hwr, chunk=hwr, s_src=hwr, s_dst=hw,
-                           residual=x.row_slice(q * hwr, x.rows))
+        P.reshard_parts(prefix + ".p2f.unpack", back, out, parts=R, rows=Fl * hwr, chunk=hwr, s_src=hwr, s_dst=hw, part_rows_src=Fl * hwr,
+                        part_rows_dst=hwr, own=r, own_other=yp.row_slice(sh.offset * hwr, (sh.offset + Fl) * hwr), own_is_src=True, residual=x)
         P.free(yp, back)
         return out
 

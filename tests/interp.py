@@ -412,14 +412,20 @@ class Interp:
     # RESHARD_ROWS ---------------------------------------------------------------------------------------
     def _op18(self, op, ext):
         rows, cols, P, s_src, s_dst, ld_src, ld_dst, dt, ld_res = op.i[0:9]
+        nparts = op.i[9] if op.i[9] > 1 else 1
+        ps_src, ps_dst, ps_res, own, own_is_src = op.i[10:15] if nparts > 1 else (0, 0, 0, -1, 0)
+        item = 2 if _TD[dt] == torch.float16 else 4
         r = torch.arange(rows)
         rs, rd = (r // P) * s_src + r % P, (r // P) * s_dst + r % P
-        src = self.mat(op.p[0], int(rs.max()) + 1, cols, ld_src, _TD[dt], ext)
-        dst = self.mat(op.p[1], int(rd.max()) + 1, cols, ld_dst, _TD[dt], ext)
-        v = src[rs].clone()
-        if op.p[2].space != "null":
-            v = v + self.mat(op.p[2], int(rd.max()) + 1, cols, ld_res, torch.float32, ext)[rd]
-        dst[rd] = v
+        for q in range(nparts):      # (multi-part form, ABI 8: part q at + q * part stride elements; the own part's other side is p[3])
+            ps = op.p[3] if (q == own and own_is_src) else op.p[0].shifted(q * ps_src * item)
+            pd = op.p[3] if (q == own and not own_is_src) else op.p[1].shifted(q * ps_dst * item)
+            src = self.mat(ps, int(rs.max()) + 1, cols, ld_src, _TD[dt], ext)
+            dst = self.mat(pd, int(rd.max()) + 1, cols, ld_dst, _TD[dt], ext)
+            v = src[rs].clone()
+            if op.p[2].space != "null":
+                v = v + self.mat(op.p[2].shifted(q * ps_res * 4), int(rd.max()) + 1, cols, ld_res, torch.float32, ext)[rd]
+            dst[rd] = v
 
     # TO_UINT8 (tensor2vid) ------------------------------------------------------------------------------
     def _op15(self, op, ext):

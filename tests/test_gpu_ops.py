@@ -666,6 +666,49 @@ def test_reshard_rows_pack_and_unpack_with_residual():
         assert torch.equal(read(got, packed).float(), torch.cat([s_[f * hw + q * hwr: f * hw + (q + 1) * hwr] for f in range(frames)]))
 
 
+def test_reshard_parts_one_launch_equals_the_per_part_launches():
+    """RESHARD_ROWS multi-part form (ABI 8, round 6): the R packs in front of a frames -> pixels all-to-all and the R unpacks (+ residual)
+    behind the way back as ONE launch each, the rank's own part going straight to / coming straight from its place in the pixel-sharded
+    tensor — bit-equal to the R single-part launches they replace, on the GPU and in the CPU interpreter."""
+    R, own, Fl, hw, C, offset, Ft = 4, 1, 3, 16, 64, 3, 11
+    hwr = hw // R
+    outs = []
+    for multi in (True, False):
+        P = Program()
+        g = _g(43)
+        n = P.alloc(Fl * hw, C, "f16")
+        stage, xp = P.alloc(R * Fl * hwr, C, "f16"), P.alloc(Ft * hwr, C, "f16")
+        yp, back = P.alloc(Ft * hwr, C, "f32"), P.alloc(R * Fl * hwr, C, "f32")
+        x, out = P.alloc(Fl * hw, C, "f32", ld=C + 4), P.alloc(Fl * hw, C, "f32")
+        xp_own, yp_own = xp.row_slice(offset * hwr, (offset + Fl) * hwr), yp.row_slice(offset * hwr, (offset + Fl) * hwr)
+        if multi:
+            P.reshard_parts("pack", n, stage, parts=R, rows=Fl * hwr, chunk=hwr, s_src=hw, s_dst=hwr, part_rows_src=hwr, part_rows_dst=Fl * hwr,
+                            own=own, own_other=xp_own, own_is_src=False)
+            P.reshard_parts("unpack", back, out, parts=R, rows=Fl * hwr, chunk=hwr, s_src=hwr, s_dst=hw, part_rows_src=Fl * hwr, part_rows_dst=hwr,
+                            own=own, own_other=yp_own, own_is_src=True, residual=x)
+            assert len(P.ops) == 2
+        else:
+            for q in range(R):
+                P.reshard_rows(f"pack{q}", n.row_slice(q * hwr, n.rows), xp_own if q == own else stage.row_slice(q * Fl * hwr, (q + 1) * Fl * hwr),
+                               rows=Fl * hwr, chunk=hwr, s_src=hw, s_dst=hwr)
+            for q in range(R):
+                P.reshard_rows(f"unpack{q}", yp_own if q == own else back.row_slice(q * Fl * hwr, (q + 1) * Fl * hwr), out.row_slice(q * hwr, out.rows),
+                               rows=Fl * hwr, chunk=hwr, s_src=hwr, s_dst=hw, residual=x.row_slice(q * hwr, x.rows))
+
+        def init(it):
+            for b in (n, yp, back, x):
+                fill(it, b, g)
+            for b in (stage, xp, out):
+                it.mat(b.ref, b.rows, b.cols, b.ld, TD[b.dtype], {}).zero_()
+        it, got, _, _ = run_both(P, {}, {}, init)
+        for b in (stage, xp, out):
+            assert torch.equal(read(it, b), read(got, b))
+        outs.append([read(got, b).clone() for b in (stage, xp, out)])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert outs[0][0][own * Fl * hwr:(own + 1) * Fl * hwr].abs().sum() == 0          # the own part never touched the staging buffer
+
+
 @pytest.mark.parametrize("n_inst,rows,C,dt,silu", [(2, 24 * 1024, 320, "f32", True),      # 32x32 level, cross-frame: 256 workgroups, 16 rows / thread
                                                    (48, 1024, 320, "f16", True),        # 32x32 level, per frame: 5 chunks per instance, 20 rows / thread
                                                    (2, 24 * 256, 640, "f16", False),    # 16x16 level, cross-frame
