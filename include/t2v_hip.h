@@ -326,6 +326,9 @@ int t2v_plan_set_comm(t2v_plan* plan, t2v_comm* comm);   /* borrowed; must outli
 int t2v_comm_window_create(t2v_comm* comm, uint64_t slot_bytes, unsigned char handle_out[64]);
 int t2v_comm_window_open(t2v_comm* comm, const unsigned char* handles);
 void t2v_comm_counters(const t2v_comm* comm, uint64_t out[2]);
+/* "uncached" | "finegrained" | "default": the kind of device memory the window got (uncached first — peers write it through the fabric and
+ * this device polls it, so its L2 must not keep lines of it; T2V_PEER_WINDOW_MEM forces one); "" without a window */
+const char* t2v_comm_window_kind(const t2v_comm* comm);
 /* In-place all-gather outside a plan, on `stream`: part q of t2v_comm_size(comm) equal parts of `bytes` bytes lives at base + q*bytes,
  * the caller's own part is in place.  The per-step exchanges around the UNet — the eps of a classifier-free-guidance pair
  * (gaussian_sampler.py:161-163 evaluates the two forwards one after the other), the uint8 frames of the decoded clip

@@ -55,7 +55,7 @@ EXPORTS = [
     "t2v_plan_num_ops", "t2v_plan_run", "t2v_plan_run_timed", "t2v_plan_destroy",
     "t2v_unet_forward", "t2v_vae_decode", "t2v_ddim_step",
     "t2v_comm_unique_id", "t2v_comm_create", "t2v_comm_size", "t2v_comm_destroy", "t2v_plan_set_comm", "t2v_comm_all_gather",
-    "t2v_comm_window_create", "t2v_comm_window_open", "t2v_comm_counters",
+    "t2v_comm_window_create", "t2v_comm_window_open", "t2v_comm_counters", "t2v_comm_window_kind",
     "t2v_async_status", "t2v_sync_reset", "t2v_debug_poison_exchange",
 ]
 
@@ -111,6 +111,8 @@ def load():
     lib.t2v_comm_window_open.argtypes = [vp, ctypes.c_char_p]
     lib.t2v_comm_counters.argtypes = [vp, u64p]
     lib.t2v_comm_counters.restype = None
+    lib.t2v_comm_window_kind.argtypes = [vp]
+    lib.t2v_comm_window_kind.restype = ctypes.c_char_p
     lib.t2v_async_status.restype = ctypes.c_int
     lib.t2v_sync_reset.argtypes = [vp, vp]
     lib.t2v_debug_poison_exchange.argtypes = [ctypes.c_int]

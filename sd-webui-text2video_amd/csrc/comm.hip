@@ -61,6 +61,7 @@ struct PeerWindow {
   size_t slot_bytes = 0, flag_bytes = 0, total = 0;
   unsigned long long pair_seq[PX_MAX_RANKS] = {};
   bool open = false;
+  const char* mem_kind = "";             // uncached | finegrained | default (t2v_comm_impl_window_create)
   unsigned long long n_window_ops = 0, n_rccl_ops = 0;
 };
 
@@ -307,15 +308,35 @@ int t2v_comm_impl_window_create(t2v_comm* c, size_t slot_bytes, unsigned char ha
   w.slot_bytes = (slot_bytes + 255) & ~(size_t)255;
   w.flag_bytes = ((size_t)c->nranks * PX_NB * PX_FLAG_STRIDE + 4095) & ~(size_t)4095;
   w.total = w.flag_bytes + (size_t)c->nranks * 2 * w.slot_bytes;
+  // Memory the PEERS write and this device polls: uncached device memory first (MTYPE UC — what RCCL itself allocates for its peer-written
+  // buffers on gfx94x / gfx950: the L2 of this device must never hold a line a peer is about to overwrite through the fabric), then
+  // fine-grained, then plain hipMalloc (coarse-grained; the kernel's system-scope sc0 sc1 accesses are then the only protection).
+  // T2V_PEER_WINDOW_MEM=uncached | finegrained | default forces one.
+  const char* forced = getenv("T2V_PEER_WINDOW_MEM");
+  struct Kind { const char* name; int flags; };
+  const Kind kinds[] = {{"uncached", (int)hipDeviceMallocUncached}, {"finegrained", (int)hipDeviceMallocFinegrained}, {"default", -1}};
   void* p = nullptr;
-  if (hipMalloc(&p, w.total) != hipSuccess || p == nullptr) { (void)hipGetLastError(); err = "peer window: hipMalloc failed"; return T2V_ERR_COMM; }
   hipIpcMemHandle_t h;
-  if (hipMemset(p, 0, w.total) != hipSuccess || hipDeviceSynchronize() != hipSuccess || hipIpcGetMemHandle(&h, p) != hipSuccess) {
+  const char* got = nullptr;
+  for (const Kind& k : kinds) {
+    if (forced && *forced && strcmp(forced, k.name) != 0) continue;
+    void* q = nullptr;
+    const hipError_t e = k.flags < 0 ? hipMalloc(&q, w.total) : hipExtMallocWithFlags(&q, w.total, (unsigned)k.flags);
+    if (e != hipSuccess || q == nullptr) { (void)hipGetLastError(); continue; }
+    if (hipMemset(q, 0, w.total) == hipSuccess && hipDeviceSynchronize() == hipSuccess && hipIpcGetMemHandle(&h, q) == hipSuccess) {
+      p = q;
+      got = k.name;
+      break;
+    }
     (void)hipGetLastError();
-    (void)hipFree(p);
-    err = "peer window: hipIpcGetMemHandle failed (HSA_ENABLE_IPC_MODE_LEGACY=0 is needed on hosts that only support dmabuf IPC)";
+    (void)hipFree(q);
+  }
+  if (p == nullptr) {
+    err = "peer window: no allocation kind could be allocated and exported (hipIpcGetMemHandle; HSA_ENABLE_IPC_MODE_LEGACY=0 is needed on hosts that "
+          "only support dmabuf IPC)";
     return T2V_ERR_COMM;
   }
+  w.mem_kind = got;
   w.local = static_cast<unsigned char*>(p);
   w.peer[c->rank] = w.local;
   memcpy(handle_out, &h, 64);
@@ -361,6 +382,8 @@ void t2v_comm_impl_counters(const t2v_comm* c, unsigned long long out[2]) {
   out[0] = c ? c->win.n_window_ops : 0;
   out[1] = c ? c->win.n_rccl_ops : 0;
 }
+
+const char* t2v_comm_impl_window_kind(const t2v_comm* c) { return (c && c->win.local) ? c->win.mem_kind : ""; }
 
 void t2v_comm_impl_destroy(t2v_comm* c) {
   if (!c) return;

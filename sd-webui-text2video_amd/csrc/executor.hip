@@ -533,6 +533,8 @@ int t2v_comm_window_open(t2v_comm* comm, const unsigned char* handles) {
   return rc == T2V_OK ? rc : fail(rc, err);
 }
 
+const char* t2v_comm_window_kind(const t2v_comm* comm) { return t2v_comm_impl_window_kind(comm); }
+
 void t2v_comm_counters(const t2v_comm* comm, uint64_t out[2]) {
   unsigned long long v[2];
   t2v_comm_impl_counters(comm, v);

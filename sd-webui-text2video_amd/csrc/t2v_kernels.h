@@ -1195,6 +1195,7 @@ int t2v_comm_impl_size(const t2v_comm* c);
 int t2v_comm_impl_window_create(t2v_comm* c, size_t slot_bytes, unsigned char handle_out[64], std::string& err);
 int t2v_comm_impl_window_open(t2v_comm* c, const unsigned char* handles, std::string& err);
 void t2v_comm_impl_counters(const t2v_comm* c, unsigned long long out[2]);
+const char* t2v_comm_impl_window_kind(const t2v_comm* c);
 int t2v_comm_allgather(t2v_comm* c, void* base, size_t bytes, int nparts, int part, hipStream_t s, std::string& err);
 int t2v_comm_impl_all_gather(t2v_comm* c, void* base, size_t bytes, hipStream_t s, std::string& err);
 int t2v_comm_halo(t2v_comm* c, void* base, size_t frame_bytes, int F, int prev, int next, hipStream_t s, std::string& err);

@@ -159,7 +159,8 @@ class Communicator:
             # some rank could not map a peer: nobody may use the windows (a rank that opened them would push into mailboxes nobody reads)
             self._lib.t2v_comm_window_open(self.handle, None)
             return None
-        return f"peer window: {n} ranks x 2 slots x {slot >> 20} MiB per rank, device-initiated stores + sequence flags (csrc/comm.hip)"
+        kind = (self._lib.t2v_comm_window_kind(self.handle) or b"").decode()
+        return f"peer window: {n} ranks x 2 slots x {slot >> 20} MiB per rank ({kind} device memory), device-initiated stores + sequence flags (csrc/comm.hip)"
 
     def counters(self) -> Tuple[int, int]:
         """(exchanges that went over the peer window, exchanges that went through RCCL) since this communicator was created."""
