@@ -64,15 +64,31 @@ __device__ __forceinline__ void gn_cast_store8(const GnCast& c, size_t row, int 
   if (c.lo) *reinterpret_cast<f16x8*>(dst + c.lo) = l;
 }
 
+// one {sum, sum of squares} pair of doubles; dev: as ONE device-scope 16-byte store (read by another workgroup of the same launch)
+__device__ __forceinline__ void gn_store_pair(double* st, double s, double q, bool dev) {
+  if (dev) {
+    const double pr[2] = {s, q};
+    f32x4 v;
+    __builtin_memcpy(&v, pr, 16);
+    t2v_st_dev(reinterpret_cast<float*>(st), v);
+  } else {
+    st[0] = s;
+    st[1] = q;
+  }
+}
+
 constexpr int GN_UNROLL = 8;   // token rows a thread keeps in flight (HBM-bound: ~48 KiB per CU must be outstanding)
 
 // Launch 1 — grid (nblk, n_inst), nblk = ceil(rows / rpb).  Threads form R row-replicas x TPR column slots of
 // 8 channels.  Deterministic: per-thread fp32 partials are parked in LDS [R][C]; `groups` threads then fold
 // replicas + the channels of their group in a fixed order in fp64 and store ONE partial per (instance,
 // block, group).  No atomics: bitwise reproducible run to run.
+// ticket != nullptr (phase 1 of a T-sharded norm, round 6): the LAST workgroup to arrive also folds all block partials into this rank's
+// {sum, sum of squares} per (instance, group) — `raw` — in gn_finalize_kernel's order (same bits as the two launches this replaces); the
+// block partials then travel with device-scope stores / loads (workgroups of one launch on different XCDs), the ticket re-arms itself.
 template <typename T>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, double* partials, int rows, int C,
-                                                       int ld, int groups, int rpb) {
+                                                       int ld, int groups, int rpb, int* ticket, double* raw) {
   extern __shared__ float sh[];  // [2][R][C] floats
   const int tid = threadIdx.x;
   const int inst = blockIdx.y;
@@ -124,18 +140,40 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
       }
     }
     for (int o = 1; o < 8; o <<= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
-    if (g < groups && sub == 0) {
-      double* st = partials + (((size_t)inst * gridDim.x + blockIdx.x) * groups + g) * 2;
-      st[0] = s;
-      st[1] = q;
-    }
+    if (g < groups && sub == 0) gn_store_pair(partials + (((size_t)inst * gridDim.x + blockIdx.x) * groups + g) * 2, s, q, ticket != nullptr);
   } else if (tid < groups) {
     double s = 0.0, q = 0.0;
     for (int k = 0; k < R; ++k)
       for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { s += (double)psum[k * C + c]; q += (double)psq[k * C + c]; }
-    double* st = partials + (((size_t)inst * gridDim.x + blockIdx.x) * groups + tid) * 2;
-    st[0] = s;
-    st[1] = q;
+    gn_store_pair(partials + (((size_t)inst * gridDim.x + blockIdx.x) * groups + tid) * 2, s, q, ticket != nullptr);
+  }
+  if (ticket == nullptr) return;
+  __shared__ int s_last;
+  t2v_wait_vm0();
+  __syncthreads();
+  if (tid == 0) {
+    const int total = gridDim.x * gridDim.y;
+    const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = t == total - 1;
+    if (s_last) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!s_last) return;
+  const int lane = tid & 63, nblk = gridDim.x, n_inst = gridDim.y;
+  for (int idx = tid >> 6; idx < n_inst * groups; idx += 4) {            // one wave per (instance, group), as gn_finalize_kernel (nparts = 1)
+    const int in2 = idx / groups, g = idx - in2 * groups;
+    double s = 0.0, q = 0.0;
+    for (int u = lane; u < nblk; u += 64) {
+      f32x4 v;
+      asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)"
+                   : "=&v"(v) : "v"(partials + (((size_t)in2 * nblk + u) * groups + g) * 2) : "memory");
+      double pr[2];
+      __builtin_memcpy(pr, &v, 16);
+      s += pr[0];
+      q += pr[1];
+    }
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+    if (lane == 0) { raw[2 * idx] = s; raw[2 * idx + 1] = q; }
   }
 }
 
@@ -244,19 +282,45 @@ __global__ __launch_bounds__(256) void gn_finalize_strips_wg_kernel(const float*
 // Launch 2 — grid (ceil(rows / (R*GN_UNROLL)), n_inst), same thread layout.  The workgroup first builds
 // scale[c] = rstd*gamma[c] and shift[c] = beta[c] - mean*scale[c] for the instance in LDS; every thread then
 // normalises GN_UNROLL rows of its 8 channels per column unit (16-byte loads issued together, 16-byte stores).
+// parts != nullptr (phase 2 of a T-sharded norm, round 6): the gathered {sum, sum of squares} parts of all ranks ([part][inst][group][2]
+// doubles, part stride part_len) are folded HERE, in rank order, by `groups` threads of every workgroup — no finalize launch in front of
+// the pass; every rank and every workgroup folds the same values in the same order: identical statistics everywhere.
 template <typename T, bool SILU>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ finals,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        f16* __restrict__ out, int rows, int C, int ld_in, int ld_out,
-                                                       int groups, int lo_off, GnCast cast) {
-  extern __shared__ float sh[];   // scale[C], shift[C]
+                                                       int groups, int lo_off, GnCast cast, const double* parts, int nparts, long part_len,
+                                                       double inv_n, float eps) {
+  extern __shared__ float sh[];   // scale[C], shift[C] (+ {mean, rstd}[groups] with parts)
   float* sc = sh;
   float* sf = sh + C;
   const int tid = threadIdx.x;
   const int inst = blockIdx.y;
   const int cv = C >> 3;
   const int cpg = C / groups;
-  {
+  if (parts != nullptr) {
+    float* fin = sh + 2 * C;
+    for (int g = tid; g < groups; g += 256) {
+      double s = 0.0, q = 0.0;
+      for (int pz = 0; pz < nparts; ++pz) {
+        const double* st = parts + (size_t)pz * part_len + ((size_t)inst * groups + g) * 2;
+        s += st[0];
+        q += st[1];
+      }
+      const double m = s * inv_n;
+      double var = q * inv_n - m * m;
+      var = var < 0.0 ? 0.0 : var;
+      fin[2 * g] = (float)m;
+      fin[2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+      const int grp = c / cpg;
+      const float a = fin[2 * grp + 1] * gamma[c];
+      sc[c] = a;
+      sf[c] = beta[c] - fin[2 * grp] * a;
+    }
+  } else {
     const float* fin = finals + (size_t)inst * groups * 2;
     for (int c = tid; c < C; c += 256) {
       const int grp = c / cpg;
@@ -1046,14 +1110,21 @@ hipError_t t2v_launch_groupnorm(const t2v_op& op, hipStream_t s) {
     else if (phase == 3 || strips1)
       hipLaunchKernelGGL(gn_finalize_strips_kernel, dim3(g2), dim3(256), 0, s, reinterpret_cast<const float*>(op.p[6]), finals, n_inst, rows / 32,
                          groups, C / groups, op.i[17], inv_n, op.f[0], raw_part);
-    else if (phase != 2)
-      hipLaunchKernelGGL(gn_stats_kernel<T>, g1, dim3(256), lds, s, x, local, rows, C, ld_in, groups, rpb);
+    else if (phase != 2) {
+      // phase 1 with a ticket word (p[5], round 6): the last workgroup folds the block partials into this rank's part — one launch
+      int* ticket = (phase == 1 && op.p[5] != 0) ? reinterpret_cast<int*>(op.p[5]) : nullptr;
+      hipLaunchKernelGGL(gn_stats_kernel<T>, g1, dim3(256), lds, s, x, local, rows, C, ld_in, groups, rpb, ticket,
+                         ticket ? partials + part_len * part : static_cast<double*>(nullptr));
+      if (ticket) return;
+    }
     if (phase == 1 && !strips1)
       hipLaunchKernelGGL(gn_finalize_kernel, dim3(g2), dim3(256), 0, s, local, finals, n_inst, nblk, groups, 0.0, 0.f, 1,
                          partials + part_len * part);
     if (phase != 1) {
-      if (phase != 3)
-        hipLaunchKernelGGL(gn_finalize_kernel, dim3(g2), dim3(256), 0, s, partials, finals, n_inst, phase == 0 ? nblk : 1, groups,
+      // phase 2 (round 6): the gathered parts are folded inside the apply pass (no finalize launch)
+      const double* parts2 = phase == 2 ? partials : nullptr;
+      if (phase == 0)
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3(g2), dim3(256), 0, s, partials, finals, n_inst, nblk, groups,
                            inv_n, op.f[0], nparts, static_cast<double*>(nullptr));
       const int rpa = R * GN_UNROLL;    // rows per normalise workgroup
       // phase 2 of a T-sharded clip (T2V_OP_STATS_HALO): i[21] / i[22] rows in front of / behind x hold the neighbours' RAW boundary
@@ -1063,9 +1134,11 @@ hipError_t t2v_launch_groupnorm(const t2v_op& op, hipStream_t s) {
       const T* ax = x - (size_t)before * ld_in;
       f16* aout = out - (size_t)before * ld_out;
       const dim3 g3((arows + rpa - 1) / rpa, n_inst);
-      const size_t lds3 = 2 * (size_t)C * sizeof(float);
-      if (silu) hipLaunchKernelGGL((gn_apply_kernel<T, true>), g3, dim3(256), lds3, s, ax, finals, gamma, beta, aout, arows, C, ld_in, ld_out, groups, lo_off, cast);
-      else hipLaunchKernelGGL((gn_apply_kernel<T, false>), g3, dim3(256), lds3, s, ax, finals, gamma, beta, aout, arows, C, ld_in, ld_out, groups, lo_off, cast);
+      const size_t lds3 = (2 * (size_t)C + (parts2 ? 2 * (size_t)groups : 0)) * sizeof(float);
+      if (silu) hipLaunchKernelGGL((gn_apply_kernel<T, true>), g3, dim3(256), lds3, s, ax, finals, gamma, beta, aout, arows, C, ld_in, ld_out, groups, lo_off, cast,
+                                   parts2, nparts, (long)part_len, inv_n, op.f[0]);
+      else hipLaunchKernelGGL((gn_apply_kernel<T, false>), g3, dim3(256), lds3, s, ax, finals, gamma, beta, aout, arows, C, ld_in, ld_out, groups, lo_off, cast,
+                              parts2, nparts, (long)part_len, inv_n, op.f[0]);
     }
   };
   if (in_dt == T2V_F32) run(reinterpret_cast<const float*>(op.p[0]));

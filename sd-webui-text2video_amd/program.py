@@ -164,6 +164,7 @@ class Program:
         self.keep_taps = False
         self.target_cus = 256                   # MI355X compute units (tile / split-K policy)
         self.force_tile = None                  # tests: pin a tile id
+        self.small_rank_tiles = False           # set by the lowering of a T-sharded program (choose_tile: 64x64 tiles for temporal convolutions)
         # GroupNorm as ONE launch when a statistics slice (rows x C/groups) is small (bytes; tools/gn_bench.py: the
         # per-frame instances of the 16x16 and lower levels and the cross-frame ones of the 4x4 level gain 8-19 us each,
         # larger slices on only 64 workgroups do not)
@@ -213,8 +214,9 @@ class Program:
         if not getattr(self, "gn_epilogue", False) or not self.ops:
             return False
         op = self.ops[-1]
-        if op.kind != L.OP_GEMM or op.i[16] != L.EPI_NONE or op.meta.get("tile") not in self._GN_EPI_TILES or op.meta.get("split", 1) != 1:
-            return False
+        if op.kind != L.OP_GEMM or op.i[16] != L.EPI_NONE or (op.meta.get("tile") not in self._GN_EPI_TILES and op.meta.get("tile") != 12) \
+                or op.meta.get("split", 1) != 1:
+            return False                                # (tile 12: _fuse_groupnorm may move the GEMM to the 128x128 tile)
         lo, hi = b.alloc_off, b.alloc_off + self.arena.live.get(b.alloc_off, 0)
         # every arena-space input of the launch: A, an arena-resident weight operand (V^T / q k^T GEMMs), bias, row bias, residual
         return any(r is not None and r.space == "arena" and lo <= r.off < hi for r in (op.p[0], op.p[1], op.p[2], op.p[3], op.p[4]))
@@ -248,6 +250,7 @@ class Program:
         cus = self.target_cus
         forced = self.force_tile is not None
         conv_like = gather in (L.GATHER_CONV3X3, L.GATHER_TCONV3)
+        r6 = L.knob("T2V_TILE_R6", "1") != "0"          # round-6 additions for the rows of T-shard ranks / VideoCrafter (A/B switch)
         if forced:
             tile = self.force_tile
         elif gather == L.GATHER_CONV3X3_C8 or n < 256 or k < 64 or k % 64 != 0:
@@ -290,11 +293,25 @@ class Program:
                 tile = 9 if L.knob("T2V_TILE8", "1") != "0" else 3      # 16x16-level QKV (12288, 1920, 640): 492 vs 452 TF/s
             else:
                 tile = 0               # (the 4-deep-ring 128x128 tile measured 640 vs 668 TF/s on the K = 2560 feed-forward GEMM)
+                if r6 and M < 12288 and n == 640:
+                    # M = 8192 (VideoCrafter's 16x16 level, a 32-frame T-shard rank): 128x256 tiles, 64 x 3 workgroups — C -> C 281 vs 269,
+                    # temporal conv 508 vs 438, ff2 557 vs 516 TF/s; at M = 12288 (24 frames, b = 2) the 128x128 kernel stays ahead
+                    tile = 3
         else:                                          # 8x8 / 4x4 levels: few rows, latency-bound
             if n >= 8192:
                 tile = 1 if M >= 1024 else (0 if M >= 512 else 5)
+                if r6 and 1024 <= M <= 2048 and n % 320 == 0:
+                    tile = 2           # (2048, 10240, 1280): 862 vs 652 TF/s
+                elif r6 and 512 <= M < 768:
+                    tile = 3           # (512, 10240, 1280): 508 vs 465
+                elif r6 and M <= 128:
+                    tile = 12          # (96, 10240, 1280): 182 vs 159
             elif n >= 2560:
                 tile = 1 if M >= 2048 else (3 if M >= 1024 else 5)
+                if r6 and M == 2048:
+                    tile = 3           # (2048, 3840, 1280): 571 vs 419 (256x256) / 469 (192x256)
+                elif r6 and M <= 512:
+                    tile = 12          # (512 / 384 / 96, 3840, 1280): 303 / 234 / 76 vs 257 / 204 / 59
                 # 256-row tiles of M = 3072 x N = 3840 are 180 workgroups for 256 CUs; 192-row tiles give 240
                 if tile == 1 and n % 256 == 0 and L.knob("T2V_TILE8", "1") != "0":
                     w1, w9 = math.ceil(M / 256) * (n // 256), math.ceil(M / 192) * (n // 256)
@@ -309,6 +326,14 @@ class Program:
                     # the 4x4 level's C -> C linears (768, 1280, 1280): 64x64 tiles with the FULL reduction = 240 workgroups, no
                     # split-K slabs and no reduction launch: 201 vs 146 TF/s (tools/gemm_sweep.py L3, round 4); longer K / wider N
                     # stay on the split-K configurations (ff2 381 vs 341, conv3x3 525 vs 410, qkv 365 vs 331)
+                    tile = 12
+                elif r6 and k <= 2560 and math.ceil(M / 128) * math.ceil(n / 128) <= 150 and L.knob("T2V_TILE12", "1") != "0" and \
+                        (gather == L.GATHER_PLAIN or (gather == L.GATHER_TCONV3 and self.small_rank_tiles)):
+                    # round 6 (SWEEP_BATCH=1 SWEEP_FRAMES=6 tools/gemm_sweep.py: the rows of a 6-frame T-shard rank): where 128x128 tiles
+                    # are <= 150 workgroups and the reduction is short, 64x64 tiles with the full reduction: (6144, 320, 320 .. 1280) 123 /
+                    # 206 / 302 vs 108 / 179 / 266 TF/s, (1536, 640, 640 / 2560) 125 / 259 vs 94 / 237, temporal conv (6144, 320, 960) 250
+                    # vs 211 and (1536, 640, 1920) 219 vs 167 — the latter only in a T-sharded program, where the cross-frame norm behind
+                    # a temporal convolution is never that GEMM's epilogue (64x64 tiles have no GroupNorm epilogue)
                     tile = 12
         if tile == 0:
             bm, bn, bk = 128, (64 if (n % 128 != 0 and n % 128 <= 64) else 128), 64
@@ -622,6 +647,11 @@ class Program:
             if not fit or fit[0] * groups * 16 > self._gn_part.rows:
                 return None
         else:
+            retile = None
+            if tile == 12 and self.force_tile is None:
+                # 64x64 tiles (chosen for a small grid, choose_tile) have no GroupNorm epilogue; the 128x128 tile with the 4-deep ring —
+                # what such a GEMM ran on before round 6 — has: the fused norm is worth more than the tile (a launch and two passes)
+                tile = retile = 5
             if tile not in self._GN_EPI_TILES or L.knob(f"T2V_GN_EPI_TILE{tile}", "1") == "0":
                 return None
             bm, bn, per_cu = self._GN_EPI_TILES[tile]
@@ -649,6 +679,8 @@ class Program:
                     if a_lo is None or not (o_hi <= a_lo or o_lo >= a_hi):
                         return None
         part = self._gn_part
+        if split == 1 and retile is not None:
+            I[22] = op.meta["tile"] = retile
         I[16] = L.EPI_GN
         I[24], I[25], I[26], I[27], I[28], I[29] = rows, out.ld, int(silu), int(lo), groups, int(x_dead)
         op.f[2] = eps
@@ -751,6 +783,8 @@ class Program:
                 # round 6: this rank's part folded from the producing GEMM's T2V_EPI_STATS strips — no statistics pass over the tensor
                 assert rows % 32 == 0 and stats.ld == 2 * x.cols and stats.rows * 32 >= x.rows
                 op1.p[6], op1.i[17] = stats.ref, x.cols
+            elif L.knob("T2V_GN_PHASE1_TICKET", "1") != "0":
+                op1.p[5] = self.sync_ref("tickets")      # round 6: the last statistics workgroup folds the block partials (one launch, not two)
             self._emit(op1)
             full = Buf(scratch.ref, nparts * part_bytes, 1, 1, "u8", scratch.alloc_off)
             if halo_raw is None:

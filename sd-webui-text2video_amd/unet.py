@@ -629,6 +629,7 @@ class _Lowering:
         self.stem_dup = False
         self.P = Program(f"unet b{B} f{F} {H}x{W}")
         self.P.keep_taps = keep_taps
+        self.P.small_rank_tiles = self.shard is not None       # (Program.choose_tile: no temporal convolution of a rank program carries a norm epilogue)
         self.packer = pk.WeightPacker()
         prefixes = tuple(getattr(net, "split_weight_prefixes", ()) or ())
         if prefixes:
