@@ -64,17 +64,9 @@ __device__ __forceinline__ void gn_cast_store8(const GnCast& c, size_t row, int 
   if (c.lo) *reinterpret_cast<f16x8*>(dst + c.lo) = l;
 }
 
-// one {sum, sum of squares} pair of doubles; dev: as ONE device-scope 16-byte store (read by another workgroup of the same launch)
-__device__ __forceinline__ void gn_store_pair(double* st, double s, double q, bool dev) {
-  if (dev) {
-    const double pr[2] = {s, q};
-    f32x4 v;
-    __builtin_memcpy(&v, pr, 16);
-    t2v_st_dev(reinterpret_cast<float*>(st), v);
-  } else {
-    st[0] = s;
-    st[1] = q;
-  }
+__device__ __forceinline__ void gn_store_pair(double* st, double s, double q) {
+  st[0] = s;
+  st[1] = q;
 }
 
 constexpr int GN_UNROLL = 8;   // token rows a thread keeps in flight (HBM-bound: ~48 KiB per CU must be outstanding)
@@ -83,12 +75,9 @@ constexpr int GN_UNROLL = 8;   // token rows a thread keeps in flight (HBM-bound
 // 8 channels.  Deterministic: per-thread fp32 partials are parked in LDS [R][C]; `groups` threads then fold
 // replicas + the channels of their group in a fixed order in fp64 and store ONE partial per (instance,
 // block, group).  No atomics: bitwise reproducible run to run.
-// ticket != nullptr (phase 1 of a T-sharded norm, round 6): the LAST workgroup to arrive also folds all block partials into this rank's
-// {sum, sum of squares} per (instance, group) — `raw` — in gn_finalize_kernel's order (same bits as the two launches this replaces); the
-// block partials then travel with device-scope stores / loads (workgroups of one launch on different XCDs), the ticket re-arms itself.
 template <typename T>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, double* partials, int rows, int C,
-                                                       int ld, int groups, int rpb, int* ticket, double* raw) {
+                                                       int ld, int groups, int rpb) {
   extern __shared__ float sh[];  // [2][R][C] floats
   const int tid = threadIdx.x;
   const int inst = blockIdx.y;
@@ -140,40 +129,12 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
       }
     }
     for (int o = 1; o < 8; o <<= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
-    if (g < groups && sub == 0) gn_store_pair(partials + (((size_t)inst * gridDim.x + blockIdx.x) * groups + g) * 2, s, q, ticket != nullptr);
+    if (g < groups && sub == 0) gn_store_pair(partials + (((size_t)inst * gridDim.x + blockIdx.x) * groups + g) * 2, s, q);
   } else if (tid < groups) {
     double s = 0.0, q = 0.0;
     for (int k = 0; k < R; ++k)
       for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { s += (double)psum[k * C + c]; q += (double)psq[k * C + c]; }
-    gn_store_pair(partials + (((size_t)inst * gridDim.x + blockIdx.x) * groups + tid) * 2, s, q, ticket != nullptr);
-  }
-  if (ticket == nullptr) return;
-  __shared__ int s_last;
-  t2v_wait_vm0();
-  __syncthreads();
-  if (tid == 0) {
-    const int total = gridDim.x * gridDim.y;
-    const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = t == total - 1;
-    if (s_last) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __syncthreads();
-  if (!s_last) return;
-  const int lane = tid & 63, nblk = gridDim.x, n_inst = gridDim.y;
-  for (int idx = tid >> 6; idx < n_inst * groups; idx += 4) {            // one wave per (instance, group), as gn_finalize_kernel (nparts = 1)
-    const int in2 = idx / groups, g = idx - in2 * groups;
-    double s = 0.0, q = 0.0;
-    for (int u = lane; u < nblk; u += 64) {
-      f32x4 v;
-      asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)"
-                   : "=&v"(v) : "v"(partials + (((size_t)in2 * nblk + u) * groups + g) * 2) : "memory");
-      double pr[2];
-      __builtin_memcpy(pr, &v, 16);
-      s += pr[0];
-      q += pr[1];
-    }
-    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
-    if (lane == 0) { raw[2 * idx] = s; raw[2 * idx + 1] = q; }
+    gn_store_pair(partials + (((size_t)inst * gridDim.x + blockIdx.x) * groups + tid) * 2, s, q);
   }
 }
 
@@ -1110,13 +1071,8 @@ hipError_t t2v_launch_groupnorm(const t2v_op& op, hipStream_t s) {
     else if (phase == 3 || strips1)
       hipLaunchKernelGGL(gn_finalize_strips_kernel, dim3(g2), dim3(256), 0, s, reinterpret_cast<const float*>(op.p[6]), finals, n_inst, rows / 32,
                          groups, C / groups, op.i[17], inv_n, op.f[0], raw_part);
-    else if (phase != 2) {
-      // phase 1 with a ticket word (p[5], round 6): the last workgroup folds the block partials into this rank's part — one launch
-      int* ticket = (phase == 1 && op.p[5] != 0) ? reinterpret_cast<int*>(op.p[5]) : nullptr;
-      hipLaunchKernelGGL(gn_stats_kernel<T>, g1, dim3(256), lds, s, x, local, rows, C, ld_in, groups, rpb, ticket,
-                         ticket ? partials + part_len * part : static_cast<double*>(nullptr));
-      if (ticket) return;
-    }
+    else if (phase != 2)
+      hipLaunchKernelGGL(gn_stats_kernel<T>, g1, dim3(256), lds, s, x, local, rows, C, ld_in, groups, rpb);
     if (phase == 1 && !strips1)
       hipLaunchKernelGGL(gn_finalize_kernel, dim3(g2), dim3(256), 0, s, local, finals, n_inst, nblk, groups, 0.0, 0.f, 1,
                          partials + part_len * part);

@@ -783,8 +783,6 @@ class Program:
                 # round 6: this rank's part folded from the producing GEMM's T2V_EPI_STATS strips — no statistics pass over the tensor
                 assert rows % 32 == 0 and stats.ld == 2 * x.cols and stats.rows * 32 >= x.rows
                 op1.p[6], op1.i[17] = stats.ref, x.cols
-            elif L.knob("T2V_GN_PHASE1_TICKET", "1") != "0":
-                op1.p[5] = self.sync_ref("tickets")      # round 6: the last statistics workgroup folds the block partials (one launch, not two)
             self._emit(op1)
             full = Buf(scratch.ref, nparts * part_bytes, 1, 1, "u8", scratch.alloc_off)
             if halo_raw is None:
