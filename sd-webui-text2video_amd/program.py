@@ -261,7 +261,10 @@ class Program:
             # 256 rows on 256 CUs; measured (tools/gemm_sweep.py L0) +13 % / +6 % on the C -> C and QKV linears, +3-6 % on the
             # K = 960 .. 2880 convolutions, -7 % on the 8-wave-deep GEGLU GEMM (LDS traffic per MFMA is higher) -> only where
             # the 256-row grid is a few, badly filled waves
-            if n % 320 == 0 and math.ceil(M / 256) * (n // 320) <= int(L.knob("T2V_TILE8_LIMIT", 640)) and L.knob("T2V_TILE8", "1") != "0":
+            if n % 320 == 0 and math.ceil(M / 256) * (n // 320) <= int(L.knob("T2V_TILE8_LIMIT", 640)) and L.knob("T2V_TILE8", "1") != "0" \
+                    and not (r6 and n != 320 and k > 320 and M > 49152):
+                # (round 6, SWEEP_FRAMES=125: at (64000, 640, 640 .. 17280) — several column tiles, several rounds of workgroups — 256x320 is
+                #  ahead of the 12-wave / 8-wave tiles by 6-19 %: 411 / 778 / 991 / 720 / 1110 vs 389 / 661 / 848 / 649 / 934 TF/s)
                 tile = 8
                 # 128x320 on 8 waves (tile 11, round 4): VideoCrafter's M = 32768 makes 171 / 513 workgroups of 192 rows for N = 320 / 960
                 # (0.67 of the last wave of CUs) and exactly 256 / 768 of 128 rows; M = 49152 never gets here (192 rows fill it)
@@ -269,6 +272,8 @@ class Program:
                 fill = lambda wgs: wgs / (math.ceil(wgs / cus) * cus)
                 if fill(w11) > fill(w8) + 0.05 and L.knob("T2V_TILE11", "1") != "0":
                     tile = 11
+            elif r6 and n == 960 and k <= 320 and M > 65536 and L.knob("T2V_TILE8", "1") != "0":
+                tile = 8               # (256000, 960, 320), the QKV projection of a 125-frame clip: 308 vs 275 TF/s on 256x256
             elif tile == 1 and n % 256 == 0 and L.knob("T2V_TILE8", "1") != "0":
                 # the stem TemporalTransformer (inner = 512): 192 x 2 tiles of 256x256 = 384 workgroups, 192x256 gives 512
                 w1, w9 = math.ceil(M / 256) * (n // 256), math.ceil(M / 192) * (n // 256)
@@ -291,20 +296,26 @@ class Program:
                 tile = 2 if n % 320 == 0 else 1
             elif n >= 1536:
                 tile = 9 if L.knob("T2V_TILE8", "1") != "0" else 3      # 16x16-level QKV (12288, 1920, 640): 492 vs 452 TF/s
+                if r6 and M < 12288:
+                    tile = 1                                            # (8192, 1920, 640): 256x256 463 vs 373 TF/s
             else:
                 tile = 0               # (the 4-deep-ring 128x128 tile measured 640 vs 668 TF/s on the K = 2560 feed-forward GEMM)
-                if r6 and M < 12288 and n == 640:
+                if r6 and n % 320 == 0 and math.ceil(M / 256) * (n // 320) >= 200:
+                    # several rounds of 256x320 tiles (125 frames: M = 16000, 1024x576: M = 27648; N = 1280): C -> C 686 vs 491, ff2 917 vs
+                    # 687, temporal conv 945 vs 726 TF/s
+                    tile = 2
+                elif r6 and M < 12288 and n == 640:
                     # M = 8192 (VideoCrafter's 16x16 level, a 32-frame T-shard rank): 128x256 tiles, 64 x 3 workgroups — C -> C 281 vs 269,
                     # temporal conv 508 vs 438, ff2 557 vs 516 TF/s; at M = 12288 (24 frames, b = 2) the 128x128 kernel stays ahead
                     tile = 3
         else:                                          # 8x8 / 4x4 levels: few rows, latency-bound
             if n >= 8192:
                 tile = 1 if M >= 1024 else (0 if M >= 512 else 5)
-                if r6 and 1024 <= M <= 2048 and n % 320 == 0:
-                    tile = 2           # (2048, 10240, 1280): 862 vs 652 TF/s
-                elif r6 and 512 <= M < 768:
-                    tile = 3           # (512, 10240, 1280): 508 vs 465
-                elif r6 and M <= 128:
+                if r6 and (1024 <= M <= 2048 or M >= 3584) and n % 320 == 0:
+                    tile = 2           # (2048, 10240, 1280): 862 vs 652 TF/s; (4000, 10240, 1280): 884 vs 797 (M = 3072 stays: 853 on 256x256)
+                elif r6 and 512 <= M < 1024:
+                    tile = 3           # (512, 10240, 1280): 508 vs 465; (768, 10240, 1280): 667 vs 613
+                elif r6 and 64 <= M <= 128:
                     tile = 12          # (96, 10240, 1280): 182 vs 159
             elif n >= 2560:
                 tile = 1 if M >= 2048 else (3 if M >= 1024 else 5)
@@ -320,20 +331,28 @@ class Program:
                         tile = 9
             elif gather == L.GATHER_CONV3X3 and k >= 8192:
                 tile = 2 if (M >= 4096 and n % 320 == 0) else 3
+                if r6 and ((3584 <= M < 4096) or (2048 <= M < 4096 and k >= 16384)):
+                    tile = 1           # (4000, 1280, 11520): 256x256 x 3 splits 886 vs 729; (3072, 1280, 23040): x 4 splits 931 vs 865
             else:
                 tile = 5                               # 128x128, 4-deep ring: 96 KiB per CU in flight
+                if r6 and math.ceil(M / 128) * math.ceil(n / 128) >= 256 and n % 256 == 0:
+                    tile = 3                           # (4000, 1280, 1280 / 3840 tconv / 5120): 128x256 411 / 595 / 647 vs 362 / 467 / 537 (M = 3072: 240 tiles, stays)
                 if M <= 1024 and n <= 1280 and k <= 1280 and L.knob("T2V_TILE12", "1") != "0":
                     # the 4x4 level's C -> C linears (768, 1280, 1280): 64x64 tiles with the FULL reduction = 240 workgroups, no
                     # split-K slabs and no reduction launch: 201 vs 146 TF/s (tools/gemm_sweep.py L3, round 4); longer K / wider N
                     # stay on the split-K configurations (ff2 381 vs 341, conv3x3 525 vs 410, qkv 365 vs 331)
                     tile = 12
-                elif r6 and k <= 2560 and math.ceil(M / 128) * math.ceil(n / 128) <= 150 and L.knob("T2V_TILE12", "1") != "0" and \
-                        (gather == L.GATHER_PLAIN or (gather == L.GATHER_TCONV3 and self.small_rank_tiles)):
+                elif r6 and gather == L.GATHER_PLAIN and k <= 640 and M >= 4096 and math.ceil(M / 128) * math.ceil(n / 128) > 150:
+                    tile = 0           # (6144, 960, 320), the QKV projection of a 6-frame rank: 219 vs 173 TF/s
+                elif r6 and k <= 2880 and math.ceil(M / 128) * math.ceil(n / 128) <= 150 and L.knob("T2V_TILE12", "1") != "0" and \
+                        (gather in (L.GATHER_PLAIN, L.GATHER_CONV3X3) or (gather == L.GATHER_TCONV3 and self.small_rank_tiles)) and \
+                        (gather != L.GATHER_CONV3X3 or k > 2560):
                     # round 6 (SWEEP_BATCH=1 SWEEP_FRAMES=6 tools/gemm_sweep.py: the rows of a 6-frame T-shard rank): where 128x128 tiles
                     # are <= 150 workgroups and the reduction is short, 64x64 tiles with the full reduction: (6144, 320, 320 .. 1280) 123 /
                     # 206 / 302 vs 108 / 179 / 266 TF/s, (1536, 640, 640 / 2560) 125 / 259 vs 94 / 237, temporal conv (6144, 320, 960) 250
                     # vs 211 and (1536, 640, 1920) 219 vs 167 — the latter only in a T-sharded program, where the cross-frame norm behind
-                    # a temporal convolution is never that GEMM's epilogue (64x64 tiles have no GroupNorm epilogue)
+                    # a temporal convolution is never that GEMM's epilogue (64x64 tiles have no GroupNorm epilogue); the 3x3 convolution
+                    # (6144, 320, 2880) 378 vs 333
                     tile = 12
         if tile == 0:
             bm, bn, bk = 128, (64 if (n % 128 != 0 and n % 128 <= 64) else 128), 64
