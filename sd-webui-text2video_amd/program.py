@@ -285,6 +285,8 @@ class Program:
                 # one CFG role per GPU (pairs / T-shard layouts: M = 24576): 192x256 on 12 waves gives 128 x ceil(N / 256)
                 # workgroups; measured (SWEEP_BATCH=1 tools/gemm_sweep.py L0) +7 % QKV, +9 % feed-forward, +13 % temporal conv
                 tile = 9
+                if r6 and n == 640 and M >= 24576:
+                    tile = 8           # (24576, 640, 640 / 2560 / 5760 conv / 1920 tconv), 48 frames b = 2: 192x320 445 / 776 / 878 / 718 vs 354 / 601 / 682 / 579
                 if n == 320 and L.knob("T2V_TILE11", "1") != "0":
                     # 128x320 on 8 waves: 192 workgroups, no padded columns (N = 320 on 256-wide tiles wastes 37 %); measured
                     # (SWEEP_BATCH=1 tools/gemm_sweep.py L0, round 4): ff2 497 vs 461 TF/s, conv3x3 681 vs 598, tconv 442 vs 419, C -> C
@@ -335,7 +337,11 @@ class Program:
                     tile = 1           # (4000, 1280, 11520): 256x256 x 3 splits 886 vs 729; (3072, 1280, 23040): x 4 splits 931 vs 865
             else:
                 tile = 5                               # 128x128, 4-deep ring: 96 KiB per CU in flight
-                if r6 and math.ceil(M / 128) * math.ceil(n / 128) >= 256 and n % 256 == 0:
+                if r6 and 6144 < M < 8192 and n == 1280 and gather in (L.GATHER_PLAIN, L.GATHER_TCONV3):
+                    # 1024x576 clips, 8x8 level (M = 6912): ONE round of 128x320 (216 workgroups) / 192x256 (180) tiles — C -> C 516, ff2 775 on
+                    # 128x320, temporal conv 718 on 192x256 vs 392 / 556 / 520 on 128x256 (270 workgroups: a second, nearly empty round)
+                    tile = 11 if gather == L.GATHER_PLAIN else 9
+                elif r6 and math.ceil(M / 128) * math.ceil(n / 128) >= 256 and n % 256 == 0:
                     tile = 3                           # (4000, 1280, 1280 / 3840 tconv / 5120): 128x256 411 / 595 / 647 vs 362 / 467 / 537 (M = 3072: 240 tiles, stays)
                 if M <= 1024 and n <= 1280 and k <= 1280 and L.knob("T2V_TILE12", "1") != "0":
                     # the 4x4 level's C -> C linears (768, 1280, 1280): 64x64 tiles with the FULL reduction = 240 workgroups, no
