@@ -296,6 +296,12 @@ class Program:
                 tile = self._fill_choice(M, n, k) if allow_splitk else 2
             elif n >= 2560:
                 tile = 2 if n % 320 == 0 else 1
+                if r6 and tile == 2 and k <= 640 and L.knob("T2V_TILE8", "1") != "0":
+                    # (12288, 2560, 320), the GEGLU projection of a 12-frame rank: 48 x 8 = 384 workgroups of 256x320 (1.5 rounds) against
+                    # 512 of 192x320 (two full rounds): 518 vs 418 TF/s
+                    fill = lambda wgs: wgs / (math.ceil(wgs / cus) * cus)
+                    if fill(math.ceil(M / 192) * (n // 320)) > fill(math.ceil(M / 256) * (n // 320)) + 0.05:
+                        tile = 8
             elif n >= 1536:
                 tile = 9 if L.knob("T2V_TILE8", "1") != "0" else 3      # 16x16-level QKV (12288, 1920, 640): 492 vs 452 TF/s
                 if r6 and M < 12288:
@@ -313,12 +319,16 @@ class Program:
         else:                                          # 8x8 / 4x4 levels: few rows, latency-bound
             if n >= 8192:
                 tile = 1 if M >= 1024 else (0 if M >= 512 else 5)
-                if r6 and (1024 <= M <= 2048 or M >= 3584) and n % 320 == 0:
-                    tile = 2           # (2048, 10240, 1280): 862 vs 652 TF/s; (4000, 10240, 1280): 884 vs 797 (M = 3072 stays: 853 on 256x256)
+                if r6 and M >= 1024 and n % 320 == 0:
+                    # 256x320 where its grid fills the last round of workgroups better than 256x256's: (2048, 10240, 1280) 256 against 320
+                    # workgroups, 862 vs 652 TF/s; (4000, ...) 884 vs 797; (1536, ...) 192 against 240: 256x256 825 vs 711; (3072, ...) 853 on 256x256
+                    fill = lambda wgs: wgs / (math.ceil(wgs / cus) * cus)
+                    w1, w2 = math.ceil(M / 256) * math.ceil(n / 256), math.ceil(M / 256) * (n // 320)
+                    tile = 2 if fill(w2) > fill(w1) else 1
                 elif r6 and 512 <= M < 1024:
                     tile = 3           # (512, 10240, 1280): 508 vs 465; (768, 10240, 1280): 667 vs 613
-                elif r6 and 64 <= M <= 128:
-                    tile = 12          # (96, 10240, 1280): 182 vs 159
+                elif r6 and 64 <= M <= 256:
+                    tile = 12          # (96 / 192, 10240, 1280): 182 / 331 vs 159 / 289
             elif n >= 2560:
                 tile = 1 if M >= 2048 else (3 if M >= 1024 else 5)
                 if r6 and M == 2048:
@@ -348,8 +358,10 @@ class Program:
                     # split-K slabs and no reduction launch: 201 vs 146 TF/s (tools/gemm_sweep.py L3, round 4); longer K / wider N
                     # stay on the split-K configurations (ff2 381 vs 341, conv3x3 525 vs 410, qkv 365 vs 331)
                     tile = 12
-                elif r6 and gather == L.GATHER_PLAIN and k <= 640 and M >= 4096 and math.ceil(M / 128) * math.ceil(n / 128) > 150:
+                elif r6 and gather == L.GATHER_PLAIN and k <= 320 and M >= 4096 and math.ceil(M / 128) * math.ceil(n / 128) > 150:
                     tile = 0           # (6144, 960, 320), the QKV projection of a 6-frame rank: 219 vs 173 TF/s
+                elif r6 and gather == L.GATHER_PLAIN and n == 1920 and 4096 <= M < 8192:
+                    tile = 9           # (6144, 1920, 640), one CFG role's 16x16-level QKV: 192x256 432 vs 335 TF/s
                 elif r6 and k <= 2880 and math.ceil(M / 128) * math.ceil(n / 128) <= 150 and L.knob("T2V_TILE12", "1") != "0" and \
                         (gather in (L.GATHER_PLAIN, L.GATHER_CONV3X3) or (gather == L.GATHER_TCONV3 and self.small_rank_tiles)) and \
                         (gather != L.GATHER_CONV3X3 or k > 2560):
