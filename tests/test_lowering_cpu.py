@@ -490,3 +490,41 @@ def test_round5_sharded_lowering_one_exchange_per_temporal_convolution(monkeypat
     monkeypatch.delenv("T2V_STATS_HALO")
     monkeypatch.setenv("T2V_GN_COOP", "0")        # what the several-processes-on-one-GPU tests set: no launch may wait for another workgroup
     assert not any(op.kind == L.OP_GEMM and op.i[16] == L.EPI_GN for op in lower(1).ops)
+
+
+def test_round6_tile_policy_headline_pinned_and_new_rows():
+    """Program.choose_tile: (1) the shapes of the 24-frame b = 2 step keep the configuration the round-4 / round-6 sweeps measured best
+    (profiles/r06_tile_policy_small_rows.txt: the policy is the best or within 2 % of it on every swept shape) — a change of the policy
+    for other row counts must not move them; (2) the round-6 rules for several-round grids (125 frames, 1024x576), VideoCrafter's rows
+    and the rows of a T-shard rank pick what their sweeps measured; (3) a 64x64-tile GEMM that a GroupNorm can fuse into moves back to
+    the 128x128 tile instead of losing the fusion."""
+    os.environ.setdefault("T2V_DEVICE_CUS", "256")
+    P = Program()
+    G0, G1, G2 = L.GATHER_PLAIN, L.GATHER_CONV3X3, L.GATHER_TCONV3
+    headline = {(49152, 320, 320, G0): (8, 1), (49152, 960, 320, G0): (8, 1), (49152, 2560, 320, G0): (2, 1), (49152, 320, 1280, G0): (8, 1),
+                (49152, 320, 2880, G1): (8, 1), (49152, 320, 960, G2): (8, 1), (12288, 640, 640, G0): (0, 1), (12288, 1920, 640, G0): (9, 1),
+                (12288, 5120, 640, G0): (2, 1), (12288, 640, 2560, G0): (0, 1), (12288, 640, 5760, G1): (8, 2), (12288, 640, 1920, G2): (0, 1),
+                (3072, 1280, 1280, G0): (5, 1), (3072, 3840, 1280, G0): (9, 1), (3072, 10240, 1280, G0): (1, 1), (3072, 1280, 5120, G0): (5, 1),
+                (3072, 1280, 11520, G1): (3, 2), (3072, 1280, 3840, G2): (5, 1), (768, 1280, 1280, G0): (12, 1), (768, 3840, 1280, G0): (5, 1),
+                (768, 1280, 5120, G0): (5, 4), (768, 1280, 11520, G1): (3, 8), (768, 1280, 3840, G2): (5, 4), (49152, 640, 5760, G1): (8, 1)}
+    for (M, n, k, g), want in headline.items():
+        assert P.choose_tile(M, n, k, g) == want, (M, n, k, g, P.choose_tile(M, n, k, g), want)
+    new = {(64000, 640, 640, G0): 2, (64000, 640, 1920, G2): 2, (16000, 1280, 1280, G0): 2, (16000, 1280, 3840, G2): 2, (4000, 1280, 1280, G0): 3,
+           (256000, 960, 320, G0): 8, (27648, 1280, 1280, G0): 2, (6912, 1280, 1280, G0): 11, (6912, 1280, 3840, G2): 9,
+           (8192, 640, 640, G0): 3, (8192, 1920, 640, G0): 1, (2048, 3840, 1280, G0): 3, (2048, 10240, 1280, G0): 2, (1536, 10240, 1280, G0): 1,
+           (512, 3840, 1280, G0): 12, (6144, 320, 320, G0): 12, (1536, 640, 640, G0): 12, (6144, 640, 640, G0): 5, (6144, 960, 320, G0): 0,
+           (12288, 2560, 320, G0): 8, (768, 10240, 1280, G0): 3}
+    for (M, n, k, g), tile in new.items():
+        assert P.choose_tile(M, n, k, g)[0] == tile, (M, n, k, g, P.choose_tile(M, n, k, g), tile)
+    assert P.choose_tile(6144, 320, 960, G2)[0] == 5              # a temporal convolution takes 64x64 tiles only in a T-sharded program
+    P.small_rank_tiles = True
+    assert P.choose_tile(6144, 320, 960, G2)[0] == 12
+    # (3): C -> C linear of a 6-frame rank on 64x64 tiles; the per-frame GroupNorm behind it fuses, the GEMM is moved to the 128x128 tile
+    Q = Program()
+    a, out = Q.alloc(6144, 320, "f16"), Q.alloc(6144, 320, "f32")
+    op = Q.gemm("lin", a, Ref("weight", 0, "w"), 320, 320, out, bias=Ref("weight", 0, "b"))
+    assert op.meta["tile"] == 12
+    y = Q.alloc(6144, 320, "f16")
+    Q.groupnorm("gn", out, Ref("weight", 0, "g"), Ref("weight", 0, "be"), y, n_inst=6, eps=1e-5, silu=True, gb=Ref("weight", 0, "gb"))
+    if Q.gn_epilogue:
+        assert len(Q.ops) == 1 and Q.ops[0].i[16] == L.EPI_GN and Q.ops[0].meta["tile"] == 5 and Q.ops[0].i[22] == 5
