@@ -948,11 +948,12 @@ class _Lowering:
             ld = 3 * inner
             q, k, v = qkv.col_slice(0, inner), qkv.col_slice(inner, 2 * inner), qkv.col_slice(2 * inner, 3 * inner)
             if kind == "spatial":
-                # >= 512 tokens (the 32x32 level; every level of a 1024x576 clip but the last): V transposed once per launch into a scratch,
-                # K / V^T tiles staged by LDS-DMA, 8 waves per tile (csrc/attention.hip attn2_kernel, round 6: 656 -> 843 TF/s at 9216
-                # tokens, 416 -> 551 at 1024 incl. the transposition; bit-identical results).  Fewer tokens: the extra launch costs more.
+                # >= 1024 tokens (the 32x32 level; the two upper levels of a 1024x576 clip): V transposed once per launch into a scratch,
+                # K / V^T tiles staged by LDS-DMA, 8 waves per tile (csrc/attention.hip attn2_kernel, round 6: 656 -> 877 TF/s at 9216
+                # tokens, 454 -> 560 at 1024 incl. the transposition; bit-identical results).  Fewer tokens: the extra launch costs more
+                # (576 tokens: 337 vs 366 TF/s, 256: 260 vs 292 — tools/attn_probe.py).
                 vt = None
-                if hw >= 512 and L.knob("T2V_ATTN2", "1") != "0":
+                if hw >= 1024 and L.knob("T2V_ATTN2", "1") != "0":
                     vt = P.alloc(B * F * heads * 64, -(-hw // 64) * 64, "f16")
                 P.attention(f"{prefix}.attn{tag}", q.ref, k.ref, v.ref, a.ref, out_buf=a, nq=hw, nk=hw, heads=heads,
                             b_outer=B * F, b_inner=1, q_strides=(ld, hw * ld, 0), kv_strides=(ld, hw * ld, 0),
