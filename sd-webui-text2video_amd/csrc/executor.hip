@@ -136,9 +136,9 @@ int validate_op(const t2v_op& op, int idx) {
         if (op.i[5] < N || (op.p[4] != 0 && (op.i[6] < N || op.i[6] % 4 != 0))) return bad("cross-tile LayerNorm output: ldc / ldr must be >= N and multiples of 4");
       }
       if (g == T2V_GATHER_PLAIN && op.i[8] == 1) {
-        if ((op.i[22] != 8 && op.i[22] != 11) || N != 320 || op.i[19] > 1 || op.i[16] != T2V_EPI_NONE || op.i[17] != T2V_F32 || op.i[18] != 0 || op.i[20] != 0 ||
+        if ((op.i[22] != 8 && op.i[22] != 11 && op.i[22] != 2) || N != 320 || op.i[19] > 1 || op.i[16] != T2V_EPI_NONE || op.i[17] != T2V_F32 || op.i[18] != 0 || op.i[20] != 0 ||
             K % 64 != 0)
-          return bad("fused LayerNorm output needs a whole-row tile (192x320 or 128x320), N == 320, fp32 out, no split-K / activation");
+          return bad("fused LayerNorm output needs a whole-row tile (192x320, 128x320 or 256x320), N == 320, fp32 out, no split-K / activation");
         if (op.p[3] == 0 || op.p[7] == 0 || op.i[9] < N || op.i[9] % 4 != 0) return bad("fused LayerNorm output: gamma|beta, output pointer or leading dimension");
         // the epilogue moves whole f32x4 / f16x4 groups without tail guards
         if (op.i[5] < N || (op.p[4] != 0 && (op.i[6] < N || op.i[6] % 4 != 0))) return bad("fused LayerNorm output: ldc / ldr must be >= N and multiples of 4");

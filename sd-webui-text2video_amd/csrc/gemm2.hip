@@ -609,8 +609,12 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm2_kernel(const GemmPar
     }
     if constexpr (XE == 1) {        // whole rows in this tile (192x320, N == 320, validated by the executor): fused LayerNorm output
       float* fs = reinterpret_cast<float*>(smem);
-      t2v_epilogue_rows_ln<TN>(p, acc, fs + wave * (32 * T2V_EPI_SP), fs + NW * (32 * T2V_EPI_SP), lane, wave, m0 + wm * 32,
-                               n0 + wn * TN * 32);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {            // (TM == 2: the 256x320 tile, round 6 — a wave's two 32-row blocks one after the other)
+        if (tm > 0) __syncthreads();                // the partner wave has read this wave's row sums of the previous block
+        t2v_epilogue_rows_ln<TN>(p, reinterpret_cast<f32x16 (&)[1][TN]>(acc[tm]), fs + wave * (32 * T2V_EPI_SP), fs + NW * (32 * T2V_EPI_SP), lane, wave,
+                                 m0 + (wm * TM + tm) * 32, n0 + wn * TN * 32);
+      }
       return;
     }
     t2v_epilogue_rows<TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wave * (32 * T2V_EPI_SP), lane, m0 + wm * TM * 32,
@@ -800,7 +804,7 @@ hipError_t launch_cfg(const GemmParams& pin, hipStream_t s) {
         }
       }
       if (p.xa_k != nullptr) return hipErrorInvalidValue;
-      if constexpr ((WM == 6 || WM == 4) && WN == 2 && TM == 1 && TN == 5 && PP != 1) {      // whole-row tiles: 192x320 / 128x320
+      if constexpr ((WM == 6 || WM == 4) && WN == 2 && (TM == 1 || (WM == 4 && TM == 2)) && TN == 5 && PP != 1) {      // whole-row tiles: 192x320 / 128x320 / 256x320
         if (p.ln_out != nullptr) {
           e = launch_cfg_gather<WM, WN, TM, TN, BK, STAGES, MINW, T2V_GATHER_PLAIN, PP, 1>(p, s);
           break;

@@ -512,7 +512,8 @@ class Program:
         if ln is not None:
             gb, gamma, beta, ln_out, ln_eps = ln
             assert out.dtype == "f32" and ln_out.dtype == "f16" and ln_out.cols == n and ln_out.rows >= M
-            ln_fused = (tile in (8, 11) and split == 1 and n == 320 and gather == L.GATHER_PLAIN and epi == L.EPI_NONE and act == 0
+            # (tile 2 = 256x320, round 6: the several-round grids of 125-frame / 1024x576 clips — a wave's two 32-row blocks one after the other)
+            ln_fused = (tile in ((8, 11, 2) if L.knob("T2V_LN_TILE2", "1") != "0" else (8, 11)) and split == 1 and n == 320 and gather == L.GATHER_PLAIN and epi == L.EPI_NONE and act == 0
                         and rowbias is None and not bias_along_m and k % 64 == 0 and L.knob("T2V_LN_FUSE", "1") != "0")
             # ... or ACROSS the column tiles of the launch (round 5, t2v_epilogue_rows_lnx): the partial row sums meet at a grid barrier, so
             # the whole grid must be resident at once (the 16x16 / 8x8 / 4x4-level C -> C linears: 480 / 240 / 240 workgroups)

@@ -985,10 +985,10 @@ def test_relpos_attention_against_explicit_formula(D, T, Tq, off, R):
     assert rel_l2(read(got, o).float(), ref.permute(2, 0, 1, 3).reshape(Tq * hw, inner)) < 2e-3
 
 
-@pytest.mark.parametrize("tile", [8, 11])
+@pytest.mark.parametrize("tile", [8, 11, 2])
 @pytest.mark.parametrize("M,K,with_res", [(400, 320, True), (192 * 3 + 5, 1280, True), (77, 64, False), (4096, 320, True)])
 def test_gemm_with_fused_layernorm_output(M, K, with_res, tile):
-    """192x320 tile with whole rows (N == 320): the epilogue writes the fp32 stream AND LayerNorm(row) * gamma + beta (fp16) —
+    """192x320 / 128x320 / 256x320 (round 6: a wave's two 32-row blocks one after the other) tile with whole rows (N == 320): the epilogue writes the fp32 stream AND LayerNorm(row) * gamma + beta (fp16) —
     checked against the interpreter and against torch.nn.functional.layer_norm of the device's own fp32 output."""
     N = 320
     P = Program()
