@@ -257,6 +257,8 @@ class Program:
             tile = 0
         elif M >= 32768:                               # 32x32 level: big tiles, 320-wide when it divides
             tile = 2 if n % 320 == 0 and n != 960 else 1
+            if r6 and M > 65536 and n == 2560 and k <= 320:
+                tile = 1               # the GEGLU projection over many rounds, (256000 / 442368, 2560, 320): 256x256 608 / 608 vs 563 / 579 TF/s
             # 192x320 on 12 waves: M = 49152 gives exactly 256 / 768 workgroups for N = 320 / 960 instead of 192 / 768 tiles of
             # 256 rows on 256 CUs; measured (tools/gemm_sweep.py L0) +13 % / +6 % on the C -> C and QKV linears, +3-6 % on the
             # K = 960 .. 2880 convolutions, -7 % on the 8-wave-deep GEGLU GEMM (LDS traffic per MFMA is higher) -> only where
